@@ -1,0 +1,170 @@
+/*
+ * hmx_oracle.h -- CPU restatement of the HM block hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is the parity oracle for libhmx (the HIP product).  It is a from-scratch plain-C
+ * restatement of the arithmetic of the reference (fr34k8/thevc = HM 7.2/8-dev) for the path
+ * named in BASELINE.json: integer DCT/DST + inverse, flat quantisation (+ sign-bit hiding),
+ * de-quantisation, transform skip, intra reference-sample preparation, intra prediction
+ * (angular / DC / planar), MC interpolation filters, bi-pred average and picture border
+ * extension.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it;
+ * the product (thevc_amd/, include/) never links or calls it.
+ *
+ * Parity status: PINNED.  The reference ships no tests or golden vectors of its own
+ * (SURVEY.md section 4), so the oracle is pinned against the reference ITSELF, compiled from
+ * /root/reference by oracle/build_ref.sh into oracle/_ref/libhmref.so: tests/test_oracle_vs_ref.py
+ * runs randomized differential checks of every function below against the reference's own
+ * functions, and tests/golden/ holds vectors generated from the reference for the GPU box.
+ *
+ * Conventions: Pel = int16_t, TCoeff = int32_t, strides in elements, B = internal bit depth
+ * (g_uiBitDepth + g_uiBitIncrement of the reference, COM/TComRom.cpp:445-448).
+ * "COM/" below = /root/reference/source/Lib/TLibCommon/.
+ */
+#ifndef HMX_ORACLE_H
+#define HMX_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMO_REG_DCT 65535u /* COM/TypeDef.h:239 */
+#define HMO_SCAN_ZIGZAG 0
+#define HMO_SCAN_HOR 1
+#define HMO_SCAN_VER 2
+#define HMO_SCAN_DIAG 3
+
+/* ---- tables (COM/TComRom.cpp:293-405, 564-698) ---- */
+void hmo_dct_matrix(int N, int16_t *T);            /* N x N row-major, N in {4,8,16,32} */
+void hmo_dst_matrix(int16_t *T);                   /* 4 x 4 */
+const uint32_t *hmo_scan(int scan_idx, int log2n); /* scan position -> raster index, N*N entries */
+int hmo_quant_scale(int rem);
+int hmo_inv_quant_scale(int rem);
+int hmo_chroma_scale(int idx); /* g_aucChromaScale[58] */
+
+/* ---- transforms (COM/TComTrQuant.cpp:417-972, 1542-1704) ---- */
+void hmo_fwd_pass(const int16_t *src, int16_t *dst, int N, int shift, int line, int use_dst);
+void hmo_inv_pass(const int16_t *src, int16_t *dst, int N, int shift, int line, int use_dst);
+void hmo_xTrMxN(const int16_t *block, int16_t *coeff, int N, unsigned mode, int B);
+void hmo_xITrMxN(const int16_t *coeff, int16_t *block, int N, unsigned mode, int B);
+void hmo_xT(unsigned mode, const int16_t *resi, int stride, int32_t *coef, int N, int B);
+void hmo_xIT(unsigned mode, const int32_t *coef, int16_t *resi, int stride, int N, int B);
+void hmo_xTransformSkip(const int16_t *resi, int stride, int32_t *coef, int N, int B);
+void hmo_xITransformSkip(const int32_t *coef, int16_t *resi, int stride, int N, int B);
+
+/* ---- quantisation (COM/TComTrQuant.cpp:192-222, 977-1355; COM/TComTrQuant.h:79-113) ---- */
+typedef struct {
+  int qp, per, rem;
+} hmo_qp;
+hmo_qp hmo_setQPforQuant(int qpy, int is_chroma, int qp_bd_offset, int chroma_qp_offset);
+
+typedef struct {
+  int per;         /* m_cQP.m_iPer (dequant) */
+  int rem;         /* m_cQP.m_iRem */
+  int per_qbits;   /* cQpBase.m_iPer: ADAPTIVE_QP_SELECTION derives iQBits from the slice base QP
+                      (COM/TComTrQuant.cpp:1169-1231); equal to per when there is no delta QP */
+  int intra_slice; /* I_SLICE -> rounding 171, else 85 */
+  int sign_hide;   /* PPS SignHideFlag */
+  int scan_idx;    /* result of getCoefScanIdx (COM/TComDataCU.cpp:4014); ZIGZAG is mapped to DIAG */
+} hmo_quant_cfg;
+
+int hmo_coef_scan_idx(int N, int is_luma, int is_intra, int dir_mode);
+void hmo_xQuant(const int32_t *src, int32_t *dst, int N, int B, const hmo_quant_cfg *cfg,
+                uint32_t *ac_sum);
+void hmo_xDeQuant(const int32_t *src, int32_t *dst, int N, int B, int per, int rem);
+/* transformNxN / invtransformNxN without the TComDataCU plumbing (COM/TComTrQuant.cpp:1373-1450) */
+void hmo_transformNxN(const int16_t *resi, int stride, int32_t *level, int N, int B, unsigned mode,
+                      int transform_skip, int bypass, const hmo_quant_cfg *cfg, uint32_t *abs_sum);
+void hmo_invtransformNxN(int bypass, unsigned mode, int16_t *resi, int stride, const int32_t *level,
+                         int N, int B, int per, int rem, int transform_skip);
+
+/* ---- intra reference samples (COM/TComPattern.cpp:213-605, COM/TComDataCU.cpp:1221-1735) ---- */
+/* flags: 4*n+1 entries (n = size_luma/4), ordered below-left(bottom first) .. left .. corner ..
+ * above .. above-right, exactly the bNeighborFlags order of COM/TComPattern.cpp:240-245.
+ * Geometry rule for one slice, one tile, no constrained intra pred.  Returns #available. */
+int hmo_intra_avail(int x, int y, int size_luma, int pic_w, int pic_h, int ctu, uint8_t *flags);
+/* rec points at the block origin inside a plane; unit = 4 (luma) or 2 (chroma) samples per flag;
+ * adi receives the (2N+1)x(2N+1) border buffer of fillReferenceSamples (row 0 and column 0). */
+void hmo_fillReferenceSamples(const int16_t *rec, int stride, const uint8_t *flags, int n_avail,
+                              int unit, int N, int B, int32_t *adi);
+/* luma: writes the [1 2 1] smoothed copy at adi + (2N+1)^2 (COM/TComPattern.cpp:265-306) */
+void hmo_filterAdi(int32_t *adi, int N);
+int hmo_use_filtered_refs(int mode, int log2n); /* getPredictorPtr decision */
+
+/* ---- intra prediction (COM/TComPrediction.cpp:129-386, 689-730, 1010-1029) ---- */
+void hmo_xPredIntraAng(const int32_t *src, int src_stride, int16_t *dst, int dst_stride, int N,
+                       int mode, int filter_edge, int B);
+void hmo_xPredIntraPlanar(const int32_t *src, int src_stride, int16_t *dst, int dst_stride, int N);
+void hmo_xDCPredFiltering(const int32_t *src, int src_stride, int16_t *dst, int dst_stride, int N);
+void hmo_predIntraLumaAng(const int32_t *adi, int mode, int16_t *dst, int dst_stride, int N, int B);
+void hmo_predIntraChromaAng(const int32_t *adi, int mode, int16_t *dst, int dst_stride, int N,
+                            int B);
+
+/* ---- inter prediction (COM/TComInterpolationFilter.cpp, COM/TComPrediction.cpp:554-642,
+ *      COM/TComYuv.cpp:401-581, COM/TComPicYuv.cpp:248-286) ---- */
+void hmo_filterHorLuma(const int16_t *src, int ss, int16_t *dst, int ds, int w, int h, int frac,
+                       int is_last, int B);
+void hmo_filterVerLuma(const int16_t *src, int ss, int16_t *dst, int ds, int w, int h, int frac,
+                       int is_first, int is_last, int B);
+void hmo_filterHorChroma(const int16_t *src, int ss, int16_t *dst, int ds, int w, int h, int frac,
+                         int is_last, int B);
+void hmo_filterVerChroma(const int16_t *src, int ss, int16_t *dst, int ds, int w, int h, int frac,
+                         int is_first, int is_last, int B);
+/* ref points at the co-located block origin in the reference plane (before the MV offset) */
+void hmo_predInterLumaBlk(const int16_t *ref, int ref_stride, int mvx, int mvy, int w, int h,
+                          int16_t *dst, int dst_stride, int bi, int B);
+void hmo_predInterChromaBlk(const int16_t *ref, int ref_stride, int mvx, int mvy, int w, int h,
+                            int16_t *dst, int dst_stride, int bi, int B); /* w,h = luma size */
+void hmo_addAvg(const int16_t *s0, int s0s, const int16_t *s1, int s1s, int16_t *dst, int ds, int w,
+                int h, int B);
+void hmo_addClip(const int16_t *pred, int ps, const int16_t *resi, int rs, int16_t *dst, int ds,
+                 int w, int h, int B);
+void hmo_subtract(const int16_t *org, int os, const int16_t *pred, int ps, int16_t *dst, int ds,
+                  int w, int h);
+void hmo_extendPicBorder(int16_t *org, int stride, int w, int h, int mx, int my);
+void hmo_clipMv(int *mvx, int *mvy, int cu_x, int cu_y, int pic_w, int pic_h, int ctu);
+
+/* ---- frame-level drivers used as the whole-picture oracle ---- */
+typedef struct {
+  uint16_t x, y;   /* sample position of the block inside its plane */
+  uint8_t log2n;   /* block size in samples of its plane */
+  uint8_t plane;   /* 0 Y, 1 Cb, 2 Cr */
+  uint8_t mode;    /* intra prediction mode 0..34 */
+  uint8_t flags;   /* bit0 transform skip */
+} hmo_tu;
+
+typedef struct {
+  int pic_w, pic_h; /* luma size */
+  int ctu;          /* 64 */
+  int B;
+  int qp;           /* slice/CU luma QP */
+  int chroma_qp_offset;
+  int sign_hide;
+} hmo_frame_cfg;
+
+/* Encoder-side all-intra reconstruction of one picture from decisions (HOT LOOP B of
+ * ENC/TEncSearch.cpp:1006-1165 / 1167-1390 with RDOQ=0): for each TU in list order,
+ * refs <- recon, pred, resi = org - pred, T, Q, IQ, IT, recon = Clip(pred + resi').
+ * planes: pointers to sample (0,0) of each plane; strides in elements.
+ * level[p]: dense TCoeff plane of the same geometry as plane p, stride = plane width. */
+void hmo_intra_frame_encode(const hmo_frame_cfg *cfg, const hmo_tu *tus, int n_tu,
+                            const int16_t *const org[3], const int org_stride[3],
+                            int16_t *const rec[3], const int rec_stride[3], int32_t *const level[3]);
+/* Decoder-side (DEC/TDecCu.cpp:469-687): levels + modes -> recon. */
+void hmo_intra_frame_decode(const hmo_frame_cfg *cfg, const hmo_tu *tus, int n_tu,
+                            int16_t *const rec[3], const int rec_stride[3],
+                            const int32_t *const level[3]);
+
+typedef struct {
+  uint16_t x, y;   /* luma position of the PU */
+  uint8_t w, h;    /* luma size */
+  uint8_t ref0, ref1; /* reference picture slot, 255 = unused list */
+  int16_t mv0x, mv0y, mv1x, mv1y; /* quarter-pel, already clipped */
+} hmo_pu;
+
+/* motionCompensation for a list of PUs of one picture (COM/TComPrediction.cpp:410-642). */
+void hmo_mc_frame(const hmo_pu *pus, int n_pu, int B, const int16_t *const *ref_planes /*[nref*3]*/,
+                  const int *ref_strides /*[3]*/, int16_t *const dst[3], const int dst_stride[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,374 @@
+// ref_tap.cpp -- tap harness around the REFERENCE's own hot-path functions.  TEST INFRASTRUCTURE.
+//
+// Compiled by oracle/build_ref.sh together with /root/reference's TLibCommon objects into
+// oracle/_ref/libhmref.so (never committed, never shipped as product).  It contains no
+// reference code: it includes the reference headers where they lie, opens their private /
+// protected sections, and forwards plain-C calls to the reference's member functions so that
+// tests/ can (a) check oracle/hmx_oracle.c against the real thing and (b) generate the golden
+// vectors of tests/golden/.
+#define private public
+#define protected public
+#include "TLibCommon/TComDataCU.h"
+#include "TLibCommon/TComInterpolationFilter.h"
+#include "TLibCommon/TComPattern.h"
+#include "TLibCommon/TComPic.h"
+#include "TLibCommon/TComPicYuv.h"
+#include "TLibCommon/TComPrediction.h"
+#include "TLibCommon/TComRom.h"
+#include "TLibCommon/TComSlice.h"
+#include "TLibCommon/TComTrQuant.h"
+#include "TLibCommon/TComYuv.h"
+#undef private
+#undef protected
+
+#include <cstring>
+
+// free functions with external linkage in TComTrQuant.cpp (MATRIX_MULT 0)
+void partialButterfly4(short *src, short *dst, int shift, int line);
+void partialButterfly8(short *src, short *dst, int shift, int line);
+void partialButterfly16(short *src, short *dst, int shift, int line);
+void partialButterfly32(short *src, short *dst, int shift, int line);
+void partialButterflyInverse4(short *src, short *dst, int shift, int line);
+void partialButterflyInverse8(short *src, short *dst, int shift, int line);
+void partialButterflyInverse16(short *src, short *dst, int shift, int line);
+void partialButterflyInverse32(short *src, short *dst, int shift, int line);
+void fastForwardDst(short *block, short *coeff, int shift);
+void fastInverseDst(short *tmp, short *block, int shift);
+void xTrMxN(short *block, short *coeff, int iWidth, int iHeight, UInt uiMode);
+void xITrMxN(short *coeff, short *block, int iWidth, int iHeight, UInt uiMode);
+
+namespace {
+struct State {
+  TComTrQuant tq;
+  TComPrediction pred;
+  TComPattern pattern;
+  TComInterpolationFilter filt;
+  TComSPS sps;
+  TComPPS pps;
+  TComPic *pic = nullptr;
+  TComDataCU sub; // scratch "temp CU" like the encoder's m_ppcTempCU
+  TComYuv yuv[3];
+  int pic_w = 0, pic_h = 0;
+  bool rom = false;
+};
+State *S = nullptr;
+} // namespace
+
+extern "C" {
+
+// bit depth / globals as TAppEncCfg::xSetGlobal does for the shipped cfgs (CTU 64, depth 4)
+int ref_init(int bit_depth, int pic_w, int pic_h, int sign_hide) {
+  if (!S) S = new State;
+  g_uiMaxCUWidth = g_uiMaxCUHeight = 64;
+  g_uiMaxCUDepth = 4;
+  g_uiAddCUDepth = 1;
+  g_uiBitDepth = 8;
+  g_uiBitIncrement = bit_depth - 8;
+  g_uiBASE_MAX = 255;
+  g_uiIBDI_MAX = (1u << bit_depth) - 1;
+  if (!S->rom) {
+    initROM();
+    UInt *p = &g_auiZscanToRaster[0];
+    initZscanToRaster(5, 1, 0, p); // total depth + 1, as TEncCu::create (ENC/TEncCu.cpp:63,101)
+    initRasterToZscan(64, 64, 5);
+    initRasterToPelXY(64, 64, 5);
+    S->tq.init(64, 64, 32, 0, NULL, NULL, NULL, false, true, true, false);
+    S->tq.setFlatScalingList();
+    S->tq.setUseScalingList(false);
+    S->pred.initTempBuff();
+    S->sub.create(256, 64, 64, false, 4, true);
+    for (int i = 0; i < 3; i++) S->yuv[i].create(64, 64);
+    S->rom = true;
+  }
+  S->sps.setMaxCUWidth(64);
+  S->sps.setMaxCUHeight(64);
+  S->sps.setMaxCUDepth(4);
+  S->sps.setMaxTrSize(32);
+  S->sps.setQpBDOffsetY(6 * (bit_depth - 8));
+  S->sps.setQpBDOffsetC(6 * (bit_depth - 8));
+  S->pps.setSignHideFlag(sign_hide);
+  S->pps.setConstrainedIntraPred(false);
+  S->pps.setSPS(&S->sps);
+  if (pic_w > 0 && (pic_w != S->pic_w || pic_h != S->pic_h)) {
+    // the previous picture is leaked on purpose: TComPicSym::destroy() walks the tile array that
+    // only the full encoder allocates
+    S->pic = new TComPic;
+    S->pic->create(pic_w, pic_h, 64, 64, 4);
+    S->pic_w = pic_w;
+    S->pic_h = pic_h;
+  }
+  if (S->pic) {
+    S->sps.setPicWidthInLumaSamples(S->pic_w);
+    S->sps.setPicHeightInLumaSamples(S->pic_h);
+    TComSlice *sl = S->pic->getSlice(0);
+    sl->setSPS(&S->sps);
+    sl->setPPS(&S->pps);
+    sl->setSliceType(I_SLICE);
+    sl->setSliceCurStartCUAddr(0);
+    sl->setDependentSliceCurStartCUAddr(0);
+    // one tile: the encoder's tile set-up (ENC/TEncGOP.cpp, TComPicSym::xInitTiles) leaves index 0
+    for (UInt a = 0; a < S->pic->getNumCUsInFrame(); a++) S->pic->getPicSym()->m_puiTileIdxMap[a] = 0;
+    for (UInt a = 0; a < S->pic->getNumCUsInFrame(); a++) S->pic->getCU(a)->initCU(S->pic, a);
+  }
+  return 0;
+}
+
+void ref_tables(short *t4, short *t8, short *t16, short *t32, short *dst4, int *q, int *iq,
+                unsigned char *chroma58) {
+  memcpy(t4, g_aiT4, sizeof(g_aiT4));
+  memcpy(t8, g_aiT8, sizeof(g_aiT8));
+  memcpy(t16, g_aiT16, sizeof(g_aiT16));
+  memcpy(t32, g_aiT32, sizeof(g_aiT32));
+  memcpy(dst4, g_as_DST_MAT_4, sizeof(g_as_DST_MAT_4));
+  memcpy(q, g_quantScales, 6 * sizeof(int));
+  memcpy(iq, g_invQuantScales, 6 * sizeof(int));
+  memcpy(chroma58, g_aucChromaScale, 58);
+}
+void ref_scan(int scan_idx, int log2n, unsigned *out) {
+  memcpy(out, g_auiSigLastScan[scan_idx][log2n - 1], sizeof(unsigned) << (2 * log2n));
+}
+
+void ref_partialButterfly(int N, short *src, short *dst, int shift, int line) {
+  if (N == 4) partialButterfly4(src, dst, shift, line);
+  if (N == 8) partialButterfly8(src, dst, shift, line);
+  if (N == 16) partialButterfly16(src, dst, shift, line);
+  if (N == 32) partialButterfly32(src, dst, shift, line);
+}
+void ref_partialButterflyInverse(int N, short *src, short *dst, int shift, int line) {
+  if (N == 4) partialButterflyInverse4(src, dst, shift, line);
+  if (N == 8) partialButterflyInverse8(src, dst, shift, line);
+  if (N == 16) partialButterflyInverse16(src, dst, shift, line);
+  if (N == 32) partialButterflyInverse32(src, dst, shift, line);
+}
+void ref_fastForwardDst(short *b, short *c, int shift) { fastForwardDst(b, c, shift); }
+void ref_fastInverseDst(short *t, short *b, int shift) { fastInverseDst(t, b, shift); }
+void ref_xTrMxN(short *b, short *c, int N, unsigned mode) { xTrMxN(b, c, N, N, mode); }
+void ref_xITrMxN(short *c, short *b, int N, unsigned mode) { xITrMxN(c, b, N, N, mode); }
+
+void ref_xT(unsigned mode, short *resi, unsigned stride, int *coef, int N) {
+  S->tq.xT(mode, resi, stride, coef, N, N);
+}
+void ref_xIT(unsigned mode, int *coef, short *resi, unsigned stride, int N) {
+  S->tq.xIT(mode, coef, resi, stride, N, N);
+}
+void ref_xTransformSkip(short *resi, unsigned stride, int *coef, int N) {
+  S->tq.xTransformSkip(resi, stride, coef, N, N);
+}
+void ref_xITransformSkip(int *coef, short *resi, unsigned stride, int N) {
+  S->tq.xITransformSkip(coef, resi, stride, N, N);
+}
+void ref_setQPforQuant(int qpy, int ttype, int bd_off, int c_off, int *out3) {
+  S->tq.setQPforQuant(qpy, (TextType)ttype, bd_off, c_off);
+  out3[0] = S->tq.m_cQP.m_iQP;
+  out3[1] = S->tq.m_cQP.m_iPer;
+  out3[2] = S->tq.m_cQP.m_iRem;
+}
+void ref_xDeQuant(int qpy, int ttype, int bd_off, int c_off, const int *src, int *dst, int N) {
+  S->tq.setQPforQuant(qpy, (TextType)ttype, bd_off, c_off);
+  S->tq.xDeQuant(src, dst, N, N, 0);
+}
+
+// transformNxN / invtransformNxN through CTU 0 of the picture with the per-TU CU state the
+// encoder would have set (ENC/TEncSearch.cpp:1006-1165): intra CU, given dir mode / TS flag.
+void ref_transformNxN(int qpy, int slice_type /*0 B,1 P,2 I*/, int ttype, int is_intra, int dir_mode,
+                      int ts, int bypass, short *resi, unsigned stride, int *level, int N,
+                      unsigned *abs_sum) {
+  TComDataCU *cu = S->pic->getCU(0);
+  TComSlice *sl = S->pic->getSlice(0);
+  sl->setSliceType((SliceType)slice_type);
+  sl->setSliceQp(qpy);
+  sl->setSliceQpBase(qpy);
+  cu->m_pcSlice = sl;
+  cu->m_pePredMode[0] = is_intra ? MODE_INTRA : MODE_INTER;
+  cu->m_puhLumaIntraDir[0] = (UChar)dir_mode;
+  cu->m_puhChromaIntraDir[0] = (UChar)dir_mode;
+  cu->m_puhDepth[0] = 0;
+  cu->m_CUTransquantBypass[0] = bypass;
+  for (int t = 0; t < 3; t++) cu->m_puhTransformSkip[t][0] = (UChar)ts;
+  Int bd = (ttype == 0) ? S->sps.getQpBDOffsetY() : S->sps.getQpBDOffsetC();
+  S->tq.setQPforQuant(qpy, (TextType)ttype, bd, 0);
+  Int *arl = NULL;
+  UInt sum = 0;
+  S->tq.transformNxN(cu, resi, stride, level, arl, N, N, sum, (TextType)ttype, 0, ts != 0);
+  *abs_sum = sum;
+}
+void ref_invtransformNxN(int qpy, int ttype, int bypass, unsigned mode, short *resi, unsigned stride,
+                         int *level, int N, int ts) {
+  Int bd = (ttype == 0) ? S->sps.getQpBDOffsetY() : S->sps.getQpBDOffsetC();
+  S->tq.setQPforQuant(qpy, (TextType)ttype, bd, 0);
+  S->tq.invtransformNxN(bypass != 0, (TextType)ttype, mode, resi, stride, level, N, N, 0, ts != 0);
+}
+
+// ---- intra ----
+void ref_fillReferenceSamples(short *rec_origin, int stride, const unsigned char *flags, int n_avail,
+                              int unit, int N, int *adi) {
+  Bool f[4 * 32 + 1];
+  int n = N / unit, total = 4 * n + 1;
+  for (int i = 0; i < total; i++) f[i] = flags[i] != 0;
+  S->pattern.fillReferenceSamples(NULL, rec_origin, adi, f, n_avail, unit, n, total, N, N, 2 * N + 1,
+                                  2 * N + 1, stride, false);
+}
+
+// set the picture's reconstruction planes (test input for initAdiPattern)
+void ref_set_recon(const short *y, const short *cb, const short *cr) {
+  TComPicYuv *r = S->pic->getPicYuvRec();
+  for (int j = 0; j < S->pic_h; j++)
+    memcpy(r->getLumaAddr() + j * r->getStride(), y + j * S->pic_w, 2 * S->pic_w);
+  for (int j = 0; j < S->pic_h / 2; j++) {
+    memcpy(r->getCbAddr() + j * r->getCStride(), cb + j * (S->pic_w / 2), S->pic_w);
+    memcpy(r->getCrAddr() + j * r->getCStride(), cr + j * (S->pic_w / 2), S->pic_w);
+  }
+}
+
+static TComDataCU *setup_sub(int x, int y, int cu_size) {
+  UInt wcu = S->pic->getFrameWidthInCU();
+  UInt addr = (y / 64) * wcu + (x / 64);
+  TComDataCU *ctu = S->pic->getCU(addr);
+  TComDataCU *c = &S->sub;
+  c->m_pcPic = S->pic;
+  c->m_pcSlice = S->pic->getSlice(0);
+  c->m_uiCUAddr = addr;
+  c->m_uiCUPelX = x;
+  c->m_uiCUPelY = y;
+  UInt raster = ((y % 64) / 4) * 16 + (x % 64) / 4;
+  c->m_uiAbsIdxInLCU = g_auiRasterToZscan[raster];
+  c->m_uiNumPartition = (cu_size / 4) * (cu_size / 4);
+  for (UInt i = 0; i < c->m_uiNumPartition; i++) {
+    c->m_puhWidth[i] = c->m_puhHeight[i] = (UChar)cu_size;
+    c->m_pePredMode[i] = MODE_INTRA;
+  }
+  c->m_pcCULeft = ctu->m_pcCULeft;
+  c->m_pcCUAbove = ctu->m_pcCUAbove;
+  c->m_pcCUAboveLeft = ctu->m_pcCUAboveLeft;
+  c->m_pcCUAboveRight = ctu->m_pcCUAboveRight;
+  for (UInt i = 0; i < 256; i++) {
+    c->m_uiSliceStartCU[i] = 0;
+    c->m_uiDependentSliceStartCU[i] = 0;
+  }
+  return c;
+}
+
+// initAdiPattern for the block at luma (x,y): cu_size = CU size, part_depth / part_z select the
+// TU inside it (the 4x4 case is CU 8, depth 1).  Copies the (2N+1)^2 x2 buffer out.
+void ref_initAdiPattern(int x_cu, int y_cu, int cu_size, int part_depth, int part_z, int *adi_out) {
+  TComDataCU *c = setup_sub(x_cu, y_cu, cu_size);
+  Bool a, l;
+  S->pattern.initAdiPattern(c, part_z, part_depth, S->pred.m_piYuvExt, S->pred.m_iYuvExtStride,
+                            S->pred.m_iYuvExtHeight, a, l, false);
+  int N = cu_size >> part_depth, W = 2 * N + 1;
+  memcpy(adi_out, S->pred.m_piYuvExt, sizeof(int) * 2 * W * W);
+}
+void ref_initAdiPatternChroma(int x_cu, int y_cu, int cu_size, int part_depth, int part_z,
+                              int *adi_out) {
+  TComDataCU *c = setup_sub(x_cu, y_cu, cu_size);
+  Bool a, l;
+  S->pattern.initAdiPatternChroma(c, part_z, part_depth, S->pred.m_piYuvExt, S->pred.m_iYuvExtStride,
+                                  S->pred.m_iYuvExtHeight, a, l);
+  int N = (cu_size >> part_depth) >> 1, W = 2 * N + 1;
+  memcpy(adi_out, S->pred.m_piYuvExt, sizeof(int) * 2 * W * W); // Cb buffer then Cr buffer
+}
+
+void ref_predIntraLumaAng(const int *adi, int mode, short *dst, unsigned stride, int N) {
+  int W = 2 * N + 1;
+  memcpy(S->pred.m_piYuvExt, adi, sizeof(int) * 2 * W * W);
+  S->pred.predIntraLumaAng(&S->pattern, mode, dst, stride, N, N, NULL, true, true);
+}
+void ref_predIntraChromaAng(const int *adi, int mode, short *dst, unsigned stride, int N) {
+  int W = 2 * N + 1;
+  memcpy(S->pred.m_piYuvExt, adi, sizeof(int) * W * W);
+  S->pred.predIntraChromaAng(&S->pattern, S->pred.m_piYuvExt, mode, dst, stride, N, N, NULL, true,
+                             true);
+}
+
+// ---- inter ----
+void ref_filterHorLuma(short *s, int ss, short *d, int ds, int w, int h, int frac, int last) {
+  S->filt.filterHorLuma(s, ss, d, ds, w, h, frac, last != 0);
+}
+void ref_filterVerLuma(short *s, int ss, short *d, int ds, int w, int h, int frac, int first,
+                       int last) {
+  S->filt.filterVerLuma(s, ss, d, ds, w, h, frac, first != 0, last != 0);
+}
+void ref_filterHorChroma(short *s, int ss, short *d, int ds, int w, int h, int frac, int last) {
+  S->filt.filterHorChroma(s, ss, d, ds, w, h, frac, last != 0);
+}
+void ref_filterVerChroma(short *s, int ss, short *d, int ds, int w, int h, int frac, int first,
+                         int last) {
+  S->filt.filterVerChroma(s, ss, d, ds, w, h, frac, first != 0, last != 0);
+}
+
+// xPredInterLumaBlk + xPredInterChromaBlk for one PU at luma (x,y) against the picture's recon
+// planes used as the reference picture (borders extended first).  Outputs dense w*h / (w/2)*(h/2).
+void ref_predInterBlk(int x, int y, int w, int h, int mvx, int mvy, int bi, short *out_y,
+                      short *out_cb, short *out_cr, int do_clip_mv) {
+  TComPicYuv *ref = S->pic->getPicYuvRec();
+  ref->m_bIsBorderExtended = false;
+  ref->extendPicBorder();
+  TComDataCU *c = setup_sub(x & ~63, y & ~63, 64);
+  // the "CU" starts at the PU origin so that partAddr 0 addresses both the reference block
+  // (cu->getZorderIdxInCU() + partAddr) and the origin of the 64x64 destination buffer
+  c->m_uiAbsIdxInLCU = g_auiRasterToZscan[((y % 64) / 4) * 16 + (x % 64) / 4];
+  c->m_uiCUPelX = x & ~63;
+  c->m_uiCUPelY = y & ~63;
+  UInt part = 0;
+  TComMv mv((Short)mvx, (Short)mvy);
+  if (do_clip_mv) {
+    // clipMv reads the CU origin; for parity with the oracle use the PU's own position
+    c->m_uiCUPelX = x;
+    c->m_uiCUPelY = y;
+    c->clipMv(mv);
+    c->m_uiCUPelX = x & ~63;
+    c->m_uiCUPelY = y & ~63;
+  }
+  TComYuv *dst = &S->yuv[0];
+  S->pred.xPredInterLumaBlk(c, ref, part, &mv, w, h, dst, bi != 0);
+  S->pred.xPredInterChromaBlk(c, ref, part, &mv, w, h, dst, bi != 0);
+  Pel *py = dst->getLumaAddr(part), *pu = dst->getCbAddr(part), *pv = dst->getCrAddr(part);
+  for (int j = 0; j < h; j++) memcpy(out_y + j * w, py + j * dst->getStride(), 2 * w);
+  for (int j = 0; j < h / 2; j++) {
+    memcpy(out_cb + j * (w / 2), pu + j * dst->getCStride(), w);
+    memcpy(out_cr + j * (w / 2), pv + j * dst->getCStride(), w);
+  }
+}
+void ref_clipMv(int cu_x, int cu_y, int *mvx, int *mvy) {
+  TComDataCU *c = setup_sub(cu_x & ~63, cu_y & ~63, 64);
+  c->m_uiCUPelX = cu_x;
+  c->m_uiCUPelY = cu_y;
+  TComMv mv((Short)*mvx, (Short)*mvy);
+  c->clipMv(mv);
+  *mvx = mv.getHor();
+  *mvy = mv.getVer();
+}
+
+// TComYuv::addAvg on dense w*h luma + (w/2)*(h/2) chroma inputs
+void ref_addAvg(const short *a[3], const short *b[3], short *o[3], int w, int h) {
+  TComYuv *A = &S->yuv[0], *B = &S->yuv[1], *O = &S->yuv[2];
+  for (int j = 0; j < h; j++) {
+    memcpy(A->getLumaAddr() + j * A->getStride(), a[0] + j * w, 2 * w);
+    memcpy(B->getLumaAddr() + j * B->getStride(), b[0] + j * w, 2 * w);
+  }
+  for (int j = 0; j < h / 2; j++) {
+    memcpy(A->getCbAddr() + j * A->getCStride(), a[1] + j * (w / 2), w);
+    memcpy(A->getCrAddr() + j * A->getCStride(), a[2] + j * (w / 2), w);
+    memcpy(B->getCbAddr() + j * B->getCStride(), b[1] + j * (w / 2), w);
+    memcpy(B->getCrAddr() + j * B->getCStride(), b[2] + j * (w / 2), w);
+  }
+  O->addAvg(A, B, 0, w, h);
+  for (int j = 0; j < h; j++) memcpy(o[0] + j * w, O->getLumaAddr() + j * O->getStride(), 2 * w);
+  for (int j = 0; j < h / 2; j++) {
+    memcpy(o[1] + j * (w / 2), O->getCbAddr() + j * O->getCStride(), w);
+    memcpy(o[2] + j * (w / 2), O->getCrAddr() + j * O->getCStride(), w);
+  }
+}
+
+// recon plane with margins after extendPicBorder: copies (w+2mx)*(h+2my) luma samples out
+void ref_extended_luma(short *out) {
+  TComPicYuv *r = S->pic->getPicYuvRec();
+  r->m_bIsBorderExtended = false;
+  r->extendPicBorder();
+  int mx = r->m_iLumaMarginX, my = r->m_iLumaMarginY, st = r->getStride();
+  for (int j = 0; j < S->pic_h + 2 * my; j++)
+    memcpy(out + j * (S->pic_w + 2 * mx), r->getLumaAddr() + (j - my) * st - mx, 2 * (S->pic_w + 2 * mx));
+}
+int ref_luma_margin() { return S->pic->getPicYuvRec()->m_iLumaMarginX; }
+
+} // extern "C"

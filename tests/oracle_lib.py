@@ -1,0 +1,191 @@
+"""ctypes access to the CPU oracle (oracle/libhmx_oracle.so) and, when present, to the compiled
+reference (oracle/_ref/libhmref.so).  TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg import this module; the product never does."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "libhmx_oracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libhmref.so")
+
+i16p = np.ctypeslib.ndpointer(np.int16, flags="C")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C")
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C")
+ci = C.c_int
+cu = C.c_uint
+
+
+class QuantCfg(C.Structure):
+    _fields_ = [("per", ci), ("rem", ci), ("per_qbits", ci), ("intra_slice", ci),
+                ("sign_hide", ci), ("scan_idx", ci)]
+
+
+class Qp(C.Structure):
+    _fields_ = [("qp", ci), ("per", ci), ("rem", ci)]
+
+
+class FrameCfg(C.Structure):
+    _fields_ = [("pic_w", ci), ("pic_h", ci), ("ctu", ci), ("B", ci), ("qp", ci),
+                ("chroma_qp_offset", ci), ("sign_hide", ci)]
+
+
+TU_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2n", "u1"), ("plane", "u1"),
+                     ("mode", "u1"), ("flags", "u1")])
+PU_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("w", "u1"), ("h", "u1"), ("ref0", "u1"),
+                     ("ref1", "u1"), ("mv0x", "<i2"), ("mv0y", "<i2"), ("mv1x", "<i2"),
+                     ("mv1y", "<i2")])
+
+_oracle = None
+_ref = None
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        if not os.path.exists(ORACLE_SO) or (os.path.getmtime(ORACLE_SO) <
+                                             os.path.getmtime(os.path.join(ROOT, "oracle", "hmx_oracle.c"))):
+            build_oracle()
+        L = C.CDLL(ORACLE_SO)
+        L.hmo_dct_matrix.argtypes = [ci, i16p]
+        L.hmo_dst_matrix.argtypes = [i16p]
+        L.hmo_scan.argtypes = [ci, ci]
+        L.hmo_scan.restype = C.POINTER(C.c_uint32)
+        L.hmo_fwd_pass.argtypes = [i16p, i16p, ci, ci, ci, ci]
+        L.hmo_inv_pass.argtypes = [i16p, i16p, ci, ci, ci, ci]
+        L.hmo_xTrMxN.argtypes = [i16p, i16p, ci, cu, ci]
+        L.hmo_xITrMxN.argtypes = [i16p, i16p, ci, cu, ci]
+        L.hmo_xT.argtypes = [cu, i16p, ci, i32p, ci, ci]
+        L.hmo_xIT.argtypes = [cu, i32p, i16p, ci, ci, ci]
+        L.hmo_xTransformSkip.argtypes = [i16p, ci, i32p, ci, ci]
+        L.hmo_xITransformSkip.argtypes = [i32p, i16p, ci, ci, ci]
+        L.hmo_setQPforQuant.argtypes = [ci, ci, ci, ci]
+        L.hmo_setQPforQuant.restype = Qp
+        L.hmo_coef_scan_idx.argtypes = [ci, ci, ci, ci]
+        L.hmo_xQuant.argtypes = [i32p, i32p, ci, ci, C.POINTER(QuantCfg), C.POINTER(C.c_uint32)]
+        L.hmo_xDeQuant.argtypes = [i32p, i32p, ci, ci, ci, ci]
+        L.hmo_transformNxN.argtypes = [i16p, ci, i32p, ci, ci, cu, ci, ci, C.POINTER(QuantCfg),
+                                       C.POINTER(C.c_uint32)]
+        L.hmo_invtransformNxN.argtypes = [ci, cu, i16p, ci, i32p, ci, ci, ci, ci, ci]
+        L.hmo_intra_avail.argtypes = [ci, ci, ci, ci, ci, ci, u8p]
+        L.hmo_fillReferenceSamples.argtypes = [C.c_void_p, ci, u8p, ci, ci, ci, ci, i32p]
+        L.hmo_filterAdi.argtypes = [i32p, ci]
+        L.hmo_use_filtered_refs.argtypes = [ci, ci]
+        L.hmo_predIntraLumaAng.argtypes = [i32p, ci, i16p, ci, ci, ci]
+        L.hmo_predIntraChromaAng.argtypes = [i32p, ci, i16p, ci, ci, ci]
+        for n in ("hmo_filterHorLuma", "hmo_filterHorChroma"):
+            getattr(L, n).argtypes = [C.c_void_p, ci, C.c_void_p, ci, ci, ci, ci, ci, ci]
+        for n in ("hmo_filterVerLuma", "hmo_filterVerChroma"):
+            getattr(L, n).argtypes = [C.c_void_p, ci, C.c_void_p, ci, ci, ci, ci, ci, ci, ci]
+        L.hmo_predInterLumaBlk.argtypes = [C.c_void_p, ci, ci, ci, ci, ci, i16p, ci, ci, ci]
+        L.hmo_predInterChromaBlk.argtypes = [C.c_void_p, ci, ci, ci, ci, ci, i16p, ci, ci, ci]
+        L.hmo_addAvg.argtypes = [i16p, ci, i16p, ci, i16p, ci, ci, ci, ci]
+        L.hmo_addClip.argtypes = [i16p, ci, i16p, ci, i16p, ci, ci, ci, ci]
+        L.hmo_subtract.argtypes = [i16p, ci, i16p, ci, i16p, ci, ci, ci]
+        L.hmo_extendPicBorder.argtypes = [C.c_void_p, ci, ci, ci, ci, ci]
+        L.hmo_clipMv.argtypes = [C.POINTER(ci), C.POINTER(ci), ci, ci, ci, ci, ci]
+        P3 = C.c_void_p * 3
+        I3 = ci * 3
+        L.hmo_intra_frame_encode.argtypes = [C.POINTER(FrameCfg), C.c_void_p, ci, P3, I3, P3, I3, P3]
+        L.hmo_intra_frame_decode.argtypes = [C.POINTER(FrameCfg), C.c_void_p, ci, P3, I3, P3]
+        L.hmo_mc_frame.argtypes = [C.c_void_p, ci, ci, C.c_void_p, I3, P3, I3]
+        _oracle = L
+    return _oracle
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    """The compiled reference (only in the build container; absent on the GPU box)."""
+    global _ref
+    if _ref is None:
+        L = C.CDLL(REF_SO)
+        L.ref_init.argtypes = [ci, ci, ci, ci]
+        L.ref_tables.argtypes = [i16p, i16p, i16p, i16p, i16p, i32p, i32p, u8p]
+        L.ref_scan.argtypes = [ci, ci, u32p]
+        L.ref_partialButterfly.argtypes = [ci, i16p, i16p, ci, ci]
+        L.ref_partialButterflyInverse.argtypes = [ci, i16p, i16p, ci, ci]
+        L.ref_fastForwardDst.argtypes = [i16p, i16p, ci]
+        L.ref_fastInverseDst.argtypes = [i16p, i16p, ci]
+        L.ref_xTrMxN.argtypes = [i16p, i16p, ci, cu]
+        L.ref_xITrMxN.argtypes = [i16p, i16p, ci, cu]
+        L.ref_xT.argtypes = [cu, i16p, cu, i32p, ci]
+        L.ref_xIT.argtypes = [cu, i32p, i16p, cu, ci]
+        L.ref_xTransformSkip.argtypes = [i16p, cu, i32p, ci]
+        L.ref_xITransformSkip.argtypes = [i32p, i16p, cu, ci]
+        L.ref_setQPforQuant.argtypes = [ci, ci, ci, ci, i32p]
+        L.ref_xDeQuant.argtypes = [ci, ci, ci, ci, i32p, i32p, ci]
+        L.ref_transformNxN.argtypes = [ci, ci, ci, ci, ci, ci, ci, i16p, cu, i32p, ci,
+                                       C.POINTER(C.c_uint32)]
+        L.ref_invtransformNxN.argtypes = [ci, ci, ci, cu, i16p, cu, i32p, ci, ci]
+        L.ref_fillReferenceSamples.argtypes = [C.c_void_p, ci, u8p, ci, ci, ci, i32p]
+        L.ref_set_recon.argtypes = [i16p, i16p, i16p]
+        L.ref_initAdiPattern.argtypes = [ci, ci, ci, ci, ci, i32p]
+        L.ref_initAdiPatternChroma.argtypes = [ci, ci, ci, ci, ci, i32p]
+        L.ref_predIntraLumaAng.argtypes = [i32p, ci, i16p, cu, ci]
+        L.ref_predIntraChromaAng.argtypes = [i32p, ci, i16p, cu, ci]
+        for n in ("ref_filterHorLuma", "ref_filterHorChroma"):
+            getattr(L, n).argtypes = [C.c_void_p, ci, C.c_void_p, ci, ci, ci, ci, ci]
+        for n in ("ref_filterVerLuma", "ref_filterVerChroma"):
+            getattr(L, n).argtypes = [C.c_void_p, ci, C.c_void_p, ci, ci, ci, ci, ci, ci]
+        L.ref_predInterBlk.argtypes = [ci, ci, ci, ci, ci, ci, ci, i16p, i16p, i16p, ci]
+        L.ref_clipMv.argtypes = [ci, ci, C.POINTER(ci), C.POINTER(ci)]
+        L.ref_addAvg.argtypes = [C.c_void_p * 3, C.c_void_p * 3, C.c_void_p * 3, ci, ci]
+        L.ref_extended_luma.argtypes = [i16p]
+        _ref = L
+    return _ref
+
+
+def ptr(a, elem_offset=0):
+    """Raw pointer into a numpy array at an element offset (for origin-inside-plane arguments)."""
+    return C.c_void_p(a.ctypes.data + elem_offset * a.itemsize)
+
+
+# ---- convenience wrappers over the oracle used by the parity tests ----
+
+def quant_cfg(per, rem, intra_slice=1, sign_hide=1, scan_idx=3, per_qbits=None):
+    return QuantCfg(per, rem, per if per_qbits is None else per_qbits, intra_slice, sign_hide,
+                    scan_idx)
+
+
+def o_transformNxN(resi, N, B, mode, ts, cfg, bypass=0):
+    resi = np.ascontiguousarray(resi, np.int16)
+    lvl = np.zeros(N * N, np.int32)
+    s = C.c_uint32(0)
+    oracle().hmo_transformNxN(resi, N, lvl, N, B, mode, ts, bypass, C.byref(cfg), C.byref(s))
+    return lvl.reshape(N, N), s.value
+
+
+def o_invtransformNxN(lvl, N, B, mode, per, rem, ts, bypass=0):
+    lvl = np.ascontiguousarray(lvl, np.int32).reshape(-1)
+    resi = np.zeros(N * N, np.int16)
+    oracle().hmo_invtransformNxN(bypass, mode, resi, N, lvl, N, B, per, rem, ts)
+    return resi.reshape(N, N)
+
+
+def o_intra_pred(rec_plane, stride, x, y, N, mode, B, pic_w, pic_h, chroma, ctu=64):
+    """refs from a recon plane (flat int16 array, origin at element 0) -> N x N prediction."""
+    L = oracle()
+    flags = np.zeros(65, np.uint8)
+    c = 1 if chroma else 0
+    nav = L.hmo_intra_avail(x << c, y << c, N << c, pic_w, pic_h, ctu, flags)
+    W = 2 * N + 1
+    adi = np.zeros(2 * W * W, np.int32)
+    L.hmo_fillReferenceSamples(ptr(rec_plane, y * stride + x), stride, flags, nav, 2 if chroma else 4,
+                               N, B, adi)
+    pred = np.zeros((N, N), np.int16)
+    if chroma:
+        L.hmo_predIntraChromaAng(adi, mode, pred.reshape(-1), N, N, B)
+    else:
+        L.hmo_filterAdi(adi, N)
+        L.hmo_predIntraLumaAng(adi, mode, pred.reshape(-1), N, N, B)
+    return pred

@@ -1,0 +1,387 @@
+"""Pins the CPU oracle (oracle/hmx_oracle.c) against the REFERENCE ITSELF compiled from
+/root/reference (oracle/build_ref.sh -> oracle/_ref/libhmref.so).  Randomized differential tests,
+bit-exact.  Skipped where the reference is absent (the GPU box); there tests/golden/ takes over."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.ref
+REG_DCT = 65535
+
+
+@pytest.fixture(scope="module", params=[8, 10])
+def B(request):
+    ol.ref().ref_init(request.param, 416, 240, 1)
+    return request.param
+
+
+def test_tables():
+    R, O = ol.ref(), ol.oracle()
+    R.ref_init(8, 416, 240, 1)
+    t = {n: np.zeros(n * n, np.int16) for n in (4, 8, 16, 32)}
+    dst = np.zeros(16, np.int16)
+    q, iq, ch = np.zeros(6, np.int32), np.zeros(6, np.int32), np.zeros(58, np.uint8)
+    R.ref_tables(t[4], t[8], t[16], t[32], dst, q, iq, ch)
+    for n in (4, 8, 16, 32):
+        m = np.zeros(n * n, np.int16)
+        O.hmo_dct_matrix(n, m)
+        assert np.array_equal(m, t[n]), n
+    m = np.zeros(16, np.int16)
+    O.hmo_dst_matrix(m)
+    assert np.array_equal(m, dst)
+    O.hmo_quant_scale.restype = C.c_int
+    assert [O.hmo_quant_scale(i) for i in range(6)] == list(q)
+    assert [O.hmo_inv_quant_scale(i) for i in range(6)] == list(iq)
+    assert [O.hmo_chroma_scale(i) for i in range(58)] == list(ch)
+    for scan in (1, 2, 3):
+        for lg in (2, 3, 4, 5):
+            r = np.zeros(1 << (2 * lg), np.uint32)
+            R.ref_scan(scan, lg, r)
+            o = np.ctypeslib.as_array(O.hmo_scan(scan, lg), shape=(1 << (2 * lg),))
+            assert np.array_equal(o, r), (scan, lg)
+
+
+@pytest.mark.parametrize("N", [4, 8, 16, 32])
+def test_1d_passes(N):
+    R, O = ol.ref(), ol.oracle()
+    R.ref_init(8, 416, 240, 1)
+    rng = np.random.default_rng(N)
+    for it in range(40):
+        # full int16 range exercises the forward wrap and the inverse clip
+        amp = [255, 4095, 32767][it % 3]
+        src = rng.integers(-amp - 1, amp + 1, N * N).astype(np.int16)
+        for shift in (1, 3, 7, 11, 12):
+            a, b = np.zeros(N * N, np.int16), np.zeros(N * N, np.int16)
+            R.ref_partialButterfly(N, src.copy(), a, shift, N)
+            O.hmo_fwd_pass(src, b, N, shift, N, 0)
+            assert np.array_equal(a, b)
+            R.ref_partialButterflyInverse(N, src.copy(), a, shift, N)
+            O.hmo_inv_pass(src, b, N, shift, N, 0)
+            assert np.array_equal(a, b)
+            if N == 4:
+                R.ref_fastForwardDst(src.copy(), a, shift)
+                O.hmo_fwd_pass(src, b, 4, shift, 4, 1)
+                assert np.array_equal(a, b)
+                R.ref_fastInverseDst(src.copy(), a, shift)
+                O.hmo_inv_pass(src, b, 4, shift, 4, 1)
+                assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("N", [4, 8, 16, 32])
+def test_2d_transforms(B, N):
+    R, O = ol.ref(), ol.oracle()
+    rng = np.random.default_rng(100 + N + B)
+    mx = (1 << B) - 1
+    for it in range(60):
+        mode = [REG_DCT, 0, 1, 10, 26, 34][it % 6]
+        amp = mx if it % 2 == 0 else 32767
+        blk = rng.integers(-amp, amp + 1, N * N).astype(np.int16)
+        a, b = np.zeros(N * N, np.int16), np.zeros(N * N, np.int16)
+        R.ref_xTrMxN(blk.copy(), a, N, mode)
+        O.hmo_xTrMxN(blk, b, N, mode, B)
+        assert np.array_equal(a, b)
+        R.ref_xITrMxN(blk.copy(), a, N, mode)
+        O.hmo_xITrMxN(blk, b, N, mode, B)
+        assert np.array_equal(a, b)
+        # strided wrappers with Int coefficients (xT/xIT) incl. out-of-short-range coefficients
+        stride = N + 5
+        resi = rng.integers(-mx, mx + 1, N * stride).astype(np.int16)
+        ca, cb = np.zeros(N * N, np.int32), np.zeros(N * N, np.int32)
+        R.ref_xT(mode, resi.copy(), stride, ca, N)
+        O.hmo_xT(mode, resi, stride, cb, N, B)
+        assert np.array_equal(ca, cb)
+        coef = rng.integers(-70000, 70000, N * N).astype(np.int32)
+        ra, rb = np.zeros(N * stride, np.int16), np.zeros(N * stride, np.int16)
+        R.ref_xIT(mode, coef.copy(), ra, stride, N)
+        O.hmo_xIT(mode, coef, rb, stride, N, B)
+        assert np.array_equal(ra, rb)
+        R.ref_xTransformSkip(resi.copy(), stride, ca, N)
+        O.hmo_xTransformSkip(resi, stride, cb, N, B)
+        assert np.array_equal(ca, cb)
+        R.ref_xITransformSkip(coef.copy(), ra, stride, N)
+        O.hmo_xITransformSkip(coef, rb, stride, N, B)
+        assert np.array_equal(ra, rb)
+
+
+def test_setqp_and_dequant(B):
+    R, O = ol.ref(), ol.oracle()
+    rng = np.random.default_rng(7 + B)
+    bd = 6 * (B - 8)
+    for qpy in range(-bd, 52):
+        for tt in (0, 1):
+            for coff in (-3, 0, 5):
+                out = np.zeros(3, np.int32)
+                R.ref_setQPforQuant(qpy, tt, bd, coff if tt else 0, out)
+                q = O.hmo_setQPforQuant(qpy, tt, bd, coff if tt else 0)
+                assert (q.qp, q.per, q.rem) == tuple(out)
+    for N in (4, 8, 16, 32):
+        for qpy in (0, 17, 32, 51):
+            out = np.zeros(3, np.int32)
+            R.ref_setQPforQuant(qpy, 0, bd, 0, out)
+            lv = rng.integers(-40000, 40000, N * N).astype(np.int32)
+            a, b = np.zeros(N * N, np.int32), np.zeros(N * N, np.int32)
+            R.ref_xDeQuant(qpy, 0, bd, 0, lv, a, N)
+            O.hmo_xDeQuant(lv, b, N, B, int(out[1]), int(out[2]))
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("N", [4, 8, 16, 32])
+def test_transformNxN_flat_quant_sbh(B, N):
+    """transformNxN with RDOQ off = xT|xTransformSkip + flat xQuant + signBitHidingHDQ, through
+    the reference's own TComDataCU plumbing (scan index from the intra direction)."""
+    R, O = ol.ref(), ol.oracle()
+    rng = np.random.default_rng(300 + N + B)
+    mx = (1 << B) - 1
+    bd = 6 * (B - 8)
+    n_changed = 0
+    for it in range(150):
+        ttype = (0, 2, 3)[it % 3]  # TextType: TEXT_LUMA, TEXT_CHROMA_U, TEXT_CHROMA_V
+        if N == 32:
+            ttype = 0  # the reference allocates no chroma quant tables at 32x32 (4:2:0, max TU 32)
+        is_intra = it % 5 != 4
+        mode = int(rng.integers(0, 35))
+        ts = int(N == 4 and it % 7 == 3)
+        qpy = int(rng.choice([12, 22, 27, 32, 37, 45]))
+        slice_type = [2, 1, 0][it % 3] if not is_intra else 2
+        amp = int(rng.choice([3, 20, 80, mx]))
+        stride = N + 3
+        resi = rng.integers(-amp, amp + 1, N * stride).astype(np.int16)
+        la = np.zeros(N * N, np.int32)
+        sa = C.c_uint32(0)
+        R.ref_transformNxN(qpy, slice_type, ttype, int(is_intra), mode, ts, 0, resi.copy(), stride, la, N,
+                           C.byref(sa))
+        q = O.hmo_setQPforQuant(qpy, int(ttype != 0), bd, 0)
+        scan = O.hmo_coef_scan_idx(N, int(ttype == 0), int(is_intra), mode)
+        cfg = ol.quant_cfg(q.per, q.rem, intra_slice=int(slice_type == 2), sign_hide=1, scan_idx=scan)
+        tmode = mode if (ttype == 0 and is_intra) else REG_DCT
+        lb = np.zeros(N * N, np.int32)
+        sb = C.c_uint32(0)
+        O.hmo_transformNxN(resi, stride, lb, N, B, tmode, ts, 0, C.byref(cfg), C.byref(sb))
+        assert np.array_equal(la, lb), (it, N, B)
+        assert sa.value == sb.value
+        # did sign-bit hiding actually fire somewhere? compare with SBH off
+        cfg2 = ol.quant_cfg(q.per, q.rem, intra_slice=int(slice_type == 2), sign_hide=0, scan_idx=scan)
+        lc = np.zeros(N * N, np.int32)
+        O.hmo_transformNxN(resi, stride, lc, N, B, tmode, ts, 0, C.byref(cfg2), C.byref(sb))
+        n_changed += int(not np.array_equal(lb, lc))
+        # inverse
+        ra, rb = np.zeros(N * stride, np.int16), np.zeros(N * stride, np.int16)
+        R.ref_invtransformNxN(qpy, ttype, 0, tmode, ra, stride, la.copy(), N, ts)
+        O.hmo_invtransformNxN(0, tmode, rb, stride, lb, N, B, q.per, q.rem, ts)
+        assert np.array_equal(ra, rb)
+    assert n_changed > 5  # the SBH path was exercised
+
+
+def _rand_flags(rng, n, kind):
+    total = 4 * n + 1
+    if kind == 0:
+        return np.zeros(total, np.uint8)
+    if kind == 1:
+        return np.ones(total, np.uint8)
+    f = (rng.random(total) < rng.choice([0.2, 0.5, 0.8])).astype(np.uint8)
+    return f
+
+
+@pytest.mark.parametrize("N,unit", [(4, 4), (8, 4), (16, 4), (32, 4), (64, 4), (4, 2), (8, 2), (16, 2), (32, 2)])
+def test_fill_reference_samples(B, N, unit):
+    R, O = ol.ref(), ol.oracle()
+    rng = np.random.default_rng(500 + N * 3 + unit + B)
+    stride = 3 * N + 7
+    plane = rng.integers(0, 1 << B, (3 * N + 3) * stride).astype(np.int16)
+    org = (N + 1) * stride + N + 1
+    W = 2 * N + 1
+    for it in range(60):
+        flags = _rand_flags(rng, N // unit, it % 4)
+        flags65 = np.zeros(max(65, flags.size), np.uint8)
+        flags65[:flags.size] = flags
+        nav = int(flags.sum())
+        a = np.full(2 * W * W, -1, np.int32)
+        b = np.full(2 * W * W, -1, np.int32)
+        R.ref_fillReferenceSamples(ol.ptr(plane, org), stride, flags65, nav, unit, N, a)
+        O.hmo_fillReferenceSamples(ol.ptr(plane, org), stride, flags65, nav, unit, N, B, b)
+        assert np.array_equal(a, b), (it, flags)
+
+
+def _planes(rng, w, h, B):
+    y = rng.integers(0, 1 << B, w * h).astype(np.int16)
+    cb = rng.integers(0, 1 << B, w * h // 4).astype(np.int16)
+    cr = rng.integers(0, 1 << B, w * h // 4).astype(np.int16)
+    return y, cb, cr
+
+
+@pytest.mark.parametrize("pic", [(416, 240), (128, 72), (192, 128)])
+def test_init_adi_pattern_geometry(pic):
+    """initAdiPattern on a real TComPic: neighbour availability from the reference's own
+    getPU*/Adi functions vs the oracle's geometric rule, at EVERY block position of the picture
+    (incl. right/bottom picture edges that cut the last CTU), luma and chroma."""
+    R, O = ol.ref(), ol.oracle()
+    w, h = pic
+    B = 8
+    R.ref_init(B, w, h, 1)
+    rng = np.random.default_rng(w)
+    y, cb, cr = _planes(rng, w, h, B)
+    R.ref_set_recon(y, cb, cr)
+    flags = np.zeros(65, np.uint8)
+    for N in (4, 8, 16, 32):
+        W = 2 * N + 1
+        for by in range(0, h - N + 1, N):
+            for bx in range(0, w - N + 1, N):
+                a = np.zeros(2 * W * W, np.int32)
+                b = np.zeros(2 * W * W, np.int32)
+                if N == 4:  # CU 8, NxN partition, TU depth 1
+                    cx, cy = bx & ~7, by & ~7
+                    part = ((by >> 2) & 1) * 2 + ((bx >> 2) & 1)
+                    R.ref_initAdiPattern(cx, cy, 8, 1, part, a)
+                else:
+                    R.ref_initAdiPattern(bx, by, N, 0, 0, a)
+                nav = O.hmo_intra_avail(bx, by, N, w, h, 64, flags)
+                O.hmo_fillReferenceSamples(ol.ptr(y, by * w + bx), w, flags, nav, 4, N, B, b)
+                O.hmo_filterAdi(b, N)
+                # only row 0 / column 0 of each buffer are defined
+                for off in (0, W * W):
+                    assert np.array_equal(a[off:off + W], b[off:off + W]), (N, bx, by)
+                    assert np.array_equal(a[off:off + W * W:W], b[off:off + W * W:W]), (N, bx, by)
+        # chroma of a luma block of size N (N >= 8): Cb then Cr buffers
+        if N >= 8:
+            Nc = N // 2
+            Wc = 2 * Nc + 1
+            for by in range(0, h - N + 1, N):
+                for bx in range(0, w - N + 1, N):
+                    a = np.zeros(2 * Wc * Wc, np.int32)
+                    R.ref_initAdiPatternChroma(bx, by, N, 0, 0, a)
+                    nav = O.hmo_intra_avail(bx, by, N, w, h, 64, flags)
+                    for k, pl in enumerate((cb, cr)):
+                        b = np.zeros(2 * Wc * Wc, np.int32)
+                        O.hmo_fillReferenceSamples(ol.ptr(pl, (by // 2) * (w // 2) + bx // 2), w // 2, flags,
+                                                   nav, 2, Nc, B, b)
+                        o = k * Wc * Wc
+                        assert np.array_equal(a[o:o + Wc], b[:Wc]), (N, bx, by, k)
+                        assert np.array_equal(a[o:o + Wc * Wc:Wc], b[:Wc * Wc:Wc]), (N, bx, by, k)
+
+
+@pytest.mark.parametrize("N", [4, 8, 16, 32, 64])
+def test_intra_prediction_all_modes(B, N):
+    R, O = ol.ref(), ol.oracle()
+    rng = np.random.default_rng(700 + N + B)
+    W = 2 * N + 1
+    for it in range(6):
+        adi = np.zeros(2 * W * W, np.int32)
+        if it == 0:
+            vals = np.full(4 * N + 1, (1 << B) - 1)
+        elif it == 1:
+            vals = np.zeros(4 * N + 1, np.int64)
+        else:
+            vals = rng.integers(0, 1 << B, 4 * N + 1)
+        adi[:W] = vals[:W]
+        adi[W:W * W:W] = vals[W:]
+        O.hmo_filterAdi(adi, N)
+        stride = N + 9
+        for mode in range(35):
+            a = np.zeros(N * stride, np.int16)
+            b = np.zeros(N * stride, np.int16)
+            R.ref_predIntraLumaAng(adi, mode, a, stride, N)
+            O.hmo_predIntraLumaAng(adi, mode, b, stride, N, B)
+            assert np.array_equal(a, b), ("luma", N, mode)
+            if N <= 32:
+                R.ref_predIntraChromaAng(adi, mode, a, stride, N)
+                O.hmo_predIntraChromaAng(adi, mode, b, stride, N, B)
+                assert np.array_equal(a, b), ("chroma", N, mode)
+
+
+def test_interpolation_filters(B):
+    R, O = ol.ref(), ol.oracle()
+    rng = np.random.default_rng(900 + B)
+    for it in range(200):
+        w = int(rng.choice([2, 4, 8, 12, 16, 24, 32, 64]))
+        h = int(rng.choice([2, 4, 8, 12, 16, 24, 32, 64]))
+        ss, ds = w + 16, w + 3
+        first_stage = it % 2 == 0
+        if first_stage:
+            src = rng.integers(0, 1 << B, (h + 16) * ss).astype(np.int16)
+        else:  # second stage input: 14-bit intermediates, full signed range to stress narrowing
+            src = rng.integers(-32768, 32768, (h + 16) * ss).astype(np.int16)
+        org = 8 * ss + 8
+        for chroma in (0, 1):
+            frac = int(rng.integers(0, 8 if chroma else 4))
+            for last in (0, 1):
+                a, b = np.zeros(h * ds, np.int16), np.zeros(h * ds, np.int16)
+                if first_stage:
+                    (R.ref_filterHorChroma if chroma else R.ref_filterHorLuma)(ol.ptr(src, org), ss, ol.ptr(a), ds, w, h, frac, last)
+                    (O.hmo_filterHorChroma if chroma else O.hmo_filterHorLuma)(ol.ptr(src, org), ss, ol.ptr(b), ds, w, h, frac, last, B)
+                    assert np.array_equal(a, b), ("hor", chroma, frac, last)
+                for first in ((1,) if first_stage else (0,)):
+                    (R.ref_filterVerChroma if chroma else R.ref_filterVerLuma)(ol.ptr(src, org), ss, ol.ptr(a), ds, w, h, frac, first, last)
+                    (O.hmo_filterVerChroma if chroma else O.hmo_filterVerLuma)(ol.ptr(src, org), ss, ol.ptr(b), ds, w, h, frac, first, last, B)
+                    assert np.array_equal(a, b), ("ver", chroma, frac, first, last)
+
+
+def test_pred_inter_blocks_and_border():
+    R, O = ol.ref(), ol.oracle()
+    for B in (8, 10):
+        w, h = 192, 128
+        R.ref_init(B, w, h, 1)
+        rng = np.random.default_rng(1100 + B)
+        y, cb, cr = _planes(rng, w, h, B)
+        R.ref_set_recon(y, cb, cr)
+        # border extension parity (luma margin 80) + build the oracle's own extended planes
+        m = 80
+        ext = np.zeros((h + 2 * m) * (w + 2 * m), np.int16)
+        R.ref_extended_luma(ext)
+        planes = []
+        for pl, (pw, ph, pm) in zip((y, cb, cr), ((w, h, m), (w // 2, h // 2, m // 2), (w // 2, h // 2, m // 2))):
+            st = pw + 2 * pm
+            e = np.zeros((ph + 2 * pm) * st, np.int16)
+            e.reshape(ph + 2 * pm, st)[pm:pm + ph, pm:pm + pw] = pl.reshape(ph, pw)
+            O.hmo_extendPicBorder(ol.ptr(e, pm * st + pm), st, pw, ph, pm, pm)
+            planes.append((e, st, pm))
+        assert np.array_equal(planes[0][0], ext)
+        shapes = [(64, 64), (64, 32), (32, 64), (32, 32), (16, 16), (8, 8), (8, 4), (4, 8), (16, 4), (4, 16),
+                  (64, 16), (16, 64), (32, 8), (8, 32), (32, 24), (24, 32), (16, 12), (12, 16)]
+        for it in range(300):
+            pw_, ph_ = shapes[it % len(shapes)]
+            px = int(rng.integers(0, (w - pw_) // 4 + 1)) * 4
+            py = int(rng.integers(0, (h - ph_) // 4 + 1)) * 4
+            if it % 3 == 0:
+                mvx, mvy = int(rng.integers(-2000, 2000)), int(rng.integers(-2000, 2000))
+            else:
+                mvx, mvy = int(rng.integers(-40, 40)), int(rng.integers(-40, 40))
+            bi = it % 2
+            cx = C.c_int(mvx)
+            cy = C.c_int(mvy)
+            O.hmo_clipMv(C.byref(cx), C.byref(cy), px, py, w, h, 64)
+            rx, ry = C.c_int(mvx), C.c_int(mvy)
+            R.ref_clipMv(px, py, C.byref(rx), C.byref(ry))
+            assert (cx.value, cy.value) == (rx.value, ry.value)
+            oy, ocb, ocr = (np.zeros(pw_ * ph_, np.int16), np.zeros(pw_ * ph_ // 4, np.int16),
+                            np.zeros(pw_ * ph_ // 4, np.int16))
+            R.ref_predInterBlk(px, py, pw_, ph_, mvx, mvy, bi, oy, ocb, ocr, 1)
+            e, st, pm = planes[0]
+            by_ = np.zeros(pw_ * ph_, np.int16)
+            O.hmo_predInterLumaBlk(ol.ptr(e, (pm + py) * st + pm + px), st, cx.value, cy.value, pw_, ph_, by_, pw_, bi, B)
+            assert np.array_equal(oy, by_), (it, pw_, ph_, mvx, mvy, bi)
+            for k, refo in ((1, ocb), (2, ocr)):
+                e, st, pm = planes[k]
+                bc = np.zeros(pw_ * ph_ // 4, np.int16)
+                O.hmo_predInterChromaBlk(ol.ptr(e, (pm + py // 2) * st + pm + px // 2), st, cx.value, cy.value, pw_,
+                                         ph_, bc, pw_ // 2, bi, B)
+                assert np.array_equal(refo, bc), (it, k)
+
+
+def test_add_avg(B):
+    R, O = ol.ref(), ol.oracle()
+    rng = np.random.default_rng(1300 + B)
+    for (w, h) in ((8, 8), (64, 64), (16, 4), (4, 16), (32, 8)):
+        a = [rng.integers(-16384, 16384, n).astype(np.int16) for n in (w * h, w * h // 4, w * h // 4)]
+        b = [rng.integers(-16384, 16384, n).astype(np.int16) for n in (w * h, w * h // 4, w * h // 4)]
+        o = [np.zeros(n, np.int16) for n in (w * h, w * h // 4, w * h // 4)]
+        P3 = C.c_void_p * 3
+        R.ref_addAvg(P3(*[x.ctypes.data for x in a]), P3(*[x.ctypes.data for x in b]),
+                     P3(*[x.ctypes.data for x in o]), w, h)
+        for k in range(3):
+            ww, hh = (w, h) if k == 0 else (w // 2, h // 2)
+            ob = np.zeros(ww * hh, np.int16)
+            O.hmo_addAvg(a[k], ww, b[k], ww, ob, ww, ww, hh, B)
+            assert np.array_equal(o[k], ob)
