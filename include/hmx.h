@@ -1,0 +1,238 @@
+/*
+ * hmx.h -- C-ABI of libhmx: the MI355X (gfx950) implementation of the HM block hot path.
+ *
+ * Drop-in boundary for the reference's block kernels.  The reference (fr34k8/thevc = HM 7.2/8-dev)
+ * has no plugin/FFI layer: the boundary is the member-function surface of TComTrQuant,
+ * TComPrediction/TComPattern and TComInterpolationFilter, called only from TEncSearch, TEncCu and
+ * TDecCu.  Every entry point below names the reference member it replaces (file:line, paths
+ * relative to /root/reference/source/Lib/).  Two families:
+ *
+ *   hmx_<name>        scalar drop-ins: the reference's own argument order, HOST pointers, one block
+ *                     per call.  Hidden reference state (bit-depth globals, m_cQP, TComDataCU
+ *                     getters) becomes the context handle and explicit scalars.  They run the
+ *                     same HIP kernels as the batched path with a batch of one (H2D, launch, D2H);
+ *                     there is no CPU arithmetic in this library.
+ *   hmx_batch_<name>  the throughput path: DEVICE pointers, descriptor arrays, asynchronous on
+ *   hmx_frame_<name>  the context's HIP stream.
+ *
+ * Types: Pel = int16_t, TCoeff = int32_t (TLibCommon/TypeDef.h:297-298); strides in elements.
+ * All functions return 0 on success, a negative hmx_status otherwise (the reference returns Void
+ * and asserts; hmx_last_error() gives the text).
+ */
+#ifndef HMX_H
+#define HMX_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int16_t hmx_pel;
+typedef int32_t hmx_coeff;
+typedef struct hmx_ctx hmx_ctx;
+
+enum hmx_status {
+  HMX_OK = 0,
+  HMX_ERR_ARG = -1,     /* unsupported size / null pointer (the reference asserts or falls through) */
+  HMX_ERR_DEVICE = -2,  /* HIP runtime error */
+  HMX_ERR_NOMEM = -3
+};
+
+#define HMX_REG_DCT 65535u /* TLibCommon/TypeDef.h:239 */
+enum hmx_text_type { HMX_TEXT_LUMA = 0, HMX_TEXT_CHROMA = 1, HMX_TEXT_CHROMA_U = 2, HMX_TEXT_CHROMA_V = 3 };
+enum hmx_slice_type { HMX_B_SLICE = 0, HMX_P_SLICE = 1, HMX_I_SLICE = 2 };
+
+/* ------------------------------------------------------------------------------------------------
+ * Context: replaces the process globals g_uiBitDepth/g_uiBitIncrement/g_uiIBDI_MAX
+ * (TLibCommon/TComRom.cpp:445-448) and the scratch members of the three classes.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int bit_depth; /* internal bit depth B = g_uiBitDepth + g_uiBitIncrement (8 or 10 in the cfgs) */
+  int device;    /* HIP device ordinal */
+  void *stream;  /* hipStream_t to launch on; NULL = the library creates its own */
+  int ctu_size;  /* g_uiMaxCUWidth, 64 in every shipped cfg */
+} hmx_config;
+
+int hmx_create(const hmx_config *cfg, hmx_ctx **out);
+void hmx_destroy(hmx_ctx *ctx);
+const char *hmx_last_error(const hmx_ctx *ctx);
+int hmx_sync(hmx_ctx *ctx);
+/* device memory + timing plumbing so that callers need no HIP headers */
+int hmx_malloc(hmx_ctx *ctx, size_t bytes, void **dptr);
+int hmx_free(hmx_ctx *ctx, void *dptr);
+int hmx_upload(hmx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int hmx_download(hmx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int hmx_memset(hmx_ctx *ctx, void *dst_dev, int value, size_t bytes);
+int hmx_event_create(hmx_ctx *ctx, void **ev);
+int hmx_event_record(hmx_ctx *ctx, void *ev); /* on the context's stream */
+int hmx_event_elapsed_ms(hmx_ctx *ctx, void *ev_start, void *ev_stop, float *ms); /* syncs ev_stop */
+int hmx_event_destroy(hmx_ctx *ctx, void *ev);
+
+/* ------------------------------------------------------------------------------------------------
+ * Quantiser state.  TComTrQuant::setQPforQuant (TLibCommon/TComTrQuant.cpp:192-222) writes the
+ * hidden member m_cQP (QpParam, TComTrQuant.h:79-113); here it returns the value.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int qp, per, rem, bits;
+} hmx_qp;
+hmx_qp hmx_setQPforQuant(int qpy, int text_type, int qp_bd_offset, int chroma_qp_offset);
+
+/* What xQuant reads through TComDataCU / TComSlice / TComPPS (TComTrQuant.cpp:1121-1267) */
+typedef struct {
+  hmx_qp qp;          /* m_cQP */
+  int per_base;       /* cQpBase.m_iPer from getSliceQpBase() (ADAPTIVE_QP_SELECTION); -1 = qp.per */
+  int slice_type;     /* hmx_slice_type: rounding 171 (I) / 85 */
+  int sign_hide;      /* PPS getSignHideFlag() */
+  int is_intra;       /* pcCU->isIntra(uiAbsPartIdx) */
+  int dir_mode;       /* luma/chroma intra direction used by getCoefScanIdx (TComDataCU.cpp:4014) */
+} hmx_quant_param;
+
+/* ------------------------------------------------------------------------------------------------
+ * Scalar drop-ins, TComTrQuant
+ * ---------------------------------------------------------------------------------------------- */
+/* xT  (TComTrQuant.cpp:1542): strided Pel residual -> Int[w*h]; w == h in {4,8,16,32} */
+int hmx_xT(hmx_ctx *ctx, unsigned mode, const hmx_pel *resi, unsigned stride, int32_t *coef, int w, int h);
+/* xIT (TComTrQuant.cpp:1583) */
+int hmx_xIT(hmx_ctx *ctx, unsigned mode, const int32_t *coef, hmx_pel *resi, unsigned stride, int w, int h);
+/* xTransformSkip / xITransformSkip (TComTrQuant.cpp:1622, 1667) */
+int hmx_xTransformSkip(hmx_ctx *ctx, const hmx_pel *resi, unsigned stride, int32_t *coef, int w, int h);
+int hmx_xITransformSkip(hmx_ctx *ctx, const int32_t *coef, hmx_pel *resi, unsigned stride, int w, int h);
+/* xQuant, flat path + signBitHidingHDQ (TComTrQuant.cpp:1102-1270, 977-1100); ac_sum accumulates */
+int hmx_xQuant(hmx_ctx *ctx, const int32_t *src, hmx_coeff *dst, int w, int h, uint32_t *ac_sum,
+               int text_type, const hmx_quant_param *qp);
+/* xDeQuant, flat path (TComTrQuant.cpp:1272-1355) */
+int hmx_xDeQuant(hmx_ctx *ctx, const hmx_coeff *src, int32_t *dst, int w, int h, const hmx_qp *qp);
+/* transformNxN (TComTrQuant.cpp:1373-1426): uiMode is derived as the reference does
+ * (luma && intra -> dir_mode, else REG_DCT) */
+int hmx_transformNxN(hmx_ctx *ctx, const hmx_pel *resi, unsigned stride, hmx_coeff *level, unsigned w,
+                     unsigned h, uint32_t *abs_sum, int text_type, const hmx_quant_param *qp,
+                     int use_transform_skip, int trans_quant_bypass);
+/* invtransformNxN (TComTrQuant.cpp:1428-1450); scaling lists are off in every shipped cfg */
+int hmx_invtransformNxN(hmx_ctx *ctx, int trans_quant_bypass, int text_type, unsigned mode, hmx_pel *resi,
+                        unsigned stride, const hmx_coeff *level, unsigned w, unsigned h, const hmx_qp *qp,
+                        int use_transform_skip);
+
+/* ------------------------------------------------------------------------------------------------
+ * Scalar drop-ins, TComPattern / TComPrediction (intra)
+ * ---------------------------------------------------------------------------------------------- */
+/* initAdiPattern / initAdiPatternChroma (TLibCommon/TComPattern.cpp:213-366): rec = sample (0,0) of a
+ * HOST reconstruction plane; (x,y,n) = block position/size in samples of that plane; neighbour
+ * availability is derived geometrically for one slice / one tile / no constrained intra pred
+ * (TComDataCU.cpp:1221-1735).  adi receives the reference layout: (2n+1)^2 Int border buffer and,
+ * for luma, the [1 2 1]-smoothed copy behind it.  adi must hold 2*(2n+1)^2 ints. */
+int hmx_initAdiPattern(hmx_ctx *ctx, const hmx_pel *rec, int stride, int x, int y, int n, int is_chroma,
+                       int pic_w_luma, int pic_h_luma, int32_t *adi);
+/* predIntraLumaAng / predIntraChromaAng (TLibCommon/TComPrediction.cpp:338-386) */
+int hmx_predIntraLumaAng(hmx_ctx *ctx, const int32_t *adi, unsigned dir_mode, hmx_pel *pred, unsigned stride,
+                         int w, int h);
+int hmx_predIntraChromaAng(hmx_ctx *ctx, const int32_t *adi, unsigned dir_mode, hmx_pel *pred, unsigned stride,
+                           int w, int h);
+
+/* ------------------------------------------------------------------------------------------------
+ * Scalar drop-ins, TComInterpolationFilter (TLibCommon/TComInterpolationFilter.cpp:323-415) and
+ * TComYuv::addAvg (TLibCommon/TComYuv.cpp:520-581).  src must be readable 3 (luma) / 1 (chroma)
+ * samples before and 4 / 2 after the block in the filtered direction, as in the reference.
+ * ---------------------------------------------------------------------------------------------- */
+int hmx_filterHorLuma(hmx_ctx *ctx, const hmx_pel *src, int src_stride, int16_t *dst, int dst_stride, int w,
+                      int h, int frac, int is_last);
+int hmx_filterVerLuma(hmx_ctx *ctx, const hmx_pel *src, int src_stride, int16_t *dst, int dst_stride, int w,
+                      int h, int frac, int is_first, int is_last);
+int hmx_filterHorChroma(hmx_ctx *ctx, const hmx_pel *src, int src_stride, int16_t *dst, int dst_stride, int w,
+                        int h, int frac, int is_last);
+int hmx_filterVerChroma(hmx_ctx *ctx, const hmx_pel *src, int src_stride, int16_t *dst, int dst_stride, int w,
+                        int h, int frac, int is_first, int is_last);
+int hmx_addAvg(hmx_ctx *ctx, const hmx_pel *src0, int s0_stride, const hmx_pel *src1, int s1_stride,
+               hmx_pel *dst, int dst_stride, int w, int h);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched device path
+ * ---------------------------------------------------------------------------------------------- */
+/* One transform / prediction block.  8 bytes, identical on host and device. */
+typedef struct {
+  uint16_t x, y;  /* position in samples of its plane */
+  uint8_t log2n;  /* 2..5 */
+  uint8_t plane;  /* 0 Y, 1 Cb, 2 Cr */
+  uint8_t mode;   /* intra prediction mode 0..34 (also selects DST for 4x4 luma and the scan) */
+  uint8_t flags;  /* HMX_TU_* */
+} hmx_tu;
+#define HMX_TU_TRANSFORM_SKIP 1u
+#define HMX_TU_INTER 2u /* non-intra CU: REG_DCT, diagonal scan, no DST */
+
+typedef struct {
+  int pic_w, pic_h;      /* luma size of the picture */
+  int qp;                /* CU QP (pcCU->getQP(0)); one QP per call */
+  int chroma_qp_offset;  /* PPS cb/cr offset */
+  int slice_type;        /* hmx_slice_type */
+  int sign_hide;
+} hmx_pic_param;
+
+/* A picture in HBM: three Pel planes; plane[i] points at sample (0,0); stride in elements. */
+typedef struct {
+  hmx_pel *plane[3];
+  int stride[3];
+} hmx_pic;
+/* Quantised levels in plane geometry: level of sample (x,y) of plane p at plane[p][y*stride[p]+x]. */
+typedef struct {
+  hmx_coeff *plane[3];
+  int stride[3];
+} hmx_levels;
+
+/* A list of blocks resident on the device.  Built once from a HOST array (the library buckets the
+ * blocks by size: one launch per size class) and reused by any number of batch calls. */
+typedef struct hmx_tu_list hmx_tu_list;
+int hmx_tu_list_create(hmx_ctx *ctx, const hmx_tu *tus, int n, hmx_tu_list **list);
+void hmx_tu_list_destroy(hmx_ctx *ctx, hmx_tu_list *list);
+
+/* transformNxN over a list of independent blocks (HOT LOOP B' of ENC/TEncSearch.cpp:4784-4990):
+ * residual planes -> level planes; d_abs_sum[i] = uiAbsSum of block i in the caller's order
+ * (device pointer, may be NULL). */
+int hmx_batch_transformNxN(hmx_ctx *ctx, const hmx_tu_list *list, const hmx_pic *resi, const hmx_levels *lev,
+                           uint32_t *d_abs_sum, const hmx_pic_param *pp);
+/* invtransformNxN over a list of blocks (DEC/TDecCu.cpp:791-831): levels -> residual planes `out`;
+ * when pred != NULL the reconstruction Clip(pred + resi) is written instead (TComYuv::addClip). */
+int hmx_batch_invtransformNxN(hmx_ctx *ctx, const hmx_tu_list *list, const hmx_levels *lev, const hmx_pic *pred,
+                              const hmx_pic *out, const hmx_pic_param *pp);
+/* Intra prediction of a list of blocks from a reconstructed picture (all neighbours are read
+ * from rec as it is: the caller guarantees the dependency order).  Output in plane geometry of
+ * `pred`.  HOT LOOP A shape (ENC/TEncSearch.cpp:2534): d_modes != NULL evaluates modes[0..n_modes) for
+ * every block from ONE reference gather and writes candidate k at element offset
+ * k * mode_plane_elems[plane] of the pred planes. */
+int hmx_batch_predIntra(hmx_ctx *ctx, const hmx_tu_list *list, const hmx_pic *rec, const hmx_pic *pred,
+                        const hmx_pic_param *pp, const uint8_t *d_modes, int n_modes,
+                        const size_t mode_plane_elems[3]);
+
+/* Whole-picture all-intra reconstruction from decisions: for every block, refs <- recon, predict,
+ * residual, T, Q, IQ, IT, recon (ENC/TEncSearch.cpp:1006-1165 with RDOQ off; DEC/TDecCu.cpp:469-687 for
+ * the decode direction).  Blocks are given per picture in coding order on the HOST; the library
+ * derives the dependency schedule (CTU diagonals x in-CTU levels) and launches one kernel per CTU
+ * diagonal over all pictures of the batch. */
+typedef struct hmx_intra_plan hmx_intra_plan;
+int hmx_intra_plan_create(hmx_ctx *ctx, const hmx_tu *tus, int n_tu, const hmx_pic_param *pp,
+                          hmx_intra_plan **plan);
+void hmx_intra_plan_destroy(hmx_ctx *ctx, hmx_intra_plan *plan);
+/* n_pics pictures share one plan (same block structure); org/rec/lev are arrays of n_pics entries. */
+int hmx_frame_intra_encode(hmx_ctx *ctx, const hmx_intra_plan *plan, int n_pics, const hmx_pic *org,
+                           const hmx_pic *rec, const hmx_levels *lev);
+int hmx_frame_intra_decode(hmx_ctx *ctx, const hmx_intra_plan *plan, int n_pics, const hmx_pic *rec,
+                           const hmx_levels *lev);
+
+/* Motion compensation of a list of PUs against reference pictures resident in HBM with the
+ * reference's margin layout (TLibCommon/TComPicYuv.cpp:82-94): motionCompensation -> xPredInterUni/Bi ->
+ * xPredInterLumaBlk/ChromaBlk -> addAvg (TLibCommon/TComPrediction.cpp:410-642). MVs already clipped. */
+typedef struct {
+  uint16_t x, y;       /* luma position */
+  uint8_t w, h;        /* luma size */
+  uint8_t ref0, ref1;  /* index into refs[], 255 = list unused */
+  int16_t mv0x, mv0y, mv1x, mv1y; /* quarter-pel */
+} hmx_pu;
+int hmx_batch_motionCompensation(hmx_ctx *ctx, const hmx_pu *d_pus, int n, const hmx_pic *refs, int n_refs,
+                                 const hmx_pic *dst);
+/* TComPicYuv::extendPicBorder (TLibCommon/TComPicYuv.cpp:248-286); margins in luma samples */
+int hmx_pic_extend_border(hmx_ctx *ctx, const hmx_pic *pic, int pic_w, int pic_h, int margin_x, int margin_y);
+/* TComDataCU::clipMv (TLibCommon/TComDataCU.cpp:3505-3517), host helper */
+void hmx_clipMv(int *mvx, int *mvy, int cu_x, int cu_y, int pic_w, int pic_h, int ctu_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

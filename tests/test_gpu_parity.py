@@ -1,0 +1,343 @@
+"""GPU parity: libhmx (HIP, through the C-ABI) vs the CPU oracle, bit-exact.  Run with -m gpu."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from thevc_amd import capi, workload
+
+pytestmark = pytest.mark.gpu
+REG_DCT = 65535
+
+
+@pytest.fixture(scope="module", params=[8, 10])
+def ctx(request):
+    c = capi.Context(bit_depth=request.param)
+    yield c
+    c.close()
+
+
+def _qparam(qpy, text_type, B, slice_type, sign_hide, is_intra, mode):
+    qp = capi.qp_for(qpy, text_type, B)
+    return capi.QuantParam(qp, -1, slice_type, sign_hide, is_intra, mode), qp
+
+
+@pytest.mark.parametrize("N", [4, 8, 16, 32])
+def test_scalar_transforms(ctx, N):
+    O, B = ol.oracle(), ctx.bit_depth
+    rng = np.random.default_rng(N + B)
+    mx = (1 << B) - 1
+    for it in range(12):
+        mode = [REG_DCT, 0, 1, 10, 26, 34][it % 6]
+        stride = N + 5
+        amp = mx if it % 2 == 0 else 32767
+        resi = rng.integers(-amp, amp + 1, N * stride).astype(np.int16)
+        ref = np.zeros(N * N, np.int32)
+        O.hmo_xT(mode, resi, stride, ref, N, B)
+        assert np.array_equal(ctx.xT(mode, resi, stride, N), ref)
+        coef = rng.integers(-70000, 70000, N * N).astype(np.int32)
+        rr = np.zeros(N * stride, np.int16)
+        O.hmo_xIT(mode, coef, rr, stride, N, B)
+        got = ctx.xIT(mode, coef, stride, N)
+        assert np.array_equal(got.reshape(N, stride)[:, :N], rr.reshape(N, stride)[:, :N])
+        O.hmo_xTransformSkip(resi, stride, ref, N, B)
+        assert np.array_equal(ctx.xTransformSkip(resi, stride, N), ref)
+        O.hmo_xITransformSkip(coef, rr, stride, N, B)
+        got = ctx.xITransformSkip(coef, stride, N)
+        assert np.array_equal(got.reshape(N, stride)[:, :N], rr.reshape(N, stride)[:, :N])
+
+
+@pytest.mark.parametrize("N", [4, 8, 16, 32])
+def test_scalar_quant_paths(ctx, N):
+    O, B = ol.oracle(), ctx.bit_depth
+    rng = np.random.default_rng(50 + N + B)
+    mx = (1 << B) - 1
+    n_sbh = 0
+    for it in range(40):
+        tt = (capi.TEXT_LUMA, capi.TEXT_CHROMA_U, capi.TEXT_CHROMA_V)[it % 3]
+        is_intra = int(it % 5 != 4)
+        mode = int(rng.integers(0, 35))
+        ts = int(N == 4 and it % 7 == 3)
+        qpy = int(rng.choice([12, 22, 27, 32, 37, 45]))
+        st = capi.I_SLICE if is_intra else (capi.P_SLICE, capi.B_SLICE)[it % 2]
+        qpar, qp = _qparam(qpy, tt, B, st, 1, is_intra, mode)
+        scan = O.hmo_coef_scan_idx(N, int(tt == 0), is_intra, mode)
+        cfg = ol.quant_cfg(qp.per, qp.rem, intra_slice=int(st == capi.I_SLICE), sign_hide=1, scan_idx=scan)
+        amp = int(rng.choice([3, 20, 80, mx]))
+        stride = N + 3
+        resi = rng.integers(-amp, amp + 1, N * stride).astype(np.int16)
+        tmode = mode if (tt == 0 and is_intra) else REG_DCT
+        ref = np.zeros(N * N, np.int32)
+        s = C.c_uint32(0)
+        O.hmo_transformNxN(resi, stride, ref, N, B, tmode, ts, 0, C.byref(cfg), C.byref(s))
+        lvl, asum = ctx.transformNxN(resi, stride, N, tt, qpar, ts)
+        assert np.array_equal(lvl, ref), (it, N, B)
+        assert asum == s.value
+        cfg0 = ol.quant_cfg(qp.per, qp.rem, intra_slice=int(st == capi.I_SLICE), sign_hide=0, scan_idx=scan)
+        ref0 = np.zeros(N * N, np.int32)
+        O.hmo_transformNxN(resi, stride, ref0, N, B, tmode, ts, 0, C.byref(cfg0), C.byref(s))
+        n_sbh += int(not np.array_equal(ref, ref0))
+        # inverse
+        rr = np.zeros(N * stride, np.int16)
+        O.hmo_invtransformNxN(0, tmode, rr, stride, ref, N, B, qp.per, qp.rem, ts)
+        got = ctx.invtransformNxN(ref, stride, N, tt, tmode, qp, ts)
+        assert np.array_equal(got.reshape(N, stride)[:, :N], rr.reshape(N, stride)[:, :N])
+        # xQuant / xDeQuant on raw Int coefficients
+        coef = rng.integers(-amp * 64, amp * 64 + 1, N * N).astype(np.int32)
+        refq = np.zeros(N * N, np.int32)
+        s2 = C.c_uint32(7)
+        O.hmo_xQuant(coef, refq, N, B, C.byref(cfg), C.byref(s2))
+        q, acs = ctx.xQuant(coef, N, tt, qpar, ac_sum=7)
+        assert np.array_equal(q, refq) and acs == s2.value
+        lv = rng.integers(-40000, 40000, N * N).astype(np.int32)
+        refd = np.zeros(N * N, np.int32)
+        O.hmo_xDeQuant(lv, refd, N, B, qp.per, qp.rem)
+        assert np.array_equal(ctx.xDeQuant(lv, N, qp), refd)
+    assert n_sbh > 0
+
+
+def test_scalar_intra(ctx):
+    O, B = ol.oracle(), ctx.bit_depth
+    w, h = 192, 136
+    planes = workload.make_planes(3 + B, w, h, B)
+    rng = np.random.default_rng(B)
+    flags = np.zeros(65, np.uint8)
+    for N in (4, 8, 16, 32):
+        W = 2 * N + 1
+        for chroma in (0, 1):
+            if chroma and N == 32:
+                continue
+            pl = planes[1] if chroma else planes[0]
+            pw, ph = pl.shape[1], pl.shape[0]
+            flat = pl.reshape(-1).copy()
+            for it in range(14):
+                bx = int(rng.integers(0, (pw - N) // N + 1)) * N
+                by = int(rng.integers(0, (ph - N) // N + 1)) * N
+                if it == 0:
+                    bx = by = 0
+                if it == 1:
+                    bx, by = pw - N, ph - N
+                adi = ctx.initAdiPattern(flat, pw, bx, by, N, chroma, w, h)
+                ref = np.zeros(2 * W * W, np.int32)
+                nav = O.hmo_intra_avail(bx << chroma, by << chroma, N << chroma, w, h, 64, flags)
+                O.hmo_fillReferenceSamples(ol.ptr(flat, by * pw + bx), pw, flags, nav, 2 if chroma else 4, N, B, ref)
+                if not chroma:
+                    O.hmo_filterAdi(ref, N)
+                assert np.array_equal(adi, ref), (N, chroma, bx, by)
+                stride = N + 2
+                for mode in range(35):
+                    rp = np.zeros(N * stride, np.int16)
+                    if chroma:
+                        O.hmo_predIntraChromaAng(ref, mode, rp, stride, N, B)
+                        got = ctx.predIntraChromaAng(adi, mode, stride, N)
+                    else:
+                        O.hmo_predIntraLumaAng(ref, mode, rp, stride, N, B)
+                        got = ctx.predIntraLumaAng(adi, mode, stride, N)
+                    assert np.array_equal(got.reshape(N, stride)[:, :N], rp.reshape(N, stride)[:, :N]), (N, chroma, mode)
+
+
+def test_scalar_interpolation(ctx):
+    O, B = ol.oracle(), ctx.bit_depth
+    rng = np.random.default_rng(900 + B)
+    for it in range(60):
+        w = int(rng.choice([2, 4, 8, 12, 16, 24, 32, 64]))
+        h = int(rng.choice([2, 4, 8, 12, 16, 24, 32, 64]))
+        ss, ds = w + 16, w + 3
+        first_stage = it % 2 == 0
+        src = (rng.integers(0, 1 << B, (h + 16) * ss) if first_stage else rng.integers(-32768, 32768, (h + 16) * ss)).astype(np.int16)
+        org = 8 * ss + 8
+        for chroma in (0, 1):
+            frac = int(rng.integers(0, 8 if chroma else 4))
+            sfx = "Chroma" if chroma else "Luma"
+            for last in (0, 1):
+                b = np.zeros(h * ds, np.int16)
+                if first_stage:
+                    getattr(O, "hmo_filterHor" + sfx)(ol.ptr(src, org), ss, ol.ptr(b), ds, w, h, frac, last, B)
+                    got = ctx.filter("filterHor" + sfx, src, org, ss, ds, w, h, frac, is_last=last)
+                    assert np.array_equal(got.reshape(h, ds)[:, :w], b.reshape(h, ds)[:, :w])
+                first = 1 if first_stage else 0
+                getattr(O, "hmo_filterVer" + sfx)(ol.ptr(src, org), ss, ol.ptr(b), ds, w, h, frac, first, last, B)
+                got = ctx.filter("filterVer" + sfx, src, org, ss, ds, w, h, frac, is_first=first, is_last=last)
+                assert np.array_equal(got.reshape(h, ds)[:, :w], b.reshape(h, ds)[:, :w])
+    for (w, h) in ((8, 8), (64, 64), (16, 4), (4, 16)):
+        a = rng.integers(-16384, 16384, w * h).astype(np.int16)
+        b = rng.integers(-16384, 16384, w * h).astype(np.int16)
+        ref = np.zeros(w * h, np.int16)
+        O.hmo_addAvg(a, w, b, w, ref, w, w, h, B)
+        assert np.array_equal(ctx.addAvg(a, b, w, h), ref)
+
+
+def _oracle_frame(tus, w, h, B, qp, org, sign_hide=1, decode_levels=None):
+    O = ol.oracle()
+    cfg = ol.FrameCfg(w, h, 64, B, qp, 0, sign_hide)
+    rec = [np.zeros_like(p) for p in org]
+    lev = [np.zeros(p.shape, np.int32) for p in org] if decode_levels is None else decode_levels
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
+    strides = I3(w, w // 2, w // 2)
+    t = np.ascontiguousarray(tus, ol.TU_DTYPE)
+    if decode_levels is None:
+        O.hmo_intra_frame_encode(C.byref(cfg), t.ctypes.data, len(t), P3(*[p.ctypes.data for p in org]), strides,
+                                 P3(*[p.ctypes.data for p in rec]), strides, P3(*[p.ctypes.data for p in lev]))
+    else:
+        O.hmo_intra_frame_decode(C.byref(cfg), t.ctypes.data, len(t), P3(*[p.ctypes.data for p in rec]), strides,
+                                 P3(*[p.ctypes.data for p in lev]))
+    return rec, lev
+
+
+@pytest.mark.parametrize("pic,tiling", [((192, 128), "mix"), ((416, 240), "mix"), ((128, 64), 4), ((128, 64), 8),
+                                        ((128, 128), 16), ((128, 128), 32), ((200, 136), "mix")])
+def test_frame_intra_encode_decode(ctx, pic, tiling):
+    """Whole-picture all-intra chain (refs <- recon, pred, T, Q, IQ, IT, recon) incl. pictures whose
+    right/bottom edge cuts the last CTU; 3 pictures per call share one plan."""
+    B = ctx.bit_depth
+    w, h = pic
+    tus = workload.make_tus(7, w, h, tiling)
+    L = capi.lib()
+    n_pics = 3
+    pp = capi.PicParam(w, h, 30, 0, capi.I_SLICE, 1)
+    plan = ctx.intra_plan(tus, pp)
+    orgs = [workload.make_planes(10 + i, w, h, B, "texture" if i else "noise") for i in range(n_pics)]
+    d_org = [capi.DevPicture(ctx, w, h).upload(o) for o in orgs]
+    d_rec = [capi.DevPicture(ctx, w, h).zero() for _ in range(n_pics)]
+    d_lev = [capi.DevPicture(ctx, w, h, dtype=np.int32).zero() for _ in range(n_pics)]
+    A = lambda lst, T: (T * n_pics)(*[x.as_pic() for x in lst])
+    ctx._chk(L.hmx_frame_intra_encode(ctx.h, plan, n_pics, A(d_org, capi.Pic), A(d_rec, capi.Pic), A(d_lev, capi.Levels)))
+    ctx.sync()
+    for i in range(n_pics):
+        rec_ref, lev_ref = _oracle_frame(tus, w, h, B, 30, orgs[i])
+        rec, lev = d_rec[i].download(), d_lev[i].download()
+        for p in range(3):
+            assert np.array_equal(lev[p], lev_ref[p]), ("levels", i, p)
+            assert np.array_equal(rec[p], rec_ref[p]), ("recon", i, p)
+    # decode direction: levels -> recon must reproduce the encoder's reconstruction
+    d_rec2 = [capi.DevPicture(ctx, w, h).zero() for _ in range(n_pics)]
+    ctx._chk(L.hmx_frame_intra_decode(ctx.h, plan, n_pics, A(d_rec2, capi.Pic), A(d_lev, capi.Levels)))
+    ctx.sync()
+    for i in range(n_pics):
+        a, b = d_rec2[i].download(), d_rec[i].download()
+        for p in range(3):
+            assert np.array_equal(a[p], b[p]), ("decode", i, p)
+    L.hmx_intra_plan_destroy(ctx.h, plan)
+    for d in d_org + d_rec + d_rec2 + d_lev:
+        d.free()
+
+
+def test_batch_lists(ctx):
+    """transformNxN / invtransformNxN (+recon) / predIntra (+35-mode fan-out) over block lists."""
+    O, B, L = ol.oracle(), ctx.bit_depth, capi.lib()
+    w, h = 192, 128
+    tus = workload.make_tus(21, w, h, "mix")
+    inter = np.random.default_rng(4).random(len(tus)) < 0.3
+    tus["flags"] = np.where(inter, tus["flags"] | capi.TU_INTER, tus["flags"]).astype(np.uint8)
+    tus["flags"] = np.where(inter, tus["flags"] & ~np.uint8(capi.TU_TRANSFORM_SKIP), tus["flags"])
+    lst = ctx.tu_list(tus)
+    mx = (1 << B) - 1
+    rng = np.random.default_rng(B)
+    resi = [rng.integers(-mx // 4, mx // 4 + 1, p).astype(np.int16) for p in ((h, w), (h // 2, w // 2), (h // 2, w // 2))]
+    pred = workload.make_planes(5, w, h, B)
+    d_resi = capi.DevPicture(ctx, w, h).upload(resi)
+    d_pred = capi.DevPicture(ctx, w, h).upload(pred)
+    d_out = capi.DevPicture(ctx, w, h).zero()
+    d_lev = capi.DevPicture(ctx, w, h, dtype=np.int32).zero()
+    d_sum = ctx.alloc(4 * len(tus))
+    pp = capi.PicParam(w, h, 27, 0, capi.P_SLICE, 1)
+    ctx._chk(L.hmx_batch_transformNxN(ctx.h, lst, C.byref(d_resi.as_pic()), C.byref(d_lev.as_pic()), d_sum.ptr, C.byref(pp)))
+    ctx._chk(L.hmx_batch_invtransformNxN(ctx.h, lst, C.byref(d_lev.as_pic()), C.byref(d_pred.as_pic()),
+                                         C.byref(d_out.as_pic()), C.byref(pp)))
+    ctx.sync()
+    lev, out, sums = d_lev.download(), d_out.download(), d_sum.download(np.uint32)
+    for i, t in enumerate(tus):
+        N, p, x, y = 1 << int(t["log2n"]), int(t["plane"]), int(t["x"]), int(t["y"])
+        is_inter = bool(t["flags"] & capi.TU_INTER)
+        ts = int(t["flags"] & capi.TU_TRANSFORM_SKIP)
+        qp = O.hmo_setQPforQuant(27, int(p != 0), 6 * (B - 8), 0)
+        scan = O.hmo_coef_scan_idx(N, int(p == 0), int(not is_inter), int(t["mode"]))
+        cfg = ol.quant_cfg(qp.per, qp.rem, intra_slice=0, sign_hide=1, scan_idx=scan)
+        tmode = int(t["mode"]) if (p == 0 and not is_inter) else REG_DCT
+        blk = np.ascontiguousarray(resi[p][y:y + N, x:x + N])
+        ref, s = ol.o_transformNxN(blk, N, B, tmode, ts, cfg)
+        assert np.array_equal(lev[p][y:y + N, x:x + N], ref), i
+        assert sums[i] == s
+        r = ol.o_invtransformNxN(ref, N, B, tmode, qp.per, qp.rem, ts)
+        rec = np.clip(pred[p][y:y + N, x:x + N].astype(np.int32) + r, 0, mx).astype(np.int16)
+        assert np.array_equal(out[p][y:y + N, x:x + N], rec), i
+    # prediction from a fixed reconstructed picture (every neighbour taken from it)
+    tus2 = workload.make_tus(22, w, h, "mix")
+    lst2 = ctx.tu_list(tus2)
+    d_pr = capi.DevPicture(ctx, w, h).zero()
+    ctx._chk(L.hmx_batch_predIntra(ctx.h, lst2, C.byref(d_pred.as_pic()), C.byref(d_pr.as_pic()), C.byref(pp), None, 0, None))
+    ctx.sync()
+    got = d_pr.download()
+    flat = [p.reshape(-1).copy() for p in pred]
+    for i, t in enumerate(tus2):
+        N, p, x, y = 1 << int(t["log2n"]), int(t["plane"]), int(t["x"]), int(t["y"])
+        ref = ol.o_intra_pred(flat[p], pred[p].shape[1], x, y, N, int(t["mode"]), B, w, h, p != 0)
+        assert np.array_equal(got[p][y:y + N, x:x + N], ref), (i, t)
+    # 35-mode fan-out on luma blocks
+    luma = tus2[tus2["plane"] == 0][:200]
+    lst3 = ctx.tu_list(luma)
+    modes = np.arange(35, dtype=np.uint8)
+    d_modes = ctx.to_device(modes)
+    fan = [ctx.alloc(2 * 35 * w * h), ctx.alloc(4), ctx.alloc(4)]
+    fp = capi.Pic()
+    fp.plane[0], fp.plane[1], fp.plane[2] = fan[0].ptr, fan[1].ptr, fan[2].ptr
+    fp.stride[0], fp.stride[1], fp.stride[2] = w, w // 2, w // 2
+    elems = (C.c_size_t * 3)(w * h, 0, 0)
+    ctx._chk(L.hmx_batch_predIntra(ctx.h, lst3, C.byref(d_pred.as_pic()), C.byref(fp), C.byref(pp), d_modes.ptr, 35, C.byref(elems)))
+    ctx.sync()
+    cand = fan[0].download(np.int16).reshape(35, h, w)
+    for t in luma[::7]:
+        N, x, y = 1 << int(t["log2n"]), int(t["x"]), int(t["y"])
+        for m in range(35):
+            ref = ol.o_intra_pred(flat[0], w, x, y, N, m, B, w, h, False)
+            assert np.array_equal(cand[m, y:y + N, x:x + N], ref), (t, m)
+    for l in (lst, lst2, lst3):
+        L.hmx_tu_list_destroy(ctx.h, l)
+
+
+def test_batch_motion_compensation(ctx):
+    O, B, L = ol.oracle(), ctx.bit_depth, capi.lib()
+    w, h, m = 256, 192, 80
+    n_refs = 2
+    refs = [workload.make_planes(40 + i, w, h, B) for i in range(n_refs)]
+    d_refs = [capi.DevPicture(ctx, w, h, m, m).upload(r) for r in refs]
+    for d in d_refs:
+        ctx._chk(L.hmx_pic_extend_border(ctx.h, C.byref(d.as_pic()), w, h, m, m))
+    ctx.sync()
+    # border extension parity + oracle-side extended planes
+    ext = []
+    for i in range(n_refs):
+        full = d_refs[i].download(with_margins=True)
+        planes = []
+        for p in range(3):
+            pw, ph, pmx, pmy = d_refs[i].dims[p]
+            st = pw + 2 * pmx
+            e = np.zeros((ph + 2 * pmy, st), np.int16)
+            e[pmy:pmy + ph, pmx:pmx + pw] = refs[i][p]
+            flat = e.reshape(-1)
+            O.hmo_extendPicBorder(ol.ptr(flat, pmy * st + pmx), st, pw, ph, pmx, pmy)
+            assert np.array_equal(full[p], e), ("border", i, p)
+            planes.append(flat)
+        ext.append(planes)
+    for bi_frac in (0.0, 0.5):
+        pus = workload.make_pus(9, w, h, n_refs=n_refs, bi_frac=bi_frac)
+        d_pus = ctx.to_device(pus)
+        d_dst = capi.DevPicture(ctx, w, h).zero()
+        ref_arr = (capi.Pic * n_refs)(*[d.as_pic() for d in d_refs])
+        ctx._chk(L.hmx_batch_motionCompensation(ctx.h, d_pus.ptr, len(pus), ref_arr, n_refs, C.byref(d_dst.as_pic())))
+        ctx.sync()
+        got = d_dst.download()
+        # oracle
+        dst = [np.zeros((h, w), np.int16), np.zeros((h // 2, w // 2), np.int16), np.zeros((h // 2, w // 2), np.int16)]
+        P3, I3 = C.c_void_p * 3, C.c_int * 3
+        ptrs = (C.c_void_p * (3 * n_refs))()
+        for i in range(n_refs):
+            for p in range(3):
+                pw, ph, pmx, pmy = d_refs[i].dims[p]
+                ptrs[i * 3 + p] = ext[i][p].ctypes.data + 2 * (pmy * (pw + 2 * pmx) + pmx)
+        rs = I3(w + 2 * m, w // 2 + m, w // 2 + m)
+        t = np.ascontiguousarray(pus, ol.PU_DTYPE)
+        O.hmo_mc_frame(t.ctypes.data, len(t), B, ptrs, rs, P3(*[d.ctypes.data for d in dst]), I3(w, w // 2, w // 2))
+        for p in range(3):
+            assert np.array_equal(got[p], dst[p]), ("mc", bi_frac, p)

@@ -1,0 +1,357 @@
+"""ctypes binding of libhmx's C-ABI (include/hmx.h) for the Python test and bench harness.
+
+This is plumbing, not product: the product is thevc_amd/libhmx.so (HIP, gfx950) behind include/hmx.h.
+There is NO fallback: if the library is missing or a call fails, this module raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhmx.so")
+
+REG_DCT = 65535
+TEXT_LUMA, TEXT_CHROMA, TEXT_CHROMA_U, TEXT_CHROMA_V = 0, 1, 2, 3
+B_SLICE, P_SLICE, I_SLICE = 0, 1, 2
+TU_TRANSFORM_SKIP, TU_INTER = 1, 2
+
+TU_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2n", "u1"), ("plane", "u1"), ("mode", "u1"),
+                     ("flags", "u1")])
+PU_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("w", "u1"), ("h", "u1"), ("ref0", "u1"), ("ref1", "u1"),
+                     ("mv0x", "<i2"), ("mv0y", "<i2"), ("mv1x", "<i2"), ("mv1y", "<i2")])
+
+
+class HmxError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("bit_depth", C.c_int), ("device", C.c_int), ("stream", C.c_void_p), ("ctu_size", C.c_int)]
+
+
+class Qp(C.Structure):
+    _fields_ = [("qp", C.c_int), ("per", C.c_int), ("rem", C.c_int), ("bits", C.c_int)]
+
+
+class QuantParam(C.Structure):
+    _fields_ = [("qp", Qp), ("per_base", C.c_int), ("slice_type", C.c_int), ("sign_hide", C.c_int),
+                ("is_intra", C.c_int), ("dir_mode", C.c_int)]
+
+
+class PicParam(C.Structure):
+    _fields_ = [("pic_w", C.c_int), ("pic_h", C.c_int), ("qp", C.c_int), ("chroma_qp_offset", C.c_int),
+                ("slice_type", C.c_int), ("sign_hide", C.c_int)]
+
+
+class Pic(C.Structure):
+    _fields_ = [("plane", C.c_void_p * 3), ("stride", C.c_int * 3)]
+
+
+class Levels(C.Structure):
+    _fields_ = [("plane", C.c_void_p * 3), ("stride", C.c_int * 3)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libhmx.so; fails loudly when the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HmxError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        vp, ci, cu = C.c_void_p, C.c_int, C.c_uint
+        L.hmx_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+        L.hmx_destroy.argtypes = [vp]
+        L.hmx_destroy.restype = None
+        L.hmx_last_error.argtypes = [vp]
+        L.hmx_last_error.restype = C.c_char_p
+        L.hmx_sync.argtypes = [vp]
+        L.hmx_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+        L.hmx_free.argtypes = [vp, vp]
+        L.hmx_upload.argtypes = [vp, vp, vp, C.c_size_t]
+        L.hmx_download.argtypes = [vp, vp, vp, C.c_size_t]
+        L.hmx_memset.argtypes = [vp, vp, ci, C.c_size_t]
+        L.hmx_event_create.argtypes = [vp, C.POINTER(vp)]
+        L.hmx_event_record.argtypes = [vp, vp]
+        L.hmx_event_elapsed_ms.argtypes = [vp, vp, vp, C.POINTER(C.c_float)]
+        L.hmx_event_destroy.argtypes = [vp, vp]
+        L.hmx_setQPforQuant.argtypes = [ci, ci, ci, ci]
+        L.hmx_setQPforQuant.restype = Qp
+        L.hmx_xT.argtypes = [vp, cu, vp, cu, vp, ci, ci]
+        L.hmx_xIT.argtypes = [vp, cu, vp, vp, cu, ci, ci]
+        L.hmx_xTransformSkip.argtypes = [vp, vp, cu, vp, ci, ci]
+        L.hmx_xITransformSkip.argtypes = [vp, vp, vp, cu, ci, ci]
+        L.hmx_xQuant.argtypes = [vp, vp, vp, ci, ci, C.POINTER(C.c_uint32), ci, C.POINTER(QuantParam)]
+        L.hmx_xDeQuant.argtypes = [vp, vp, vp, ci, ci, C.POINTER(Qp)]
+        L.hmx_transformNxN.argtypes = [vp, vp, cu, vp, cu, cu, C.POINTER(C.c_uint32), ci, C.POINTER(QuantParam),
+                                       ci, ci]
+        L.hmx_invtransformNxN.argtypes = [vp, ci, ci, cu, vp, cu, vp, cu, cu, C.POINTER(Qp), ci]
+        L.hmx_initAdiPattern.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
+        L.hmx_predIntraLumaAng.argtypes = [vp, vp, cu, vp, cu, ci, ci]
+        L.hmx_predIntraChromaAng.argtypes = [vp, vp, cu, vp, cu, ci, ci]
+        for n in ("hmx_filterHorLuma", "hmx_filterHorChroma"):
+            getattr(L, n).argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci]
+        for n in ("hmx_filterVerLuma", "hmx_filterVerChroma"):
+            getattr(L, n).argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, ci]
+        L.hmx_addAvg.argtypes = [vp, vp, ci, vp, ci, vp, ci, ci, ci]
+        L.hmx_tu_list_create.argtypes = [vp, vp, ci, C.POINTER(vp)]
+        L.hmx_tu_list_destroy.argtypes = [vp, vp]
+        L.hmx_tu_list_destroy.restype = None
+        L.hmx_batch_transformNxN.argtypes = [vp, vp, C.POINTER(Pic), C.POINTER(Levels), vp, C.POINTER(PicParam)]
+        L.hmx_batch_invtransformNxN.argtypes = [vp, vp, C.POINTER(Levels), C.POINTER(Pic), C.POINTER(Pic),
+                                                C.POINTER(PicParam)]
+        L.hmx_batch_predIntra.argtypes = [vp, vp, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(PicParam), vp, ci,
+                                          C.POINTER(C.c_size_t * 3)]
+        L.hmx_intra_plan_create.argtypes = [vp, vp, ci, C.POINTER(PicParam), C.POINTER(vp)]
+        L.hmx_intra_plan_destroy.argtypes = [vp, vp]
+        L.hmx_intra_plan_destroy.restype = None
+        L.hmx_frame_intra_encode.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(Levels)]
+        L.hmx_frame_intra_decode.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Levels)]
+        L.hmx_batch_motionCompensation.argtypes = [vp, vp, ci, C.POINTER(Pic), ci, C.POINTER(Pic)]
+        L.hmx_pic_extend_border.argtypes = [vp, C.POINTER(Pic), ci, ci, ci, ci]
+        L.hmx_clipMv.argtypes = [C.POINTER(ci), C.POINTER(ci), ci, ci, ci, ci, ci]
+        L.hmx_clipMv.restype = None
+        _lib = L
+    return _lib
+
+
+def _hp(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class DevBuf:
+    """A device allocation owned by a Context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        p = C.c_void_p()
+        ctx._chk(lib().hmx_malloc(ctx.h, max(nbytes, 4), C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._chk(lib().hmx_upload(self.ctx.h, self.ptr, _hp(arr), arr.nbytes))
+        return self
+
+    def download(self, dtype, count=None):
+        dtype = np.dtype(dtype)
+        count = self.nbytes // dtype.itemsize if count is None else count
+        out = np.empty(count, dtype)
+        self.ctx._chk(lib().hmx_download(self.ctx.h, _hp(out), self.ptr, out.nbytes))
+        return out
+
+    def zero(self):
+        self.ctx._chk(lib().hmx_memset(self.ctx.h, self.ptr, 0, self.nbytes))
+        return self
+
+    def free(self):
+        if self.ptr:
+            lib().hmx_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """hmx_ctx wrapper.  One per GPU/process."""
+
+    def __init__(self, bit_depth=8, device=0, stream=None, ctu_size=64):
+        cfg = Config(bit_depth, device, stream, ctu_size)
+        h = C.c_void_p()
+        rc = lib().hmx_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise HmxError(f"hmx_create failed ({rc}): no usable HIP device?")
+        self.h = h
+        self.bit_depth = bit_depth
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HmxError(f"libhmx error {rc}: {lib().hmx_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            lib().hmx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        self._chk(lib().hmx_sync(self.h))
+
+    def alloc(self, nbytes):
+        return DevBuf(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DevBuf(self, arr.nbytes).upload(arr)
+
+    # --- timing on the context's stream ---
+    def event(self):
+        e = C.c_void_p()
+        self._chk(lib().hmx_event_create(self.h, C.byref(e)))
+        return e
+
+    def record(self, e):
+        self._chk(lib().hmx_event_record(self.h, e))
+
+    def elapsed_ms(self, a, b):
+        ms = C.c_float()
+        self._chk(lib().hmx_event_elapsed_ms(self.h, a, b, C.byref(ms)))
+        return ms.value
+
+    # --- scalar drop-ins (host numpy arrays) ---
+    def xT(self, mode, resi, stride, n):
+        resi = np.ascontiguousarray(resi, np.int16)
+        coef = np.zeros(n * n, np.int32)
+        self._chk(lib().hmx_xT(self.h, mode, _hp(resi), stride, _hp(coef), n, n))
+        return coef
+
+    def xIT(self, mode, coef, stride, n):
+        coef = np.ascontiguousarray(coef, np.int32)
+        resi = np.zeros(n * stride, np.int16)
+        self._chk(lib().hmx_xIT(self.h, mode, _hp(coef), _hp(resi), stride, n, n))
+        return resi
+
+    def xTransformSkip(self, resi, stride, n):
+        resi = np.ascontiguousarray(resi, np.int16)
+        coef = np.zeros(n * n, np.int32)
+        self._chk(lib().hmx_xTransformSkip(self.h, _hp(resi), stride, _hp(coef), n, n))
+        return coef
+
+    def xITransformSkip(self, coef, stride, n):
+        coef = np.ascontiguousarray(coef, np.int32)
+        resi = np.zeros(n * stride, np.int16)
+        self._chk(lib().hmx_xITransformSkip(self.h, _hp(coef), _hp(resi), stride, n, n))
+        return resi
+
+    def xQuant(self, src, n, text_type, qparam, ac_sum=0):
+        src = np.ascontiguousarray(src, np.int32)
+        dst = np.zeros(n * n, np.int32)
+        s = C.c_uint32(ac_sum)
+        self._chk(lib().hmx_xQuant(self.h, _hp(src), _hp(dst), n, n, C.byref(s), text_type, C.byref(qparam)))
+        return dst, s.value
+
+    def xDeQuant(self, src, n, qp):
+        src = np.ascontiguousarray(src, np.int32)
+        dst = np.zeros(n * n, np.int32)
+        self._chk(lib().hmx_xDeQuant(self.h, _hp(src), _hp(dst), n, n, C.byref(qp)))
+        return dst
+
+    def transformNxN(self, resi, stride, n, text_type, qparam, ts=0, bypass=0):
+        resi = np.ascontiguousarray(resi, np.int16)
+        lvl = np.zeros(n * n, np.int32)
+        s = C.c_uint32(0)
+        self._chk(lib().hmx_transformNxN(self.h, _hp(resi), stride, _hp(lvl), n, n, C.byref(s), text_type,
+                                         C.byref(qparam), ts, bypass))
+        return lvl, s.value
+
+    def invtransformNxN(self, lvl, stride, n, text_type, mode, qp, ts=0, bypass=0):
+        lvl = np.ascontiguousarray(lvl, np.int32)
+        resi = np.zeros(n * stride, np.int16)
+        self._chk(lib().hmx_invtransformNxN(self.h, bypass, text_type, mode, _hp(resi), stride, _hp(lvl), n, n,
+                                            C.byref(qp), ts))
+        return resi
+
+    def initAdiPattern(self, rec, stride, x, y, n, is_chroma, pic_w, pic_h):
+        rec = np.ascontiguousarray(rec, np.int16)
+        W = 2 * n + 1
+        adi = np.zeros(2 * W * W, np.int32)
+        self._chk(lib().hmx_initAdiPattern(self.h, _hp(rec), stride, x, y, n, is_chroma, pic_w, pic_h, _hp(adi)))
+        return adi
+
+    def predIntraLumaAng(self, adi, mode, stride, n):
+        adi = np.ascontiguousarray(adi, np.int32)
+        pred = np.zeros(n * stride, np.int16)
+        self._chk(lib().hmx_predIntraLumaAng(self.h, _hp(adi), mode, _hp(pred), stride, n, n))
+        return pred
+
+    def predIntraChromaAng(self, adi, mode, stride, n):
+        adi = np.ascontiguousarray(adi, np.int32)
+        pred = np.zeros(n * stride, np.int16)
+        self._chk(lib().hmx_predIntraChromaAng(self.h, _hp(adi), mode, _hp(pred), stride, n, n))
+        return pred
+
+    def filter(self, name, src, src_off, ss, ds, w, h, frac, is_first=None, is_last=1):
+        """name in filterHorLuma/filterVerLuma/filterHorChroma/filterVerChroma; src is a padded host plane."""
+        src = np.ascontiguousarray(src, np.int16)
+        dst = np.zeros(h * ds, np.int16)
+        sp = C.c_void_p(src.ctypes.data + 2 * src_off)
+        f = getattr(lib(), "hmx_" + name)
+        if "Hor" in name:
+            self._chk(f(self.h, sp, ss, _hp(dst), ds, w, h, frac, is_last))
+        else:
+            self._chk(f(self.h, sp, ss, _hp(dst), ds, w, h, frac, is_first, is_last))
+        return dst
+
+    def addAvg(self, a, b, w, h):
+        a = np.ascontiguousarray(a, np.int16)
+        b = np.ascontiguousarray(b, np.int16)
+        d = np.zeros(w * h, np.int16)
+        self._chk(lib().hmx_addAvg(self.h, _hp(a), w, _hp(b), w, _hp(d), w, w, h))
+        return d
+
+    # --- batched device path ---
+    def tu_list(self, tus):
+        tus = np.ascontiguousarray(tus, TU_DTYPE)
+        h = C.c_void_p()
+        self._chk(lib().hmx_tu_list_create(self.h, _hp(tus), len(tus), C.byref(h)))
+        return h
+
+    def intra_plan(self, tus, pp):
+        tus = np.ascontiguousarray(tus, TU_DTYPE)
+        h = C.c_void_p()
+        self._chk(lib().hmx_intra_plan_create(self.h, _hp(tus), len(tus), C.byref(pp), C.byref(h)))
+        return h
+
+
+def qp_for(qpy, text_type, bit_depth, chroma_qp_offset=0):
+    return lib().hmx_setQPforQuant(qpy, text_type, 6 * (bit_depth - 8), chroma_qp_offset)
+
+
+class DevPicture:
+    """Three Pel planes in HBM with the reference's margin layout (TComPicYuv.cpp:82-94):
+    luma margin mx,my; chroma half of it.  Also usable without margins (mx = my = 0)."""
+
+    def __init__(self, ctx, w, h, mx=0, my=0, dtype=np.int16):
+        self.ctx, self.w, self.h, self.mx, self.my = ctx, w, h, mx, my
+        self.dtype = np.dtype(dtype)
+        self.dims = [(w, h, mx, my), (w // 2, h // 2, mx // 2, my // 2), (w // 2, h // 2, mx // 2, my // 2)]
+        self.strides = [pw + 2 * pmx for (pw, ph, pmx, pmy) in self.dims]
+        self.elems = [(pw + 2 * pmx) * (ph + 2 * pmy) for (pw, ph, pmx, pmy) in self.dims]
+        self.bufs = [ctx.alloc(e * self.dtype.itemsize) for e in self.elems]
+
+    def origin_ptr(self, p):
+        pw, ph, pmx, pmy = self.dims[p]
+        return self.bufs[p].ptr + (pmy * self.strides[p] + pmx) * self.dtype.itemsize
+
+    def as_pic(self):
+        s = Pic() if self.dtype == np.int16 else Levels()
+        for p in range(3):
+            s.plane[p] = self.origin_ptr(p)
+            s.stride[p] = self.strides[p]
+        return s
+
+    def upload(self, planes):
+        """planes: three 2-D arrays (h x w) without margins"""
+        for p in range(3):
+            pw, ph, pmx, pmy = self.dims[p]
+            full = np.zeros((ph + 2 * pmy, pw + 2 * pmx), self.dtype)
+            full[pmy:pmy + ph, pmx:pmx + pw] = np.asarray(planes[p]).reshape(ph, pw)
+            self.bufs[p].upload(full)
+        return self
+
+    def download(self, with_margins=False):
+        out = []
+        for p in range(3):
+            pw, ph, pmx, pmy = self.dims[p]
+            full = self.bufs[p].download(self.dtype).reshape(ph + 2 * pmy, pw + 2 * pmx)
+            out.append(full if with_margins else full[pmy:pmy + ph, pmx:pmx + pw].copy())
+        return out
+
+    def zero(self):
+        for b in self.bufs:
+            b.zero()
+        return self
+
+    def free(self):
+        for b in self.bufs:
+            b.free()

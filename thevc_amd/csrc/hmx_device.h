@@ -1,0 +1,459 @@
+// hmx_device.h -- device-side building blocks of libhmx (gfx950).
+//
+// Work decomposition used by every block kernel: a block (TU) of N x N samples is owned by a group
+// of N consecutive lanes of one wavefront; lane r keeps one row (or one column) of the block in
+// registers.  The two 1-D passes of a separable transform run entirely in registers, the N x N
+// transposition between them goes through a padded LDS tile.  64/N blocks share a wavefront
+// (16 4x4, 8 8x8, 4 16x16, 2 32x32), so all cross-lane traffic of a block stays inside a wave.
+//
+// Arithmetic contract (bit-exact with the reference, see include/hmx.h for file:line):
+//   forward pass  y[k] = wrap16((sum_n M[k][n] x[n] + rnd) >> shift)      TComTrQuant.cpp:417-795
+//   inverse pass  y[n] = clip16((sum_k M[k][n] c[k] + rnd) >> shift)
+// The even/odd recursion below is an exact integer factorisation of those sums (no overflow:
+// |sum| < 2^27), so the result equals the reference's partial butterflies.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hmx {
+
+// ---------------------------------------------------------------------------------------------
+// Tables
+// ---------------------------------------------------------------------------------------------
+// integer chosen by HEVC for cos(p*pi/64), p = 0..32 (first column of the 32-point matrix)
+__host__ __device__ constexpr int cos64(int p) {
+  constexpr int t[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                         61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9,  4,  0};
+  return t[p];
+}
+// M_N[k][n]: fold the angle (2n+1)k*(32/N)*pi/64 into the first quadrant
+__host__ __device__ constexpr int dct_coef(int N, int k, int n) {
+  int p = ((2 * n + 1) * k * (32 / N)) & 127;
+  int s = 1;
+  if (p > 64) p = 128 - p;
+  if (p > 32) {
+    p = 64 - p;
+    s = -1;
+  }
+  return s * cos64(p);
+}
+__host__ __device__ constexpr int dst_coef(int k, int n) {
+  constexpr int t[4][4] = {{29, 55, 74, 84}, {74, 74, 0, -74}, {84, -29, -74, 55}, {55, -84, 74, -29}};
+  return t[k][n];
+}
+
+__device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
+__device__ __forceinline__ int wrap16(int v) { return (int)(short)v; }
+
+// ---------------------------------------------------------------------------------------------
+// 1-D transforms on register arrays (raw sums, no rounding)
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void dct_fwd_raw(const int *x, int *y) {
+  if constexpr (N == 2) {
+    y[0] = 64 * (x[0] + x[1]);
+    y[1] = 64 * (x[0] - x[1]);
+  } else {
+    int e[N / 2], o[N / 2], ye[N / 2];
+#pragma unroll
+    for (int n = 0; n < N / 2; n++) {
+      e[n] = x[n] + x[N - 1 - n];
+      o[n] = x[n] - x[N - 1 - n];
+    }
+    dct_fwd_raw<N / 2>(e, ye);
+#pragma unroll
+    for (int m = 0; m < N / 2; m++) {
+      y[2 * m] = ye[m];
+      int acc = 0;
+#pragma unroll
+      for (int n = 0; n < N / 2; n++) acc += dct_coef(N, 2 * m + 1, n) * o[n];
+      y[2 * m + 1] = acc;
+    }
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void dct_inv_raw(const int *c, int *out) {
+  if constexpr (N == 2) {
+    out[0] = 64 * (c[0] + c[1]);
+    out[1] = 64 * (c[0] - c[1]);
+  } else {
+    int ce[N / 2], ee[N / 2];
+#pragma unroll
+    for (int m = 0; m < N / 2; m++) ce[m] = c[2 * m];
+    dct_inv_raw<N / 2>(ce, ee);
+#pragma unroll
+    for (int n = 0; n < N / 2; n++) {
+      int acc = 0;
+#pragma unroll
+      for (int m = 0; m < N / 2; m++) acc += dct_coef(N, 2 * m + 1, n) * c[2 * m + 1];
+      out[n] = ee[n] + acc;
+      out[N - 1 - n] = ee[n] - acc;
+    }
+  }
+}
+
+// forward pass with the reference's rounding and implicit store-to-short wrap
+template <int N>
+__device__ __forceinline__ void fwd_pass(const int *x, int *y, int shift, bool use_dst) {
+  int rnd = 1 << (shift - 1);
+  if (N == 4 && use_dst) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int acc = 0;
+#pragma unroll
+      for (int n = 0; n < 4; n++) acc += dst_coef(k, n) * x[n];
+      y[k] = wrap16((acc + rnd) >> shift);
+    }
+  } else {
+    int raw[N];
+    dct_fwd_raw<N>(x, raw);
+#pragma unroll
+    for (int k = 0; k < N; k++) y[k] = wrap16((raw[k] + rnd) >> shift);
+  }
+}
+
+// inverse pass with Clip3(-32768, 32767)
+template <int N>
+__device__ __forceinline__ void inv_pass(const int *c, int *y, int shift, bool use_dst) {
+  int rnd = 1 << (shift - 1);
+  if (N == 4 && use_dst) {
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      int acc = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc += dst_coef(k, n) * c[k];
+      y[n] = clip3(-32768, 32767, (acc + rnd) >> shift);
+    }
+  } else {
+    int raw[N];
+    dct_inv_raw<N>(c, raw);
+#pragma unroll
+    for (int n = 0; n < N; n++) y[n] = clip3(-32768, 32767, (raw[n] + rnd) >> shift);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Quantiser parameters (host-prepared, one set per plane type) and scan tables
+// ---------------------------------------------------------------------------------------------
+struct QuantDev {
+  int q;          // g_quantScales[rem]
+  int per_qbits;  // per used for iQBits (slice base QP)
+  int iq_scale;   // g_invQuantScales[rem] << per
+  int rnd_factor; // 171 (I) or 85
+};
+
+struct PicDev { // parameters shared by the block kernels
+  int pic_w, pic_h; // luma
+  int ctu;          // 64
+  int bit_depth;
+  int sign_hide;
+  QuantDev qd[2];   // [0] luma, [1] chroma
+};
+
+// scan position -> (y,x) inside a 4x4 coefficient group / group order, TComRom.cpp:564-698
+__device__ __forceinline__ int diag4_pos(int i) { // up-right diagonal of a 4x4, returns y*4+x
+  constexpr unsigned char t[16] = {0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15};
+  return t[i];
+}
+__device__ __forceinline__ int diag_group(int G, int g) { // group index in diag order -> gy*G+gx
+  if (G == 1) return 0;
+  if (G == 2) {
+    constexpr unsigned char t[4] = {0, 2, 1, 3};
+    return t[g];
+  }
+  if (G == 4) return diag4_pos(g);
+  // 8x8 grid: walk the diagonals (64 entries; computed, not stored)
+  int d = 0, base = 0;
+  for (;;) {
+    int len = d < 8 ? d + 1 : 15 - d;
+    if (g < base + len) break;
+    base += len;
+    d++;
+  }
+  int x = (d < 8 ? 0 : d - 7) + (g - base);
+  return (d - x) * 8 + x;
+}
+// raster position inside the N x N block of scan entry (group g, index i)
+template <int N>
+__device__ __forceinline__ int scan_pos(int scan_idx, int g, int i) {
+  constexpr int G = N / 4;
+  int gy, gx, y, x;
+  if (scan_idx == 1) { // horizontal: groups raster, raster inside
+    gy = g / G;
+    gx = g % G;
+    y = i >> 2;
+    x = i & 3;
+  } else if (scan_idx == 2) { // vertical
+    gx = g / G;
+    gy = g % G;
+    x = i >> 2;
+    y = i & 3;
+  } else {
+    int gp = diag_group(G, g), ip = diag4_pos(i);
+    gy = gp / G;
+    gx = gp % G;
+    y = ip >> 2;
+    x = ip & 3;
+  }
+  return (gy * 4 + y) * N + gx * 4 + x;
+}
+
+// getCoefScanIdx (TComDataCU.cpp:4014-4063); 0 (zigzag) is used as diagonal by xQuant
+__device__ __forceinline__ int coef_scan_idx(int N, bool luma, bool intra, int mode) {
+  if (!intra) return 0;
+  bool multi = luma ? (N == 4 || N == 8) : (N == 4);
+  if (!multi) return 0;
+  if (abs(mode - 26) < 5) return 1;
+  if (abs(mode - 10) < 5) return 2;
+  return 0;
+}
+
+// LDS scratch of one block.  tile: transposition buffer, then the quantised levels;
+// du: (deltaU << 1) | (unquantised coefficient < 0), the two things sign-bit hiding reads.
+template <int N>
+struct TuLds {
+  int tile[N][N + 1];
+  int du[N][N + 1];
+  int line[4 * N + 2];
+  int fline[4 * N + 2];
+  unsigned nzmask[2]; // bit g: coefficient group g (scan order) holds a non-zero level
+};
+
+// Flat quantisation of one coefficient (TComTrQuant.cpp:1241-1259)
+__device__ __forceinline__ void quant_one(int c, const QuantDev &qd, int qbits, long long add, int &level,
+                                          int &delta_u, int &abs_level) {
+  long long t = (long long)abs(c) * qd.q;
+  int l = (int)((t + add) >> qbits);
+  delta_u = (int)((t - ((long long)l << qbits)) >> (qbits - 8));
+  abs_level = l;
+  level = clip3(-32768, 32767, c < 0 ? -l : l);
+}
+
+// signBitHidingHDQ (TComTrQuant.cpp:977-1100) for ONE 16-coefficient group; groups are independent
+// except for the reference's lastCG flag: first_nz_group = this is the highest group in scan order
+// that holds a non-zero level (its candidate loop starts at the last non-zero, not at 15).
+template <int N>
+__device__ __forceinline__ void sbh_group(TuLds<N> &L, int scan_idx, int g, bool first_nz_group) {
+  int first = 16, last = -1, sum = 0;
+  int pos[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    pos[i] = scan_pos<N>(scan_idx, g, i);
+    int q = L.tile[pos[i] / N][pos[i] % N];
+    if (q) {
+      if (first == 16) first = i;
+      last = i;
+    }
+  }
+  if (last - first < 4) return;
+  for (int i = first; i <= last; i++) sum += L.tile[pos[i] / N][pos[i] % N];
+  int q_first = L.tile[pos[first] / N][pos[first] % N];
+  int signbit = q_first > 0 ? 0 : 1;
+  if (signbit == (sum & 1)) return;
+  int best_cost = 0x7fffffff, best_pos = -1, best_chg = 0;
+  for (int i = first_nz_group ? last : 15; i >= 0; i--) {
+    int p = pos[i], r = p / N, c = p % N;
+    int q = L.tile[r][c], du = L.du[r][c] >> 1;
+    int cost = 0x7fffffff, chg = 0;
+    if (q != 0) {
+      if (du > 0) {
+        cost = -du;
+        chg = 1;
+      } else if (!(i == first && abs(q) == 1)) {
+        cost = du;
+        chg = -1;
+      }
+    } else if (i < first) {
+      int this_sign = L.du[r][c] & 1;
+      if (this_sign == signbit) {
+        cost = -du;
+        chg = 1;
+      }
+    } else {
+      cost = -du;
+      chg = 1;
+    }
+    if (cost < best_cost) {
+      best_cost = cost;
+      best_chg = chg;
+      best_pos = p;
+    }
+  }
+  int r = best_pos / N, c = best_pos % N;
+  int q = L.tile[r][c];
+  if (q == 32767 || q == -32768) best_chg = -1;
+  L.tile[r][c] = (L.du[r][c] & 1) ? q - best_chg : q + best_chg;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Intra reference samples and prediction
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ unsigned zorder4(unsigned cx, unsigned cy) { // 4-bit coordinates
+  unsigned z = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) z |= ((cx >> b) & 1u) << (2 * b) | ((cy >> b) & 1u) << (2 * b + 1);
+  return z;
+}
+
+// Availability mask of the 4n+1 neighbour units of a block at luma (x,y), luma size `size`
+// (TComPattern.cpp:607-786 + TComDataCU.cpp:1221-1735; one slice, one tile, no constrained intra):
+// bit u follows the bNeighborFlags order: below-left (bottom first), left, corner, above, above-right.
+__host__ __device__ __forceinline__ unsigned long long intra_avail_mask(int x, int y, int size, const PicDev &P) {
+  int n = size >> 2, U = P.ctu >> 2;
+  int cx = (x & (P.ctu - 1)) >> 2, cy = (y & (P.ctu - 1)) >> 2;
+  unsigned long long m = 0;
+  if (x > 0 && y > 0) m |= 1ull << (2 * n);
+  if (y > 0) m |= ((1ull << n) - 1) << (2 * n + 1);
+  if (x > 0) m |= ((1ull << n) - 1) << n;
+  int rx = cx + n - 1, by = cy + n - 1;
+  int ctu_col = x / P.ctu, ctu_cols = (P.pic_w + P.ctu - 1) / P.ctu;
+  for (int o = 1; o <= n; o++) {
+    bool a;
+    if (x + size - 4 + 4 * o >= P.pic_w)
+      a = false;
+    else if (rx + o < U)
+      a = cy > 0 ? (zorder4(rx, cy) > zorder4(rx + o, cy - 1)) : (y > 0);
+    else
+      a = (cy == 0) && y > 0 && ctu_col < ctu_cols - 1;
+    if (a) m |= 1ull << (3 * n + o);
+    bool b;
+    if (y + size - 4 + 4 * o >= P.pic_h)
+      b = false;
+    else if (by + o < U)
+      b = cx > 0 ? (zorder4(cx, by) > zorder4(cx - 1, by + o)) : (x > 0);
+    else
+      b = false;
+    if (b) m |= 1ull << (n - o);
+  }
+  return m;
+}
+
+// Reference line of a block: L[0..4N], L[0] = lowest below-left sample, L[2N] = corner,
+// L[4N] = right-most above-right sample (fillReferenceSamples, TComPattern.cpp:368-552).
+// Every sample is one independent load: an unavailable sample copies the nearest available
+// sample before it (or the first available one for a leading run), which is what the reference's
+// sequential padding loop produces.  rec points at the block origin.
+template <int N>
+__device__ __forceinline__ void build_ref_line(const short *rec, int stride, unsigned long long avail,
+                                               int unit_log2, int bit_depth, int gl, int *L) {
+  const int unit = 1 << unit_log2, n = N >> unit_log2;
+  for (int p = gl; p <= 4 * N; p += N) {
+    int v;
+    if (avail == 0) {
+      v = 1 << (bit_depth - 1);
+    } else {
+      int u = p < 2 * N ? (p >> unit_log2) : (p == 2 * N ? 2 * n : 2 * n + 1 + ((p - 2 * N - 1) >> unit_log2));
+      int q = p;
+      if (!((avail >> u) & 1)) {
+        unsigned long long lower = avail & ((1ull << u) - 1);
+        if (lower) {
+          int u2 = 63 - __clzll((long long)lower); // last sample of the nearest available unit below
+          q = u2 < 2 * n ? (u2 << unit_log2) + unit - 1 : (u2 == 2 * n ? 2 * N : 2 * N + ((u2 - 2 * n) << unit_log2));
+        } else {
+          int u2 = __ffsll((long long)avail) - 1; // first sample of the first available unit
+          q = u2 < 2 * n ? (u2 << unit_log2) : (u2 == 2 * n ? 2 * N : 2 * N + 1 + ((u2 - 2 * n - 1) << unit_log2));
+        }
+      }
+      v = q < 2 * N ? rec[(2 * N - 1 - q) * stride - 1] : (q == 2 * N ? rec[-stride - 1] : rec[-stride + (q - 2 * N - 1)]);
+    }
+    L[p] = v;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void smooth_ref_line(const int *L, int *F, int gl) { // [1 2 1], :265-306
+  for (int p = gl; p <= 4 * N; p += N)
+    F[p] = (p == 0 || p == 4 * N) ? L[p] : (L[p - 1] + 2 * L[p] + L[p + 1] + 2) >> 2;
+}
+
+__device__ __forceinline__ bool use_filtered_refs(int mode, int log2n) { // TComPattern.cpp:49-56,577-605
+  const int thr = log2n == 2 ? 10 : log2n == 3 ? 7 : log2n == 4 ? 1 : log2n == 5 ? 0 : 10;
+  if (mode == 1) return false;
+  return min(abs(mode - 10), abs(mode - 26)) > thr;
+}
+
+// Row r of the N x N prediction (TComPrediction.cpp:129-386, 689-730, 1010-1029).
+// R = reference line (raw or smoothed); top(k) = R[2N+k], left(k) = R[2N-k], k = 0 is the corner.
+template <int N>
+__device__ __forceinline__ void intra_pred_row(const int *R, int mode, bool luma, int bit_depth, int r, int *p) {
+  constexpr int LOG2N = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+  const int *top = R + 2 * N; // top[k]
+  // left(k) = R[2N - k]
+  if (mode == 0) { // planar, closed form of the accumulators
+    int left = R[2 * N - (r + 1)], tr = top[N + 1], bl = R[2 * N - (N + 1)];
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+      int t = top[c + 1];
+      int hor = (left << LOG2N) + N + (c + 1) * (tr - left);
+      int ver = (t << LOG2N) + (r + 1) * (bl - t);
+      p[c] = (short)((hor + ver) >> (LOG2N + 1));
+    }
+    return;
+  }
+  if (mode == 1) { // DC (+ edge smoothing for luma, any size)
+    int sum = 0;
+    for (int i = 1; i <= N; i++) sum += top[i] + R[2 * N - i];
+    int dc = (sum + N) >> (LOG2N + 1);
+#pragma unroll
+    for (int c = 0; c < N; c++) p[c] = dc;
+    if (luma) {
+      if (r == 0) {
+#pragma unroll
+        for (int c = 1; c < N; c++) p[c] = (short)((top[c + 1] + 3 * dc + 2) >> 2);
+        p[0] = (short)((top[1] + R[2 * N - 1] + 2 * dc + 2) >> 2);
+      } else {
+        p[0] = (short)((R[2 * N - (r + 1)] + 3 * dc + 2) >> 2);
+      }
+    }
+    return;
+  }
+  const bool ver = mode >= 18;
+  const int idx = ver ? mode - 26 : 10 - mode;
+  const int aidx = abs(idx);
+  constexpr int ang_tab[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};
+  constexpr int inv_tab[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};
+  int angle = ang_tab[0], inv_angle = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++)
+    if (i == aidx) {
+      angle = ang_tab[i];
+      inv_angle = inv_tab[i];
+    }
+  if (idx < 0) angle = -angle;
+  // main(i) for i in [-N, 2N]: i >= 0 -> main reference, i < 0 -> projected side reference
+  auto mref = [&](int i) -> int {
+    int k = i >= 0 ? i : (128 + (-i) * inv_angle) >> 8; // index into main (i>=0) or side (i<0)
+    bool use_top = (i >= 0) == ver;
+    return (short)(use_top ? top[k] : R[2 * N - k]);
+  };
+  const int max_v = (1 << bit_depth) - 1;
+  if (angle == 0) {
+    if (ver) {
+#pragma unroll
+      for (int c = 0; c < N; c++) p[c] = (short)top[c + 1];
+      if (luma) p[0] = clip3(0, max_v, p[0] + (((short)R[2 * N - (r + 1)] - (short)top[0]) >> 1));
+    } else {
+      int v = (short)R[2 * N - (r + 1)];
+#pragma unroll
+      for (int c = 0; c < N; c++) p[c] = v;
+      if (luma && r == 0) {
+#pragma unroll
+        for (int c = 0; c < N; c++) p[c] = clip3(0, max_v, p[c] + (((short)top[c + 1] - (short)top[0]) >> 1));
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < N; c++) {
+    // main-frame coordinates (k = distance from the main reference, l = position along it)
+    int k = ver ? r : c, l = ver ? c : r;
+    int pos = (k + 1) * angle;
+    int di = pos >> 5, df = pos & 31;
+    int i = l + di + 1;
+    int a = mref(i);
+    p[c] = df ? (short)(((32 - df) * a + df * mref(i + 1) + 16) >> 5) : a;
+  }
+}
+
+} // namespace hmx

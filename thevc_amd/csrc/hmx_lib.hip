@@ -1,0 +1,1320 @@
+// hmx_lib.hip -- libhmx: kernels + C-ABI (include/hmx.h) for gfx950.
+// Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared (see __graft_entry__.build()).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hmx_kernels.h"
+
+using namespace hmx;
+
+// =============================================================================================
+// Kernels
+// =============================================================================================
+struct DTu { // device descriptor of the list kernels: hmx_tu + index in the caller's order
+  hmx_tu t;
+  uint32_t idx;
+};
+
+#define HMX_SMEM_BYTES (16 * (int)sizeof(TuLds<16>)) /* largest of Slots<N> * sizeof(TuLds<N>) */
+static_assert(64 * sizeof(TuLds<4>) <= HMX_SMEM_BYTES && 32 * sizeof(TuLds<8>) <= HMX_SMEM_BYTES &&
+                  4 * sizeof(TuLds<32>) <= HMX_SMEM_BYTES,
+              "LDS scratch");
+
+enum ListOp { OP_TRANSFORM_NXN, OP_INVTRANSFORM_NXN, OP_XT, OP_XIT, OP_XQUANT, OP_XDEQUANT, OP_PRED };
+
+struct ListArgs {
+  const DTu *tus;
+  int n;
+  PlanesDev a;   // residual in (transform) / prediction in (inverse with recon) / recon (pred)
+  PlanesDev b;   // output planes
+  LevelsDev lev; // levels / coefficients (Int)
+  LevelsDev lev2;
+  uint32_t *abs_sum;
+  int have_pred;
+  const uint8_t *modes; // OP_PRED fan-out
+  int n_modes;
+  size_t mode_elems[3];
+  PicDev P;
+};
+
+// One kernel per (operation, block size): every block of the launch has size N.
+template <int N, int OP>
+__global__ __launch_bounds__(256) void k_list(ListArgs A) {
+  __shared__ __attribute__((aligned(16))) char smem[HMX_SMEM_BYTES];
+  constexpr int SL = Slots<N>::v;
+  const int tid = threadIdx.x, slot = tid / N, gl = tid % N;
+  const bool lane_on = slot < SL;
+  TuLds<N> &L = reinterpret_cast<TuLds<N> *>(smem)[lane_on ? slot : 0];
+  const int i = blockIdx.x * SL + slot;
+  const bool active = lane_on && i < A.n;
+  DTu d = A.tus[active ? i : 0];
+  const hmx_tu t = d.t;
+  const int pl = t.plane, x = t.x, y = t.y;
+  const bool luma = pl == 0, inter = t.flags & HMX_TU_INTER, ts = t.flags & HMX_TU_TRANSFORM_SKIP;
+  const bool use_dst = luma && !inter; // uiMode != REG_DCT, only consulted for N == 4
+  const int scan_idx = coef_scan_idx(N, luma, !inter, t.mode);
+  int row[N];
+
+  if constexpr (OP == OP_TRANSFORM_NXN || OP == OP_XT) {
+    if (active) load_row16<N>(A.a.p[pl] + (size_t)(y + gl) * A.a.s[pl] + x, row);
+    int sum = fwd_tq_block<N>(L, gl, active, row, ts, use_dst, luma, scan_idx, OP == OP_TRANSFORM_NXN, A.P);
+    if (active) {
+      load_row32<N>(&L.tile[gl][0], row);
+      store_row32<N>(A.lev.p[pl] + (size_t)(y + gl) * A.lev.s[pl] + x, row);
+      if (OP == OP_TRANSFORM_NXN && gl == 0 && A.abs_sum) A.abs_sum[d.idx] = (uint32_t)sum;
+    }
+  } else if constexpr (OP == OP_XQUANT) {
+    // coefficients (Int) in lev -> levels in lev2; reuses the quantiser half of fwd_tq_block
+    // through the transform-skip entry with shift 0 semantics: load rows straight into the tile.
+    constexpr int LG = Log2<N>::v;
+    const int tshift = 15 - A.P.bit_depth - LG;
+    const QuantDev &qd = A.P.qd[luma ? 0 : 1];
+    const int qbits = 14 + qd.per_qbits + tshift;
+    const long long add = (long long)qd.rnd_factor << (qbits - 9);
+    if (active && gl == 0) L.nzmask[0] = L.nzmask[1] = 0;
+    int sum = 0;
+    if (active) {
+      load_row32<N>(A.lev.p[pl] + (size_t)(y + gl) * A.lev.s[pl] + x, row);
+#pragma unroll
+      for (int k = 0; k < N; k++) {
+        int lvl, du, al;
+        quant_one(row[k], qd, qbits, add, lvl, du, al);
+        sum += al;
+        L.tile[gl][k] = lvl;
+        L.du[gl][k] = (du << 1) | (row[k] < 0 ? 1 : 0);
+      }
+    }
+    sum = group_sum(active ? sum : 0, N);
+    __syncthreads();
+    constexpr int NG = (N / 4) * (N / 4);
+    const bool hide = A.P.sign_hide && sum >= 2;
+    if (hide)
+      for (int g = gl; g < NG; g += N) {
+        bool nz = false;
+        for (int q = 0; q < 16; q++) {
+          int p = scan_pos<N>(scan_idx, g, q);
+          nz |= L.tile[p / N][p % N] != 0;
+        }
+        if (nz) atomicOr(&L.nzmask[g >> 5], 1u << (g & 31));
+      }
+    __syncthreads();
+    if (hide) {
+      const unsigned long long mask = (unsigned long long)L.nzmask[0] | ((unsigned long long)L.nzmask[1] << 32);
+      for (int g = gl; g < NG; g += N)
+        if ((mask >> g) & 1) sbh_group<N>(L, scan_idx, g, g < 63 ? (mask >> (g + 1)) == 0 : true);
+    }
+    __syncthreads();
+    if (active) {
+      load_row32<N>(&L.tile[gl][0], row);
+      store_row32<N>(A.lev2.p[pl] + (size_t)(y + gl) * A.lev2.s[pl] + x, row);
+      if (gl == 0 && A.abs_sum) A.abs_sum[d.idx] = (uint32_t)sum;
+    }
+  } else if constexpr (OP == OP_INVTRANSFORM_NXN || OP == OP_XIT) {
+    if (active) {
+      load_row32<N>(A.lev.p[pl] + (size_t)(y + gl) * A.lev.s[pl] + x, row);
+      store_row32<N>(&L.tile[gl][0], row);
+    }
+    __syncthreads();
+    inv_tq_block<N>(L, gl, active, ts, use_dst, luma, OP == OP_INVTRANSFORM_NXN, A.P, row);
+    if (active) {
+      if (A.have_pred) {
+        int pr[N];
+        load_row16<N>(A.a.p[pl] + (size_t)(y + gl) * A.a.s[pl] + x, pr);
+        const int mx = (1 << A.P.bit_depth) - 1;
+#pragma unroll
+        for (int k = 0; k < N; k++) row[k] = clip3(0, mx, pr[k] + row[k]);
+      }
+      store_row16<N>(A.b.p[pl] + (size_t)(y + gl) * A.b.s[pl] + x, row);
+    }
+  } else if constexpr (OP == OP_XDEQUANT) {
+    constexpr int LG = Log2<N>::v;
+    const int tshift = 15 - A.P.bit_depth - LG, dshift = 6 - tshift, dadd = 1 << (dshift - 1);
+    const QuantDev &qd = A.P.qd[luma ? 0 : 1];
+    if (active) {
+      load_row32<N>(A.lev.p[pl] + (size_t)(y + gl) * A.lev.s[pl] + x, row);
+#pragma unroll
+      for (int k = 0; k < N; k++) {
+        int l = clip3(-32768, 32767, row[k]);
+        row[k] = clip3(-32768, 32767, (int)((unsigned)l * (unsigned)qd.iq_scale + (unsigned)dadd) >> dshift);
+      }
+      store_row32<N>(A.lev2.p[pl] + (size_t)(y + gl) * A.lev2.s[pl] + x, row);
+    }
+  } else { // OP_PRED
+    intra_refs<N>(L, gl, active, A.a.p[pl], A.a.s[pl], x, y, luma, A.P);
+    if (active) {
+      if (A.n_modes <= 0) {
+        intra_pred_block<N>(L, gl, t.mode, luma, A.P, row);
+        store_row16<N>(A.b.p[pl] + (size_t)(y + gl) * A.b.s[pl] + x, row);
+      } else {
+        for (int m = 0; m < A.n_modes; m++) {
+          intra_pred_block<N>(L, gl, A.modes[m], luma, A.P, row);
+          store_row16<N>(A.b.p[pl] + m * A.mode_elems[pl] + (size_t)(y + gl) * A.b.s[pl] + x, row);
+        }
+      }
+    }
+  }
+}
+
+// ---- whole-picture all-intra reconstruction: one launch per CTU diagonal ----
+struct Seg { // a run of same-size blocks of one dependency level of one (CTU, plane)
+  uint32_t start;
+  uint16_t count;
+  uint8_t log2n;
+  uint8_t pad;
+};
+struct FrameArgs {
+  const hmx_tu *tus;
+  const Seg *segs;
+  const uint32_t *seg_range; // [(ctu*3+plane)*2 + {0,1}] -> begin,end in segs
+  const uint32_t *wave_ctus; // CTU ids of this diagonal
+  int n_wave_ctus;
+  int n_pics;
+  const PlanesDev *org; // [n_pics]
+  const PlanesDev *rec;
+  const LevelsDev *lev;
+  PicDev P;
+};
+
+template <int N, bool ENC>
+__device__ __forceinline__ void intra_tu_chain(char *smem, const FrameArgs &A, const PlanesDev &org, const PlanesDev &rec,
+                                               const LevelsDev &lev, const hmx_tu *tus, int count) {
+  constexpr int SL = Slots<N>::v;
+  const int tid = threadIdx.x, slot = tid / N, gl = tid % N;
+  const bool lane_on = slot < SL;
+  TuLds<N> &L = reinterpret_cast<TuLds<N> *>(smem)[lane_on ? slot : 0];
+  for (int base = 0; base < count; base += SL) {
+    const int i = base + slot;
+    const bool active = lane_on && i < count;
+    const hmx_tu t = tus[active ? i : 0];
+    const int pl = t.plane, x = t.x, y = t.y;
+    const bool luma = pl == 0, ts = t.flags & HMX_TU_TRANSFORM_SKIP;
+    const int scan_idx = coef_scan_idx(N, luma, true, t.mode);
+    int pred[N], row[N];
+    intra_refs<N>(L, gl, active, rec.p[pl], rec.s[pl], x, y, luma, A.P);
+    if (active) intra_pred_block<N>(L, gl, t.mode, luma, A.P, pred);
+    int *lev_row = lev.p[pl] + (size_t)(y + gl) * lev.s[pl] + x;
+    if (ENC) {
+      if (active) {
+        load_row16<N>(org.p[pl] + (size_t)(y + gl) * org.s[pl] + x, row);
+#pragma unroll
+        for (int k = 0; k < N; k++) row[k] = wrap16(row[k] - pred[k]);
+      }
+      fwd_tq_block<N>(L, gl, active, row, ts, luma, luma, scan_idx, true, A.P);
+      if (active) {
+        load_row32<N>(&L.tile[gl][0], row);
+        store_row32<N>(lev_row, row);
+      }
+    } else {
+      if (active) {
+        load_row32<N>(lev_row, row);
+        store_row32<N>(&L.tile[gl][0], row);
+      }
+      __syncthreads();
+    }
+    // inverse of all-zero levels is exactly zero, so the reference's "if (uiAbsSum)" needs no branch
+    inv_tq_block<N>(L, gl, active, ts, luma, luma, true, A.P, row);
+    if (active) {
+      const int mx = (1 << A.P.bit_depth) - 1;
+#pragma unroll
+      for (int k = 0; k < N; k++) row[k] = clip3(0, mx, pred[k] + row[k]);
+      store_row16<N>(rec.p[pl] + (size_t)(y + gl) * rec.s[pl] + x, row);
+    }
+  }
+}
+
+template <bool ENC>
+__global__ __launch_bounds__(256) void k_intra_wave(FrameArgs A) {
+  __shared__ __attribute__((aligned(16))) char smem[HMX_SMEM_BYTES];
+  // work item = (picture, CTU of the diagonal, plane); planes of a CTU are independent
+  int w = blockIdx.x;
+  const int plane = w % 3;
+  w /= 3;
+  const int ctu = A.wave_ctus[w % A.n_wave_ctus];
+  const int pic = w / A.n_wave_ctus;
+  const PlanesDev org = ENC ? A.org[pic] : A.rec[pic];
+  const PlanesDev rec = A.rec[pic];
+  const LevelsDev lev = A.lev[pic];
+  const uint32_t sb = A.seg_range[(ctu * 3 + plane) * 2], se = A.seg_range[(ctu * 3 + plane) * 2 + 1];
+  for (uint32_t s = sb; s < se; s++) {
+    const Seg sg = A.segs[s];
+    const hmx_tu *tus = A.tus + sg.start;
+    // every segment boundary is a dependency-level or size boundary: make the reconstruction
+    // written so far visible to the whole workgroup before the next blocks gather references
+    __syncthreads();
+    switch (sg.log2n) {
+    case 2: intra_tu_chain<4, ENC>(smem, A, org, rec, lev, tus, sg.count); break;
+    case 3: intra_tu_chain<8, ENC>(smem, A, org, rec, lev, tus, sg.count); break;
+    case 4: intra_tu_chain<16, ENC>(smem, A, org, rec, lev, tus, sg.count); break;
+    default: intra_tu_chain<32, ENC>(smem, A, org, rec, lev, tus, sg.count); break;
+    }
+  }
+}
+
+// =============================================================================================
+// Host side
+// =============================================================================================
+struct hmx_ctx {
+  hmx_config cfg;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  // scratch for the scalar drop-ins (one block): device staging
+  char *d_scratch = nullptr;
+  size_t scratch_bytes = 0;
+  // per-call picture tables of the frame path
+  PlanesDev *d_org = nullptr, *d_rec = nullptr;
+  LevelsDev *d_lev = nullptr;
+  int pic_cap = 0;
+};
+
+struct hmx_intra_plan {
+  hmx_tu *d_tus = nullptr;
+  Seg *d_segs = nullptr;
+  uint32_t *d_seg_range = nullptr;
+  uint32_t *d_wave_ctus = nullptr;
+  std::vector<std::pair<uint32_t, uint32_t>> waves; // offset,count into d_wave_ctus
+  PicDev P;
+  int n_tu = 0;
+};
+
+static int fail(hmx_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
+  if (c) {
+    c->err = what;
+    if (e != hipSuccess) {
+      c->err += ": ";
+      c->err += hipGetErrorString(e);
+    }
+  }
+  return code;
+}
+#define HIPCHK(ctx, call)                                                   \
+  do {                                                                      \
+    hipError_t e_ = (call);                                                 \
+    if (e_ != hipSuccess) return fail(ctx, HMX_ERR_DEVICE, #call, e_);      \
+  } while (0)
+
+static inline int ilog2i(int n) {
+  int l = 0;
+  while ((1 << l) < n) l++;
+  return l;
+}
+static const int kQuantScales[6] = {26214, 23302, 20560, 18396, 16384, 14564}; // TComRom.cpp:293
+static const int kInvQuantScales[6] = {40, 45, 51, 57, 64, 72};                // TComRom.cpp:298
+static int chroma_scale(int idx) { // g_aucChromaScale[58], TComRom.cpp:380
+  static const unsigned char mid[13] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37};
+  return idx < 30 ? idx : (idx >= 43 ? idx - 6 : mid[idx - 30]);
+}
+
+extern "C" hmx_qp hmx_setQPforQuant(int qpy, int text_type, int qp_bd_offset, int chroma_qp_offset) {
+  int q;
+  if (text_type == HMX_TEXT_LUMA)
+    q = qpy + qp_bd_offset;
+  else {
+    q = std::min(57, std::max(-qp_bd_offset, qpy + chroma_qp_offset));
+    q = q < 0 ? q + qp_bd_offset : chroma_scale(q) + qp_bd_offset;
+  }
+  hmx_qp r = {q, q / 6, q % 6, 15 + q / 6};
+  return r;
+}
+
+static QuantDev make_qd(const hmx_qp &qp, int per_base, int slice_type) {
+  QuantDev d;
+  d.q = kQuantScales[qp.rem];
+  d.per_qbits = per_base >= 0 ? per_base : qp.per;
+  d.iq_scale = kInvQuantScales[qp.rem] << qp.per;
+  d.rnd_factor = slice_type == HMX_I_SLICE ? 171 : 85;
+  return d;
+}
+
+static PicDev make_picdev(const hmx_ctx *c, const hmx_pic_param *pp) {
+  PicDev P;
+  P.pic_w = pp->pic_w;
+  P.pic_h = pp->pic_h;
+  P.ctu = c->cfg.ctu_size;
+  P.bit_depth = c->cfg.bit_depth;
+  P.sign_hide = pp->sign_hide;
+  const int bd = 6 * (c->cfg.bit_depth - 8);
+  P.qd[0] = make_qd(hmx_setQPforQuant(pp->qp, HMX_TEXT_LUMA, bd, 0), -1, pp->slice_type);
+  P.qd[1] = make_qd(hmx_setQPforQuant(pp->qp, HMX_TEXT_CHROMA, bd, pp->chroma_qp_offset), -1, pp->slice_type);
+  return P;
+}
+
+extern "C" int hmx_create(const hmx_config *cfg, hmx_ctx **out) {
+  if (!cfg || !out) return HMX_ERR_ARG;
+  if (cfg->bit_depth < 8 || cfg->bit_depth > 12 || (cfg->ctu_size != 64 && cfg->ctu_size != 32 && cfg->ctu_size != 16))
+    return HMX_ERR_ARG;
+  hmx_ctx *c = new hmx_ctx;
+  c->cfg = *cfg;
+  hipError_t e = hipSetDevice(cfg->device);
+  if (e != hipSuccess) {
+    delete c;
+    return HMX_ERR_DEVICE;
+  }
+  if (cfg->stream)
+    c->stream = (hipStream_t)cfg->stream;
+  else {
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete c;
+      return HMX_ERR_DEVICE;
+    }
+    c->own_stream = true;
+  }
+  c->scratch_bytes = 1 << 20;
+  e = hipMalloc((void **)&c->d_scratch, c->scratch_bytes);
+  if (e != hipSuccess) {
+    delete c;
+    return HMX_ERR_NOMEM;
+  }
+  *out = c;
+  return HMX_OK;
+}
+
+extern "C" void hmx_destroy(hmx_ctx *c) {
+  if (!c) return;
+  hipStreamSynchronize(c->stream);
+  hipFree(c->d_scratch);
+  hipFree(c->d_org);
+  hipFree(c->d_rec);
+  hipFree(c->d_lev);
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+extern "C" const char *hmx_last_error(const hmx_ctx *c) { return c ? c->err.c_str() : "null context"; }
+extern "C" int hmx_sync(hmx_ctx *c) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HMX_OK;
+}
+extern "C" int hmx_malloc(hmx_ctx *c, size_t bytes, void **dptr) {
+  hipError_t e = hipMalloc(dptr, bytes);
+  if (e != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc", e);
+  return HMX_OK;
+}
+extern "C" int hmx_free(hmx_ctx *c, void *dptr) {
+  HIPCHK(c, hipFree(dptr));
+  return HMX_OK;
+}
+extern "C" int hmx_upload(hmx_ctx *c, void *dst, const void *src, size_t bytes) {
+  HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HMX_OK;
+}
+extern "C" int hmx_download(hmx_ctx *c, void *dst, const void *src, size_t bytes) {
+  HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HMX_OK;
+}
+extern "C" int hmx_memset(hmx_ctx *c, void *dst, int value, size_t bytes) {
+  HIPCHK(c, hipMemsetAsync(dst, value, bytes, c->stream));
+  return HMX_OK;
+}
+extern "C" int hmx_event_create(hmx_ctx *c, void **ev) {
+  hipEvent_t e;
+  HIPCHK(c, hipEventCreate(&e));
+  *ev = (void *)e;
+  return HMX_OK;
+}
+extern "C" int hmx_event_record(hmx_ctx *c, void *ev) {
+  HIPCHK(c, hipEventRecord((hipEvent_t)ev, c->stream));
+  return HMX_OK;
+}
+extern "C" int hmx_event_elapsed_ms(hmx_ctx *c, void *a, void *b, float *ms) {
+  HIPCHK(c, hipEventSynchronize((hipEvent_t)b));
+  HIPCHK(c, hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+  return HMX_OK;
+}
+extern "C" int hmx_event_destroy(hmx_ctx *c, void *ev) {
+  HIPCHK(c, hipEventDestroy((hipEvent_t)ev));
+  return HMX_OK;
+}
+
+// ---- list launches ----
+template <int OP>
+static int launch_list(hmx_ctx *c, int log2n, const ListArgs &A) {
+  if (A.n <= 0) return HMX_OK;
+  dim3 blk(256);
+  switch (log2n) {
+  case 2: hipLaunchKernelGGL((k_list<4, OP>), dim3((A.n + Slots<4>::v - 1) / Slots<4>::v), blk, 0, c->stream, A); break;
+  case 3: hipLaunchKernelGGL((k_list<8, OP>), dim3((A.n + Slots<8>::v - 1) / Slots<8>::v), blk, 0, c->stream, A); break;
+  case 4: hipLaunchKernelGGL((k_list<16, OP>), dim3((A.n + Slots<16>::v - 1) / Slots<16>::v), blk, 0, c->stream, A); break;
+  case 5: hipLaunchKernelGGL((k_list<32, OP>), dim3((A.n + Slots<32>::v - 1) / Slots<32>::v), blk, 0, c->stream, A); break;
+  default: return fail(c, HMX_ERR_ARG, "unsupported block size");
+  }
+  HIPCHK(c, hipGetLastError());
+  return HMX_OK;
+}
+
+static int launch_op(hmx_ctx *c, int op, int log2n, const ListArgs &A) {
+  switch (op) {
+  case OP_TRANSFORM_NXN: return launch_list<OP_TRANSFORM_NXN>(c, log2n, A);
+  case OP_INVTRANSFORM_NXN: return launch_list<OP_INVTRANSFORM_NXN>(c, log2n, A);
+  case OP_XT: return launch_list<OP_XT>(c, log2n, A);
+  case OP_XIT: return launch_list<OP_XIT>(c, log2n, A);
+  case OP_XQUANT: return launch_list<OP_XQUANT>(c, log2n, A);
+  case OP_XDEQUANT: return launch_list<OP_XDEQUANT>(c, log2n, A);
+  default: return launch_list<OP_PRED>(c, log2n, A);
+  }
+}
+
+// A block list resident on the device, bucketed by block size.
+struct hmx_tu_list {
+  DTu *d = nullptr;
+  int off[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
+  int n = 0;
+};
+
+extern "C" int hmx_tu_list_create(hmx_ctx *c, const hmx_tu *tus, int n, hmx_tu_list **out) {
+  if (!c || !out || (n > 0 && !tus)) return fail(c, HMX_ERR_ARG, "hmx_tu_list_create: null argument");
+  hmx_tu_list *l = new hmx_tu_list;
+  std::vector<DTu> v;
+  v.reserve(n);
+  for (int s = 2; s <= 5; s++) {
+    l->off[s - 2] = (int)v.size();
+    for (int i = 0; i < n; i++)
+      if (tus[i].log2n == s) v.push_back(DTu{tus[i], (uint32_t)i});
+    l->cnt[s - 2] = (int)v.size() - l->off[s - 2];
+  }
+  if ((int)v.size() != n) {
+    delete l;
+    return fail(c, HMX_ERR_ARG, "hmx_tu_list_create: block size outside 4..32");
+  }
+  l->n = n;
+  if (n) {
+    if (hipMalloc((void **)&l->d, sizeof(DTu) * n) != hipSuccess) {
+      delete l;
+      return fail(c, HMX_ERR_NOMEM, "hipMalloc tu list");
+    }
+    int r = hmx_upload(c, l->d, v.data(), sizeof(DTu) * n);
+    if (r) return r;
+  }
+  *out = l;
+  return HMX_OK;
+}
+extern "C" void hmx_tu_list_destroy(hmx_ctx *c, hmx_tu_list *l) {
+  (void)c;
+  if (!l) return;
+  hipFree(l->d);
+  delete l;
+}
+
+static PlanesDev to_dev(const hmx_pic *p) {
+  PlanesDev d;
+  for (int i = 0; i < 3; i++) {
+    d.p[i] = p ? p->plane[i] : nullptr;
+    d.s[i] = p ? p->stride[i] : 0;
+  }
+  return d;
+}
+static LevelsDev to_dev(const hmx_levels *p) {
+  LevelsDev d;
+  for (int i = 0; i < 3; i++) {
+    d.p[i] = p ? p->plane[i] : nullptr;
+    d.s[i] = p ? p->stride[i] : 0;
+  }
+  return d;
+}
+
+static int run_list(hmx_ctx *c, int op, const hmx_tu_list *l, ListArgs A) {
+  for (int s = 0; s < 4; s++) {
+    if (!l->cnt[s]) continue;
+    A.tus = l->d + l->off[s];
+    A.n = l->cnt[s];
+    int r = launch_op(c, op, s + 2, A);
+    if (r) return r;
+  }
+  return HMX_OK;
+}
+
+extern "C" int hmx_batch_transformNxN(hmx_ctx *c, const hmx_tu_list *l, const hmx_pic *resi, const hmx_levels *lev,
+                                      uint32_t *d_abs_sum, const hmx_pic_param *pp) {
+  if (!c || !l || !resi || !lev || !pp) return fail(c, HMX_ERR_ARG, "hmx_batch_transformNxN: null argument");
+  ListArgs A{};
+  A.a = to_dev(resi);
+  A.lev = to_dev(lev);
+  A.abs_sum = d_abs_sum;
+  A.P = make_picdev(c, pp);
+  return run_list(c, OP_TRANSFORM_NXN, l, A);
+}
+
+extern "C" int hmx_batch_invtransformNxN(hmx_ctx *c, const hmx_tu_list *l, const hmx_levels *lev, const hmx_pic *pred,
+                                         const hmx_pic *out, const hmx_pic_param *pp) {
+  if (!c || !l || !out || !lev || !pp) return fail(c, HMX_ERR_ARG, "hmx_batch_invtransformNxN: null argument");
+  ListArgs A{};
+  A.a = to_dev(pred);
+  A.have_pred = pred != nullptr;
+  A.b = to_dev(out);
+  A.lev = to_dev(lev);
+  A.P = make_picdev(c, pp);
+  return run_list(c, OP_INVTRANSFORM_NXN, l, A);
+}
+
+extern "C" int hmx_batch_predIntra(hmx_ctx *c, const hmx_tu_list *l, const hmx_pic *rec, const hmx_pic *pred,
+                                   const hmx_pic_param *pp, const uint8_t *d_modes, int n_modes,
+                                   const size_t mode_plane_elems[3]) {
+  if (!c || !l || !rec || !pred || !pp) return fail(c, HMX_ERR_ARG, "hmx_batch_predIntra: null argument");
+  ListArgs A{};
+  A.a = to_dev(rec);
+  A.b = to_dev(pred);
+  A.P = make_picdev(c, pp);
+  A.modes = d_modes;
+  A.n_modes = d_modes ? n_modes : 0;
+  for (int i = 0; i < 3; i++) A.mode_elems[i] = mode_plane_elems ? mode_plane_elems[i] : 0;
+  return run_list(c, OP_PRED, l, A);
+}
+
+// ---- intra frame plan: dependency schedule ----
+extern "C" int hmx_intra_plan_create(hmx_ctx *c, const hmx_tu *tus, int n_tu, const hmx_pic_param *pp,
+                                     hmx_intra_plan **out) {
+  if (!c || !tus || !pp || !out || n_tu <= 0) return fail(c, HMX_ERR_ARG, "hmx_intra_plan_create: bad argument");
+  const int ctu = c->cfg.ctu_size, U = ctu / 4;
+  const int cw = (pp->pic_w + ctu - 1) / ctu, ch = (pp->pic_h + ctu - 1) / ctu, n_ctu = cw * ch;
+  PicDev P = make_picdev(c, pp);
+  // bucket blocks per (CTU, plane), keeping coding order
+  std::vector<std::vector<int>> bucket((size_t)n_ctu * 3);
+  for (int i = 0; i < n_tu; i++) {
+    const hmx_tu &t = tus[i];
+    if (t.plane > 2 || t.log2n < 2 || t.log2n > 5) return fail(c, HMX_ERR_ARG, "hmx_intra_plan_create: bad block");
+    const int sh = t.plane ? 1 : 0, lx = t.x << sh, ly = t.y << sh, ls = (1 << t.log2n) << sh;
+    if (lx + ls > cw * ctu || ly + ls > ch * ctu || (lx % ctu) + ls > ctu || (ly % ctu) + ls > ctu)
+      return fail(c, HMX_ERR_ARG, "hmx_intra_plan_create: block crosses a CTU");
+    bucket[((size_t)(ly / ctu) * cw + lx / ctu) * 3 + t.plane].push_back(i);
+  }
+  std::vector<hmx_tu> stus;
+  stus.reserve(n_tu);
+  std::vector<Seg> segs;
+  std::vector<uint32_t> seg_range((size_t)n_ctu * 3 * 2);
+  std::vector<int> level(n_tu);
+  std::vector<int> grid((size_t)U * U);
+  for (int b = 0; b < n_ctu * 3; b++) {
+    std::fill(grid.begin(), grid.end(), 0);
+    auto &ids = bucket[b];
+    for (int id : ids) {
+      const hmx_tu &t = tus[id];
+      const int sh = t.plane ? 1 : 0, lx = t.x << sh, ly = t.y << sh, ls = (1 << t.log2n) << sh;
+      const int n = ls / 4, cx = (lx % ctu) / 4, cy = (ly % ctu) / 4;
+      unsigned long long m = intra_avail_mask(lx, ly, ls, P);
+      int lv = 0;
+      auto dep = [&](int ux, int uy) { // unit coordinates relative to the CTU
+        if (ux >= 0 && uy >= 0 && ux < U && uy < U) lv = std::max(lv, grid[uy * U + ux]);
+      };
+      for (int u = 0; u < 4 * n + 1; u++) {
+        if (!((m >> u) & 1)) continue;
+        if (u < 2 * n)
+          dep(cx - 1, cy + 2 * n - 1 - u);
+        else if (u == 2 * n)
+          dep(cx - 1, cy - 1);
+        else
+          dep(cx + (u - 2 * n - 1), cy - 1);
+      }
+      level[id] = lv + 1;
+      for (int j = 0; j < n; j++)
+        for (int i2 = 0; i2 < n; i2++) grid[(cy + j) * U + cx + i2] = lv + 1;
+    }
+    std::stable_sort(ids.begin(), ids.end(), [&](int a, int b2) {
+      if (level[a] != level[b2]) return level[a] < level[b2];
+      return tus[a].log2n < tus[b2].log2n;
+    });
+    seg_range[(size_t)b * 2] = (uint32_t)segs.size();
+    for (size_t k = 0; k < ids.size();) {
+      size_t e = k;
+      while (e < ids.size() && level[ids[e]] == level[ids[k]] && tus[ids[e]].log2n == tus[ids[k]].log2n &&
+             e - k < 65535)
+        e++;
+      Seg s;
+      s.start = (uint32_t)stus.size();
+      s.count = (uint16_t)(e - k);
+      s.log2n = tus[ids[k]].log2n;
+      s.pad = 0;
+      segs.push_back(s);
+      for (size_t q = k; q < e; q++) stus.push_back(tus[ids[q]]);
+      k = e;
+    }
+    seg_range[(size_t)b * 2 + 1] = (uint32_t)segs.size();
+  }
+  // CTU diagonals d = X + 2Y: (X,Y) needs (X-1,Y), (X-1,Y-1), (X,Y-1), (X+1,Y-1)
+  hmx_intra_plan *pl = new hmx_intra_plan;
+  pl->P = P;
+  pl->n_tu = n_tu;
+  std::vector<uint32_t> wave_ctus;
+  for (int d = 0; d <= (cw - 1) + 2 * (ch - 1); d++) {
+    uint32_t off = (uint32_t)wave_ctus.size();
+    for (int Y = 0; Y < ch; Y++) {
+      int X = d - 2 * Y;
+      if (X >= 0 && X < cw) wave_ctus.push_back((uint32_t)(Y * cw + X));
+    }
+    pl->waves.push_back({off, (uint32_t)wave_ctus.size() - off});
+  }
+  auto up = [&](void **dp, const void *src, size_t bytes) -> int {
+    if (hipMalloc(dp, bytes ? bytes : 4) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc plan");
+    return bytes ? hmx_upload(c, *dp, src, bytes) : HMX_OK;
+  };
+  int r = up((void **)&pl->d_tus, stus.data(), stus.size() * sizeof(hmx_tu));
+  if (!r) r = up((void **)&pl->d_segs, segs.data(), segs.size() * sizeof(Seg));
+  if (!r) r = up((void **)&pl->d_seg_range, seg_range.data(), seg_range.size() * sizeof(uint32_t));
+  if (!r) r = up((void **)&pl->d_wave_ctus, wave_ctus.data(), wave_ctus.size() * sizeof(uint32_t));
+  if (r) {
+    hmx_intra_plan_destroy(c, pl);
+    return r;
+  }
+  *out = pl;
+  return HMX_OK;
+}
+
+extern "C" void hmx_intra_plan_destroy(hmx_ctx *c, hmx_intra_plan *pl) {
+  (void)c;
+  if (!pl) return;
+  hipFree(pl->d_tus);
+  hipFree(pl->d_segs);
+  hipFree(pl->d_seg_range);
+  hipFree(pl->d_wave_ctus);
+  delete pl;
+}
+
+static int frame_intra(hmx_ctx *c, const hmx_intra_plan *pl, int n_pics, const hmx_pic *org, const hmx_pic *rec,
+                       const hmx_levels *lev, bool enc) {
+  if (!c || !pl || n_pics <= 0 || !rec || !lev || (enc && !org)) return fail(c, HMX_ERR_ARG, "frame_intra: null argument");
+  if (n_pics > c->pic_cap) {
+    hipFree(c->d_org);
+    hipFree(c->d_rec);
+    hipFree(c->d_lev);
+    c->pic_cap = 0;
+    if (hipMalloc((void **)&c->d_org, sizeof(PlanesDev) * n_pics) != hipSuccess ||
+        hipMalloc((void **)&c->d_rec, sizeof(PlanesDev) * n_pics) != hipSuccess ||
+        hipMalloc((void **)&c->d_lev, sizeof(LevelsDev) * n_pics) != hipSuccess)
+      return fail(c, HMX_ERR_NOMEM, "hipMalloc picture tables");
+    c->pic_cap = n_pics;
+  }
+  std::vector<PlanesDev> ho(n_pics), hr(n_pics);
+  std::vector<LevelsDev> hl(n_pics);
+  for (int i = 0; i < n_pics; i++) {
+    ho[i] = to_dev(enc ? &org[i] : &rec[i]);
+    hr[i] = to_dev(&rec[i]);
+    hl[i] = to_dev(&lev[i]);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_org, ho.data(), sizeof(PlanesDev) * n_pics, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_rec, hr.data(), sizeof(PlanesDev) * n_pics, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_lev, hl.data(), sizeof(LevelsDev) * n_pics, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream)); // the host vectors go out of scope
+  FrameArgs A;
+  A.tus = pl->d_tus;
+  A.segs = pl->d_segs;
+  A.seg_range = pl->d_seg_range;
+  A.n_pics = n_pics;
+  A.org = c->d_org;
+  A.rec = c->d_rec;
+  A.lev = c->d_lev;
+  A.P = pl->P;
+  for (auto &w : pl->waves) {
+    if (!w.second) continue;
+    A.wave_ctus = pl->d_wave_ctus + w.first;
+    A.n_wave_ctus = (int)w.second;
+    dim3 grid((unsigned)(w.second * n_pics * 3));
+    if (enc)
+      hipLaunchKernelGGL(k_intra_wave<true>, grid, dim3(256), 0, c->stream, A);
+    else
+      hipLaunchKernelGGL(k_intra_wave<false>, grid, dim3(256), 0, c->stream, A);
+  }
+  HIPCHK(c, hipGetLastError());
+  return HMX_OK;
+}
+
+extern "C" int hmx_frame_intra_encode(hmx_ctx *c, const hmx_intra_plan *pl, int n_pics, const hmx_pic *org,
+                                      const hmx_pic *rec, const hmx_levels *lev) {
+  return frame_intra(c, pl, n_pics, org, rec, lev, true);
+}
+extern "C" int hmx_frame_intra_decode(hmx_ctx *c, const hmx_intra_plan *pl, int n_pics, const hmx_pic *rec,
+                                      const hmx_levels *lev) {
+  return frame_intra(c, pl, n_pics, nullptr, rec, lev, false);
+}
+
+// =============================================================================================
+// Scalar drop-ins: host pointers, one block, same kernels (batch of one)
+// =============================================================================================
+namespace {
+struct Scratch { // carve the context's device scratch
+  hmx_ctx *c;
+  size_t off = 0;
+  template <typename T>
+  T *take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T *p = reinterpret_cast<T *>(c->d_scratch + off);
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+int up2d(hmx_ctx *c, void *dst, const void *src, size_t elem, int w, int h, size_t src_stride_elems) {
+  HIPCHK(c, hipMemcpy2DAsync(dst, w * elem, src, src_stride_elems * elem, w * elem, h, hipMemcpyHostToDevice, c->stream));
+  return HMX_OK;
+}
+int down2d(hmx_ctx *c, void *dst, size_t dst_stride_elems, const void *src, size_t elem, int w, int h) {
+  HIPCHK(c, hipMemcpy2DAsync(dst, dst_stride_elems * elem, src, w * elem, w * elem, h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HMX_OK;
+}
+
+struct One { // a one-block launch: dense N x N buffers at plane origin
+  ListArgs A{};
+  DTu *d_tu;
+};
+int one_block(hmx_ctx *c, Scratch &s, One &o, int n, int plane, unsigned mode, unsigned flags, const PicDev &P) {
+  DTu h{};
+  h.t.x = h.t.y = 0;
+  h.t.log2n = (uint8_t)ilog2i(n);
+  h.t.plane = (uint8_t)plane;
+  h.t.mode = (uint8_t)(mode > 255 ? 255 : mode);
+  h.t.flags = (uint8_t)flags;
+  h.idx = 0;
+  o.d_tu = s.take<DTu>(1);
+  HIPCHK(c, hipMemcpyAsync(o.d_tu, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream)); // h is a stack object
+  o.A.tus = o.d_tu;
+  o.A.n = 1;
+  o.A.P = P;
+  return HMX_OK;
+}
+bool size_ok(int w, int h) { return w == h && (w == 4 || w == 8 || w == 16 || w == 32); }
+
+PicDev scalar_picdev(hmx_ctx *c, const hmx_qp *qp, int per_base, int slice_type, int sign_hide) {
+  PicDev P{};
+  P.pic_w = P.pic_h = 1 << 14;
+  P.ctu = c->cfg.ctu_size;
+  P.bit_depth = c->cfg.bit_depth;
+  P.sign_hide = sign_hide;
+  hmx_qp q = qp ? *qp : hmx_qp{0, 0, 0, 15};
+  P.qd[0] = P.qd[1] = make_qd(q, per_base, slice_type);
+  return P;
+}
+} // namespace
+
+// uiMode -> flags: the list kernels derive DST/scan from (plane, INTER flag, mode)
+static unsigned mode_flags(unsigned mode) { return mode == HMX_REG_DCT ? HMX_TU_INTER : 0; }
+
+extern "C" int hmx_xT(hmx_ctx *c, unsigned mode, const hmx_pel *resi, unsigned stride, int32_t *coef, int w, int h) {
+  if (!c || !resi || !coef || !size_ok(w, h)) return fail(c, HMX_ERR_ARG, "hmx_xT: unsupported size or null");
+  Scratch s{c};
+  short *d_in = s.take<short>(w * h);
+  int *d_out = s.take<int>(w * h);
+  int r = up2d(c, d_in, resi, 2, w, h, stride);
+  if (r) return r;
+  One o;
+  if ((r = one_block(c, s, o, w, 0, mode, mode_flags(mode), scalar_picdev(c, nullptr, -1, HMX_I_SLICE, 0)))) return r;
+  o.A.a.p[0] = d_in;
+  o.A.a.s[0] = w;
+  o.A.lev.p[0] = d_out;
+  o.A.lev.s[0] = w;
+  if ((r = launch_op(c, OP_XT, ilog2i(w), o.A))) return r;
+  return down2d(c, coef, w, d_out, 4, w, h);
+}
+
+extern "C" int hmx_xIT(hmx_ctx *c, unsigned mode, const int32_t *coef, hmx_pel *resi, unsigned stride, int w, int h) {
+  if (!c || !resi || !coef || !size_ok(w, h)) return fail(c, HMX_ERR_ARG, "hmx_xIT: unsupported size or null");
+  Scratch s{c};
+  int *d_in = s.take<int>(w * h);
+  short *d_out = s.take<short>(w * h);
+  int r = up2d(c, d_in, coef, 4, w, h, w);
+  if (r) return r;
+  One o;
+  if ((r = one_block(c, s, o, w, 0, mode, mode_flags(mode), scalar_picdev(c, nullptr, -1, HMX_I_SLICE, 0)))) return r;
+  o.A.lev.p[0] = d_in;
+  o.A.lev.s[0] = w;
+  o.A.b.p[0] = d_out;
+  o.A.b.s[0] = w;
+  if ((r = launch_op(c, OP_XIT, ilog2i(w), o.A))) return r;
+  return down2d(c, resi, stride, d_out, 2, w, h);
+}
+
+extern "C" int hmx_xTransformSkip(hmx_ctx *c, const hmx_pel *resi, unsigned stride, int32_t *coef, int w, int h) {
+  if (!c || !resi || !coef || !size_ok(w, h)) return fail(c, HMX_ERR_ARG, "hmx_xTransformSkip: unsupported size or null");
+  Scratch s{c};
+  short *d_in = s.take<short>(w * h);
+  int *d_out = s.take<int>(w * h);
+  int r = up2d(c, d_in, resi, 2, w, h, stride);
+  if (r) return r;
+  One o;
+  if ((r = one_block(c, s, o, w, 0, 0, HMX_TU_TRANSFORM_SKIP, scalar_picdev(c, nullptr, -1, HMX_I_SLICE, 0)))) return r;
+  o.A.a.p[0] = d_in;
+  o.A.a.s[0] = w;
+  o.A.lev.p[0] = d_out;
+  o.A.lev.s[0] = w;
+  if ((r = launch_op(c, OP_XT, ilog2i(w), o.A))) return r;
+  return down2d(c, coef, w, d_out, 4, w, h);
+}
+
+extern "C" int hmx_xITransformSkip(hmx_ctx *c, const int32_t *coef, hmx_pel *resi, unsigned stride, int w, int h) {
+  if (!c || !resi || !coef || !size_ok(w, h)) return fail(c, HMX_ERR_ARG, "hmx_xITransformSkip: unsupported size or null");
+  Scratch s{c};
+  int *d_in = s.take<int>(w * h);
+  short *d_out = s.take<short>(w * h);
+  int r = up2d(c, d_in, coef, 4, w, h, w);
+  if (r) return r;
+  One o;
+  if ((r = one_block(c, s, o, w, 0, 0, HMX_TU_TRANSFORM_SKIP, scalar_picdev(c, nullptr, -1, HMX_I_SLICE, 0)))) return r;
+  o.A.lev.p[0] = d_in;
+  o.A.lev.s[0] = w;
+  o.A.b.p[0] = d_out;
+  o.A.b.s[0] = w;
+  if ((r = launch_op(c, OP_XIT, ilog2i(w), o.A))) return r;
+  return down2d(c, resi, stride, d_out, 2, w, h);
+}
+
+static int plane_of(int text_type) { return text_type == HMX_TEXT_LUMA ? 0 : (text_type == HMX_TEXT_CHROMA_V ? 2 : 1); }
+
+extern "C" int hmx_xQuant(hmx_ctx *c, const int32_t *src, hmx_coeff *dst, int w, int h, uint32_t *ac_sum, int text_type,
+                          const hmx_quant_param *qp) {
+  if (!c || !src || !dst || !qp || !ac_sum || !size_ok(w, h)) return fail(c, HMX_ERR_ARG, "hmx_xQuant: unsupported size or null");
+  Scratch s{c};
+  int *d_in = s.take<int>(w * h), *d_out = s.take<int>(w * h);
+  uint32_t *d_sum = s.take<uint32_t>(1);
+  int r = up2d(c, d_in, src, 4, w, h, w);
+  if (r) return r;
+  One o;
+  unsigned flags = qp->is_intra ? 0 : HMX_TU_INTER;
+  if ((r = one_block(c, s, o, w, plane_of(text_type), qp->dir_mode, flags,
+                     scalar_picdev(c, &qp->qp, qp->per_base, qp->slice_type, qp->sign_hide))))
+    return r;
+  o.A.lev.p[plane_of(text_type)] = d_in;
+  o.A.lev.s[plane_of(text_type)] = w;
+  o.A.lev2.p[plane_of(text_type)] = d_out;
+  o.A.lev2.s[plane_of(text_type)] = w;
+  o.A.abs_sum = d_sum;
+  if ((r = launch_op(c, OP_XQUANT, ilog2i(w), o.A))) return r;
+  uint32_t hs = 0;
+  HIPCHK(c, hipMemcpyAsync(&hs, d_sum, 4, hipMemcpyDeviceToHost, c->stream));
+  r = down2d(c, dst, w, d_out, 4, w, h);
+  *ac_sum += hs; // uiAcSum is accumulated by reference (:1256)
+  return r;
+}
+
+extern "C" int hmx_xDeQuant(hmx_ctx *c, const hmx_coeff *src, int32_t *dst, int w, int h, const hmx_qp *qp) {
+  if (!c || !src || !dst || !qp || !size_ok(w, h)) return fail(c, HMX_ERR_ARG, "hmx_xDeQuant: unsupported size or null");
+  Scratch s{c};
+  int *d_in = s.take<int>(w * h), *d_out = s.take<int>(w * h);
+  int r = up2d(c, d_in, src, 4, w, h, w);
+  if (r) return r;
+  One o;
+  if ((r = one_block(c, s, o, w, 0, 0, 0, scalar_picdev(c, qp, -1, HMX_I_SLICE, 0)))) return r;
+  o.A.lev.p[0] = d_in;
+  o.A.lev.s[0] = w;
+  o.A.lev2.p[0] = d_out;
+  o.A.lev2.s[0] = w;
+  if ((r = launch_op(c, OP_XDEQUANT, ilog2i(w), o.A))) return r;
+  return down2d(c, dst, w, d_out, 4, w, h);
+}
+
+extern "C" int hmx_transformNxN(hmx_ctx *c, const hmx_pel *resi, unsigned stride, hmx_coeff *level, unsigned w, unsigned h,
+                                uint32_t *abs_sum, int text_type, const hmx_quant_param *qp, int use_ts, int bypass) {
+  if (!c || !resi || !level || !qp || !abs_sum || !size_ok((int)w, (int)h))
+    return fail(c, HMX_ERR_ARG, "hmx_transformNxN: unsupported size or null");
+  if (bypass) { // TComTrQuant.cpp:1388-1399: a copy, no arithmetic to offload
+    *abs_sum = 0;
+    for (unsigned k = 0; k < h; k++)
+      for (unsigned j = 0; j < w; j++) {
+        level[k * w + j] = resi[k * stride + j];
+        *abs_sum += (uint32_t)abs((int)resi[k * stride + j]);
+      }
+    return HMX_OK;
+  }
+  Scratch s{c};
+  const int pl = plane_of(text_type);
+  short *d_in = s.take<short>(w * h);
+  int *d_out = s.take<int>(w * h);
+  uint32_t *d_sum = s.take<uint32_t>(1);
+  int r = up2d(c, d_in, resi, 2, (int)w, (int)h, stride);
+  if (r) return r;
+  One o;
+  unsigned flags = (qp->is_intra ? 0 : HMX_TU_INTER) | (use_ts ? HMX_TU_TRANSFORM_SKIP : 0);
+  if ((r = one_block(c, s, o, (int)w, pl, qp->dir_mode, flags,
+                     scalar_picdev(c, &qp->qp, qp->per_base, qp->slice_type, qp->sign_hide))))
+    return r;
+  o.A.a.p[pl] = d_in;
+  o.A.a.s[pl] = (int)w;
+  o.A.lev.p[pl] = d_out;
+  o.A.lev.s[pl] = (int)w;
+  o.A.abs_sum = d_sum;
+  if ((r = launch_op(c, OP_TRANSFORM_NXN, ilog2i((int)w), o.A))) return r;
+  HIPCHK(c, hipMemcpyAsync(abs_sum, d_sum, 4, hipMemcpyDeviceToHost, c->stream));
+  return down2d(c, level, w, d_out, 4, (int)w, (int)h);
+}
+
+extern "C" int hmx_invtransformNxN(hmx_ctx *c, int bypass, int text_type, unsigned mode, hmx_pel *resi, unsigned stride,
+                                   const hmx_coeff *level, unsigned w, unsigned h, const hmx_qp *qp, int use_ts) {
+  if (!c || !resi || !level || !qp || !size_ok((int)w, (int)h))
+    return fail(c, HMX_ERR_ARG, "hmx_invtransformNxN: unsupported size or null");
+  if (bypass) { // :1430-1440
+    for (unsigned k = 0; k < h; k++)
+      for (unsigned j = 0; j < w; j++) resi[k * stride + j] = (hmx_pel)level[k * w + j];
+    return HMX_OK;
+  }
+  Scratch s{c};
+  const int pl = plane_of(text_type);
+  int *d_in = s.take<int>(w * h);
+  short *d_out = s.take<short>(w * h);
+  int r = up2d(c, d_in, level, 4, (int)w, (int)h, w);
+  if (r) return r;
+  One o;
+  // the caller passes uiMode explicitly here (REG_DCT for chroma / inter), like the reference
+  unsigned flags = (mode == HMX_REG_DCT ? HMX_TU_INTER : 0) | (use_ts ? HMX_TU_TRANSFORM_SKIP : 0);
+  // DST is selected by (luma plane && !INTER); a chroma call with a luma mode must still be DCT
+  if ((r = one_block(c, s, o, (int)w, mode == HMX_REG_DCT ? pl : 0, mode, flags, scalar_picdev(c, qp, -1, HMX_I_SLICE, 0))))
+    return r;
+  const int kp = mode == HMX_REG_DCT ? pl : 0;
+  o.A.lev.p[kp] = d_in;
+  o.A.lev.s[kp] = (int)w;
+  o.A.b.p[kp] = d_out;
+  o.A.b.s[kp] = (int)w;
+  if ((r = launch_op(c, OP_INVTRANSFORM_NXN, ilog2i((int)w), o.A))) return r;
+  return down2d(c, resi, stride, d_out, 2, (int)w, (int)h);
+}
+
+// =============================================================================================
+// Intra scalar drop-ins: initAdiPattern, predIntraLumaAng / predIntraChromaAng
+// =============================================================================================
+template <int N>
+__global__ __launch_bounds__(64) void k_adi(const short *win, int stride, int bx, int by, int x, int y, int chroma,
+                                            PicDev P, int *adi) {
+  __shared__ TuLds<N> L;
+  const int gl = threadIdx.x;
+  const bool on = gl < N;
+  constexpr int W = 2 * N + 1;
+  if (on) {
+    unsigned long long avail = intra_avail_mask(x << chroma, y << chroma, N << chroma, P);
+    build_ref_line<N>(win + (size_t)by * stride + bx, stride, avail, chroma ? 1 : 2, P.bit_depth, gl, L.line);
+  }
+  __syncthreads();
+  if (on && !chroma) smooth_ref_line<N>(L.line, L.fline, gl);
+  __syncthreads();
+  // reference layout: row 0 = corner + 2N above, column 0 = 2N left; second buffer = smoothed (luma)
+  for (int i = threadIdx.x; i < 2 * W * W; i += blockDim.x) adi[i] = 0;
+  __syncthreads();
+  if (on) {
+    for (int p = gl; p <= 4 * N; p += N) {
+      int cell = p >= 2 * N ? p - 2 * N : (2 * N - p) * W;
+      adi[cell] = L.line[p];
+      if (!chroma) adi[W * W + cell] = L.fline[p];
+    }
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void k_pred_adi(const int *adi, int mode, int luma, PicDev P, short *pred) {
+  __shared__ TuLds<N> L;
+  const int gl = threadIdx.x;
+  constexpr int W = 2 * N + 1;
+  if (gl < N) {
+    for (int p = gl; p <= 4 * N; p += N) {
+      int cell = p >= 2 * N ? p - 2 * N : (2 * N - p) * W;
+      L.line[p] = adi[cell];
+      L.fline[p] = luma ? adi[W * W + cell] : 0;
+    }
+  }
+  __syncthreads();
+  if (gl < N) {
+    int row[N];
+    intra_pred_block<N>(L, gl, mode, luma != 0, P, row);
+    store_row16<N>(pred + gl * N, row);
+  }
+}
+
+extern "C" int hmx_initAdiPattern(hmx_ctx *c, const hmx_pel *rec, int stride, int x, int y, int n, int is_chroma,
+                                  int pic_w, int pic_h, int32_t *adi) {
+  if (!c || !rec || !adi || !size_ok(n, n)) return fail(c, HMX_ERR_ARG, "hmx_initAdiPattern: unsupported size or null");
+  const int pw = is_chroma ? pic_w / 2 : pic_w, ph = is_chroma ? pic_h / 2 : pic_h;
+  if (x < 0 || y < 0 || x + n > pw || y + n > ph) return fail(c, HMX_ERR_ARG, "hmx_initAdiPattern: block outside picture");
+  const int x0 = std::max(x - 1, 0), y0 = std::max(y - 1, 0), x1 = std::min(x + 2 * n, pw), y1 = std::min(y + 2 * n, ph);
+  const int ww = x1 - x0, wh = y1 - y0, W = 2 * n + 1;
+  Scratch s{c};
+  short *d_win = s.take<short>((size_t)ww * wh);
+  int *d_adi = s.take<int>((size_t)2 * W * W);
+  int r = up2d(c, d_win, rec + (size_t)y0 * stride + x0, 2, ww, wh, stride);
+  if (r) return r;
+  hmx_pic_param pp{pic_w, pic_h, 0, 0, HMX_I_SLICE, 0};
+  PicDev P = make_picdev(c, &pp);
+  const int bx = x - x0, by = y - y0;
+  switch (n) {
+  case 4: hipLaunchKernelGGL(k_adi<4>, dim3(1), dim3(64), 0, c->stream, d_win, ww, bx, by, x, y, is_chroma, P, d_adi); break;
+  case 8: hipLaunchKernelGGL(k_adi<8>, dim3(1), dim3(64), 0, c->stream, d_win, ww, bx, by, x, y, is_chroma, P, d_adi); break;
+  case 16: hipLaunchKernelGGL(k_adi<16>, dim3(1), dim3(64), 0, c->stream, d_win, ww, bx, by, x, y, is_chroma, P, d_adi); break;
+  default: hipLaunchKernelGGL(k_adi<32>, dim3(1), dim3(64), 0, c->stream, d_win, ww, bx, by, x, y, is_chroma, P, d_adi); break;
+  }
+  HIPCHK(c, hipGetLastError());
+  return hmx_download(c, adi, d_adi, sizeof(int) * 2 * W * W);
+}
+
+static int pred_from_adi(hmx_ctx *c, const int32_t *adi, unsigned mode, hmx_pel *pred, unsigned stride, int w, int h,
+                         int luma) {
+  if (!c || !adi || !pred || !size_ok(w, h) || mode > 34) return fail(c, HMX_ERR_ARG, "predIntra: unsupported size/mode or null");
+  const int W = 2 * w + 1;
+  Scratch s{c};
+  int *d_adi = s.take<int>((size_t)2 * W * W);
+  short *d_pred = s.take<short>((size_t)w * h);
+  int r = hmx_upload(c, d_adi, adi, sizeof(int) * (luma ? 2 : 1) * W * W);
+  if (r) return r;
+  hmx_pic_param pp{1 << 14, 1 << 14, 0, 0, HMX_I_SLICE, 0};
+  PicDev P = make_picdev(c, &pp);
+  switch (w) {
+  case 4: hipLaunchKernelGGL(k_pred_adi<4>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred); break;
+  case 8: hipLaunchKernelGGL(k_pred_adi<8>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred); break;
+  case 16: hipLaunchKernelGGL(k_pred_adi<16>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred); break;
+  default: hipLaunchKernelGGL(k_pred_adi<32>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred); break;
+  }
+  HIPCHK(c, hipGetLastError());
+  return down2d(c, pred, stride, d_pred, 2, w, h);
+}
+extern "C" int hmx_predIntraLumaAng(hmx_ctx *c, const int32_t *adi, unsigned mode, hmx_pel *pred, unsigned stride, int w,
+                                    int h) {
+  return pred_from_adi(c, adi, mode, pred, stride, w, h, 1);
+}
+extern "C" int hmx_predIntraChromaAng(hmx_ctx *c, const int32_t *adi, unsigned mode, hmx_pel *pred, unsigned stride, int w,
+                                      int h) {
+  return pred_from_adi(c, adi, mode, pred, stride, w, h, 0);
+}
+
+// =============================================================================================
+// Interpolation (TComInterpolationFilter.cpp), addAvg, motion compensation, border extension
+// =============================================================================================
+__device__ __forceinline__ int luma_tap(int frac, int t) {
+  constexpr signed char k[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1},
+                                   {0, 1, -5, 17, 58, -10, 4, -1}};
+  return k[frac][t];
+}
+__device__ __forceinline__ int chroma_tap(int frac, int t) {
+  constexpr signed char k[8][4] = {{0, 64, 0, 0},   {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4},
+                                   {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
+  return k[frac][t];
+}
+
+// One output sample of filterHor*/filterVer* incl. the frac == 0 filterCopy cases (:91-244).
+// src points at the sample co-located with the output; step = 1 (horizontal) or the stride.
+template <int NTAP>
+__device__ __forceinline__ int interp_sample(const short *src, int step, int frac, bool first, bool last, int B) {
+  const int head = 14 - B, maxv = (1 << B) - 1;
+  if (frac == 0) {
+    int v = src[0];
+    if (first == last) return v;
+    if (first) return wrap16(wrap16(v << head) - 8192);
+    int off = wrap16(8192 + (head ? (1 << (head - 1)) : 0));
+    return clip3(0, maxv, wrap16((v + off) >> head));
+  }
+  int shift = 6, offset;
+  if (last) {
+    shift += first ? 0 : head;
+    offset = (1 << (shift - 1)) + (first ? 0 : 8192 << 6);
+  } else {
+    shift -= first ? head : 0;
+    offset = first ? -(8192 << shift) : 0;
+  }
+  int sum = 0;
+#pragma unroll
+  for (int t = 0; t < NTAP; t++) sum += src[(t - (NTAP / 2 - 1)) * step] * (NTAP == 8 ? luma_tap(frac, t) : chroma_tap(frac, t));
+  int v = wrap16((sum + offset) >> shift); // narrowed to Short before the clip (:232-236)
+  return last ? clip3(0, maxv, v) : v;
+}
+
+__global__ void k_filter(const short *src, int ss, short *dst, int ds, int w, int h, int frac, int chroma, int vertical,
+                         int first, int last, int B) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w * h) return;
+  int r = i / w, col = i % w;
+  const short *p = src + (size_t)r * ss + col;
+  int step = vertical ? ss : 1;
+  dst[(size_t)r * ds + col] =
+      (short)(chroma ? interp_sample<4>(p, step, frac, first, last, B) : interp_sample<8>(p, step, frac, first, last, B));
+}
+
+static int filter_scalar(hmx_ctx *c, const hmx_pel *src, int ss, int16_t *dst, int ds, int w, int h, int frac, int chroma,
+                         int vertical, int first, int last) {
+  if (!c || !src || !dst || w <= 0 || h <= 0 || w > 128 || h > 128 || frac < 0 || frac >= (chroma ? 8 : 4))
+    return fail(c, HMX_ERR_ARG, "filter: bad argument");
+  const int before = frac ? (chroma ? 1 : 3) : 0, after = frac ? (chroma ? 2 : 4) : 0;
+  const int ww = w + (vertical ? 0 : before + after), wh = h + (vertical ? before + after : 0);
+  Scratch s{c};
+  short *d_in = s.take<short>((size_t)ww * wh), *d_out = s.take<short>((size_t)w * h);
+  const hmx_pel *h0 = src - (vertical ? (ptrdiff_t)before * ss : before);
+  int r = up2d(c, d_in, h0, 2, ww, wh, ss);
+  if (r) return r;
+  const short *d_org = d_in + (vertical ? before * ww : before);
+  hipLaunchKernelGGL(k_filter, dim3((w * h + 255) / 256), dim3(256), 0, c->stream, d_org, ww, d_out, w, w, h, frac, chroma,
+                     vertical, first, last, c->cfg.bit_depth);
+  HIPCHK(c, hipGetLastError());
+  return down2d(c, dst, ds, d_out, 2, w, h);
+}
+extern "C" int hmx_filterHorLuma(hmx_ctx *c, const hmx_pel *src, int ss, int16_t *dst, int ds, int w, int h, int frac,
+                                 int is_last) {
+  return filter_scalar(c, src, ss, dst, ds, w, h, frac, 0, 0, 1, is_last);
+}
+extern "C" int hmx_filterVerLuma(hmx_ctx *c, const hmx_pel *src, int ss, int16_t *dst, int ds, int w, int h, int frac,
+                                 int is_first, int is_last) {
+  return filter_scalar(c, src, ss, dst, ds, w, h, frac, 0, 1, is_first, is_last);
+}
+extern "C" int hmx_filterHorChroma(hmx_ctx *c, const hmx_pel *src, int ss, int16_t *dst, int ds, int w, int h, int frac,
+                                   int is_last) {
+  return filter_scalar(c, src, ss, dst, ds, w, h, frac, 1, 0, 1, is_last);
+}
+extern "C" int hmx_filterVerChroma(hmx_ctx *c, const hmx_pel *src, int ss, int16_t *dst, int ds, int w, int h, int frac,
+                                   int is_first, int is_last) {
+  return filter_scalar(c, src, ss, dst, ds, w, h, frac, 1, 1, is_first, is_last);
+}
+
+__device__ __forceinline__ int add_avg(int a, int b, int B) { // TComYuv.cpp:539-540
+  const int sh = 15 - B, off = (1 << (sh - 1)) + 2 * 8192;
+  return clip3(0, (1 << B) - 1, (a + b + off) >> sh);
+}
+__global__ void k_addavg(const short *a, const short *b, short *d, int n, int B) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = (short)add_avg(a[i], b[i], B);
+}
+extern "C" int hmx_addAvg(hmx_ctx *c, const hmx_pel *s0, int s0s, const hmx_pel *s1, int s1s, hmx_pel *dst, int ds, int w,
+                          int h) {
+  if (!c || !s0 || !s1 || !dst || w <= 0 || h <= 0 || w > 128 || h > 128) return fail(c, HMX_ERR_ARG, "hmx_addAvg: bad argument");
+  Scratch s{c};
+  short *da = s.take<short>((size_t)w * h), *db = s.take<short>((size_t)w * h), *dd = s.take<short>((size_t)w * h);
+  int r = up2d(c, da, s0, 2, w, h, s0s);
+  if (!r) r = up2d(c, db, s1, 2, w, h, s1s);
+  if (r) return r;
+  hipLaunchKernelGGL(k_addavg, dim3((w * h + 255) / 256), dim3(256), 0, c->stream, da, db, dd, w * h, c->cfg.bit_depth);
+  HIPCHK(c, hipGetLastError());
+  return down2d(c, dst, ds, dd, 2, w, h);
+}
+
+// ---- motionCompensation over a PU list: one workgroup per (PU, plane) ----
+struct McArgs {
+  const hmx_pu *pus;
+  int n;
+  const PlanesDev *refs; // [n_refs]
+  PlanesDev dst;
+  int B;
+};
+
+// prediction of one list into out[] (dense w x h, stride 64): xPredInterLumaBlk / ChromaBlk, :554-642
+template <int NTAP>
+__device__ __forceinline__ void mc_one_list(const short *ref, int rs, int mvx, int mvy, int w, int h, bool bi, int B, short *tmp,
+                                            short *out, int os) {
+  constexpr int SH = NTAP == 8 ? 2 : 3, MASK = (1 << SH) - 1, HALF = NTAP / 2;
+  ref += (mvx >> SH) + (ptrdiff_t)(mvy >> SH) * rs;
+  const int xf = mvx & MASK, yf = mvy & MASK;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  if (yf == 0) {
+    for (int i = tid; i < w * h; i += nt) {
+      int r = i / w, cc = i % w;
+      out[r * os + cc] = (short)interp_sample<NTAP>(ref + (ptrdiff_t)r * rs + cc, 1, xf, true, !bi, B);
+    }
+  } else if (xf == 0) {
+    for (int i = tid; i < w * h; i += nt) {
+      int r = i / w, cc = i % w;
+      out[r * os + cc] = (short)interp_sample<NTAP>(ref + (ptrdiff_t)r * rs + cc, rs, yf, true, !bi, B);
+    }
+  } else {
+    const int th = h + NTAP - 1;
+    for (int i = tid; i < w * th; i += nt) {
+      int r = i / w, cc = i % w;
+      tmp[r * 64 + cc] = (short)interp_sample<NTAP>(ref + (ptrdiff_t)(r - (HALF - 1)) * rs + cc, 1, xf, true, false, B);
+    }
+    __syncthreads();
+    for (int i = tid; i < w * h; i += nt) {
+      int r = i / w, cc = i % w;
+      out[r * os + cc] = (short)interp_sample<NTAP>(tmp + (r + HALF - 1) * 64 + cc, 64, yf, false, !bi, B);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mc(McArgs A) {
+  __shared__ short tmp[(64 + 7) * 64];
+  __shared__ short pb[2][64 * 64];
+  const int pu_i = blockIdx.x / 3, pl = blockIdx.x % 3;
+  const hmx_pu u = A.pus[pu_i];
+  const int c = pl ? 1 : 0, x = u.x >> c, y = u.y >> c, w = u.w >> c, h = u.h >> c;
+  const bool bi = u.ref0 != 255 && u.ref1 != 255;
+  short *d = A.dst.p[pl] + (size_t)y * A.dst.s[pl] + x;
+  for (int l = 0; l < 2; l++) {
+    const int ri = l ? u.ref1 : u.ref0;
+    if (ri == 255) continue; // uniform over the workgroup
+    const PlanesDev &R = A.refs[ri];
+    const short *ref = R.p[pl] + (ptrdiff_t)y * R.s[pl] + x;
+    const int mvx = l ? u.mv1x : u.mv0x, mvy = l ? u.mv1y : u.mv0y;
+    short *out = bi ? pb[l] : d;
+    const int os = bi ? 64 : A.dst.s[pl];
+    if (pl == 0)
+      mc_one_list<8>(ref, R.s[pl], mvx, mvy, w, h, bi, A.B, tmp, out, os);
+    else
+      mc_one_list<4>(ref, R.s[pl], mvx, mvy, w, h, bi, A.B, tmp, out, os);
+    __syncthreads();
+  }
+  if (bi)
+    for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
+      int r = i / w, cc = i % w;
+      d[(size_t)r * A.dst.s[pl] + cc] = (short)add_avg(pb[0][r * 64 + cc], pb[1][r * 64 + cc], A.B);
+    }
+}
+
+extern "C" int hmx_batch_motionCompensation(hmx_ctx *c, const hmx_pu *d_pus, int n, const hmx_pic *refs, int n_refs,
+                                            const hmx_pic *dst) {
+  if (!c || !d_pus || !refs || !dst || n_refs <= 0 || n_refs > 16) return fail(c, HMX_ERR_ARG, "hmx_batch_motionCompensation: bad argument");
+  if (n <= 0) return HMX_OK;
+  if (n_refs > c->pic_cap) { // reuse the picture-table allocation of the frame path
+    hipFree(c->d_org);
+    hipFree(c->d_rec);
+    hipFree(c->d_lev);
+    c->pic_cap = 0;
+    if (hipMalloc((void **)&c->d_org, sizeof(PlanesDev) * 16) != hipSuccess ||
+        hipMalloc((void **)&c->d_rec, sizeof(PlanesDev) * 16) != hipSuccess ||
+        hipMalloc((void **)&c->d_lev, sizeof(LevelsDev) * 16) != hipSuccess)
+      return fail(c, HMX_ERR_NOMEM, "hipMalloc picture tables");
+    c->pic_cap = 16;
+  }
+  PlanesDev hr[16];
+  for (int i = 0; i < n_refs; i++) hr[i] = to_dev(&refs[i]);
+  HIPCHK(c, hipMemcpyAsync(c->d_rec, hr, sizeof(PlanesDev) * n_refs, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  McArgs A;
+  A.pus = d_pus;
+  A.n = n;
+  A.refs = c->d_rec;
+  A.dst = to_dev(dst);
+  A.B = c->cfg.bit_depth;
+  hipLaunchKernelGGL(k_mc, dim3((unsigned)n * 3), dim3(256), 0, c->stream, A);
+  HIPCHK(c, hipGetLastError());
+  return HMX_OK;
+}
+
+// ---- extendPicBorder: left/right first, then whole extended rows up and down ----
+__global__ void k_border_lr(short *org, int stride, int w, int h, int mx) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= h * mx) return;
+  int y = i / mx, k = i % mx + 1;
+  short *row = org + (size_t)y * stride;
+  row[-k] = row[0];
+  row[w - 1 + k] = row[w - 1];
+}
+__global__ void k_border_tb(short *org, int stride, int w, int h, int mx, int my) {
+  const int ww = w + 2 * mx;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ww * my) return;
+  int k = i / ww + 1, x = i % ww - mx;
+  org[-(ptrdiff_t)k * stride + x] = org[x];
+  org[(ptrdiff_t)(h - 1 + k) * stride + x] = org[(ptrdiff_t)(h - 1) * stride + x];
+}
+extern "C" int hmx_pic_extend_border(hmx_ctx *c, const hmx_pic *pic, int pic_w, int pic_h, int mx, int my) {
+  if (!c || !pic || mx < 0 || my < 0) return fail(c, HMX_ERR_ARG, "hmx_pic_extend_border: bad argument");
+  for (int p = 0; p < 3; p++) {
+    const int sh = p ? 1 : 0, w = pic_w >> sh, h = pic_h >> sh, pmx = mx >> sh, pmy = my >> sh;
+    if (pmx) hipLaunchKernelGGL(k_border_lr, dim3((h * pmx + 255) / 256), dim3(256), 0, c->stream, pic->plane[p], pic->stride[p], w, h, pmx);
+    if (pmy)
+      hipLaunchKernelGGL(k_border_tb, dim3(((w + 2 * pmx) * pmy + 255) / 256), dim3(256), 0, c->stream, pic->plane[p],
+                         pic->stride[p], w, h, pmx, pmy);
+  }
+  HIPCHK(c, hipGetLastError());
+  return HMX_OK;
+}
+
+extern "C" void hmx_clipMv(int *mvx, int *mvy, int cu_x, int cu_y, int pic_w, int pic_h, int ctu) {
+  const int hmax = (pic_w + 8 - cu_x - 1) << 2, hmin = (-ctu - 8 - cu_x + 1) * 4; // TComDataCU.cpp:3505-3517
+  const int vmax = (pic_h + 8 - cu_y - 1) << 2, vmin = (-ctu - 8 - cu_y + 1) * 4;
+  *mvx = std::min(hmax, std::max(hmin, *mvx));
+  *mvy = std::min(vmax, std::max(vmin, *mvy));
+}
