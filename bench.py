@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the HM block hot path on MI355X.
+
+Metric (BASELINE.json): Mpixels/sec through transform + pred (+MC), all-intra, bit-exact vs HM.
+One "step" = one pass of the all-intra chain (refs <- recon, intra prediction, residual, T, Q, IQ,
+IT, reconstruction) over a batch of synthetic pictures that is resident in HBM before the timed
+region starts.  Weak scaling: every rank (one process per GPU) owns its own batch of pictures
+(IntraPeriod 1 => pictures are independent, no data-path collective).
+
+    python bench.py --gpus N --steps K --warmup W [--workload ai2160p10|ai2160p8|ai1080p8] [--frames F]
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (k_intra_wave) against the
+HBM peak with ALGORITHMIC bytes; `cpu_baseline` times the reference's own CPU
+functions (oracle/_ref, kind "reference") or, if that library is absent, the CPU oracle (kind "port")
+on a bounded sample of the same workload, rank 0 at N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (width, height, bit depth, qp, BASELINE.json config it stands for)
+    "ai2160p10": (3840, 2160, 10, 32, "configs[4] All-intra he10 3840x2160 10-bit"),
+    "ai2160p8": (3840, 2160, 8, 32, "all-intra main 3840x2160 8-bit (metric's 2160p all-intra, main profile)"),
+    "ai1080p8": (1920, 1080, 8, 32, "configs[1] All-intra main 1920x1080 8-bit"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(tus, n_pics):
+    """Bytes the all-intra chain must move per step: per sample 2 (original) +
+    4 (level written) + 2 (reconstruction written), plus the 4N+1 reference samples (2 B) each block
+    gathers from the reconstruction."""
+    n = (1 << tus["log2n"].astype(np.int64))
+    return int(((n * n) * 8 + (4 * n + 1) * 2).sum()) * n_pics
+
+
+def cpu_baseline(tus, w, h, B, qp, seconds_target=15.0):
+    """Time the CPU path on one picture of the same workload (one thread)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from thevc_amd import workload
+
+    org = workload.make_planes(100, w, h, B, "texture")
+    kind = "reference" if ol.have_ref() else "port"
+    fn = ol.r_intra_frame_encode if kind == "reference" else ol.o_intra_frame_encode
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        fn(tus, w, h, B, qp, org)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds_target or n >= 8:
+            break
+    return {"value": round(n * w * h / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": kind,
+            "sample": f"{n} picture(s) {w}x{h} of the same block structure, single thread, "
+                      + ("HM's own functions from oracle/_ref" if kind == "reference" else "CPU oracle (oracle/hmx_oracle.c)")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="ai2160p10", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=32, help="pictures per GPU per step")
+    ap.add_argument("--tiling", default="mix", help="mix | 4 | 8 | 16 | 32 (uniform transform size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="check picture 0 against the oracle after the run")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from thevc_amd import capi, workload
+
+    w, h, B, qp, cfg_name = WORKLOADS[args.workload]
+    h_c = h - (h % 8)  # pictures are coded in multiples of the minimum CU (8): 1080 -> 1072 + cropped row
+    tiling = args.tiling if args.tiling == "mix" else int(args.tiling)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = capi.Context(bit_depth=B, device=local_rank, stream=stream)
+    L = capi.lib()
+    tus = workload.make_tus(1, w, h_c, tiling)
+    pp = capi.PicParam(w, h_c, qp, 0, capi.I_SLICE, 1)
+    plan = ctx.intra_plan(tus, pp)
+
+    F = args.frames
+    n_src = min(F, 4)  # distinct synthetic pictures, cycled over the batch (per-rank seeds)
+    src = [workload.make_planes(1000 * rank + i, w, h_c, B, "texture") for i in range(n_src)]
+    d_org = [capi.DevPicture(ctx, w, h_c).upload(src[i % n_src]) for i in range(F)]
+    d_rec = [capi.DevPicture(ctx, w, h_c).zero() for _ in range(F)]
+    d_lev = [capi.DevPicture(ctx, w, h_c, dtype=np.int32).zero() for _ in range(F)]
+    org_arr = (capi.Pic * F)(*[d.as_pic() for d in d_org])
+    rec_arr = (capi.Pic * F)(*[d.as_pic() for d in d_rec])
+    lev_arr = (capi.Levels * F)(*[d.as_pic() for d in d_lev])
+
+    def step():
+        ctx._chk(L.hmx_frame_intra_encode(ctx.h, plan, F, org_arr, rec_arr, lev_arr))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = ctx.event(), ctx.event()
+    t0 = time.perf_counter()
+    ctx.record(ev0)
+    for _ in range(args.steps):
+        step()
+    ctx.record(ev1)
+    fence()
+    dt = time.perf_counter() - t0
+    kernel_ms = ctx.elapsed_ms(ev0, ev1)  # HIP events on the stream the kernels run on
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    verified = None
+    if args.verify and rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as ol
+        rec, lev = d_rec[0].download(), d_lev[0].download()
+        ro, lo = ol.o_intra_frame_encode(tus, w, h_c, B, qp, src[0])
+        verified = all(np.array_equal(rec[p], ro[p]) and np.array_equal(lev[p], lo[p]) for p in range(3))
+
+    if rank == 0:
+        px_step = w * h_c * F
+        n_launch = (-(-w // 64) - 1) + 2 * (-(-h_c // 64) - 1) + 1  # CTU diagonals = launches per step
+        bytes_step = algorithmic_bytes(tus, F)
+        ach = bytes_step * args.steps / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mpixels/sec transform+pred+MC, 2160p all-intra, 1/2/4/8 MI355X; bit-exact vs HM",
+            "value": round(px_step * args.steps * world / dt / 1e6, 2),
+            "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {cfg_name}; all-intra chain (intra refs+pred, T, flat Q+SBH, IQ, IT, recon), "
+                                   f"{F} pictures {w}x{h_c} per GPU per step, QP {qp}, TU tiling '{args.tiling}' "
+                                   f"({len(tus)} blocks/picture), frames sharded over ranks, no collective",
+                       "pictures_per_gpu": F, "width": w, "height": h_c, "bit_depth": B, "qp": qp, "tiling": str(args.tiling)},
+            "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "k_intra_wave<true>", "launches_per_step": n_launch,
+                         "algorithmic_bytes_per_launch": round(bytes_step / n_launch),
+                         "avg_launch_us": round(kernel_ms * 1e3 / args.steps / n_launch, 2)},
+        }
+        if verified is not None:
+            out["verified_bit_exact_vs_oracle"] = bool(verified)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(tus, w, h_c, B, qp)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

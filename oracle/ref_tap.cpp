@@ -371,4 +371,78 @@ void ref_extended_luma(short *out) {
 }
 int ref_luma_margin() { return S->pic->getPicYuvRec()->m_iLumaMarginX; }
 
+// ---- whole-picture all-intra reconstruction with the reference's OWN functions ----
+// The hot loop of ENC/TEncSearch.cpp:1006-1165 (luma) / 1167-1390 (chroma) with RDOQ off, driven
+// from a decision list: initAdiPattern[Chroma] (neighbour availability from the reference's
+// getPU* functions on the real TComPic) -> predIntraLumaAng/ChromaAng -> residual ->
+// transformNxN -> invtransformNxN -> Clip(pred + resi) into the picture's reconstruction.
+// Used (a) to pin the oracle's frame driver and (b) as bench.py's "reference" CPU baseline.
+struct RefTu {
+  unsigned short x, y;
+  unsigned char log2n, plane, mode, flags;
+};
+void ref_intra_frame_encode(const RefTu *tus, int n_tu, int qp, const short *org_y, const short *org_cb,
+                            const short *org_cr, short *rec_y, short *rec_cb, short *rec_cr, int *lev_y, int *lev_cb,
+                            int *lev_cr) {
+  TComPicYuv *r = S->pic->getPicYuvRec();
+  const short *org[3] = {org_y, org_cb, org_cr};
+  int *lev[3] = {lev_y, lev_cb, lev_cr};
+  Pel *rp[3] = {r->getLumaAddr(), r->getCbAddr(), r->getCrAddr()};
+  int rs[3] = {r->getStride(), r->getCStride(), r->getCStride()};
+  int pw[3] = {S->pic_w, S->pic_w / 2, S->pic_w / 2}, ph[3] = {S->pic_h, S->pic_h / 2, S->pic_h / 2};
+  for (int p = 0; p < 3; p++)
+    for (int j = 0; j < ph[p]; j++) memset(rp[p] + j * rs[p], 0, 2 * pw[p]);
+  static short pred[32 * 32], resi[32 * 32];
+  static int lvl[32 * 32];
+  TComSlice *sl = S->pic->getSlice(0);
+  sl->setSliceType(I_SLICE);
+  sl->setSliceQp(qp);
+  sl->setSliceQpBase(qp);
+  const int maxv = (int)g_uiIBDI_MAX;
+  for (int i = 0; i < n_tu; i++) {
+    const RefTu &t = tus[i];
+    const int N = 1 << t.log2n, p = t.plane, ts = t.flags & 1;
+    Bool a, l;
+    if (p == 0) {
+      TComDataCU *c;
+      int depth = 0, part = 0;
+      if (N == 4) {
+        c = setup_sub(t.x & ~7, t.y & ~7, 8);
+        depth = 1;
+        part = ((t.y >> 2) & 1) * 2 + ((t.x >> 2) & 1);
+      } else
+        c = setup_sub(t.x, t.y, N);
+      S->pattern.initAdiPattern(c, part, depth, S->pred.m_piYuvExt, S->pred.m_iYuvExtStride, S->pred.m_iYuvExtHeight,
+                                a, l, false);
+      S->pred.predIntraLumaAng(&S->pattern, t.mode, pred, N, N, N, c, a, l);
+    } else {
+      TComDataCU *c = setup_sub(t.x * 2, t.y * 2, 2 * N);
+      S->pattern.initAdiPatternChroma(c, 0, 0, S->pred.m_piYuvExt, S->pred.m_iYuvExtStride, S->pred.m_iYuvExtHeight, a, l);
+      Int *src = p == 1 ? S->pattern.getAdiCbBuf(N, N, S->pred.m_piYuvExt) : S->pattern.getAdiCrBuf(N, N, S->pred.m_piYuvExt);
+      S->pred.predIntraChromaAng(&S->pattern, src, t.mode, pred, N, N, N, c, a, l);
+    }
+    const short *o = org[p] + t.y * pw[p] + t.x;
+    for (int j = 0; j < N; j++)
+      for (int k = 0; k < N; k++) resi[j * N + k] = o[j * pw[p] + k] - pred[j * N + k];
+    unsigned abs_sum = 0;
+    const int ttype = p == 0 ? 0 : p + 1; // TEXT_LUMA, TEXT_CHROMA_U, TEXT_CHROMA_V
+    ref_transformNxN(qp, I_SLICE, ttype, 1, t.mode, ts, 0, resi, N, lvl, N, &abs_sum);
+    if (abs_sum)
+      ref_invtransformNxN(qp, ttype, 0, p == 0 ? t.mode : REG_DCT, resi, N, lvl, N, ts);
+    else
+      memset(resi, 0, sizeof(short) * N * N);
+    Pel *d = rp[p] + t.y * rs[p] + t.x;
+    int *lo = lev[p] + t.y * pw[p] + t.x;
+    for (int j = 0; j < N; j++)
+      for (int k = 0; k < N; k++) {
+        int v = pred[j * N + k] + resi[j * N + k];
+        d[j * rs[p] + k] = (Pel)(v < 0 ? 0 : (v > maxv ? maxv : v));
+        lo[j * pw[p] + k] = lvl[j * N + k];
+      }
+  }
+  short *out[3] = {rec_y, rec_cb, rec_cr};
+  for (int p = 0; p < 3; p++)
+    for (int j = 0; j < ph[p]; j++) memcpy(out[p] + j * pw[p], rp[p] + j * rs[p], 2 * pw[p]);
+}
+
 } // extern "C"

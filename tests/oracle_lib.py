@@ -141,6 +141,7 @@ def ref():
         L.ref_clipMv.argtypes = [ci, ci, C.POINTER(ci), C.POINTER(ci)]
         L.ref_addAvg.argtypes = [C.c_void_p * 3, C.c_void_p * 3, C.c_void_p * 3, ci, ci]
         L.ref_extended_luma.argtypes = [i16p]
+        L.ref_intra_frame_encode.argtypes = [C.c_void_p, ci, ci, i16p, i16p, i16p, i16p, i16p, i16p, i32p, i32p, i32p]
         _ref = L
     return _ref
 
@@ -189,3 +190,33 @@ def o_intra_pred(rec_plane, stride, x, y, N, mode, B, pic_w, pic_h, chroma, ctu=
         L.hmo_filterAdi(adi, N)
         L.hmo_predIntraLumaAng(adi, mode, pred.reshape(-1), N, N, B)
     return pred
+
+
+def frame_cfg(w, h, B, qp, sign_hide=1, chroma_qp_offset=0, ctu=64):
+    return FrameCfg(w, h, ctu, B, qp, chroma_qp_offset, sign_hide)
+
+
+def o_intra_frame_encode(tus, w, h, B, qp, org, sign_hide=1):
+    """oracle: decisions + original planes -> (recon planes, level planes)"""
+    cfg = frame_cfg(w, h, B, qp, sign_hide)
+    rec = [np.zeros_like(p) for p in org]
+    lev = [np.zeros(p.shape, np.int32) for p in org]
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
+    st = I3(w, w // 2, w // 2)
+    t = np.ascontiguousarray(tus, TU_DTYPE)
+    oracle().hmo_intra_frame_encode(C.byref(cfg), t.ctypes.data, len(t), P3(*[p.ctypes.data for p in org]), st,
+                                    P3(*[p.ctypes.data for p in rec]), st, P3(*[p.ctypes.data for p in lev]))
+    return rec, lev
+
+
+def r_intra_frame_encode(tus, w, h, B, qp, org, sign_hide=1):
+    """the compiled reference's own functions chained over the same decisions"""
+    R = ref()
+    R.ref_init(B, w, h, sign_hide)
+    rec = [np.zeros(p.shape, np.int16) for p in org]
+    lev = [np.zeros(p.shape, np.int32) for p in org]
+    t = np.ascontiguousarray(tus, TU_DTYPE)
+    o = [np.ascontiguousarray(p, np.int16).reshape(-1) for p in org]
+    R.ref_intra_frame_encode(t.ctypes.data, len(t), qp, o[0], o[1], o[2], rec[0].reshape(-1), rec[1].reshape(-1),
+                             rec[2].reshape(-1), lev[0].reshape(-1), lev[1].reshape(-1), lev[2].reshape(-1))
+    return rec, lev

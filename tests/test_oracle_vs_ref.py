@@ -385,3 +385,21 @@ def test_add_avg(B):
             ob = np.zeros(ww * hh, np.int16)
             O.hmo_addAvg(a[k], ww, b[k], ww, ob, ww, ww, hh, B)
             assert np.array_equal(o[k], ob)
+
+
+@pytest.mark.parametrize("pic,tiling,B,qp", [((416, 240), "mix", 8, 32), ((416, 240), "mix", 10, 27), ((192, 128), 4, 8, 22),
+                                             ((256, 128), 32, 8, 37), ((200, 136), "mix", 8, 32)])
+def test_whole_picture_intra_encode(pic, tiling, B, qp):
+    """Whole-picture pin: the oracle's all-intra frame driver vs the reference's own functions
+    (initAdiPattern on a real TComPic, predIntra*Ang, transformNxN, invtransformNxN) chained over the
+    same decision list: reconstruction and levels must be identical."""
+    from thevc_amd import workload
+    w, h = pic
+    tus = workload.make_tus(5, w, h, tiling)
+    for kind in ("texture", "noise"):
+        org = workload.make_planes(11, w, h, B, kind)
+        ro, lo = ol.o_intra_frame_encode(tus, w, h, B, qp, org)
+        rr, lr = ol.r_intra_frame_encode(tus, w, h, B, qp, org)
+        for p in range(3):
+            assert np.array_equal(lo[p], lr[p]), ("levels", kind, p)
+            assert np.array_equal(ro[p], rr[p]), ("recon", kind, p)
