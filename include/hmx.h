@@ -215,6 +215,12 @@ int hmx_frame_intra_encode(hmx_ctx *ctx, const hmx_intra_plan *plan, int n_pics,
                            const hmx_pic *rec, const hmx_levels *lev);
 int hmx_frame_intra_decode(hmx_ctx *ctx, const hmx_intra_plan *plan, int n_pics, const hmx_pic *rec,
                            const hmx_levels *lev);
+/* The general form: picture i follows plans[i] (every picture its own block structure and modes, as in a
+ * real stream); all plans of one call share picture size, QP and slice settings. */
+int hmx_frame_intra_encode_multi(hmx_ctx *ctx, const hmx_intra_plan *const *plans, int n_pics, const hmx_pic *org,
+                                 const hmx_pic *rec, const hmx_levels *lev);
+int hmx_frame_intra_decode_multi(hmx_ctx *ctx, const hmx_intra_plan *const *plans, int n_pics, const hmx_pic *rec,
+                                 const hmx_levels *lev);
 
 /* Motion compensation of a list of PUs against reference pictures resident in HBM with the
  * reference's margin layout (TLibCommon/TComPicYuv.cpp:82-94): motionCompensation -> xPredInterUni/Bi ->

@@ -233,28 +233,33 @@ __device__ __forceinline__ void quant_one(int c, const QuantDev &qd, int qbits, 
 // signBitHidingHDQ (TComTrQuant.cpp:977-1100) for ONE 16-coefficient group; groups are independent
 // except for the reference's lastCG flag: first_nz_group = this is the highest group in scan order
 // that holds a non-zero level (its candidate loop starts at the last non-zero, not at 15).
+// Fully unrolled over the 16 scan positions so that nothing is indexed at run time (no scratch).
 template <int N>
 __device__ __forceinline__ void sbh_group(TuLds<N> &L, int scan_idx, int g, bool first_nz_group) {
+  int qv[16], dv[16];
   int first = 16, last = -1, sum = 0;
-  int pos[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    pos[i] = scan_pos<N>(scan_idx, g, i);
-    int q = L.tile[pos[i] / N][pos[i] % N];
-    if (q) {
-      if (first == 16) first = i;
+    const int p = scan_pos<N>(scan_idx, g, i);
+    qv[i] = L.tile[p / N][p % N];
+    dv[i] = L.du[p / N][p % N]; // (deltaU << 1) | sign of the unquantised coefficient
+    sum += qv[i];
+    if (qv[i]) {
+      first = min(first, i);
       last = i;
     }
   }
   if (last - first < 4) return;
-  for (int i = first; i <= last; i++) sum += L.tile[pos[i] / N][pos[i] % N];
-  int q_first = L.tile[pos[first] / N][pos[first] % N];
-  int signbit = q_first > 0 ? 0 : 1;
+  int q_first = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) q_first = (i == first) ? qv[i] : q_first;
+  const int signbit = q_first > 0 ? 0 : 1;
   if (signbit == (sum & 1)) return;
-  int best_cost = 0x7fffffff, best_pos = -1, best_chg = 0;
-  for (int i = first_nz_group ? last : 15; i >= 0; i--) {
-    int p = pos[i], r = p / N, c = p % N;
-    int q = L.tile[r][c], du = L.du[r][c] >> 1;
+  const int start = first_nz_group ? last : 15;
+  int best_cost = 0x7fffffff, best_i = -1, best_chg = 0;
+#pragma unroll
+  for (int i = 15; i >= 0; i--) {
+    const int q = qv[i], du = dv[i] >> 1;
     int cost = 0x7fffffff, chg = 0;
     if (q != 0) {
       if (du > 0) {
@@ -265,8 +270,7 @@ __device__ __forceinline__ void sbh_group(TuLds<N> &L, int scan_idx, int g, bool
         chg = -1;
       }
     } else if (i < first) {
-      int this_sign = L.du[r][c] & 1;
-      if (this_sign == signbit) {
+      if ((dv[i] & 1) == signbit) {
         cost = -du;
         chg = 1;
       }
@@ -274,16 +278,22 @@ __device__ __forceinline__ void sbh_group(TuLds<N> &L, int scan_idx, int g, bool
       cost = -du;
       chg = 1;
     }
-    if (cost < best_cost) {
+    if (i <= start && cost < best_cost) {
       best_cost = cost;
       best_chg = chg;
-      best_pos = p;
+      best_i = i;
     }
   }
-  int r = best_pos / N, c = best_pos % N;
-  int q = L.tile[r][c];
+  int q = 0, neg = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++)
+    if (i == best_i) {
+      q = qv[i];
+      neg = dv[i] & 1;
+    }
   if (q == 32767 || q == -32768) best_chg = -1;
-  L.tile[r][c] = (L.du[r][c] & 1) ? q - best_chg : q + best_chg;
+  const int p = scan_pos<N>(scan_idx, g, best_i);
+  L.tile[p / N][p % N] = neg ? q - best_chg : q + best_chg;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -334,11 +344,11 @@ __host__ __device__ __forceinline__ unsigned long long intra_avail_mask(int x, i
 // Every sample is one independent load: an unavailable sample copies the nearest available
 // sample before it (or the first available one for a leading run), which is what the reference's
 // sequential padding loop produces.  rec points at the block origin.
-template <int N>
+template <int N, int NL>
 __device__ __forceinline__ void build_ref_line(const short *rec, int stride, unsigned long long avail,
                                                int unit_log2, int bit_depth, int gl, int *L) {
   const int unit = 1 << unit_log2, n = N >> unit_log2;
-  for (int p = gl; p <= 4 * N; p += N) {
+  for (int p = gl; p <= 4 * N; p += NL) {
     int v;
     if (avail == 0) {
       v = 1 << (bit_depth - 1);
@@ -361,9 +371,9 @@ __device__ __forceinline__ void build_ref_line(const short *rec, int stride, uns
   }
 }
 
-template <int N>
+template <int N, int NL>
 __device__ __forceinline__ void smooth_ref_line(const int *L, int *F, int gl) { // [1 2 1], :265-306
-  for (int p = gl; p <= 4 * N; p += N)
+  for (int p = gl; p <= 4 * N; p += NL)
     F[p] = (p == 0 || p == 4 * N) ? L[p] : (L[p - 1] + 2 * L[p] + L[p + 1] + 2) >> 2;
 }
 
@@ -373,38 +383,36 @@ __device__ __forceinline__ bool use_filtered_refs(int mode, int log2n) { // TCom
   return min(abs(mode - 10), abs(mode - 26)) > thr;
 }
 
-// Row r of the N x N prediction (TComPrediction.cpp:129-386, 689-730, 1010-1029).
-// R = reference line (raw or smoothed); top(k) = R[2N+k], left(k) = R[2N-k], k = 0 is the corner.
-template <int N>
-__device__ __forceinline__ void intra_pred_row(const int *R, int mode, bool luma, int bit_depth, int r, int *p) {
+// NC samples of row r of the N x N prediction (TComPrediction.cpp:129-386, 689-730, 1010-1029):
+// p[s] = pred(r, col(s)).  R = reference line (raw or smoothed); top(k) = R[2N+k], left(k) = R[2N-k],
+// k = 0 is the corner.  dc_sum = sum of the N above and N left neighbours (only read for mode 1).
+template <int N, int NC, typename ColFn>
+__device__ __forceinline__ void intra_pred_cols(const int *R, int mode, bool luma, int bit_depth, int r, int dc_sum,
+                                                ColFn col, int *p) {
   constexpr int LOG2N = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
-  const int *top = R + 2 * N; // top[k]
-  // left(k) = R[2N - k]
+  const int *top = R + 2 * N; // top[k]; left(k) = R[2N - k]
   if (mode == 0) { // planar, closed form of the accumulators
     int left = R[2 * N - (r + 1)], tr = top[N + 1], bl = R[2 * N - (N + 1)];
 #pragma unroll
-    for (int c = 0; c < N; c++) {
-      int t = top[c + 1];
+    for (int s = 0; s < NC; s++) {
+      const int c = col(s), t = top[c + 1];
       int hor = (left << LOG2N) + N + (c + 1) * (tr - left);
       int ver = (t << LOG2N) + (r + 1) * (bl - t);
-      p[c] = (short)((hor + ver) >> (LOG2N + 1));
+      p[s] = (short)((hor + ver) >> (LOG2N + 1));
     }
     return;
   }
   if (mode == 1) { // DC (+ edge smoothing for luma, any size)
-    int sum = 0;
-    for (int i = 1; i <= N; i++) sum += top[i] + R[2 * N - i];
-    int dc = (sum + N) >> (LOG2N + 1);
+    const int dc = (dc_sum + N) >> (LOG2N + 1);
 #pragma unroll
-    for (int c = 0; c < N; c++) p[c] = dc;
-    if (luma) {
-      if (r == 0) {
-#pragma unroll
-        for (int c = 1; c < N; c++) p[c] = (short)((top[c + 1] + 3 * dc + 2) >> 2);
-        p[0] = (short)((top[1] + R[2 * N - 1] + 2 * dc + 2) >> 2);
-      } else {
-        p[0] = (short)((R[2 * N - (r + 1)] + 3 * dc + 2) >> 2);
+    for (int s = 0; s < NC; s++) {
+      const int c = col(s);
+      int v = dc;
+      if (luma) {
+        if (r == 0) v = c == 0 ? (top[1] + R[2 * N - 1] + 2 * dc + 2) >> 2 : (top[c + 1] + 3 * dc + 2) >> 2;
+        else if (c == 0) v = (R[2 * N - (r + 1)] + 3 * dc + 2) >> 2;
       }
+      p[s] = (short)v;
     }
     return;
   }
@@ -423,36 +431,37 @@ __device__ __forceinline__ void intra_pred_row(const int *R, int mode, bool luma
   if (idx < 0) angle = -angle;
   // main(i) for i in [-N, 2N]: i >= 0 -> main reference, i < 0 -> projected side reference
   auto mref = [&](int i) -> int {
-    int k = i >= 0 ? i : (128 + (-i) * inv_angle) >> 8; // index into main (i>=0) or side (i<0)
+    int k = i >= 0 ? i : (128 + (-i) * inv_angle) >> 8;
     bool use_top = (i >= 0) == ver;
     return (short)(use_top ? top[k] : R[2 * N - k]);
   };
   const int max_v = (1 << bit_depth) - 1;
   if (angle == 0) {
-    if (ver) {
 #pragma unroll
-      for (int c = 0; c < N; c++) p[c] = (short)top[c + 1];
-      if (luma) p[0] = clip3(0, max_v, p[0] + (((short)R[2 * N - (r + 1)] - (short)top[0]) >> 1));
-    } else {
-      int v = (short)R[2 * N - (r + 1)];
-#pragma unroll
-      for (int c = 0; c < N; c++) p[c] = v;
-      if (luma && r == 0) {
-#pragma unroll
-        for (int c = 0; c < N; c++) p[c] = clip3(0, max_v, p[c] + (((short)top[c + 1] - (short)top[0]) >> 1));
+    for (int s = 0; s < NC; s++) {
+      const int c = col(s);
+      int v;
+      if (ver) {
+        v = (short)top[c + 1];
+        if (luma && c == 0) v = clip3(0, max_v, v + (((short)R[2 * N - (r + 1)] - (short)top[0]) >> 1));
+      } else {
+        v = (short)R[2 * N - (r + 1)];
+        if (luma && r == 0) v = clip3(0, max_v, v + (((short)top[c + 1] - (short)top[0]) >> 1));
       }
+      p[s] = v;
     }
     return;
   }
 #pragma unroll
-  for (int c = 0; c < N; c++) {
+  for (int s = 0; s < NC; s++) {
+    const int c = col(s);
     // main-frame coordinates (k = distance from the main reference, l = position along it)
     int k = ver ? r : c, l = ver ? c : r;
     int pos = (k + 1) * angle;
     int di = pos >> 5, df = pos & 31;
     int i = l + di + 1;
     int a = mref(i);
-    p[c] = df ? (short)(((32 - df) * a + df * mref(i + 1) + 16) >> 5) : a;
+    p[s] = df ? (short)(((32 - df) * a + df * mref(i + 1) + 16) >> 5) : a;
   }
 }
 

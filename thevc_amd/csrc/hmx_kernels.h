@@ -1,4 +1,9 @@
-// hmx_kernels.h -- block-level device routines built on hmx_device.h and the __global__ kernels.
+// hmx_kernels.h -- block-level device routines built on hmx_device.h.
+//
+// Synchronisation model: a block never spans wavefronts (N <= 32 lanes per block, groups aligned to
+// N; the 32x32 MFMA path uses exactly one wave), and LDS instructions of one wave execute in issue
+// order.  So the only barrier these routines need is wave_sync(): a compiler-level fence that keeps
+// LDS stores before / loads after it.  No s_barrier, no workgroup coupling: waves are autonomous.
 #pragma once
 #include "hmx_device.h"
 
@@ -10,12 +15,6 @@ template <int N>
 struct Log2 {
   static constexpr int v = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
 };
-// lanes of a workgroup that take part for block size N: 256, except 32x32 whose LDS scratch
-// (9.6 KB per block) is kept to four blocks per workgroup
-template <int N>
-struct Slots {
-  static constexpr int v = N == 32 ? 4 : 256 / N;
-};
 
 struct PlanesDev { // one picture: three planes, element strides
   short *p[3];
@@ -26,16 +25,81 @@ struct LevelsDev {
   int s[3];
 };
 
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// make this wave's global stores visible to its own later loads issued by other lanes
+__device__ __forceinline__ void wave_global_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 __device__ __forceinline__ int group_sum(int v, int width) { // sum over `width` consecutive lanes
   for (int off = width >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, width);
   return v;
 }
 
 // ---------------------------------------------------------------------------------------------
-// transformNxN core: residual row (lane gl holds row gl) -> final levels in L.tile[row][col].
-// Called by all lanes of the workgroup (contains barriers); `active` masks idle block slots.
-//   ts      transform skip (TComTrQuant.cpp:1622)      use_dst  4x4 luma intra (DST)
-// Returns the reference's uiAbsSum (sum of |level| BEFORE sign-bit hiding, :1256).
+// Quantise the coefficients a lane holds and run sign-bit hiding on the block (TComTrQuant.cpp
+// :1130-1267, :977-1100).  coef[k] sits at (row, col) = pos(k); NL lanes own the block, NCOEF per lane.
+// Leaves the final levels in L.tile[row][col]; returns uiAbsSum (before sign-bit hiding, :1256).
+// ---------------------------------------------------------------------------------------------
+template <int N, int NL, int NCOEF, typename RowFn, typename ColFn>
+__device__ __forceinline__ int quant_sbh_block(TuLds<N> &L, int gl, bool active, const int *coef, RowFn row_of, ColFn col_of,
+                                               bool luma, int scan_idx, const PicDev &P) {
+  constexpr int LG = Log2<N>::v;
+  const int tshift = 15 - P.bit_depth - LG;
+  const QuantDev &qd = P.qd[luma ? 0 : 1];
+  const int qbits = 14 + qd.per_qbits + tshift;
+  const long long add = (long long)qd.rnd_factor << (qbits - 9);
+  int sum = 0;
+  if (active) { // idle lanes may alias another block's scratch: never let them write
+    if (gl == 0) L.nzmask[0] = L.nzmask[1] = 0;
+#pragma unroll
+    for (int k = 0; k < NCOEF; k++) {
+      int lvl, du, al;
+      quant_one(coef[k], qd, qbits, add, lvl, du, al);
+      sum += al;
+      const int r = row_of(k), c = col_of(k);
+      L.tile[r][c] = lvl;
+      L.du[r][c] = (du << 1) | (coef[k] < 0 ? 1 : 0);
+    }
+  }
+  sum = group_sum(active ? sum : 0, NL);
+  wave_sync();
+  constexpr int NG = (N / 4) * (N / 4);
+  const bool hide = P.sign_hide && sum >= 2; // uniform over the block's lanes
+  if (hide) {
+    for (int g = gl; g < NG; g += NL) {
+      bool nz = false;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        int p = scan_pos<N>(scan_idx, g, i);
+        nz |= L.tile[p / N][p % N] != 0;
+      }
+      if (nz) atomicOr(&L.nzmask[g >> 5], 1u << (g & 31));
+    }
+  }
+  wave_sync();
+  if (hide) {
+    const unsigned long long mask = (unsigned long long)L.nzmask[0] | ((unsigned long long)L.nzmask[1] << 32);
+    for (int g = gl; g < NG; g += NL) {
+      if (!((mask >> g) & 1)) continue;
+      bool higher = g < 63 ? (mask >> (g + 1)) != 0 : false;
+      sbh_group<N>(L, scan_idx, g, !higher);
+    }
+  }
+  wave_sync();
+  return sum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// VALU path (N = 4, 8, 16; also 32 in the list kernels): lane gl owns row/column gl of the block.
+// transformNxN core: residual row -> final levels in L.tile.  ts = transform skip (:1622),
+// use_dst = 4x4 luma intra.  do_quant = false leaves the Int coefficients (xT / xTransformSkip).
 // ---------------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ int fwd_tq_block(TuLds<N> &L, int gl, bool active, const int *x, bool ts, bool use_dst,
@@ -43,7 +107,6 @@ __device__ __forceinline__ int fwd_tq_block(TuLds<N> &L, int gl, bool active, co
   constexpr int LG = Log2<N>::v;
   const int B = P.bit_depth, tshift = 15 - B - LG;
   int coef[N];
-  if (active && gl == 0) L.nzmask[0] = L.nzmask[1] = 0;
   if (ts) {
 #pragma unroll
     for (int k = 0; k < N; k++) coef[k] = tshift >= 0 ? x[k] << tshift : (x[k] + (1 << (-tshift - 1))) >> (-tshift);
@@ -54,16 +117,14 @@ __device__ __forceinline__ int fwd_tq_block(TuLds<N> &L, int gl, bool active, co
 #pragma unroll
       for (int k = 0; k < N; k++) L.tile[k][gl] = y1[k]; // transposed store, like dst[k*line + j]
     }
-  }
-  __syncthreads();
-  if (!ts) {
+    wave_sync();
     int z[N];
 #pragma unroll
     for (int n = 0; n < N; n++) z[n] = L.tile[gl][n];
     fwd_pass<N>(z, coef, LG + 6, use_dst); // coef[k] is coefficient (row k, col gl)
+    wave_sync();
   }
-  __syncthreads();
-  if (!do_quant) { // xT / xTransformSkip only: leave the Int coefficients in the tile
+  if (!do_quant) {
     if (active) {
 #pragma unroll
       for (int k = 0; k < N; k++) {
@@ -73,120 +134,81 @@ __device__ __forceinline__ int fwd_tq_block(TuLds<N> &L, int gl, bool active, co
           L.tile[k][gl] = coef[k];
       }
     }
-    __syncthreads();
+    wave_sync();
     return 0;
   }
-  const QuantDev &qd = P.qd[luma ? 0 : 1];
-  const int qbits = 14 + qd.per_qbits + tshift;
-  const long long add = (long long)qd.rnd_factor << (qbits - 9);
-  int sum = 0;
-  if (active) { // idle lanes of a partly filled workgroup may alias another block's scratch
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-      int lvl, du, al;
-      quant_one(coef[k], qd, qbits, add, lvl, du, al);
-      sum += al;
-      const int r = ts ? gl : k, c = ts ? k : gl;
-      L.tile[r][c] = lvl;
-      L.du[r][c] = (du << 1) | (coef[k] < 0 ? 1 : 0);
-    }
-  }
-  sum = group_sum(active ? sum : 0, N);
-  __syncthreads();
-  constexpr int NG = (N / 4) * (N / 4);
-  const bool hide = P.sign_hide && sum >= 2; // uniform over the block's lanes
-  if (hide) {
-    for (int g = gl; g < NG; g += N) {
-      bool nz = false;
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        int p = scan_pos<N>(scan_idx, g, i);
-        nz |= L.tile[p / N][p % N] != 0;
-      }
-      if (nz) atomicOr(&L.nzmask[g >> 5], 1u << (g & 31));
-    }
-  }
-  __syncthreads();
-  if (hide) {
-    const unsigned long long mask = (unsigned long long)L.nzmask[0] | ((unsigned long long)L.nzmask[1] << 32);
-    for (int g = gl; g < NG; g += N) {
-      if (!((mask >> g) & 1)) continue;
-      bool higher = g < 63 ? (mask >> (g + 1)) != 0 : false;
-      sbh_group<N>(L, scan_idx, g, !higher);
-    }
-  }
-  __syncthreads();
-  return sum;
+  return quant_sbh_block<N, N, N>(
+      L, gl, active, coef, [&](int k) { return ts ? gl : k; }, [&](int k) { return ts ? k : gl; }, luma, scan_idx, P);
 }
 
-// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int dequant_one(int v, int iq_scale, int dshift) { // :1343-1354, 32-bit product
+  int l = clip3(-32768, 32767, v);
+  return clip3(-32768, 32767, (int)((unsigned)l * (unsigned)iq_scale + (1u << (dshift - 1))) >> dshift);
+}
+
 // invtransformNxN core: levels in L.tile[row][col] -> residual row gl in out[N].
-// ---------------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void inv_tq_block(TuLds<N> &L, int gl, bool active, bool ts, bool use_dst, bool luma,
                                              bool do_dequant, const PicDev &P, int *out) {
   constexpr int LG = Log2<N>::v;
   const int B = P.bit_depth, tshift = 15 - B - LG;
   const QuantDev &qd = P.qd[luma ? 0 : 1];
-  const int dshift = 6 - tshift, dadd = 1 << (dshift - 1);
+  const int dshift = 6 - tshift;
   int c[N], t[N];
 #pragma unroll
   for (int k = 0; k < N; k++) {
     int v = ts ? L.tile[gl][k] : L.tile[k][gl];
-    if (do_dequant) { // xDeQuant flat path, 32-bit product like the reference (:1343-1354)
-      int l = clip3(-32768, 32767, v);
-      v = clip3(-32768, 32767, (int)((unsigned)l * (unsigned)qd.iq_scale + (unsigned)dadd) >> dshift);
-    }
-    c[k] = v;
+    c[k] = do_dequant ? dequant_one(v, qd.iq_scale, dshift) : v;
   }
   if (ts) { // xITransformSkip (:1667-1704)
 #pragma unroll
     for (int k = 0; k < N; k++) out[k] = wrap16(tshift > 0 ? (c[k] + (1 << (tshift - 1))) >> tshift : c[k] << (-tshift));
-  } else {
-#pragma unroll
-    for (int k = 0; k < N; k++) c[k] = wrap16(c[k]); // coeff[j] = (short)plCoef[j], :1602
-    inv_pass<N>(c, t, 7, use_dst); // row gl of the intermediate block
+    return;
   }
-  __syncthreads(); // every lane has read its levels
-  if (!ts && active) {
+#pragma unroll
+  for (int k = 0; k < N; k++) c[k] = wrap16(c[k]); // coeff[j] = (short)plCoef[j], :1602
+  inv_pass<N>(c, t, 7, use_dst);                    // row gl of the intermediate block
+  wave_sync();                                      // every lane has read its levels
+  if (active) {
 #pragma unroll
     for (int n = 0; n < N; n++) L.tile[gl][n] = t[n];
   }
-  __syncthreads();
-  if (!ts) {
-    int u[N];
+  wave_sync();
+  int u[N];
 #pragma unroll
-    for (int k = 0; k < N; k++) u[k] = L.tile[k][gl];
-    inv_pass<N>(u, out, 12 - (B - 8), use_dst);
-  }
-  __syncthreads();
+  for (int k = 0; k < N; k++) u[k] = L.tile[k][gl];
+  inv_pass<N>(u, out, 12 - (B - 8), use_dst);
+  wave_sync();
 }
 
 // ---------------------------------------------------------------------------------------------
-// Intra prediction of one block: lane gl -> row gl of the prediction in p[N].
-// rec_plane points at sample (0,0) of the plane the block lives in.
+// Intra references and prediction of one block owned by NL lanes.
 // ---------------------------------------------------------------------------------------------
-template <int N>
+template <int N, int NL>
 __device__ __forceinline__ void intra_refs(TuLds<N> &L, int gl, bool active, const short *rec_plane, int stride, int x,
-                                           int y, bool luma, const PicDev &P) {
-  if (active) {
-    const int c = luma ? 0 : 1;
-    unsigned long long avail = intra_avail_mask(x << c, y << c, N << c, P);
-    build_ref_line<N>(rec_plane + (size_t)y * stride + x, stride, avail, luma ? 2 : 1, P.bit_depth, gl, L.line);
-  }
-  __syncthreads();
-  if (active && luma) smooth_ref_line<N>(L.line, L.fline, gl);
-  __syncthreads();
+                                           int y, bool luma, unsigned long long avail, const PicDev &P) {
+  if (active) build_ref_line<N, NL>(rec_plane + (size_t)y * stride + x, stride, avail, luma ? 2 : 1, P.bit_depth, gl, L.line);
+  wave_sync();
+  if (active && luma && N > 4) smooth_ref_line<N, NL>(L.line, L.fline, gl); // 4x4 never uses the smoothed line
+  wave_sync();
+}
+
+// sum of the N above + N left neighbours, shared by the block's NL lanes (DC mode)
+template <int N, int NL>
+__device__ __forceinline__ int dc_sum_block(const TuLds<N> &L, int gl) {
+  int s = 0;
+  for (int i = gl; i < 2 * N; i += NL) s += i < N ? L.line[2 * N + 1 + i] : L.line[2 * N - 1 - (i - N)];
+  return group_sum(s, NL);
 }
 
 template <int N>
 __device__ __forceinline__ void intra_pred_block(TuLds<N> &L, int gl, int mode, bool luma, const PicDev &P, int *p) {
   const int *R = (luma && use_filtered_refs(mode, Log2<N>::v)) ? L.fline : L.line;
-  intra_pred_row<N>(R, mode, luma, P.bit_depth, gl, p);
+  const int dcs = dc_sum_block<N, N>(L, gl); // shuffles: every lane of the wave executes this
+  intra_pred_cols<N, N>(R, mode, luma, P.bit_depth, gl, dcs, [](int s) { return s; }, p);
 }
 
-// vectorised row access helpers (rows of N int16 / int32, natural alignment not guaranteed
-// for Pel rows of 4 samples inside a plane with odd strides, so go through 2-byte loads when needed)
+// row access helpers (a block row inside a plane is not guaranteed to be more than 2-byte aligned)
 template <int N>
 __device__ __forceinline__ void load_row16(const short *src, int *x) {
 #pragma unroll
@@ -206,6 +228,121 @@ template <int N>
 __device__ __forceinline__ void store_row32(int *dst, const int *x) {
 #pragma unroll
   for (int k = 0; k < N; k++) dst[k] = x[k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// 32x32 on the matrix cores.  One wave owns one block; lane l = (r = l & 31, h = l >> 5).
+// v_mfma_i32_32x32x32_i8 multiplies slot (h, s) of A's lane (row, h) with slot (h, s) of B's lane
+// (col, h) and leaves C[row mrow(g,h)][col r] in accumulator g (layout verified on gfx950 with exact
+// integer data, tools/mfma_i8_probe.hip).  Any consistent assignment of K indices to slots is valid,
+// so slot (h, s) is bound to index mrow(s, h): a result tile can then be fed back as the next
+// operand without any cross-lane movement:
+//   forward  pass 1  C1 = X * M^T         data = A (lane = row j of X),        const B = TF
+//            pass 2  C2 = M * C1          const A = TF,                         data = B (C1 as it lies)
+//   inverse  pass 1  T1 = c^T * M         data = A (c as it lies: lane = col),  const B = TI
+//            pass 2  R^T = M^T * T1       const A = TI,                         data = B (T1 as it lies)
+// 16-bit data are split x = 256*hi + (lo + 128) with hi, lo in int8: two MFMAs per pass plus a
+// constant 128 * (row or column sum of M), which is 2048 for DCT row 0 and 0 for every other row.
+// Integer arithmetic, exact: bit-identical to the partial butterflies (TComTrQuant.cpp:678-795).
+// ---------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+__host__ __device__ constexpr int mrow(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
+
+struct MfmaTables {
+  signed char tf[32][2][16]; // tf[r][h][s] = M[r][mrow(s,h)]
+  signed char ti[32][2][16]; // ti[r][h][s] = M[mrow(s,h)][r]
+  int colsum[32];            // sum_k M[k][n]
+  int csp[2][16];            // csp[h][g] = 128 * colsum[mrow(g,h)]
+  constexpr MfmaTables() : tf{}, ti{}, colsum{}, csp{} {
+    for (int r = 0; r < 32; r++) {
+      int cs = 0;
+      for (int k = 0; k < 32; k++) cs += dct_coef(32, k, r);
+      colsum[r] = cs;
+      for (int h = 0; h < 2; h++)
+        for (int g = 0; g < 16; g++)
+          if (mrow(g, h) == r) csp[h][g] = 128 * cs;
+      for (int h = 0; h < 2; h++)
+        for (int s = 0; s < 16; s++) {
+          tf[r][h][s] = (signed char)dct_coef(32, r, mrow(s, h));
+          ti[r][h][s] = (signed char)dct_coef(32, mrow(s, h), r);
+        }
+    }
+  }
+};
+__constant__ MfmaTables kMfma = MfmaTables();
+
+// 16 int16-range values -> hi bytes / (lo bytes ^ 0x80) packed four per dword
+__device__ __forceinline__ void split_hi_lo(const int *v, v4i &hi, v4i &lo) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    unsigned w01 = __builtin_amdgcn_perm((unsigned)v[4 * q + 1], (unsigned)v[4 * q], 0x05040100u);     // x1.lo16 : x0.lo16
+    unsigned w23 = __builtin_amdgcn_perm((unsigned)v[4 * q + 3], (unsigned)v[4 * q + 2], 0x05040100u); // x3.lo16 : x2.lo16
+    hi[q] = (int)__builtin_amdgcn_perm(w23, w01, 0x07050301u);
+    lo[q] = (int)(__builtin_amdgcn_perm(w23, w01, 0x06040200u) ^ 0x80808080u);
+  }
+}
+
+__device__ __forceinline__ v4i load_const_operand(const signed char (*tab)[2][16], int r, int h) {
+  return *reinterpret_cast<const v4i *>(&tab[r][h][0]);
+}
+
+// data as the A operand: out[g] = sum_slot data(lane, slot) * konst(col r, slot) + 128 * fix_col (per lane)
+__device__ __forceinline__ void mfma_data_a(const int *data, v4i konst, int fix, int *raw) {
+  v4i hi, lo;
+  split_hi_lo(data, hi, lo);
+  v16i ch = {0}, cl = {0};
+  ch = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, konst, ch, 0, 0, 0);
+  cl = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, konst, cl, 0, 0, 0);
+#pragma unroll
+  for (int g = 0; g < 16; g++) raw[g] = 256 * ch[g] + cl[g] + fix;
+}
+// data as the B operand; fix[g] = 128 * (row sum of the constant A for the row this accumulator holds)
+template <typename FixFn>
+__device__ __forceinline__ void mfma_data_b(const int *data, v4i konst, FixFn fix, int *raw) {
+  v4i hi, lo;
+  split_hi_lo(data, hi, lo);
+  v16i ch = {0}, cl = {0};
+  ch = __builtin_amdgcn_mfma_i32_32x32x32_i8(konst, hi, ch, 0, 0, 0);
+  cl = __builtin_amdgcn_mfma_i32_32x32x32_i8(konst, lo, cl, 0, 0, 0);
+#pragma unroll
+  for (int g = 0; g < 16; g++) raw[g] = 256 * ch[g] + cl[g] + fix(g);
+}
+
+// forward 32x32 DCT: x[s] = residual (row r, col mrow(s,h)) -> coef[g] = coefficient (row mrow(g,h), col r)
+__device__ __forceinline__ void fwd32_mfma(const int *x, int r, int h, int B, int *coef) {
+  const v4i tf = load_const_operand(kMfma.tf, r, h);
+  int raw[16], t[16];
+  const int s1 = 4 + (B - 8), s2 = 11;
+  mfma_data_a(x, tf, r == 0 ? 128 * 2048 : 0, raw);
+#pragma unroll
+  for (int g = 0; g < 16; g++) t[g] = wrap16((raw[g] + (1 << (s1 - 1))) >> s1);
+  mfma_data_b(t, tf, [&](int g) { return (g == 0 && h == 0) ? 128 * 2048 : 0; }, raw);
+#pragma unroll
+  for (int g = 0; g < 16; g++) coef[g] = wrap16((raw[g] + (1 << (s2 - 1))) >> s2);
+}
+
+// inverse 32x32 DCT: c[g] = coefficient (row mrow(g,h), col r) -> out[g] = residual (row r, col mrow(g,h))
+__device__ __forceinline__ void inv32_mfma(const int *c, int r, int h, int B, int *out) {
+  const v4i ti = load_const_operand(kMfma.ti, r, h);
+  int raw[16], t[16];
+  const int s2 = 12 - (B - 8);
+  mfma_data_a(c, ti, 128 * kMfma.colsum[r], raw);
+#pragma unroll
+  for (int g = 0; g < 16; g++) t[g] = clip3(-32768, 32767, (raw[g] + 64) >> 7);
+  int fix[16];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const v4i f = *reinterpret_cast<const v4i *>(&kMfma.csp[h][4 * q]);
+    fix[4 * q] = f[0];
+    fix[4 * q + 1] = f[1];
+    fix[4 * q + 2] = f[2];
+    fix[4 * q + 3] = f[3];
+  }
+  mfma_data_b(t, ti, [&](int g) { return fix[g]; }, raw);
+#pragma unroll
+  for (int g = 0; g < 16; g++) out[g] = clip3(-32768, 32767, (raw[g] + (1 << (s2 - 1))) >> s2);
 }
 
 } // namespace hmx

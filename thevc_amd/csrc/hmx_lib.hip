@@ -20,6 +20,11 @@ struct DTu { // device descriptor of the list kernels: hmx_tu + index in the cal
   uint32_t idx;
 };
 
+// list kernels: 256-thread workgroups = four autonomous waves; blocks per workgroup
+template <int N>
+struct Slots {
+  static constexpr int v = N == 32 ? 4 : 256 / N; // 32x32 scratch (9.5 KB) is kept to four blocks
+};
 #define HMX_SMEM_BYTES (16 * (int)sizeof(TuLds<16>)) /* largest of Slots<N> * sizeof(TuLds<N>) */
 static_assert(64 * sizeof(TuLds<4>) <= HMX_SMEM_BYTES && 32 * sizeof(TuLds<8>) <= HMX_SMEM_BYTES &&
                   4 * sizeof(TuLds<32>) <= HMX_SMEM_BYTES,
@@ -69,46 +74,10 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
       if (OP == OP_TRANSFORM_NXN && gl == 0 && A.abs_sum) A.abs_sum[d.idx] = (uint32_t)sum;
     }
   } else if constexpr (OP == OP_XQUANT) {
-    // coefficients (Int) in lev -> levels in lev2; reuses the quantiser half of fwd_tq_block
-    // through the transform-skip entry with shift 0 semantics: load rows straight into the tile.
-    constexpr int LG = Log2<N>::v;
-    const int tshift = 15 - A.P.bit_depth - LG;
-    const QuantDev &qd = A.P.qd[luma ? 0 : 1];
-    const int qbits = 14 + qd.per_qbits + tshift;
-    const long long add = (long long)qd.rnd_factor << (qbits - 9);
-    if (active && gl == 0) L.nzmask[0] = L.nzmask[1] = 0;
-    int sum = 0;
-    if (active) {
-      load_row32<N>(A.lev.p[pl] + (size_t)(y + gl) * A.lev.s[pl] + x, row);
-#pragma unroll
-      for (int k = 0; k < N; k++) {
-        int lvl, du, al;
-        quant_one(row[k], qd, qbits, add, lvl, du, al);
-        sum += al;
-        L.tile[gl][k] = lvl;
-        L.du[gl][k] = (du << 1) | (row[k] < 0 ? 1 : 0);
-      }
-    }
-    sum = group_sum(active ? sum : 0, N);
-    __syncthreads();
-    constexpr int NG = (N / 4) * (N / 4);
-    const bool hide = A.P.sign_hide && sum >= 2;
-    if (hide)
-      for (int g = gl; g < NG; g += N) {
-        bool nz = false;
-        for (int q = 0; q < 16; q++) {
-          int p = scan_pos<N>(scan_idx, g, q);
-          nz |= L.tile[p / N][p % N] != 0;
-        }
-        if (nz) atomicOr(&L.nzmask[g >> 5], 1u << (g & 31));
-      }
-    __syncthreads();
-    if (hide) {
-      const unsigned long long mask = (unsigned long long)L.nzmask[0] | ((unsigned long long)L.nzmask[1] << 32);
-      for (int g = gl; g < NG; g += N)
-        if ((mask >> g) & 1) sbh_group<N>(L, scan_idx, g, g < 63 ? (mask >> (g + 1)) == 0 : true);
-    }
-    __syncthreads();
+    // Int coefficients in lev -> levels in lev2 (the quantiser half of transformNxN on its own)
+    if (active) load_row32<N>(A.lev.p[pl] + (size_t)(y + gl) * A.lev.s[pl] + x, row);
+    int sum = quant_sbh_block<N, N, N>(
+        L, gl, active, row, [&](int) { return gl; }, [&](int k) { return k; }, luma, scan_idx, A.P);
     if (active) {
       load_row32<N>(&L.tile[gl][0], row);
       store_row32<N>(A.lev2.p[pl] + (size_t)(y + gl) * A.lev2.s[pl] + x, row);
@@ -119,7 +88,7 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
       load_row32<N>(A.lev.p[pl] + (size_t)(y + gl) * A.lev.s[pl] + x, row);
       store_row32<N>(&L.tile[gl][0], row);
     }
-    __syncthreads();
+    wave_sync();
     inv_tq_block<N>(L, gl, active, ts, use_dst, luma, OP == OP_INVTRANSFORM_NXN, A.P, row);
     if (active) {
       if (A.have_pred) {
@@ -145,7 +114,9 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
       store_row32<N>(A.lev2.p[pl] + (size_t)(y + gl) * A.lev2.s[pl] + x, row);
     }
   } else { // OP_PRED
-    intra_refs<N>(L, gl, active, A.a.p[pl], A.a.s[pl], x, y, luma, A.P);
+    const int sh = luma ? 0 : 1;
+    const unsigned long long avail = active ? intra_avail_mask(x << sh, y << sh, N << sh, A.P) : 0;
+    intra_refs<N, N>(L, gl, active, A.a.p[pl], A.a.s[pl], x, y, luma, avail, A.P);
     if (active) {
       if (A.n_modes <= 0) {
         intra_pred_block<N>(L, gl, t.mode, luma, A.P, row);
@@ -161,50 +132,62 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
 }
 
 // ---- whole-picture all-intra reconstruction: one launch per CTU diagonal ----
+// Work item = (picture, CTU of the diagonal, plane), owned by ONE autonomous wave (64-thread
+// workgroup): no workgroup barrier anywhere.  The host plan lists the item's blocks as segments of
+// equal size and equal dependency level; a wave walks its segments, 64/N blocks at a time on the
+// VALU path (N <= 16), one 32x32 block at a time on the matrix cores.
 struct Seg { // a run of same-size blocks of one dependency level of one (CTU, plane)
   uint32_t start;
   uint16_t count;
   uint8_t log2n;
-  uint8_t pad;
+  uint8_t new_level; // 1: first segment of a dependency level (needs the previous level's recon)
 };
-struct FrameArgs {
-  const hmx_tu *tus;
+struct FTu { // block descriptor of the frame path: geometry + precomputed neighbour availability
+  hmx_tu t;
+  uint32_t avail_lo, avail_hi;
+};
+struct PicWork { // per picture: planes + the plan it follows
+  PlanesDev org, rec;
+  LevelsDev lev;
+  const FTu *tus;
   const Seg *segs;
   const uint32_t *seg_range; // [(ctu*3+plane)*2 + {0,1}] -> begin,end in segs
+};
+struct FrameArgs {
+  const PicWork *pics;
   const uint32_t *wave_ctus; // CTU ids of this diagonal
   int n_wave_ctus;
-  int n_pics;
-  const PlanesDev *org; // [n_pics]
-  const PlanesDev *rec;
-  const LevelsDev *lev;
   PicDev P;
 };
 
+#define HMX_WAVE_SMEM (4 * (int)sizeof(TuLds<16>))
+static_assert(16 * sizeof(TuLds<4>) <= HMX_WAVE_SMEM && 8 * sizeof(TuLds<8>) <= HMX_WAVE_SMEM &&
+                  sizeof(TuLds<32>) <= HMX_WAVE_SMEM,
+              "per-wave LDS scratch");
+
 template <int N, bool ENC>
-__device__ __forceinline__ void intra_tu_chain(char *smem, const FrameArgs &A, const PlanesDev &org, const PlanesDev &rec,
-                                               const LevelsDev &lev, const hmx_tu *tus, int count) {
-  constexpr int SL = Slots<N>::v;
-  const int tid = threadIdx.x, slot = tid / N, gl = tid % N;
-  const bool lane_on = slot < SL;
-  TuLds<N> &L = reinterpret_cast<TuLds<N> *>(smem)[lane_on ? slot : 0];
+__device__ __forceinline__ void wave_chain_valu(char *smem, const PicWork &W, const PicDev &P, const FTu *tus, int count) {
+  constexpr int SL = 64 / N;
+  const int lane = threadIdx.x, slot = lane / N, gl = lane % N;
+  TuLds<N> &L = reinterpret_cast<TuLds<N> *>(smem)[slot];
   for (int base = 0; base < count; base += SL) {
     const int i = base + slot;
-    const bool active = lane_on && i < count;
-    const hmx_tu t = tus[active ? i : 0];
+    const bool active = i < count;
+    const FTu ft = tus[active ? i : 0];
+    const hmx_tu t = ft.t;
     const int pl = t.plane, x = t.x, y = t.y;
     const bool luma = pl == 0, ts = t.flags & HMX_TU_TRANSFORM_SKIP;
     const int scan_idx = coef_scan_idx(N, luma, true, t.mode);
+    const unsigned long long avail = (unsigned long long)ft.avail_lo | ((unsigned long long)ft.avail_hi << 32);
     int pred[N], row[N];
-    intra_refs<N>(L, gl, active, rec.p[pl], rec.s[pl], x, y, luma, A.P);
-    if (active) intra_pred_block<N>(L, gl, t.mode, luma, A.P, pred);
-    int *lev_row = lev.p[pl] + (size_t)(y + gl) * lev.s[pl] + x;
+    int *lev_row = W.lev.p[pl] + (size_t)(y + gl) * W.lev.s[pl] + x;
+    if (ENC && active) load_row16<N>(W.org.p[pl] + (size_t)(y + gl) * W.org.s[pl] + x, row); // independent of the refs
+    intra_refs<N, N>(L, gl, active, W.rec.p[pl], W.rec.s[pl], x, y, luma, avail, P);
+    intra_pred_block<N>(L, gl, t.mode, luma, P, pred);
     if (ENC) {
-      if (active) {
-        load_row16<N>(org.p[pl] + (size_t)(y + gl) * org.s[pl] + x, row);
 #pragma unroll
-        for (int k = 0; k < N; k++) row[k] = wrap16(row[k] - pred[k]);
-      }
-      fwd_tq_block<N>(L, gl, active, row, ts, luma, luma, scan_idx, true, A.P);
+      for (int k = 0; k < N; k++) row[k] = wrap16(row[k] - pred[k]);
+      fwd_tq_block<N>(L, gl, active, row, ts, luma, luma, scan_idx, true, P);
       if (active) {
         load_row32<N>(&L.tile[gl][0], row);
         store_row32<N>(lev_row, row);
@@ -214,43 +197,90 @@ __device__ __forceinline__ void intra_tu_chain(char *smem, const FrameArgs &A, c
         load_row32<N>(lev_row, row);
         store_row32<N>(&L.tile[gl][0], row);
       }
-      __syncthreads();
+      wave_sync();
     }
     // inverse of all-zero levels is exactly zero, so the reference's "if (uiAbsSum)" needs no branch
-    inv_tq_block<N>(L, gl, active, ts, luma, luma, true, A.P, row);
+    inv_tq_block<N>(L, gl, active, ts, luma, luma, true, P, row);
     if (active) {
-      const int mx = (1 << A.P.bit_depth) - 1;
+      const int mx = (1 << P.bit_depth) - 1;
 #pragma unroll
       for (int k = 0; k < N; k++) row[k] = clip3(0, mx, pred[k] + row[k]);
-      store_row16<N>(rec.p[pl] + (size_t)(y + gl) * rec.s[pl] + x, row);
+      store_row16<N>(W.rec.p[pl] + (size_t)(y + gl) * W.rec.s[pl] + x, row);
     }
   }
 }
 
 template <bool ENC>
-__global__ __launch_bounds__(256) void k_intra_wave(FrameArgs A) {
-  __shared__ __attribute__((aligned(16))) char smem[HMX_SMEM_BYTES];
-  // work item = (picture, CTU of the diagonal, plane); planes of a CTU are independent
+__device__ __forceinline__ void wave_chain_32(char *smem, const PicWork &W, const PicDev &P, const FTu *tus, int count) {
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  TuLds<32> &L = *reinterpret_cast<TuLds<32> *>(smem);
+  constexpr int LG = 5;
+  for (int i = 0; i < count; i++) {
+    const FTu ft = tus[i];
+    const hmx_tu t = ft.t;
+    const int pl = t.plane, x = t.x, y = t.y;
+    const bool luma = pl == 0;
+    const unsigned long long avail = (unsigned long long)ft.avail_lo | ((unsigned long long)ft.avail_hi << 32);
+    int pred[16], v[16];
+    short *rec_row = W.rec.p[pl] + (size_t)(y + r) * W.rec.s[pl] + x;
+    if (ENC) {
+      const short *org_row = W.org.p[pl] + (size_t)(y + r) * W.org.s[pl] + x;
+#pragma unroll
+      for (int s = 0; s < 16; s++) v[s] = org_row[mrow(s, h)];
+    }
+    intra_refs<32, 64>(L, lane, true, W.rec.p[pl], W.rec.s[pl], x, y, luma, avail, P);
+    const int *R = (luma && use_filtered_refs(t.mode, LG)) ? L.fline : L.line;
+    const int dcs = dc_sum_block<32, 64>(L, lane);
+    intra_pred_cols<32, 16>(R, t.mode, luma, P.bit_depth, r, dcs, [&](int s) { return mrow(s, h); }, pred);
+    if (ENC) {
+      int coef[16];
+#pragma unroll
+      for (int s = 0; s < 16; s++) v[s] = wrap16(v[s] - pred[s]);
+      fwd32_mfma(v, r, h, P.bit_depth, coef);
+      quant_sbh_block<32, 64, 16>(
+          L, lane, true, coef, [&](int k) { return mrow(k, h); }, [&](int) { return r; }, luma, 0, P);
+#pragma unroll
+      for (int g = 0; g < 16; g++) {
+        v[g] = L.tile[mrow(g, h)][r];
+        W.lev.p[pl][(size_t)(y + mrow(g, h)) * W.lev.s[pl] + x + r] = v[g];
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 16; g++) v[g] = W.lev.p[pl][(size_t)(y + mrow(g, h)) * W.lev.s[pl] + x + r];
+    }
+    const int tshift = 15 - P.bit_depth - LG;
+    const QuantDev &qd = P.qd[luma ? 0 : 1];
+    int out[16];
+#pragma unroll
+    for (int g = 0; g < 16; g++) v[g] = wrap16(dequant_one(v[g], qd.iq_scale, 6 - tshift));
+    inv32_mfma(v, r, h, P.bit_depth, out);
+    const int mx = (1 << P.bit_depth) - 1;
+#pragma unroll
+    for (int s = 0; s < 16; s++) rec_row[mrow(s, h)] = (short)clip3(0, mx, pred[s] + out[s]);
+    wave_sync();
+  }
+}
+
+template <bool ENC>
+__global__ __launch_bounds__(64) void k_intra_wave(FrameArgs A) {
+  __shared__ __attribute__((aligned(16))) char smem[HMX_WAVE_SMEM];
   int w = blockIdx.x;
   const int plane = w % 3;
   w /= 3;
   const int ctu = A.wave_ctus[w % A.n_wave_ctus];
-  const int pic = w / A.n_wave_ctus;
-  const PlanesDev org = ENC ? A.org[pic] : A.rec[pic];
-  const PlanesDev rec = A.rec[pic];
-  const LevelsDev lev = A.lev[pic];
-  const uint32_t sb = A.seg_range[(ctu * 3 + plane) * 2], se = A.seg_range[(ctu * 3 + plane) * 2 + 1];
+  const PicWork &W = A.pics[w / A.n_wave_ctus];
+  const uint32_t sb = W.seg_range[(ctu * 3 + plane) * 2], se = W.seg_range[(ctu * 3 + plane) * 2 + 1];
   for (uint32_t s = sb; s < se; s++) {
-    const Seg sg = A.segs[s];
-    const hmx_tu *tus = A.tus + sg.start;
-    // every segment boundary is a dependency-level or size boundary: make the reconstruction
-    // written so far visible to the whole workgroup before the next blocks gather references
-    __syncthreads();
+    const Seg sg = W.segs[s];
+    const FTu *tus = W.tus + sg.start;
+    // a new dependency level gathers references from the reconstruction written by the previous one
+    if (sg.new_level) wave_global_sync();
+    wave_sync(); // the LDS scratch is re-interpreted per block size
     switch (sg.log2n) {
-    case 2: intra_tu_chain<4, ENC>(smem, A, org, rec, lev, tus, sg.count); break;
-    case 3: intra_tu_chain<8, ENC>(smem, A, org, rec, lev, tus, sg.count); break;
-    case 4: intra_tu_chain<16, ENC>(smem, A, org, rec, lev, tus, sg.count); break;
-    default: intra_tu_chain<32, ENC>(smem, A, org, rec, lev, tus, sg.count); break;
+    case 2: wave_chain_valu<4, ENC>(smem, W, A.P, tus, sg.count); break;
+    case 3: wave_chain_valu<8, ENC>(smem, W, A.P, tus, sg.count); break;
+    case 4: wave_chain_valu<16, ENC>(smem, W, A.P, tus, sg.count); break;
+    default: wave_chain_32<ENC>(smem, W, A.P, tus, sg.count); break;
     }
   }
 }
@@ -266,20 +296,21 @@ struct hmx_ctx {
   // scratch for the scalar drop-ins (one block): device staging
   char *d_scratch = nullptr;
   size_t scratch_bytes = 0;
-  // per-call picture tables of the frame path
-  PlanesDev *d_org = nullptr, *d_rec = nullptr;
-  LevelsDev *d_lev = nullptr;
-  int pic_cap = 0;
+  // per-call picture tables: PicWork[] of the frame path / reference planes of motion compensation
+  PicWork *d_work = nullptr;
+  int work_cap = 0;
+  PlanesDev *d_refs = nullptr; // [16]
 };
 
 struct hmx_intra_plan {
-  hmx_tu *d_tus = nullptr;
+  FTu *d_tus = nullptr;
   Seg *d_segs = nullptr;
   uint32_t *d_seg_range = nullptr;
   uint32_t *d_wave_ctus = nullptr;
   std::vector<std::pair<uint32_t, uint32_t>> waves; // offset,count into d_wave_ctus
   PicDev P;
   int n_tu = 0;
+  int qp = 0, chroma_qp_offset = 0, slice_type = 0;
 };
 
 static int fail(hmx_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
@@ -379,9 +410,8 @@ extern "C" void hmx_destroy(hmx_ctx *c) {
   if (!c) return;
   hipStreamSynchronize(c->stream);
   hipFree(c->d_scratch);
-  hipFree(c->d_org);
-  hipFree(c->d_rec);
-  hipFree(c->d_lev);
+  hipFree(c->d_work);
+  hipFree(c->d_refs);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -584,8 +614,9 @@ extern "C" int hmx_intra_plan_create(hmx_ctx *c, const hmx_tu *tus, int n_tu, co
       return fail(c, HMX_ERR_ARG, "hmx_intra_plan_create: block crosses a CTU");
     bucket[((size_t)(ly / ctu) * cw + lx / ctu) * 3 + t.plane].push_back(i);
   }
-  std::vector<hmx_tu> stus;
+  std::vector<FTu> stus;
   stus.reserve(n_tu);
+  std::vector<unsigned long long> masks(n_tu);
   std::vector<Seg> segs;
   std::vector<uint32_t> seg_range((size_t)n_ctu * 3 * 2);
   std::vector<int> level(n_tu);
@@ -598,6 +629,7 @@ extern "C" int hmx_intra_plan_create(hmx_ctx *c, const hmx_tu *tus, int n_tu, co
       const int sh = t.plane ? 1 : 0, lx = t.x << sh, ly = t.y << sh, ls = (1 << t.log2n) << sh;
       const int n = ls / 4, cx = (lx % ctu) / 4, cy = (ly % ctu) / 4;
       unsigned long long m = intra_avail_mask(lx, ly, ls, P);
+      masks[id] = m;
       int lv = 0;
       auto dep = [&](int ux, int uy) { // unit coordinates relative to the CTU
         if (ux >= 0 && uy >= 0 && ux < U && uy < U) lv = std::max(lv, grid[uy * U + ux]);
@@ -629,9 +661,10 @@ extern "C" int hmx_intra_plan_create(hmx_ctx *c, const hmx_tu *tus, int n_tu, co
       s.start = (uint32_t)stus.size();
       s.count = (uint16_t)(e - k);
       s.log2n = tus[ids[k]].log2n;
-      s.pad = 0;
+      s.new_level = (k == 0 || level[ids[k]] != level[ids[k - 1]]) ? 1 : 0;
       segs.push_back(s);
-      for (size_t q = k; q < e; q++) stus.push_back(tus[ids[q]]);
+      for (size_t q = k; q < e; q++)
+        stus.push_back(FTu{tus[ids[q]], (uint32_t)masks[ids[q]], (uint32_t)(masks[ids[q]] >> 32)});
       k = e;
     }
     seg_range[(size_t)b * 2 + 1] = (uint32_t)segs.size();
@@ -640,6 +673,9 @@ extern "C" int hmx_intra_plan_create(hmx_ctx *c, const hmx_tu *tus, int n_tu, co
   hmx_intra_plan *pl = new hmx_intra_plan;
   pl->P = P;
   pl->n_tu = n_tu;
+  pl->qp = pp->qp;
+  pl->chroma_qp_offset = pp->chroma_qp_offset;
+  pl->slice_type = pp->slice_type;
   std::vector<uint32_t> wave_ctus;
   for (int d = 0; d <= (cw - 1) + 2 * (ch - 1); d++) {
     uint32_t off = (uint32_t)wave_ctus.size();
@@ -653,7 +689,7 @@ extern "C" int hmx_intra_plan_create(hmx_ctx *c, const hmx_tu *tus, int n_tu, co
     if (hipMalloc(dp, bytes ? bytes : 4) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc plan");
     return bytes ? hmx_upload(c, *dp, src, bytes) : HMX_OK;
   };
-  int r = up((void **)&pl->d_tus, stus.data(), stus.size() * sizeof(hmx_tu));
+  int r = up((void **)&pl->d_tus, stus.data(), stus.size() * sizeof(FTu));
   if (!r) r = up((void **)&pl->d_segs, segs.data(), segs.size() * sizeof(Seg));
   if (!r) r = up((void **)&pl->d_seg_range, seg_range.data(), seg_range.size() * sizeof(uint32_t));
   if (!r) r = up((void **)&pl->d_wave_ctus, wave_ctus.data(), wave_ctus.size() * sizeof(uint32_t));
@@ -675,49 +711,46 @@ extern "C" void hmx_intra_plan_destroy(hmx_ctx *c, hmx_intra_plan *pl) {
   delete pl;
 }
 
-static int frame_intra(hmx_ctx *c, const hmx_intra_plan *pl, int n_pics, const hmx_pic *org, const hmx_pic *rec,
-                       const hmx_levels *lev, bool enc) {
-  if (!c || !pl || n_pics <= 0 || !rec || !lev || (enc && !org)) return fail(c, HMX_ERR_ARG, "frame_intra: null argument");
-  if (n_pics > c->pic_cap) {
-    hipFree(c->d_org);
-    hipFree(c->d_rec);
-    hipFree(c->d_lev);
-    c->pic_cap = 0;
-    if (hipMalloc((void **)&c->d_org, sizeof(PlanesDev) * n_pics) != hipSuccess ||
-        hipMalloc((void **)&c->d_rec, sizeof(PlanesDev) * n_pics) != hipSuccess ||
-        hipMalloc((void **)&c->d_lev, sizeof(LevelsDev) * n_pics) != hipSuccess)
-      return fail(c, HMX_ERR_NOMEM, "hipMalloc picture tables");
-    c->pic_cap = n_pics;
+static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_stride, int n_pics, const hmx_pic *org,
+                       const hmx_pic *rec, const hmx_levels *lev, bool enc) {
+  if (!c || !plans || !plans[0] || n_pics <= 0 || !rec || !lev || (enc && !org))
+    return fail(c, HMX_ERR_ARG, "frame_intra: null argument");
+  const hmx_intra_plan *p0 = plans[0];
+  if (n_pics > c->work_cap) {
+    hipFree(c->d_work);
+    c->work_cap = 0;
+    if (hipMalloc((void **)&c->d_work, sizeof(PicWork) * n_pics) != hipSuccess)
+      return fail(c, HMX_ERR_NOMEM, "hipMalloc picture table");
+    c->work_cap = n_pics;
   }
-  std::vector<PlanesDev> ho(n_pics), hr(n_pics);
-  std::vector<LevelsDev> hl(n_pics);
+  std::vector<PicWork> hw(n_pics);
   for (int i = 0; i < n_pics; i++) {
-    ho[i] = to_dev(enc ? &org[i] : &rec[i]);
-    hr[i] = to_dev(&rec[i]);
-    hl[i] = to_dev(&lev[i]);
+    const hmx_intra_plan *pl = plans[i * plan_stride];
+    if (!pl || pl->P.pic_w != p0->P.pic_w || pl->P.pic_h != p0->P.pic_h || pl->qp != p0->qp ||
+        pl->chroma_qp_offset != p0->chroma_qp_offset || pl->slice_type != p0->slice_type ||
+        pl->P.sign_hide != p0->P.sign_hide)
+      return fail(c, HMX_ERR_ARG, "frame_intra: plans of one call must share picture size and quantiser settings");
+    hw[i].org = to_dev(enc ? &org[i] : &rec[i]);
+    hw[i].rec = to_dev(&rec[i]);
+    hw[i].lev = to_dev(&lev[i]);
+    hw[i].tus = pl->d_tus;
+    hw[i].segs = pl->d_segs;
+    hw[i].seg_range = pl->d_seg_range;
   }
-  HIPCHK(c, hipMemcpyAsync(c->d_org, ho.data(), sizeof(PlanesDev) * n_pics, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_rec, hr.data(), sizeof(PlanesDev) * n_pics, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_lev, hl.data(), sizeof(LevelsDev) * n_pics, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream)); // the host vectors go out of scope
+  HIPCHK(c, hipMemcpyAsync(c->d_work, hw.data(), sizeof(PicWork) * n_pics, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream)); // hw goes out of scope
   FrameArgs A;
-  A.tus = pl->d_tus;
-  A.segs = pl->d_segs;
-  A.seg_range = pl->d_seg_range;
-  A.n_pics = n_pics;
-  A.org = c->d_org;
-  A.rec = c->d_rec;
-  A.lev = c->d_lev;
-  A.P = pl->P;
-  for (auto &w : pl->waves) {
+  A.pics = c->d_work;
+  A.P = p0->P;
+  for (auto &w : p0->waves) {
     if (!w.second) continue;
-    A.wave_ctus = pl->d_wave_ctus + w.first;
+    A.wave_ctus = p0->d_wave_ctus + w.first;
     A.n_wave_ctus = (int)w.second;
     dim3 grid((unsigned)(w.second * n_pics * 3));
     if (enc)
-      hipLaunchKernelGGL(k_intra_wave<true>, grid, dim3(256), 0, c->stream, A);
+      hipLaunchKernelGGL(k_intra_wave<true>, grid, dim3(64), 0, c->stream, A);
     else
-      hipLaunchKernelGGL(k_intra_wave<false>, grid, dim3(256), 0, c->stream, A);
+      hipLaunchKernelGGL(k_intra_wave<false>, grid, dim3(64), 0, c->stream, A);
   }
   HIPCHK(c, hipGetLastError());
   return HMX_OK;
@@ -725,11 +758,19 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *pl, int n_pics, const h
 
 extern "C" int hmx_frame_intra_encode(hmx_ctx *c, const hmx_intra_plan *pl, int n_pics, const hmx_pic *org,
                                       const hmx_pic *rec, const hmx_levels *lev) {
-  return frame_intra(c, pl, n_pics, org, rec, lev, true);
+  return frame_intra(c, &pl, 0, n_pics, org, rec, lev, true);
 }
 extern "C" int hmx_frame_intra_decode(hmx_ctx *c, const hmx_intra_plan *pl, int n_pics, const hmx_pic *rec,
                                       const hmx_levels *lev) {
-  return frame_intra(c, pl, n_pics, nullptr, rec, lev, false);
+  return frame_intra(c, &pl, 0, n_pics, nullptr, rec, lev, false);
+}
+extern "C" int hmx_frame_intra_encode_multi(hmx_ctx *c, const hmx_intra_plan *const *plans, int n_pics, const hmx_pic *org,
+                                            const hmx_pic *rec, const hmx_levels *lev) {
+  return frame_intra(c, plans, 1, n_pics, org, rec, lev, true);
+}
+extern "C" int hmx_frame_intra_decode_multi(hmx_ctx *c, const hmx_intra_plan *const *plans, int n_pics, const hmx_pic *rec,
+                                            const hmx_levels *lev) {
+  return frame_intra(c, plans, 1, n_pics, nullptr, rec, lev, false);
 }
 
 // =============================================================================================
@@ -984,10 +1025,10 @@ __global__ __launch_bounds__(64) void k_adi(const short *win, int stride, int bx
   constexpr int W = 2 * N + 1;
   if (on) {
     unsigned long long avail = intra_avail_mask(x << chroma, y << chroma, N << chroma, P);
-    build_ref_line<N>(win + (size_t)by * stride + bx, stride, avail, chroma ? 1 : 2, P.bit_depth, gl, L.line);
+    build_ref_line<N, N>(win + (size_t)by * stride + bx, stride, avail, chroma ? 1 : 2, P.bit_depth, gl, L.line);
   }
   __syncthreads();
-  if (on && !chroma) smooth_ref_line<N>(L.line, L.fline, gl);
+  if (on && !chroma) smooth_ref_line<N, N>(L.line, L.fline, gl);
   __syncthreads();
   // reference layout: row 0 = corner + 2N above, column 0 = 2N left; second buffer = smoothed (luma)
   for (int i = threadIdx.x; i < 2 * W * W; i += blockDim.x) adi[i] = 0;
@@ -1256,25 +1297,16 @@ extern "C" int hmx_batch_motionCompensation(hmx_ctx *c, const hmx_pu *d_pus, int
                                             const hmx_pic *dst) {
   if (!c || !d_pus || !refs || !dst || n_refs <= 0 || n_refs > 16) return fail(c, HMX_ERR_ARG, "hmx_batch_motionCompensation: bad argument");
   if (n <= 0) return HMX_OK;
-  if (n_refs > c->pic_cap) { // reuse the picture-table allocation of the frame path
-    hipFree(c->d_org);
-    hipFree(c->d_rec);
-    hipFree(c->d_lev);
-    c->pic_cap = 0;
-    if (hipMalloc((void **)&c->d_org, sizeof(PlanesDev) * 16) != hipSuccess ||
-        hipMalloc((void **)&c->d_rec, sizeof(PlanesDev) * 16) != hipSuccess ||
-        hipMalloc((void **)&c->d_lev, sizeof(LevelsDev) * 16) != hipSuccess)
-      return fail(c, HMX_ERR_NOMEM, "hipMalloc picture tables");
-    c->pic_cap = 16;
-  }
+  if (!c->d_refs && hipMalloc((void **)&c->d_refs, sizeof(PlanesDev) * 16) != hipSuccess)
+    return fail(c, HMX_ERR_NOMEM, "hipMalloc reference table");
   PlanesDev hr[16];
   for (int i = 0; i < n_refs; i++) hr[i] = to_dev(&refs[i]);
-  HIPCHK(c, hipMemcpyAsync(c->d_rec, hr, sizeof(PlanesDev) * n_refs, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_refs, hr, sizeof(PlanesDev) * n_refs, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   McArgs A;
   A.pus = d_pus;
   A.n = n;
-  A.refs = c->d_rec;
+  A.refs = c->d_refs;
   A.dst = to_dev(dst);
   A.B = c->cfg.bit_depth;
   hipLaunchKernelGGL(k_mc, dim3((unsigned)n * 3), dim3(256), 0, c->stream, A);
