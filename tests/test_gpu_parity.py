@@ -185,11 +185,14 @@ def _oracle_frame(tus, w, h, B, qp, org, sign_hide=1, decode_levels=None):
     return rec, lev
 
 
+@pytest.mark.parametrize("schedule", ["wave", "level"])
 @pytest.mark.parametrize("pic,tiling", [((192, 128), "mix"), ((416, 240), "mix"), ((128, 64), 4), ((128, 64), 8),
                                         ((128, 128), 16), ((128, 128), 32), ((200, 136), "mix")])
-def test_frame_intra_encode_decode(ctx, pic, tiling):
+def test_frame_intra_encode_decode(ctx, pic, tiling, schedule, monkeypatch):
     """Whole-picture all-intra chain (refs <- recon, pred, T, Q, IQ, IT, recon) incl. pictures whose
-    right/bottom edge cuts the last CTU; 3 pictures per call share one plan."""
+    right/bottom edge cuts the last CTU; 3 pictures per call share one plan.  Both dependency
+    schedules of the library (CTU-diagonal waves / picture-wide levels) must give the same bits."""
+    monkeypatch.setenv("HMX_INTRA_SCHEDULE", schedule)
     B = ctx.bit_depth
     w, h = pic
     tus = workload.make_tus(7, w, h, tiling)
@@ -341,3 +344,35 @@ def test_batch_motion_compensation(ctx):
         O.hmo_mc_frame(t.ctypes.data, len(t), B, ptrs, rs, P3(*[d.ctypes.data for d in dst]), I3(w, w // 2, w // 2))
         for p in range(3):
             assert np.array_equal(got[p], dst[p]), ("mc", bi_frac, p)
+
+
+@pytest.mark.parametrize("schedule", ["wave", "level"])
+def test_frame_intra_multi_plan(ctx, schedule, monkeypatch):
+    """Every picture with its own block structure and modes (hmx_frame_intra_encode_multi)."""
+    monkeypatch.setenv("HMX_INTRA_SCHEDULE", schedule)
+    B, L = ctx.bit_depth, capi.lib()
+    w, h, n = 256, 192, 4
+    pp = capi.PicParam(w, h, 27, 0, capi.I_SLICE, 1)
+    tus = [workload.make_tus(30 + i, w, h, "mix" if i % 2 == 0 else (4, 16)[i // 2 % 2]) for i in range(n)]
+    plans = [ctx.intra_plan(t, pp) for t in tus]
+    orgs = [workload.make_planes(60 + i, w, h, B, "texture") for i in range(n)]
+    d_org = [capi.DevPicture(ctx, w, h).upload(o) for o in orgs]
+    d_rec = [capi.DevPicture(ctx, w, h).zero() for _ in range(n)]
+    d_lev = [capi.DevPicture(ctx, w, h, dtype=np.int32).zero() for _ in range(n)]
+    A = lambda lst, T: (T * n)(*[x.as_pic() for x in lst])
+    parr = (C.c_void_p * n)(*[p.value for p in plans])
+    ctx._chk(L.hmx_frame_intra_encode_multi(ctx.h, parr, n, A(d_org, capi.Pic), A(d_rec, capi.Pic), A(d_lev, capi.Levels)))
+    ctx.sync()
+    for i in range(n):
+        rr, lr = ol.o_intra_frame_encode(tus[i], w, h, B, 27, orgs[i])
+        rec, lev = d_rec[i].download(), d_lev[i].download()
+        for p in range(3):
+            assert np.array_equal(lev[p], lr[p]) and np.array_equal(rec[p], rr[p]), (i, p)
+    d_rec2 = [capi.DevPicture(ctx, w, h).zero() for _ in range(n)]
+    ctx._chk(L.hmx_frame_intra_decode_multi(ctx.h, parr, n, A(d_rec2, capi.Pic), A(d_lev, capi.Levels)))
+    ctx.sync()
+    for i in range(n):
+        a, b = d_rec2[i].download(), d_rec[i].download()
+        assert all(np.array_equal(a[p], b[p]) for p in range(3))
+    for p in plans:
+        L.hmx_intra_plan_destroy(ctx.h, p)

@@ -109,6 +109,8 @@ def lib():
         L.hmx_intra_plan_destroy.restype = None
         L.hmx_frame_intra_encode.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(Levels)]
         L.hmx_frame_intra_decode.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Levels)]
+        L.hmx_frame_intra_encode_multi.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(Levels)]
+        L.hmx_frame_intra_decode_multi.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Levels)]
         L.hmx_batch_motionCompensation.argtypes = [vp, vp, ci, C.POINTER(Pic), ci, C.POINTER(Pic)]
         L.hmx_pic_extend_border.argtypes = [vp, C.POINTER(Pic), ci, ci, ci, ci]
         L.hmx_clipMv.argtypes = [C.POINTER(ci), C.POINTER(ci), ci, ci, ci, ci, ci]

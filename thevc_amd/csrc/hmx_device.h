@@ -151,52 +151,70 @@ struct PicDev { // parameters shared by the block kernels
   QuantDev qd[2];   // [0] luma, [1] chroma
 };
 
-// scan position -> (y,x) inside a 4x4 coefficient group / group order, TComRom.cpp:564-698
-__device__ __forceinline__ int diag4_pos(int i) { // up-right diagonal of a 4x4, returns y*4+x
-  constexpr unsigned char t[16] = {0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15};
-  return t[i];
+// Scan tables g_auiSigLastScan (TComRom.cpp:564-698 with REMOVAL_8x2_2x8_CG): coefficient groups
+// of 4x4, groups ordered like the samples inside a group.  Index 0 = diagonal (also used for the
+// reference's "zigzag" index, TComTrQuant.cpp:1135), 1 = horizontal, 2 = vertical.  Entry = raster
+// position inside the N x N block.  Built at compile time, kept in constant memory.
+__host__ __device__ constexpr int diag_xy(int W, int i) { // i-th position of the up-right diagonal scan of a WxW grid -> y*W+x
+  int c = 0;
+  for (int d = 0; d <= 2 * W - 2; d++)
+    for (int x = (d < W ? 0 : d - W + 1); x <= d && x < W; x++) {
+      if (c == i) return (d - x) * W + x;
+      c++;
+    }
+  return 0;
 }
-__device__ __forceinline__ int diag_group(int G, int g) { // group index in diag order -> gy*G+gx
-  if (G == 1) return 0;
-  if (G == 2) {
-    constexpr unsigned char t[4] = {0, 2, 1, 3};
-    return t[g];
+template <int N, typename T>
+struct ScanTab {
+  T t[3][N * N];
+  constexpr ScanTab() : t{} {
+    constexpr int G = N / 4;
+    for (int sc = 0; sc < 3; sc++)
+      for (int g = 0; g < G * G; g++)
+        for (int i = 0; i < 16; i++) {
+          int gy = 0, gx = 0, y = 0, x = 0;
+          if (sc == 1) {
+            gy = g / G, gx = g % G, y = i >> 2, x = i & 3;
+          } else if (sc == 2) {
+            gx = g / G, gy = g % G, x = i >> 2, y = i & 3;
+          } else {
+            int gp = diag_xy(G, g), ip = diag_xy(4, i);
+            gy = gp / G, gx = gp % G, y = ip >> 2, x = ip & 3;
+          }
+          t[sc][g * 16 + i] = (T)((gy * 4 + y) * N + gx * 4 + x);
+        }
   }
-  if (G == 4) return diag4_pos(g);
-  // 8x8 grid: walk the diagonals (64 entries; computed, not stored)
-  int d = 0, base = 0;
-  for (;;) {
-    int len = d < 8 ? d + 1 : 15 - d;
-    if (g < base + len) break;
-    base += len;
-    d++;
-  }
-  int x = (d < 8 ? 0 : d - 7) + (g - base);
-  return (d - x) * 8 + x;
-}
-// raster position inside the N x N block of scan entry (group g, index i)
+};
+__constant__ ScanTab<4, unsigned char> kScan4 = ScanTab<4, unsigned char>();
+__constant__ ScanTab<8, unsigned char> kScan8 = ScanTab<8, unsigned char>();
+__constant__ ScanTab<16, unsigned char> kScan16 = ScanTab<16, unsigned char>();
+__constant__ ScanTab<32, unsigned short> kScan32 = ScanTab<32, unsigned short>();
+
+// the 16 raster positions of coefficient group g in scan order (one or two 16-byte loads)
 template <int N>
-__device__ __forceinline__ int scan_pos(int scan_idx, int g, int i) {
-  constexpr int G = N / 4;
-  int gy, gx, y, x;
-  if (scan_idx == 1) { // horizontal: groups raster, raster inside
-    gy = g / G;
-    gx = g % G;
-    y = i >> 2;
-    x = i & 3;
-  } else if (scan_idx == 2) { // vertical
-    gx = g / G;
-    gy = g % G;
-    x = i >> 2;
-    y = i & 3;
+__device__ __forceinline__ void scan_group(int scan_idx, int g, int *pos) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  if constexpr (N == 32) {
+    const u4 *p = reinterpret_cast<const u4 *>(&kScan32.t[scan_idx][g * 16]);
+    const u4 a = p[0], b = p[1];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      pos[2 * q] = a[q] & 0xffff;
+      pos[2 * q + 1] = a[q] >> 16;
+      pos[8 + 2 * q] = b[q] & 0xffff;
+      pos[8 + 2 * q + 1] = b[q] >> 16;
+    }
   } else {
-    int gp = diag_group(G, g), ip = diag4_pos(i);
-    gy = gp / G;
-    gx = gp % G;
-    y = ip >> 2;
-    x = ip & 3;
+    const unsigned char *base = N == 4 ? &kScan4.t[scan_idx][g * 16] : N == 8 ? &kScan8.t[scan_idx][g * 16] : &kScan16.t[scan_idx][g * 16];
+    const u4 a = *reinterpret_cast<const u4 *>(base);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      pos[4 * q] = a[q] & 255;
+      pos[4 * q + 1] = (a[q] >> 8) & 255;
+      pos[4 * q + 2] = (a[q] >> 16) & 255;
+      pos[4 * q + 3] = a[q] >> 24;
+    }
   }
-  return (gy * 4 + y) * N + gx * 4 + x;
 }
 
 // getCoefScanIdx (TComDataCU.cpp:4014-4063); 0 (zigzag) is used as diagonal by xQuant
@@ -209,57 +227,66 @@ __device__ __forceinline__ int coef_scan_idx(int N, bool luma, bool intra, int m
   return 0;
 }
 
-// LDS scratch of one block.  tile: transposition buffer, then the quantised levels;
-// du: (deltaU << 1) | (unquantised coefficient < 0), the two things sign-bit hiding reads.
+// LDS scratch of one block.  tile: transposition buffer, then the quantiser's packed words
+//   bits 0..15  level (signed)      bits 16..31  (deltaU << 1) | (unquantised coefficient < 0)
+// i.e. everything sign-bit hiding reads about a coefficient in one word.
 template <int N>
 struct TuLds {
   int tile[N][N + 1];
-  int du[N][N + 1];
   int line[4 * N + 2];
   int fline[4 * N + 2];
   unsigned nzmask[2]; // bit g: coefficient group g (scan order) holds a non-zero level
 };
 
-// Flat quantisation of one coefficient (TComTrQuant.cpp:1241-1259)
-__device__ __forceinline__ void quant_one(int c, const QuantDev &qd, int qbits, long long add, int &level,
-                                          int &delta_u, int &abs_level) {
-  long long t = (long long)abs(c) * qd.q;
-  int l = (int)((t + add) >> qbits);
-  delta_u = (int)((t - ((long long)l << qbits)) >> (qbits - 8));
+__device__ __forceinline__ int level_of(int word) { return (int)(short)word; }
+
+// Flat quantisation of one coefficient (TComTrQuant.cpp:1241-1259) -> packed word.  WIDE = false is
+// for coefficients known to lie in [-32768, 32768] (anything that went through a forward pass or
+// transform skip): |c| * q < 2^30 and every intermediate fits 32 bits, identical results.
+template <bool WIDE>
+__device__ __forceinline__ int quant_one(int c, int q, int qbits, int rnd_factor, int &abs_level) {
+  int l, du;
+  if (WIDE) {
+    const long long t = (long long)abs(c) * q, add = (long long)rnd_factor << (qbits - 9);
+    l = (int)((t + add) >> qbits);
+    du = (int)((t - ((long long)l << qbits)) >> (qbits - 8));
+  } else {
+    const unsigned t = (unsigned)abs(c) * (unsigned)q, add = (unsigned)rnd_factor << (qbits - 9);
+    l = (int)((t + add) >> qbits);
+    du = ((int)t - (l << qbits)) >> (qbits - 8);
+  }
   abs_level = l;
-  level = clip3(-32768, 32767, c < 0 ? -l : l);
+  const int level = clip3(-32768, 32767, c < 0 ? -l : l);
+  return (level & 0xffff) | ((du << 1 | (c < 0 ? 1 : 0)) << 16);
 }
 
-// signBitHidingHDQ (TComTrQuant.cpp:977-1100) for ONE 16-coefficient group; groups are independent
-// except for the reference's lastCG flag: first_nz_group = this is the highest group in scan order
-// that holds a non-zero level (its candidate loop starts at the last non-zero, not at 15).
-// Fully unrolled over the 16 scan positions so that nothing is indexed at run time (no scratch).
-template <int N>
-__device__ __forceinline__ void sbh_group(TuLds<N> &L, int scan_idx, int g, bool first_nz_group) {
-  int qv[16], dv[16];
+// signBitHidingHDQ (TComTrQuant.cpp:977-1100) for ONE 16-coefficient group, given its 16 packed words
+// w[] in scan order.  Groups are independent except for the reference's lastCG flag:
+// first_nz_group = this is the highest group in scan order that holds a non-zero level (its
+// candidate loop starts at the last non-zero, not at 15).  Fully unrolled: no run-time indexing.
+// Returns the scan index whose level changes (or -1) and the new packed word.
+__device__ __forceinline__ int sbh_decide(const int *w, bool first_nz_group, int &new_word) {
   int first = 16, last = -1, sum = 0;
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    const int p = scan_pos<N>(scan_idx, g, i);
-    qv[i] = L.tile[p / N][p % N];
-    dv[i] = L.du[p / N][p % N]; // (deltaU << 1) | sign of the unquantised coefficient
-    sum += qv[i];
-    if (qv[i]) {
+    const int q = level_of(w[i]);
+    sum += q;
+    if (q) {
       first = min(first, i);
       last = i;
     }
   }
-  if (last - first < 4) return;
+  if (last - first < 4) return -1;
   int q_first = 0;
 #pragma unroll
-  for (int i = 0; i < 16; i++) q_first = (i == first) ? qv[i] : q_first;
+  for (int i = 0; i < 16; i++) q_first = (i == first) ? level_of(w[i]) : q_first;
   const int signbit = q_first > 0 ? 0 : 1;
-  if (signbit == (sum & 1)) return;
+  if (signbit == (sum & 1)) return -1;
   const int start = first_nz_group ? last : 15;
   int best_cost = 0x7fffffff, best_i = -1, best_chg = 0;
 #pragma unroll
   for (int i = 15; i >= 0; i--) {
-    const int q = qv[i], du = dv[i] >> 1;
+    const int q = level_of(w[i]), dus = w[i] >> 16, du = dus >> 1;
     int cost = 0x7fffffff, chg = 0;
     if (q != 0) {
       if (du > 0) {
@@ -270,7 +297,7 @@ __device__ __forceinline__ void sbh_group(TuLds<N> &L, int scan_idx, int g, bool
         chg = -1;
       }
     } else if (i < first) {
-      if ((dv[i] & 1) == signbit) {
+      if ((dus & 1) == signbit) {
         cost = -du;
         chg = 1;
       }
@@ -284,16 +311,14 @@ __device__ __forceinline__ void sbh_group(TuLds<N> &L, int scan_idx, int g, bool
       best_i = i;
     }
   }
-  int q = 0, neg = 0;
+  int wsel = 0;
 #pragma unroll
-  for (int i = 0; i < 16; i++)
-    if (i == best_i) {
-      q = qv[i];
-      neg = dv[i] & 1;
-    }
+  for (int i = 0; i < 16; i++) wsel = (i == best_i) ? w[i] : wsel;
+  const int q = level_of(wsel), neg = (wsel >> 16) & 1;
   if (q == 32767 || q == -32768) best_chg = -1;
-  const int p = scan_pos<N>(scan_idx, g, best_i);
-  L.tile[p / N][p % N] = neg ? q - best_chg : q + best_chg;
+  const int nq = neg ? q - best_chg : q + best_chg;
+  new_word = (wsel & 0xffff0000) | (nq & 0xffff);
+  return best_i;
 }
 
 // ---------------------------------------------------------------------------------------------

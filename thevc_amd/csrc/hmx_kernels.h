@@ -45,51 +45,65 @@ __device__ __forceinline__ int group_sum(int v, int width) { // sum over `width`
 // ---------------------------------------------------------------------------------------------
 // Quantise the coefficients a lane holds and run sign-bit hiding on the block (TComTrQuant.cpp
 // :1130-1267, :977-1100).  coef[k] sits at (row, col) = pos(k); NL lanes own the block, NCOEF per lane.
-// Leaves the final levels in L.tile[row][col]; returns uiAbsSum (before sign-bit hiding, :1256).
+// Leaves packed words (level in the low half) in L.tile[row][col]; returns uiAbsSum (before sign-bit
+// hiding, :1256).  WIDE: see quant_one.
 // ---------------------------------------------------------------------------------------------
-template <int N, int NL, int NCOEF, typename RowFn, typename ColFn>
+template <int N, int NL, int NCOEF, bool WIDE, typename RowFn, typename ColFn>
 __device__ __forceinline__ int quant_sbh_block(TuLds<N> &L, int gl, bool active, const int *coef, RowFn row_of, ColFn col_of,
                                                bool luma, int scan_idx, const PicDev &P) {
   constexpr int LG = Log2<N>::v;
   const int tshift = 15 - P.bit_depth - LG;
   const QuantDev &qd = P.qd[luma ? 0 : 1];
   const int qbits = 14 + qd.per_qbits + tshift;
-  const long long add = (long long)qd.rnd_factor << (qbits - 9);
   int sum = 0;
   if (active) { // idle lanes may alias another block's scratch: never let them write
     if (gl == 0) L.nzmask[0] = L.nzmask[1] = 0;
 #pragma unroll
     for (int k = 0; k < NCOEF; k++) {
-      int lvl, du, al;
-      quant_one(coef[k], qd, qbits, add, lvl, du, al);
+      int al;
+      const int word = quant_one<WIDE>(coef[k], qd.q, qbits, qd.rnd_factor, al);
       sum += al;
-      const int r = row_of(k), c = col_of(k);
-      L.tile[r][c] = lvl;
-      L.du[r][c] = (du << 1) | (coef[k] < 0 ? 1 : 0);
+      L.tile[row_of(k)][col_of(k)] = word;
     }
   }
   sum = group_sum(active ? sum : 0, NL);
   wave_sync();
-  constexpr int NG = (N / 4) * (N / 4);
+  constexpr int NG = (N / 4) * (N / 4), PER = (NG + NL - 1) / NL;
   const bool hide = P.sign_hide && sum >= 2; // uniform over the block's lanes
+  int w[PER][16], pos[PER][16];
   if (hide) {
-    for (int g = gl; g < NG; g += NL) {
-      bool nz = false;
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        int p = scan_pos<N>(scan_idx, g, i);
-        nz |= L.tile[p / N][p % N] != 0;
+    for (int q = 0; q < PER; q++) {
+      const int g = gl + q * NL;
+      if (g < NG) {
+        scan_group<N>(scan_idx, g, pos[q]);
+        bool nz = false;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          w[q][i] = L.tile[pos[q][i] / N][pos[q][i] % N];
+          nz |= (w[q][i] & 0xffff) != 0;
+        }
+        if (nz) atomicOr(&L.nzmask[g >> 5], 1u << (g & 31));
       }
-      if (nz) atomicOr(&L.nzmask[g >> 5], 1u << (g & 31));
     }
   }
   wave_sync();
   if (hide) {
     const unsigned long long mask = (unsigned long long)L.nzmask[0] | ((unsigned long long)L.nzmask[1] << 32);
-    for (int g = gl; g < NG; g += NL) {
-      if (!((mask >> g) & 1)) continue;
-      bool higher = g < 63 ? (mask >> (g + 1)) != 0 : false;
-      sbh_group<N>(L, scan_idx, g, !higher);
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const int g = gl + q * NL;
+      if (g < NG && ((mask >> g) & 1)) {
+        const bool higher = g < 63 ? (mask >> (g + 1)) != 0 : false;
+        int nw;
+        const int bi = sbh_decide(w[q], !higher, nw);
+        if (bi >= 0) {
+          int p = 0;
+#pragma unroll
+          for (int i = 0; i < 16; i++) p = (i == bi) ? pos[q][i] : p;
+          L.tile[p / N][p % N] = nw;
+        }
+      }
     }
   }
   wave_sync();
@@ -104,6 +118,8 @@ __device__ __forceinline__ int quant_sbh_block(TuLds<N> &L, int gl, bool active,
 template <int N>
 __device__ __forceinline__ int fwd_tq_block(TuLds<N> &L, int gl, bool active, const int *x, bool ts, bool use_dst,
                                             bool luma, int scan_idx, bool do_quant, const PicDev &P) {
+  // everything quantised here went through a forward pass (int16) or transform skip (|x| << shift
+  // with |x| < 2^(B+1)), so the 32-bit quantiser is exact
   constexpr int LG = Log2<N>::v;
   const int B = P.bit_depth, tshift = 15 - B - LG;
   int coef[N];
@@ -137,7 +153,7 @@ __device__ __forceinline__ int fwd_tq_block(TuLds<N> &L, int gl, bool active, co
     wave_sync();
     return 0;
   }
-  return quant_sbh_block<N, N, N>(
+  return quant_sbh_block<N, N, N, false>(
       L, gl, active, coef, [&](int k) { return ts ? gl : k; }, [&](int k) { return ts ? k : gl; }, luma, scan_idx, P);
 }
 
@@ -158,7 +174,7 @@ __device__ __forceinline__ void inv_tq_block(TuLds<N> &L, int gl, bool active, b
 #pragma unroll
   for (int k = 0; k < N; k++) {
     int v = ts ? L.tile[gl][k] : L.tile[k][gl];
-    c[k] = do_dequant ? dequant_one(v, qd.iq_scale, dshift) : v;
+    c[k] = do_dequant ? dequant_one(level_of(v), qd.iq_scale, dshift) : v;
   }
   if (ts) { // xITransformSkip (:1667-1704)
 #pragma unroll

@@ -70,22 +70,32 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
     int sum = fwd_tq_block<N>(L, gl, active, row, ts, use_dst, luma, scan_idx, OP == OP_TRANSFORM_NXN, A.P);
     if (active) {
       load_row32<N>(&L.tile[gl][0], row);
+      if (OP == OP_TRANSFORM_NXN) {
+#pragma unroll
+        for (int k = 0; k < N; k++) row[k] = level_of(row[k]);
+      }
       store_row32<N>(A.lev.p[pl] + (size_t)(y + gl) * A.lev.s[pl] + x, row);
       if (OP == OP_TRANSFORM_NXN && gl == 0 && A.abs_sum) A.abs_sum[d.idx] = (uint32_t)sum;
     }
   } else if constexpr (OP == OP_XQUANT) {
     // Int coefficients in lev -> levels in lev2 (the quantiser half of transformNxN on its own)
     if (active) load_row32<N>(A.lev.p[pl] + (size_t)(y + gl) * A.lev.s[pl] + x, row);
-    int sum = quant_sbh_block<N, N, N>(
+    int sum = quant_sbh_block<N, N, N, true>(
         L, gl, active, row, [&](int) { return gl; }, [&](int k) { return k; }, luma, scan_idx, A.P);
     if (active) {
       load_row32<N>(&L.tile[gl][0], row);
+#pragma unroll
+      for (int k = 0; k < N; k++) row[k] = level_of(row[k]);
       store_row32<N>(A.lev2.p[pl] + (size_t)(y + gl) * A.lev2.s[pl] + x, row);
       if (gl == 0 && A.abs_sum) A.abs_sum[d.idx] = (uint32_t)sum;
     }
   } else if constexpr (OP == OP_INVTRANSFORM_NXN || OP == OP_XIT) {
     if (active) {
       load_row32<N>(A.lev.p[pl] + (size_t)(y + gl) * A.lev.s[pl] + x, row);
+      if (OP == OP_INVTRANSFORM_NXN) { // the tile holds packed words: xDeQuant's input clip happens here
+#pragma unroll
+        for (int k = 0; k < N; k++) row[k] = clip3(-32768, 32767, row[k]) & 0xffff;
+      }
       store_row32<N>(&L.tile[gl][0], row);
     }
     wave_sync();
@@ -146,12 +156,19 @@ struct FTu { // block descriptor of the frame path: geometry + precomputed neigh
   hmx_tu t;
   uint32_t avail_lo, avail_hi;
 };
+struct LevelRow { // blocks of one picture-wide dependency level, bucketed by size (log2n - 2)
+  uint32_t start[4];
+  uint32_t count[4];
+};
 struct PicWork { // per picture: planes + the plan it follows
   PlanesDev org, rec;
   LevelsDev lev;
   const FTu *tus;
   const Seg *segs;
   const uint32_t *seg_range; // [(ctu*3+plane)*2 + {0,1}] -> begin,end in segs
+  const FTu *ltus;           // level schedule: blocks sorted by (level, size)
+  const LevelRow *ltab;      // [n_levels]
+  int n_levels;
 };
 struct FrameArgs {
   const PicWork *pics;
@@ -190,11 +207,15 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const PicWork &W, co
       fwd_tq_block<N>(L, gl, active, row, ts, luma, luma, scan_idx, true, P);
       if (active) {
         load_row32<N>(&L.tile[gl][0], row);
+#pragma unroll
+        for (int k = 0; k < N; k++) row[k] = level_of(row[k]);
         store_row32<N>(lev_row, row);
       }
     } else {
       if (active) {
         load_row32<N>(lev_row, row);
+#pragma unroll
+        for (int k = 0; k < N; k++) row[k] = clip3(-32768, 32767, row[k]) & 0xffff;
         store_row32<N>(&L.tile[gl][0], row);
       }
       wave_sync();
@@ -237,11 +258,11 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const PicWork &W, cons
 #pragma unroll
       for (int s = 0; s < 16; s++) v[s] = wrap16(v[s] - pred[s]);
       fwd32_mfma(v, r, h, P.bit_depth, coef);
-      quant_sbh_block<32, 64, 16>(
+      quant_sbh_block<32, 64, 16, false>(
           L, lane, true, coef, [&](int k) { return mrow(k, h); }, [&](int) { return r; }, luma, 0, P);
 #pragma unroll
       for (int g = 0; g < 16; g++) {
-        v[g] = L.tile[mrow(g, h)][r];
+        v[g] = level_of(L.tile[mrow(g, h)][r]);
         W.lev.p[pl][(size_t)(y + mrow(g, h)) * W.lev.s[pl] + x + r] = v[g];
       }
     } else {
@@ -261,8 +282,42 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const PicWork &W, cons
   }
 }
 
+// Level-synchronous schedule: one launch per picture-wide dependency level.  Every block of a level
+// is independent of every other, so the launch is a plain list kernel: blockIdx.y = picture,
+// blockIdx.x = chunk of 64/N blocks (one 32x32 block) of that picture's level, all sizes in one grid.
+struct LevelArgs {
+  const PicWork *pics;
+  int level;
+  PicDev P;
+};
 template <bool ENC>
-__global__ __launch_bounds__(64) void k_intra_wave(FrameArgs A) {
+__global__ __launch_bounds__(64, 4) void k_intra_level(LevelArgs A) {
+  __shared__ __attribute__((aligned(16))) char smem[HMX_WAVE_SMEM];
+  const PicWork &W = A.pics[blockIdx.y];
+  if (A.level >= W.n_levels) return;
+  const LevelRow row = W.ltab[A.level];
+  int c = blockIdx.x;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int per = s == 3 ? 1 : (16 >> (2 * s)) * 1; // blocks per wave: 16, 8(=64/8), 4, 1
+    const int slots = s == 0 ? 16 : s == 1 ? 8 : s == 2 ? 4 : 1;
+    (void)per;
+    const int chunks = (int)(row.count[s] + slots - 1) / slots;
+    if (c < chunks) {
+      const FTu *tus = W.ltus + row.start[s] + (size_t)c * slots;
+      const int n = min(slots, (int)row.count[s] - c * slots);
+      if (s == 0) wave_chain_valu<4, ENC>(smem, W, A.P, tus, n);
+      else if (s == 1) wave_chain_valu<8, ENC>(smem, W, A.P, tus, n);
+      else if (s == 2) wave_chain_valu<16, ENC>(smem, W, A.P, tus, n);
+      else wave_chain_32<ENC>(smem, W, A.P, tus, n);
+      return;
+    }
+    c -= chunks;
+  }
+}
+
+template <bool ENC>
+__global__ __launch_bounds__(64, 4) void k_intra_wave(FrameArgs A) {
   __shared__ __attribute__((aligned(16))) char smem[HMX_WAVE_SMEM];
   int w = blockIdx.x;
   const int plane = w % 3;
@@ -299,6 +354,7 @@ struct hmx_ctx {
   // per-call picture tables: PicWork[] of the frame path / reference planes of motion compensation
   PicWork *d_work = nullptr;
   int work_cap = 0;
+  int level_mode_min_pics = 16;
   PlanesDev *d_refs = nullptr; // [16]
 };
 
@@ -308,6 +364,9 @@ struct hmx_intra_plan {
   uint32_t *d_seg_range = nullptr;
   uint32_t *d_wave_ctus = nullptr;
   std::vector<std::pair<uint32_t, uint32_t>> waves; // offset,count into d_wave_ctus
+  FTu *d_ltus = nullptr;       // level schedule
+  LevelRow *d_ltab = nullptr;
+  std::vector<uint32_t> level_chunks; // waves needed per level
   PicDev P;
   int n_tu = 0;
   int qp = 0, chroma_qp_offset = 0, slice_type = 0;
@@ -669,8 +728,59 @@ extern "C" int hmx_intra_plan_create(hmx_ctx *c, const hmx_tu *tus, int n_tu, co
     }
     seg_range[(size_t)b * 2 + 1] = (uint32_t)segs.size();
   }
+  // Picture-wide dependency levels (level schedule): level = 1 + max level of the blocks that
+  // cover the available neighbour units, over the whole plane, blocks visited in coding order.
+  std::vector<FTu> ltus(n_tu);
+  std::vector<LevelRow> ltab;
+  std::vector<uint32_t> level_chunks;
+  {
+    const int uw = cw * U, uh = ch * U;
+    std::vector<int> g3((size_t)uw * uh * 3, 0);
+    std::vector<int> glevel(n_tu);
+    int max_level = 0;
+    for (int i = 0; i < n_tu; i++) {
+      const hmx_tu &t = tus[i];
+      const int sh = t.plane ? 1 : 0, lx = t.x << sh, ly = t.y << sh, ls = (1 << t.log2n) << sh;
+      const int n = ls / 4, ux = lx / 4, uy = ly / 4;
+      int *g = g3.data() + (size_t)t.plane * uw * uh;
+      const unsigned long long m = masks[i];
+      int lv = 0;
+      for (int u = 0; u < 4 * n + 1; u++) {
+        if (!((m >> u) & 1)) continue;
+        int qx, qy;
+        if (u < 2 * n) qx = ux - 1, qy = uy + 2 * n - 1 - u;
+        else if (u == 2 * n) qx = ux - 1, qy = uy - 1;
+        else qx = ux + (u - 2 * n - 1), qy = uy - 1;
+        lv = std::max(lv, g[(size_t)qy * uw + qx]); // available => inside the picture
+      }
+      glevel[i] = lv; // zero-based level
+      max_level = std::max(max_level, lv);
+      for (int j = 0; j < n; j++)
+        for (int i2 = 0; i2 < n; i2++) g[(size_t)(uy + j) * uw + ux + i2] = lv + 1;
+    }
+    ltab.assign((size_t)max_level + 1, LevelRow{{0, 0, 0, 0}, {0, 0, 0, 0}});
+    for (int i = 0; i < n_tu; i++) ltab[glevel[i]].count[tus[i].log2n - 2]++;
+    uint32_t off = 0;
+    level_chunks.resize(ltab.size());
+    for (size_t l = 0; l < ltab.size(); l++) {
+      uint32_t chunks = 0;
+      for (int sidx = 0; sidx < 4; sidx++) {
+        ltab[l].start[sidx] = off;
+        off += ltab[l].count[sidx];
+        const uint32_t slots = sidx == 0 ? 16 : sidx == 1 ? 8 : sidx == 2 ? 4 : 1;
+        chunks += (ltab[l].count[sidx] + slots - 1) / slots;
+      }
+      level_chunks[l] = chunks;
+    }
+    std::vector<uint32_t> fill(ltab.size() * 4, 0);
+    for (int i = 0; i < n_tu; i++) {
+      const int l = glevel[i], sidx = tus[i].log2n - 2;
+      ltus[ltab[l].start[sidx] + fill[(size_t)l * 4 + sidx]++] = FTu{tus[i], (uint32_t)masks[i], (uint32_t)(masks[i] >> 32)};
+    }
+  }
   // CTU diagonals d = X + 2Y: (X,Y) needs (X-1,Y), (X-1,Y-1), (X,Y-1), (X+1,Y-1)
   hmx_intra_plan *pl = new hmx_intra_plan;
+  pl->level_chunks = level_chunks;
   pl->P = P;
   pl->n_tu = n_tu;
   pl->qp = pp->qp;
@@ -693,6 +803,8 @@ extern "C" int hmx_intra_plan_create(hmx_ctx *c, const hmx_tu *tus, int n_tu, co
   if (!r) r = up((void **)&pl->d_segs, segs.data(), segs.size() * sizeof(Seg));
   if (!r) r = up((void **)&pl->d_seg_range, seg_range.data(), seg_range.size() * sizeof(uint32_t));
   if (!r) r = up((void **)&pl->d_wave_ctus, wave_ctus.data(), wave_ctus.size() * sizeof(uint32_t));
+  if (!r) r = up((void **)&pl->d_ltus, ltus.data(), ltus.size() * sizeof(FTu));
+  if (!r) r = up((void **)&pl->d_ltab, ltab.data(), ltab.size() * sizeof(LevelRow));
   if (r) {
     hmx_intra_plan_destroy(c, pl);
     return r;
@@ -708,6 +820,8 @@ extern "C" void hmx_intra_plan_destroy(hmx_ctx *c, hmx_intra_plan *pl) {
   hipFree(pl->d_segs);
   hipFree(pl->d_seg_range);
   hipFree(pl->d_wave_ctus);
+  hipFree(pl->d_ltus);
+  hipFree(pl->d_ltab);
   delete pl;
 }
 
@@ -736,9 +850,43 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
     hw[i].tus = pl->d_tus;
     hw[i].segs = pl->d_segs;
     hw[i].seg_range = pl->d_seg_range;
+    hw[i].ltus = pl->d_ltus;
+    hw[i].ltab = pl->d_ltab;
+    hw[i].n_levels = (int)pl->level_chunks.size();
   }
   HIPCHK(c, hipMemcpyAsync(c->d_work, hw.data(), sizeof(PicWork) * n_pics, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream)); // hw goes out of scope
+  // Two schedules: "level" = one launch per picture-wide dependency level,
+  // lane-packed, throughput-oriented, wants many pictures; "wave" = one launch per CTU diagonal with
+  // autonomous waves, far fewer launches, better for a handful of pictures.
+  bool use_level = n_pics >= c->level_mode_min_pics;
+  if (const char *e = getenv("HMX_INTRA_SCHEDULE")) use_level = e[0] == 'l' ? true : (e[0] == 'w' ? false : use_level);
+  if (use_level) {
+    size_t n_levels = 0;
+    for (int i = 0; i < n_pics; i++) n_levels = std::max(n_levels, plans[i * plan_stride]->level_chunks.size());
+    LevelArgs LA;
+    LA.pics = c->d_work;
+    LA.P = p0->P;
+    for (size_t l = 0; l < n_levels; l++) {
+      uint32_t chunks = 0;
+      if (plan_stride == 0)
+        chunks = p0->level_chunks[l];
+      else
+        for (int i = 0; i < n_pics; i++) {
+          const auto &lc = plans[i]->level_chunks;
+          if (l < lc.size()) chunks = std::max(chunks, lc[l]);
+        }
+      if (!chunks) continue;
+      LA.level = (int)l;
+      dim3 grid(chunks, (unsigned)n_pics);
+      if (enc)
+        hipLaunchKernelGGL(k_intra_level<true>, grid, dim3(64), 0, c->stream, LA);
+      else
+        hipLaunchKernelGGL(k_intra_level<false>, grid, dim3(64), 0, c->stream, LA);
+    }
+    HIPCHK(c, hipGetLastError());
+    return HMX_OK;
+  }
   FrameArgs A;
   A.pics = c->d_work;
   A.P = p0->P;
