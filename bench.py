@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="ai2160p10", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames", type=int, default=32, help="pictures per GPU per step")
+    ap.add_argument("--frames", type=int, default=512, help="pictures per GPU per step (100 MB of HBM each at 2160p)")
     ap.add_argument("--tiling", default="mix", help="mix | 4 | 8 | 16 | 32 (uniform transform size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check picture 0 against the oracle after the run")

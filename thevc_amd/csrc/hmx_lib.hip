@@ -351,10 +351,22 @@ struct hmx_ctx {
   // scratch for the scalar drop-ins (one block): device staging
   char *d_scratch = nullptr;
   size_t scratch_bytes = 0;
-  // per-call picture tables: PicWork[] of the frame path / reference planes of motion compensation
-  PicWork *d_work = nullptr;
-  int work_cap = 0;
+  // whole-picture calls recorded as HIP graphs (see frame_intra)
+  struct GraphEntry {
+    uint64_t key;
+    int n_pics;
+    hipGraphExec_t exec;
+    PicWork *d_work;
+    uint64_t stamp;
+  };
+  std::vector<GraphEntry> graphs;
+  uint64_t graph_clock = 0;
   int level_mode_min_pics = 16;
+  // level schedule: picture groups run on side streams so that launches of different groups overlap
+  static const int kMaxSide = 8;
+  hipStream_t side[kMaxSide] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {};
+  int n_side = 0;
   PlanesDev *d_refs = nullptr; // [16]
 };
 
@@ -469,8 +481,16 @@ extern "C" void hmx_destroy(hmx_ctx *c) {
   if (!c) return;
   hipStreamSynchronize(c->stream);
   hipFree(c->d_scratch);
-  hipFree(c->d_work);
+  for (auto &e : c->graphs) {
+    hipGraphExecDestroy(e.exec);
+    hipFree(e.d_work);
+  }
   hipFree(c->d_refs);
+  for (int g = 0; g < c->n_side; g++) {
+    hipStreamDestroy(c->side[g]);
+    hipEventDestroy(c->ev_join[g]);
+  }
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -772,10 +792,24 @@ extern "C" int hmx_intra_plan_create(hmx_ctx *c, const hmx_tu *tus, int n_tu, co
       }
       level_chunks[l] = chunks;
     }
-    std::vector<uint32_t> fill(ltab.size() * 4, 0);
-    for (int i = 0; i < n_tu; i++) {
-      const int l = glevel[i], sidx = tus[i].log2n - 2;
-      ltus[ltab[l].start[sidx] + fill[(size_t)l * 4 + sidx]++] = FTu{tus[i], (uint32_t)masks[i], (uint32_t)(masks[i] >> 32)};
+    // Blocks of one (level, size) bucket are independent: order them so that the 64/N blocks that
+    // share a wave take the same code paths (plane class = DST vs DCT and chroma rules, transform
+    // skip, prediction mode class, then mode) instead of diverging.
+    auto mode_class = [](int m) { return m == 0 ? 0 : m == 1 ? 1 : (m == 10 || m == 26) ? 2 : (m > 10 && m < 26) ? 3 : 4; };
+    auto path_key = [&](const hmx_tu &t) {
+      return (uint32_t)((t.plane ? 1u : 0u) << 24 | (uint32_t)(t.flags & 1u) << 20 | (uint32_t)mode_class(t.mode) << 16 |
+                        (uint32_t)t.mode << 8 | t.plane);
+    };
+    std::vector<int> order(n_tu);
+    for (int i = 0; i < n_tu; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b2) {
+      if (glevel[a] != glevel[b2]) return glevel[a] < glevel[b2];
+      if (tus[a].log2n != tus[b2].log2n) return tus[a].log2n < tus[b2].log2n;
+      return path_key(tus[a]) < path_key(tus[b2]);
+    });
+    for (int k = 0; k < n_tu; k++) {
+      const int i = order[k];
+      ltus[k] = FTu{tus[i], (uint32_t)masks[i], (uint32_t)(masks[i] >> 32)};
     }
   }
   // CTU diagonals d = X + 2Y: (X,Y) needs (X-1,Y), (X-1,Y-1), (X,Y-1), (X+1,Y-1)
@@ -814,8 +848,15 @@ extern "C" int hmx_intra_plan_create(hmx_ctx *c, const hmx_tu *tus, int n_tu, co
 }
 
 extern "C" void hmx_intra_plan_destroy(hmx_ctx *c, hmx_intra_plan *pl) {
-  (void)c;
   if (!pl) return;
+  if (c) { // recorded graphs may refer to this plan (and its addresses may be re-used): drop them
+    hipStreamSynchronize(c->stream);
+    for (auto &e : c->graphs) {
+      hipGraphExecDestroy(e.exec);
+      hipFree(e.d_work);
+    }
+    c->graphs.clear();
+  }
   hipFree(pl->d_tus);
   hipFree(pl->d_segs);
   hipFree(pl->d_seg_range);
@@ -825,18 +866,78 @@ extern "C" void hmx_intra_plan_destroy(hmx_ctx *c, hmx_intra_plan *pl) {
   delete pl;
 }
 
+// Issue the launches of one whole-picture call on `main` (and the side streams).  Also used under
+// stream capture to record the call as a HIP graph.
+static int issue_intra_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_stride, int n_pics,
+                                const PicWork *d_work, bool enc, bool use_level, int groups, hipStream_t main) {
+  const hmx_intra_plan *p0 = plans[0];
+  if (use_level) {
+    // Pictures are split into groups; each group walks its levels on its own stream.  A launch
+    // of one group fills only part of the chip (its duration is one block-chain latency), so
+    // launches of different groups overlap.  Fork/join through events on the main stream.
+    if (groups > 1) HIPCHK(c, hipEventRecord(c->ev_fork, main));
+    std::vector<int> first(groups + 1);
+    std::vector<size_t> glevels(groups, 0);
+    for (int g = 0; g <= groups; g++) first[g] = (int)((long long)n_pics * g / groups);
+    for (int g = 0; g < groups; g++) {
+      if (groups > 1) HIPCHK(c, hipStreamWaitEvent(c->side[g], c->ev_fork, 0));
+      for (int i = first[g]; i < first[g + 1]; i++) glevels[g] = std::max(glevels[g], plans[i * plan_stride]->level_chunks.size());
+    }
+    size_t n_levels = 0;
+    for (int g = 0; g < groups; g++) n_levels = std::max(n_levels, glevels[g]);
+    LevelArgs LA;
+    LA.P = p0->P;
+    for (size_t l = 0; l < n_levels; l++)
+      for (int g = 0; g < groups; g++) {
+        if (l >= glevels[g]) continue;
+        uint32_t chunks = 0;
+        if (plan_stride == 0)
+          chunks = p0->level_chunks[l];
+        else
+          for (int i = first[g]; i < first[g + 1]; i++) {
+            const auto &lc = plans[i]->level_chunks;
+            if (l < lc.size()) chunks = std::max(chunks, lc[l]);
+          }
+        if (!chunks) continue;
+        LA.pics = d_work + first[g];
+        LA.level = (int)l;
+        dim3 grid(chunks, (unsigned)(first[g + 1] - first[g]));
+        hipStream_t st = groups > 1 ? c->side[g] : main;
+        if (enc)
+          hipLaunchKernelGGL(k_intra_level<true>, grid, dim3(64), 0, st, LA);
+        else
+          hipLaunchKernelGGL(k_intra_level<false>, grid, dim3(64), 0, st, LA);
+      }
+    if (groups > 1)
+      for (int g = 0; g < groups; g++) {
+        HIPCHK(c, hipEventRecord(c->ev_join[g], c->side[g]));
+        HIPCHK(c, hipStreamWaitEvent(main, c->ev_join[g], 0));
+      }
+    HIPCHK(c, hipGetLastError());
+    return HMX_OK;
+  }
+  FrameArgs A;
+  A.pics = d_work;
+  A.P = p0->P;
+  for (auto &w : p0->waves) {
+    if (!w.second) continue;
+    A.wave_ctus = p0->d_wave_ctus + w.first;
+    A.n_wave_ctus = (int)w.second;
+    dim3 grid((unsigned)(w.second * n_pics * 3));
+    if (enc)
+      hipLaunchKernelGGL(k_intra_wave<true>, grid, dim3(64), 0, main, A);
+    else
+      hipLaunchKernelGGL(k_intra_wave<false>, grid, dim3(64), 0, main, A);
+  }
+  HIPCHK(c, hipGetLastError());
+  return HMX_OK;
+}
+
 static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_stride, int n_pics, const hmx_pic *org,
                        const hmx_pic *rec, const hmx_levels *lev, bool enc) {
   if (!c || !plans || !plans[0] || n_pics <= 0 || !rec || !lev || (enc && !org))
     return fail(c, HMX_ERR_ARG, "frame_intra: null argument");
   const hmx_intra_plan *p0 = plans[0];
-  if (n_pics > c->work_cap) {
-    hipFree(c->d_work);
-    c->work_cap = 0;
-    if (hipMalloc((void **)&c->d_work, sizeof(PicWork) * n_pics) != hipSuccess)
-      return fail(c, HMX_ERR_NOMEM, "hipMalloc picture table");
-    c->work_cap = n_pics;
-  }
   std::vector<PicWork> hw(n_pics);
   for (int i = 0; i < n_pics; i++) {
     const hmx_intra_plan *pl = plans[i * plan_stride];
@@ -844,6 +945,7 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
         pl->chroma_qp_offset != p0->chroma_qp_offset || pl->slice_type != p0->slice_type ||
         pl->P.sign_hide != p0->P.sign_hide)
       return fail(c, HMX_ERR_ARG, "frame_intra: plans of one call must share picture size and quantiser settings");
+    memset(&hw[i], 0, sizeof(PicWork));
     hw[i].org = to_dev(enc ? &org[i] : &rec[i]);
     hw[i].rec = to_dev(&rec[i]);
     hw[i].lev = to_dev(&lev[i]);
@@ -854,53 +956,88 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
     hw[i].ltab = pl->d_ltab;
     hw[i].n_levels = (int)pl->level_chunks.size();
   }
-  HIPCHK(c, hipMemcpyAsync(c->d_work, hw.data(), sizeof(PicWork) * n_pics, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream)); // hw goes out of scope
   // Two schedules: "level" = one launch per picture-wide dependency level,
   // lane-packed, throughput-oriented, wants many pictures; "wave" = one launch per CTU diagonal with
   // autonomous waves, far fewer launches, better for a handful of pictures.
   bool use_level = n_pics >= c->level_mode_min_pics;
   if (const char *e = getenv("HMX_INTRA_SCHEDULE")) use_level = e[0] == 'l' ? true : (e[0] == 'w' ? false : use_level);
+  int groups = 1;
   if (use_level) {
-    size_t n_levels = 0;
-    for (int i = 0; i < n_pics; i++) n_levels = std::max(n_levels, plans[i * plan_stride]->level_chunks.size());
-    LevelArgs LA;
-    LA.pics = c->d_work;
-    LA.P = p0->P;
-    for (size_t l = 0; l < n_levels; l++) {
-      uint32_t chunks = 0;
-      if (plan_stride == 0)
-        chunks = p0->level_chunks[l];
-      else
-        for (int i = 0; i < n_pics; i++) {
-          const auto &lc = plans[i]->level_chunks;
-          if (l < lc.size()) chunks = std::max(chunks, lc[l]);
-        }
-      if (!chunks) continue;
-      LA.level = (int)l;
-      dim3 grid(chunks, (unsigned)n_pics);
-      if (enc)
-        hipLaunchKernelGGL(k_intra_level<true>, grid, dim3(64), 0, c->stream, LA);
-      else
-        hipLaunchKernelGGL(k_intra_level<false>, grid, dim3(64), 0, c->stream, LA);
+    // measured on MI355X: launches of different streams do not overlap usefully (the dispatcher
+    // retires ~140k small kernels/s whatever the stream count), so one stream is the default
+    groups = 1;
+    if (const char *e = getenv("HMX_INTRA_STREAMS")) groups = std::min(std::max(atoi(e), 1), std::min(n_pics, (int)hmx_ctx::kMaxSide));
+    if (groups > 1 && c->n_side < groups) {
+      if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+      for (int g = c->n_side; g < groups; g++) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->side[g], hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming));
+      }
+      c->n_side = groups;
     }
-    HIPCHK(c, hipGetLastError());
+  }
+  // A call is thousands of dependent launches whose arguments depend only on (plans, planes): it is
+  // recorded once as a HIP graph and replayed while the same pictures/plans come back (steady-state
+  // pipelines re-use their picture pools).  Key = the picture table itself.
+  uint64_t key = 1469598103934665603ull;
+  auto mix = [&](const void *p, size_t n) {
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < n; i++) key = (key ^ b[i]) * 1099511628211ull;
+  };
+  mix(hw.data(), sizeof(PicWork) * n_pics);
+  const int flags[4] = {enc, use_level, groups, n_pics};
+  mix(flags, sizeof(flags));
+  for (int i = 0; i < n_pics; i++) {
+    const void *pp = plans[i * plan_stride];
+    mix(&pp, sizeof(pp));
+  }
+  const bool use_graph = getenv("HMX_GRAPH") != nullptr; // measured: replay is not faster than eager launches here
+  hmx_ctx::GraphEntry *hit = nullptr;
+  for (auto &e : c->graphs)
+    if (e.key == key && e.n_pics == n_pics) hit = &e;
+  if (use_graph && hit) {
+    hit->stamp = ++c->graph_clock;
+    HIPCHK(c, hipGraphLaunch(hit->exec, c->stream));
     return HMX_OK;
   }
-  FrameArgs A;
-  A.pics = c->d_work;
-  A.P = p0->P;
-  for (auto &w : p0->waves) {
-    if (!w.second) continue;
-    A.wave_ctus = p0->d_wave_ctus + w.first;
-    A.n_wave_ctus = (int)w.second;
-    dim3 grid((unsigned)(w.second * n_pics * 3));
-    if (enc)
-      hipLaunchKernelGGL(k_intra_wave<true>, grid, dim3(64), 0, c->stream, A);
-    else
-      hipLaunchKernelGGL(k_intra_wave<false>, grid, dim3(64), 0, c->stream, A);
+  // miss: a fresh picture table (it must outlive the graph) and, if enabled, a capture
+  PicWork *d_work = nullptr;
+  if (hipMalloc((void **)&d_work, sizeof(PicWork) * n_pics) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc picture table");
+  HIPCHK(c, hipMemcpyAsync(d_work, hw.data(), sizeof(PicWork) * n_pics, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream)); // hw goes out of scope
+  if (!use_graph) {
+    int r = issue_intra_launches(c, plans, plan_stride, n_pics, d_work, enc, use_level, groups, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(d_work);
+    return r;
   }
-  HIPCHK(c, hipGetLastError());
+  hipGraph_t graph = nullptr;
+  HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  int r = issue_intra_launches(c, plans, plan_stride, n_pics, d_work, enc, use_level, groups, c->stream);
+  hipError_t ce = hipStreamEndCapture(c->stream, &graph);
+  if (r != HMX_OK || ce != hipSuccess) {
+    if (graph) hipGraphDestroy(graph);
+    hipFree(d_work);
+    return r != HMX_OK ? r : fail(c, HMX_ERR_DEVICE, "hipStreamEndCapture", ce);
+  }
+  hipGraphExec_t exec = nullptr;
+  ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (ce != hipSuccess) {
+    hipFree(d_work);
+    return fail(c, HMX_ERR_DEVICE, "hipGraphInstantiate", ce);
+  }
+  if (c->graphs.size() >= 6) { // evict the least recently used entry
+    size_t v = 0;
+    for (size_t i = 1; i < c->graphs.size(); i++)
+      if (c->graphs[i].stamp < c->graphs[v].stamp) v = i;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipGraphExecDestroy(c->graphs[v].exec);
+    hipFree(c->graphs[v].d_work);
+    c->graphs.erase(c->graphs.begin() + v);
+  }
+  c->graphs.push_back(hmx_ctx::GraphEntry{key, n_pics, exec, d_work, ++c->graph_clock});
+  HIPCHK(c, hipGraphLaunch(exec, c->stream));
   return HMX_OK;
 }
 
