@@ -135,7 +135,7 @@ def main():
     src = [cache[sd] for sd in seeds]
     d_org = [capi.DevPicture(ctx, w, h_c).upload(src[i]) for i in range(F)]
     d_rec = [capi.DevPicture(ctx, w, h_c).zero() for _ in range(F)]
-    d_lev = [capi.DevPicture(ctx, w, h_c, dtype=np.int32).zero() for _ in range(F)]
+    d_lev = [capi.DevLevelsZ(ctx, w, h_c).zero() for _ in range(F)]  # the reference's own coefficient layout
     org_arr = (capi.Pic * F)(*[d.as_pic() for d in d_org])
     rec_arr = (capi.Pic * F)(*[d.as_pic() for d in d_rec])
     lev_arr = (capi.Levels * F)(*[d.as_pic() for d in d_lev])
@@ -166,7 +166,7 @@ def main():
     if args.verify and rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as ol
-        rec, lev = d_rec[0].download(), d_lev[0].download()
+        rec, lev = d_rec[0].download(), d_lev[0].to_planes(tus)
         ro, lo = ol.o_intra_frame_encode(tus, w, h_c, B, qp, src[0])
         verified = all(np.array_equal(rec[p], ro[p]) and np.array_equal(lev[p], lo[p]) for p in range(3))
 

@@ -376,3 +376,31 @@ def test_frame_intra_multi_plan(ctx, schedule, monkeypatch):
         assert all(np.array_equal(a[p], b[p]) for p in range(3))
     for p in plans:
         L.hmx_intra_plan_destroy(ctx.h, p)
+
+
+@pytest.mark.parametrize("schedule", ["wave", "level"])
+@pytest.mark.parametrize("pic,tiling", [((416, 240), "mix"), ((200, 136), "mix"), ((128, 128), 32)])
+def test_frame_intra_zorder_levels(ctx, pic, tiling, schedule, monkeypatch):
+    """Levels in the reference's Z-order coefficient layout (hmx_levels.stride == 0), encode + decode."""
+    monkeypatch.setenv("HMX_INTRA_SCHEDULE", schedule)
+    B, L = ctx.bit_depth, capi.lib()
+    w, h = pic
+    tus = workload.make_tus(17, w, h, tiling)
+    pp = capi.PicParam(w, h, 32, 0, capi.I_SLICE, 1)
+    plan = ctx.intra_plan(tus, pp)
+    org = workload.make_planes(18, w, h, B, "texture")
+    d_org = capi.DevPicture(ctx, w, h).upload(org)
+    d_rec = capi.DevPicture(ctx, w, h).zero()
+    d_lev = capi.DevLevelsZ(ctx, w, h).zero()
+    ctx._chk(L.hmx_frame_intra_encode(ctx.h, plan, 1, C.byref(d_org.as_pic()), C.byref(d_rec.as_pic()), C.byref(d_lev.as_pic())))
+    ctx.sync()
+    rr, lr = ol.o_intra_frame_encode(tus, w, h, B, 32, org)
+    rec, lev = d_rec.download(), d_lev.to_planes(tus)
+    for p in range(3):
+        assert np.array_equal(lev[p], lr[p]) and np.array_equal(rec[p], rr[p]), p
+    d_rec2 = capi.DevPicture(ctx, w, h).zero()
+    ctx._chk(L.hmx_frame_intra_decode(ctx.h, plan, 1, C.byref(d_rec2.as_pic()), C.byref(d_lev.as_pic())))
+    ctx.sync()
+    rec2 = d_rec2.download()
+    assert all(np.array_equal(rec2[p], rr[p]) for p in range(3))
+    L.hmx_intra_plan_destroy(ctx.h, plan)

@@ -357,3 +357,63 @@ class DevPicture:
     def free(self):
         for b in self.bufs:
             b.free()
+
+
+def _spread4(t):
+    return (t & 1) | ((t & 2) << 1) | ((t & 4) << 2) | ((t & 8) << 3)
+
+
+class DevLevelsZ:
+    """Quantised levels in the reference's own coefficient layout (stride 0 in hmx_levels): per plane,
+    CTU blocks in raster order (C*C ints, C = 64 luma / 32 chroma); inside a CTU the N x N block of a
+    transform block whose origin is 4x4 unit (ux, uy) sits at 16 * Zorder(ux, uy), row-major
+    (TComDataCU::m_pcTrCoeffY + 16 * partition index)."""
+
+    def __init__(self, ctx, w, h, ctu=64):
+        self.ctx, self.w, self.h, self.ctu = ctx, w, h, ctu
+        self.cw, self.ch = -(-w // ctu), -(-h // ctu)
+        self.elems = [self.cw * self.ch * ctu * ctu, self.cw * self.ch * ctu * ctu // 4, self.cw * self.ch * ctu * ctu // 4]
+        self.bufs = [ctx.alloc(4 * e) for e in self.elems]
+
+    def as_pic(self):
+        s = Levels()
+        for p in range(3):
+            s.plane[p] = self.bufs[p].ptr
+            s.stride[p] = 0
+        return s
+
+    def zero(self):
+        for b in self.bufs:
+            b.zero()
+        return self
+
+    def free(self):
+        for b in self.bufs:
+            b.free()
+
+    def block_offset(self, plane, x, y):
+        c = self.ctu >> (1 if plane else 0)
+        m = c - 1
+        z = _spread4((x & m) >> 2) | (_spread4((y & m) >> 2) << 1)
+        return ((y // c) * self.cw + (x // c)) * c * c + z * 16
+
+    def to_planes(self, tus):
+        """Gather into plane geometry (numpy) following the block list."""
+        raw = [b.download(np.int32) for b in self.bufs]
+        out = [np.zeros((self.h, self.w), np.int32), np.zeros((self.h // 2, self.w // 2), np.int32),
+               np.zeros((self.h // 2, self.w // 2), np.int32)]
+        for t in tus:
+            n, p, x, y = 1 << int(t["log2n"]), int(t["plane"]), int(t["x"]), int(t["y"])
+            o = self.block_offset(p, x, y)
+            out[p][y:y + n, x:x + n] = raw[p][o:o + n * n].reshape(n, n)
+        return out
+
+    def from_planes(self, planes, tus):
+        raw = [np.zeros(e, np.int32) for e in self.elems]
+        for t in tus:
+            n, p, x, y = 1 << int(t["log2n"]), int(t["plane"]), int(t["x"]), int(t["y"])
+            o = self.block_offset(p, x, y)
+            raw[p][o:o + n * n] = np.asarray(planes[p])[y:y + n, x:x + n].reshape(-1)
+        for p in range(3):
+            self.bufs[p].upload(raw[p])
+        return self

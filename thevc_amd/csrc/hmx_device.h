@@ -368,10 +368,11 @@ __host__ __device__ __forceinline__ unsigned long long intra_avail_mask(int x, i
 // L[4N] = right-most above-right sample (fillReferenceSamples, TComPattern.cpp:368-552).
 // Every sample is one independent load: an unavailable sample copies the nearest available
 // sample before it (or the first available one for a leading run), which is what the reference's
-// sequential padding loop produces.  rec points at the block origin.
-template <int N, int NL>
-__device__ __forceinline__ void build_ref_line(const short *rec, int stride, unsigned long long avail,
-                                               int unit_log2, int bit_depth, int gl, int *L) {
+// sequential padding loop produces.  fetch(dx, dy) returns the reconstructed sample at offset
+// (dx, dy) from the block origin (plane or tiled addressing is the caller's business).
+template <int N, int NL, typename Fetch>
+__device__ __forceinline__ void build_ref_line(Fetch fetch, unsigned long long avail, int unit_log2, int bit_depth, int gl,
+                                               int *L) {
   const int unit = 1 << unit_log2, n = N >> unit_log2;
   for (int p = gl; p <= 4 * N; p += NL) {
     int v;
@@ -390,7 +391,7 @@ __device__ __forceinline__ void build_ref_line(const short *rec, int stride, uns
           q = u2 < 2 * n ? (u2 << unit_log2) : (u2 == 2 * n ? 2 * N : 2 * N + 1 + ((u2 - 2 * n - 1) << unit_log2));
         }
       }
-      v = q < 2 * N ? rec[(2 * N - 1 - q) * stride - 1] : (q == 2 * N ? rec[-stride - 1] : rec[-stride + (q - 2 * N - 1)]);
+      v = q < 2 * N ? fetch(-1, 2 * N - 1 - q) : (q == 2 * N ? fetch(-1, -1) : fetch(q - 2 * N - 1, -1));
     }
     L[p] = v;
   }

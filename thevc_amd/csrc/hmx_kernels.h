@@ -20,6 +20,54 @@ struct PlanesDev { // one picture: three planes, element strides
   short *p[3];
   int s[3];
 };
+
+// Working layout of the whole-picture path ("tiled"): the plane is cut into CTU blocks (C x C samples,
+// raster order); a CTU block holds its 4x4 tiles in Z-order, a tile is row-major.  Every aligned
+// N x N block is then one contiguous run of N*N samples, the right column / bottom row of a
+// neighbour sit in one or two 64-byte sectors, and HBM sees whole sectors instead of 8-byte pieces
+// of scattered rows.  The same addressing with 16 ints per 4x4 unit and row-major N x N blocks is the
+// reference's own coefficient layout (TComDataCU::m_pcTrCoeffY + 16 * partition index).
+struct TiledPlane {
+  short *p;
+  int ctu_w; // CTU blocks per row
+  int clog;  // log2 of the CTU size in this plane (6 luma, 5 chroma for CTU 64)
+};
+__host__ __device__ __forceinline__ unsigned spread4(unsigned t) { return (t & 1) | ((t & 2) << 1) | ((t & 4) << 2) | ((t & 8) << 3); }
+// element offset of the 4x4 tile that holds (x,y); ctu block base + Z index * 16
+__host__ __device__ __forceinline__ size_t tile_base(int ctu_w, int clog, int x, int y) {
+  const int m = (1 << clog) - 1;
+  const unsigned tx = (unsigned)(x & m) >> 2, ty = (unsigned)(y & m) >> 2;
+  return ((size_t)((y >> clog) * ctu_w + (x >> clog)) << (2 * clog)) + ((spread4(tx) | (spread4(ty) << 1)) << 4);
+}
+__device__ __forceinline__ size_t taddr(const TiledPlane &T, int x, int y) {
+  return tile_base(T.ctu_w, T.clog, x, y) + ((y & 3) << 2) + (x & 3);
+}
+// offset of tile (q, rr) (tile units) inside an aligned block whose origin tile has Z index z0
+__host__ __device__ __forceinline__ unsigned tile_in_block(unsigned q, unsigned rr) { return (spread4(q) | (spread4(rr) << 1)) << 4; }
+
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef int i4v __attribute__((ext_vector_type(4)));
+
+// row r of the aligned N x N block whose first sample is at element offset b0 of a tiled plane
+template <int N>
+__device__ __forceinline__ void tload_row(const short *p, size_t b0, int r, int *x) {
+#pragma unroll
+  for (int q = 0; q < N / 4; q++) {
+    const s4v v = *reinterpret_cast<const s4v *>(p + b0 + tile_in_block(q, r >> 2) + ((r & 3) << 2));
+    x[4 * q] = v[0];
+    x[4 * q + 1] = v[1];
+    x[4 * q + 2] = v[2];
+    x[4 * q + 3] = v[3];
+  }
+}
+template <int N>
+__device__ __forceinline__ void tstore_row(short *p, size_t b0, int r, const int *x) {
+#pragma unroll
+  for (int q = 0; q < N / 4; q++) {
+    s4v v = {(short)x[4 * q], (short)x[4 * q + 1], (short)x[4 * q + 2], (short)x[4 * q + 3]};
+    *reinterpret_cast<s4v *>(p + b0 + tile_in_block(q, r >> 2) + ((r & 3) << 2)) = v;
+  }
+}
 struct LevelsDev {
   int *p[3];
   int s[3];
@@ -200,10 +248,10 @@ __device__ __forceinline__ void inv_tq_block(TuLds<N> &L, int gl, bool active, b
 // ---------------------------------------------------------------------------------------------
 // Intra references and prediction of one block owned by NL lanes.
 // ---------------------------------------------------------------------------------------------
-template <int N, int NL>
-__device__ __forceinline__ void intra_refs(TuLds<N> &L, int gl, bool active, const short *rec_plane, int stride, int x,
-                                           int y, bool luma, unsigned long long avail, const PicDev &P) {
-  if (active) build_ref_line<N, NL>(rec_plane + (size_t)y * stride + x, stride, avail, luma ? 2 : 1, P.bit_depth, gl, L.line);
+template <int N, int NL, typename Fetch>
+__device__ __forceinline__ void intra_refs(TuLds<N> &L, int gl, bool active, Fetch fetch, bool luma,
+                                           unsigned long long avail, const PicDev &P) {
+  if (active) build_ref_line<N, NL>(fetch, avail, luma ? 2 : 1, P.bit_depth, gl, L.line);
   wave_sync();
   if (active && luma && N > 4) smooth_ref_line<N, NL>(L.line, L.fline, gl); // 4x4 never uses the smoothed line
   wave_sync();

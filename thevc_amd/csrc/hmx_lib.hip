@@ -126,7 +126,9 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
   } else { // OP_PRED
     const int sh = luma ? 0 : 1;
     const unsigned long long avail = active ? intra_avail_mask(x << sh, y << sh, N << sh, A.P) : 0;
-    intra_refs<N, N>(L, gl, active, A.a.p[pl], A.a.s[pl], x, y, luma, avail, A.P);
+    const short *rec0 = A.a.p[pl] + (size_t)y * A.a.s[pl] + x;
+    const int rst = A.a.s[pl];
+    intra_refs<N, N>(L, gl, active, [&](int dx, int dy) { return (int)rec0[(ptrdiff_t)dy * rst + dx]; }, luma, avail, A.P);
     if (active) {
       if (A.n_modes <= 0) {
         intra_pred_block<N>(L, gl, t.mode, luma, A.P, row);
@@ -160,9 +162,10 @@ struct LevelRow { // blocks of one picture-wide dependency level, bucketed by si
   uint32_t start[4];
   uint32_t count[4];
 };
-struct PicWork { // per picture: planes + the plan it follows
-  PlanesDev org, rec;
-  LevelsDev lev;
+struct PicWork { // per picture: working planes + the plan it follows
+  TiledPlane org[3], rec[3]; // tiled working copies (see TiledPlane)
+  int *lev[3];
+  int lev_stride[3];         // > 0: plane geometry; 0: the reference's Z-order coefficient layout
   const FTu *tus;
   const Seg *segs;
   const uint32_t *seg_range; // [(ctu*3+plane)*2 + {0,1}] -> begin,end in segs
@@ -182,6 +185,13 @@ static_assert(16 * sizeof(TuLds<4>) <= HMX_WAVE_SMEM && 8 * sizeof(TuLds<8>) <= 
                   sizeof(TuLds<32>) <= HMX_WAVE_SMEM,
               "per-wave LDS scratch");
 
+// element offset of row r of the N x N block at (x,y) in a level buffer
+template <int N>
+__device__ __forceinline__ size_t lev_row_off(const PicWork &W, int pl, int x, int y, int r) {
+  return W.lev_stride[pl] ? (size_t)(y + r) * W.lev_stride[pl] + x
+                          : tile_base(W.rec[pl].ctu_w, W.rec[pl].clog, x, y) + (size_t)r * N;
+}
+
 template <int N, bool ENC>
 __device__ __forceinline__ void wave_chain_valu(char *smem, const PicWork &W, const PicDev &P, const FTu *tus, int count) {
   constexpr int SL = 64 / N;
@@ -196,10 +206,12 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const PicWork &W, co
     const bool luma = pl == 0, ts = t.flags & HMX_TU_TRANSFORM_SKIP;
     const int scan_idx = coef_scan_idx(N, luma, true, t.mode);
     const unsigned long long avail = (unsigned long long)ft.avail_lo | ((unsigned long long)ft.avail_hi << 32);
+    const TiledPlane &R = W.rec[pl];
+    const size_t b0 = tile_base(R.ctu_w, R.clog, x, y); // same geometry for org and rec
     int pred[N], row[N];
-    int *lev_row = W.lev.p[pl] + (size_t)(y + gl) * W.lev.s[pl] + x;
-    if (ENC && active) load_row16<N>(W.org.p[pl] + (size_t)(y + gl) * W.org.s[pl] + x, row); // independent of the refs
-    intra_refs<N, N>(L, gl, active, W.rec.p[pl], W.rec.s[pl], x, y, luma, avail, P);
+    int *lev_row = W.lev[pl] + lev_row_off<N>(W, pl, x, y, gl);
+    if (ENC && active) tload_row<N>(W.org[pl].p, b0, gl, row); // independent of the references
+    intra_refs<N, N>(L, gl, active, [&](int dx, int dy) { return (int)R.p[taddr(R, x + dx, y + dy)]; }, luma, avail, P);
     intra_pred_block<N>(L, gl, t.mode, luma, P, pred);
     if (ENC) {
 #pragma unroll
@@ -226,7 +238,7 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const PicWork &W, co
       const int mx = (1 << P.bit_depth) - 1;
 #pragma unroll
       for (int k = 0; k < N; k++) row[k] = clip3(0, mx, pred[k] + row[k]);
-      store_row16<N>(W.rec.p[pl] + (size_t)(y + gl) * W.rec.s[pl] + x, row);
+      tstore_row<N>(R.p, b0, gl, row);
     }
   }
 }
@@ -242,17 +254,25 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const PicWork &W, cons
     const int pl = t.plane, x = t.x, y = t.y;
     const bool luma = pl == 0;
     const unsigned long long avail = (unsigned long long)ft.avail_lo | ((unsigned long long)ft.avail_hi << 32);
+    const TiledPlane &R = W.rec[pl];
+    const size_t b0 = tile_base(R.ctu_w, R.clog, x, y);
+    // this lane's samples of row r: columns mrow(s,h) = tile column 2*(s>>2)+h, all four samples of the tile row
+    const size_t row_off = b0 + ((r & 3) << 2);
     int pred[16], v[16];
-    short *rec_row = W.rec.p[pl] + (size_t)(y + r) * W.rec.s[pl] + x;
     if (ENC) {
-      const short *org_row = W.org.p[pl] + (size_t)(y + r) * W.org.s[pl] + x;
 #pragma unroll
-      for (int s = 0; s < 16; s++) v[s] = org_row[mrow(s, h)];
+      for (int q = 0; q < 4; q++) {
+        const s4v o = *reinterpret_cast<const s4v *>(W.org[pl].p + row_off + tile_in_block(2 * q + h, r >> 2));
+        v[4 * q] = o[0], v[4 * q + 1] = o[1], v[4 * q + 2] = o[2], v[4 * q + 3] = o[3];
+      }
     }
-    intra_refs<32, 64>(L, lane, true, W.rec.p[pl], W.rec.s[pl], x, y, luma, avail, P);
-    const int *R = (luma && use_filtered_refs(t.mode, LG)) ? L.fline : L.line;
+    intra_refs<32, 64>(L, lane, true, [&](int dx, int dy) { return (int)R.p[taddr(R, x + dx, y + dy)]; }, luma, avail, P);
+    const int *RL = (luma && use_filtered_refs(t.mode, LG)) ? L.fline : L.line;
     const int dcs = dc_sum_block<32, 64>(L, lane);
-    intra_pred_cols<32, 16>(R, t.mode, luma, P.bit_depth, r, dcs, [&](int s) { return mrow(s, h); }, pred);
+    intra_pred_cols<32, 16>(RL, t.mode, luma, P.bit_depth, r, dcs, [&](int s) { return mrow(s, h); }, pred);
+    const bool zlev = W.lev_stride[pl] == 0;
+    int *lev0 = W.lev[pl] + (zlev ? b0 + r : (size_t)y * W.lev_stride[pl] + x + r);
+    const int lstep = zlev ? 32 : W.lev_stride[pl];
     if (ENC) {
       int coef[16];
 #pragma unroll
@@ -263,11 +283,11 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const PicWork &W, cons
 #pragma unroll
       for (int g = 0; g < 16; g++) {
         v[g] = level_of(L.tile[mrow(g, h)][r]);
-        W.lev.p[pl][(size_t)(y + mrow(g, h)) * W.lev.s[pl] + x + r] = v[g];
+        lev0[(size_t)mrow(g, h) * lstep] = v[g];
       }
     } else {
 #pragma unroll
-      for (int g = 0; g < 16; g++) v[g] = W.lev.p[pl][(size_t)(y + mrow(g, h)) * W.lev.s[pl] + x + r];
+      for (int g = 0; g < 16; g++) v[g] = lev0[(size_t)mrow(g, h) * lstep];
     }
     const int tshift = 15 - P.bit_depth - LG;
     const QuantDev &qd = P.qd[luma ? 0 : 1];
@@ -277,8 +297,48 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const PicWork &W, cons
     inv32_mfma(v, r, h, P.bit_depth, out);
     const int mx = (1 << P.bit_depth) - 1;
 #pragma unroll
-    for (int s = 0; s < 16; s++) rec_row[mrow(s, h)] = (short)clip3(0, mx, pred[s] + out[s]);
+    for (int q = 0; q < 4; q++) {
+      s4v o = {(short)clip3(0, mx, pred[4 * q] + out[4 * q]), (short)clip3(0, mx, pred[4 * q + 1] + out[4 * q + 1]),
+               (short)clip3(0, mx, pred[4 * q + 2] + out[4 * q + 2]), (short)clip3(0, mx, pred[4 * q + 3] + out[4 * q + 3])};
+      *reinterpret_cast<s4v *>(R.p + row_off + tile_in_block(2 * q + h, r >> 2)) = o;
+    }
     wave_sync();
+  }
+}
+
+// plane <-> tiled conversion: one thread per tile row (4 samples), a 256-thread workgroup = 64 tiles
+// = a 32x32 region in Z-order: tiled side fully coalesced, plane side whole 64-byte sectors.
+struct ConvJob { // one plane of one picture
+  short *plane;
+  int stride, w, h;
+  TiledPlane T;
+};
+template <bool TO_TILED>
+__global__ __launch_bounds__(256) void k_convert_tiled(const ConvJob *jobs) {
+  const ConvJob J = jobs[blockIdx.y];
+  short *plane = J.plane;
+  const int stride = J.stride, w = J.w, h = J.h;
+  const TiledPlane T = J.T;
+  const int tiles_per_ctu = 1 << (2 * T.clog - 4);
+  const long long tt = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int r = threadIdx.x & 3;
+  const int ctu = (int)(tt / tiles_per_ctu), z = (int)(tt % tiles_per_ctu);
+  unsigned tx = 0, ty = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    tx |= ((z >> (2 * b)) & 1) << b;
+    ty |= ((z >> (2 * b + 1)) & 1) << b;
+  }
+  const int x = ((ctu % T.ctu_w) << T.clog) + (tx << 2), y = ((ctu / T.ctu_w) << T.clog) + (ty << 2) + r;
+  if (x >= w || y >= h) return;
+  short *tp = T.p + ((size_t)tt << 4) + (r << 2);
+  short *pp = plane + (size_t)y * stride + x;
+  if (TO_TILED) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) tp[k] = pp[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) pp[k] = tp[k];
   }
 }
 
@@ -351,6 +411,15 @@ struct hmx_ctx {
   // scratch for the scalar drop-ins (one block): device staging
   char *d_scratch = nullptr;
   size_t scratch_bytes = 0;
+  // working pictures of the whole-picture path in tiled layout (grow-only pool, one slot per picture)
+  struct TiledSlot {
+    short *org[3];
+    short *rec[3];
+  };
+  std::vector<TiledSlot> tiled;
+  int tiled_cw = 0, tiled_ch = 0; // CTU grid the pool was sized for
+  ConvJob *d_jobs = nullptr;      // [2][n_pics*3]: to-tiled jobs, then from-tiled jobs
+  int jobs_cap = 0;
   // whole-picture calls recorded as HIP graphs (see frame_intra)
   struct GraphEntry {
     uint64_t key;
@@ -485,6 +554,12 @@ extern "C" void hmx_destroy(hmx_ctx *c) {
     hipGraphExecDestroy(e.exec);
     hipFree(e.d_work);
   }
+  for (auto &t : c->tiled)
+    for (int p = 0; p < 3; p++) {
+      hipFree(t.org[p]);
+      hipFree(t.rec[p]);
+    }
+  hipFree(c->d_jobs);
   hipFree(c->d_refs);
   for (int g = 0; g < c->n_side; g++) {
     hipStreamDestroy(c->side[g]);
@@ -868,7 +943,28 @@ extern "C" void hmx_intra_plan_destroy(hmx_ctx *c, hmx_intra_plan *pl) {
 
 // Issue the launches of one whole-picture call on `main` (and the side streams).  Also used under
 // stream capture to record the call as a HIP graph.
+static int issue_chain_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_stride, int n_pics,
+                                const PicWork *d_work, bool enc, bool use_level, int groups, hipStream_t main);
+
 static int issue_intra_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_stride, int n_pics,
+                                const PicWork *d_work, const ConvJob *d_jobs, bool enc, bool use_level, int groups,
+                                hipStream_t main) {
+  // original planes -> tiled working copies (encode), chain, tiled reconstruction -> caller's planes
+  const hmx_intra_plan *p0 = plans[0];
+  const int ctu = 1 << 6; // tiles are counted per luma CTU grid; chroma planes have 1/4 of the tiles
+  (void)ctu;
+  const int cw = (p0->P.pic_w + p0->P.ctu - 1) / p0->P.ctu, ch = (p0->P.pic_h + p0->P.ctu - 1) / p0->P.ctu;
+  const unsigned luma_tiles = (unsigned)(cw * ch) * (unsigned)((p0->P.ctu / 4) * (p0->P.ctu / 4));
+  dim3 cgrid((luma_tiles + 63) / 64, (unsigned)n_pics * 3);
+  if (enc) hipLaunchKernelGGL(k_convert_tiled<true>, cgrid, dim3(256), 0, main, d_jobs);
+  int r = issue_chain_launches(c, plans, plan_stride, n_pics, d_work, enc, use_level, groups, main);
+  if (r) return r;
+  hipLaunchKernelGGL(k_convert_tiled<false>, cgrid, dim3(256), 0, main, d_jobs + (size_t)n_pics * 3);
+  HIPCHK(c, hipGetLastError());
+  return HMX_OK;
+}
+
+static int issue_chain_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_stride, int n_pics,
                                 const PicWork *d_work, bool enc, bool use_level, int groups, hipStream_t main) {
   const hmx_intra_plan *p0 = plans[0];
   if (use_level) {
@@ -938,7 +1034,32 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
   if (!c || !plans || !plans[0] || n_pics <= 0 || !rec || !lev || (enc && !org))
     return fail(c, HMX_ERR_ARG, "frame_intra: null argument");
   const hmx_intra_plan *p0 = plans[0];
+  // tiled working pool: one slot per picture, planes padded to whole CTUs
+  const int ctu = p0->P.ctu, cw = (p0->P.pic_w + ctu - 1) / ctu, ch = (p0->P.pic_h + ctu - 1) / ctu;
+  int clog = 0;
+  while ((1 << clog) < ctu) clog++;
+  if (c->tiled_cw != cw || c->tiled_ch != ch) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto &t : c->tiled)
+      for (int p = 0; p < 3; p++) {
+        hipFree(t.org[p]);
+        hipFree(t.rec[p]);
+      }
+    c->tiled.clear();
+    c->tiled_cw = cw;
+    c->tiled_ch = ch;
+  }
+  while ((int)c->tiled.size() < n_pics) {
+    hmx_ctx::TiledSlot t{};
+    for (int p = 0; p < 3; p++) {
+      const size_t elems = (size_t)cw * ch * ((size_t)ctu * ctu >> (p ? 2 : 0));
+      if (hipMalloc((void **)&t.org[p], elems * 2) != hipSuccess || hipMalloc((void **)&t.rec[p], elems * 2) != hipSuccess)
+        return fail(c, HMX_ERR_NOMEM, "hipMalloc tiled working picture");
+    }
+    c->tiled.push_back(t);
+  }
   std::vector<PicWork> hw(n_pics);
+  std::vector<ConvJob> jobs((size_t)n_pics * 6);
   for (int i = 0; i < n_pics; i++) {
     const hmx_intra_plan *pl = plans[i * plan_stride];
     if (!pl || pl->P.pic_w != p0->P.pic_w || pl->P.pic_h != p0->P.pic_h || pl->qp != p0->qp ||
@@ -946,9 +1067,15 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
         pl->P.sign_hide != p0->P.sign_hide)
       return fail(c, HMX_ERR_ARG, "frame_intra: plans of one call must share picture size and quantiser settings");
     memset(&hw[i], 0, sizeof(PicWork));
-    hw[i].org = to_dev(enc ? &org[i] : &rec[i]);
-    hw[i].rec = to_dev(&rec[i]);
-    hw[i].lev = to_dev(&lev[i]);
+    for (int p = 0; p < 3; p++) {
+      const int pclog = p ? clog - 1 : clog, pw = p0->P.pic_w >> (p ? 1 : 0), ph = p0->P.pic_h >> (p ? 1 : 0);
+      hw[i].org[p] = TiledPlane{c->tiled[i].org[p], cw, pclog};
+      hw[i].rec[p] = TiledPlane{c->tiled[i].rec[p], cw, pclog};
+      hw[i].lev[p] = lev[i].plane[p];
+      hw[i].lev_stride[p] = lev[i].stride[p];
+      if (enc) jobs[(size_t)i * 3 + p] = ConvJob{org[i].plane[p], org[i].stride[p], pw, ph, hw[i].org[p]};
+      jobs[(size_t)(n_pics + i) * 3 + p] = ConvJob{rec[i].plane[p], rec[i].stride[p], pw, ph, hw[i].rec[p]};
+    }
     hw[i].tus = pl->d_tus;
     hw[i].segs = pl->d_segs;
     hw[i].seg_range = pl->d_seg_range;
@@ -985,6 +1112,7 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
     for (size_t i = 0; i < n; i++) key = (key ^ b[i]) * 1099511628211ull;
   };
   mix(hw.data(), sizeof(PicWork) * n_pics);
+  mix(jobs.data(), sizeof(ConvJob) * jobs.size());
   const int flags[4] = {enc, use_level, groups, n_pics};
   mix(flags, sizeof(flags));
   for (int i = 0; i < n_pics; i++) {
@@ -1002,18 +1130,32 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
   }
   // miss: a fresh picture table (it must outlive the graph) and, if enabled, a capture
   PicWork *d_work = nullptr;
-  if (hipMalloc((void **)&d_work, sizeof(PicWork) * n_pics) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc picture table");
-  HIPCHK(c, hipMemcpyAsync(d_work, hw.data(), sizeof(PicWork) * n_pics, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream)); // hw goes out of scope
-  if (!use_graph) {
-    int r = issue_intra_launches(c, plans, plan_stride, n_pics, d_work, enc, use_level, groups, c->stream);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    hipFree(d_work);
-    return r;
+  const size_t table_bytes = sizeof(PicWork) * n_pics + sizeof(ConvJob) * jobs.size();
+  if (!use_graph) { // eager path: one grow-only table in the context, no synchronisation after the launches
+    if ((int)table_bytes > c->jobs_cap) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      hipFree(c->d_jobs);
+      c->jobs_cap = 0;
+      if (hipMalloc((void **)&c->d_jobs, table_bytes) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc picture table");
+      c->jobs_cap = (int)table_bytes;
+    }
+    char *base = reinterpret_cast<char *>(c->d_jobs);
+    HIPCHK(c, hipMemcpyAsync(base, hw.data(), sizeof(PicWork) * n_pics, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(base + sizeof(PicWork) * n_pics, jobs.data(), sizeof(ConvJob) * jobs.size(), hipMemcpyHostToDevice,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // hw / jobs go out of scope
+    return issue_intra_launches(c, plans, plan_stride, n_pics, reinterpret_cast<PicWork *>(base),
+                                reinterpret_cast<ConvJob *>(base + sizeof(PicWork) * n_pics), enc, use_level, groups, c->stream);
   }
+  if (hipMalloc((void **)&d_work, table_bytes) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc picture table");
+  HIPCHK(c, hipMemcpyAsync(d_work, hw.data(), sizeof(PicWork) * n_pics, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(reinterpret_cast<char *>(d_work) + sizeof(PicWork) * n_pics, jobs.data(),
+                           sizeof(ConvJob) * jobs.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream)); // hw / jobs go out of scope
+  const ConvJob *d_jobs = reinterpret_cast<const ConvJob *>(reinterpret_cast<char *>(d_work) + sizeof(PicWork) * n_pics);
   hipGraph_t graph = nullptr;
   HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-  int r = issue_intra_launches(c, plans, plan_stride, n_pics, d_work, enc, use_level, groups, c->stream);
+  int r = issue_intra_launches(c, plans, plan_stride, n_pics, d_work, d_jobs, enc, use_level, groups, c->stream);
   hipError_t ce = hipStreamEndCapture(c->stream, &graph);
   if (r != HMX_OK || ce != hipSuccess) {
     if (graph) hipGraphDestroy(graph);
@@ -1310,7 +1452,9 @@ __global__ __launch_bounds__(64) void k_adi(const short *win, int stride, int bx
   constexpr int W = 2 * N + 1;
   if (on) {
     unsigned long long avail = intra_avail_mask(x << chroma, y << chroma, N << chroma, P);
-    build_ref_line<N, N>(win + (size_t)by * stride + bx, stride, avail, chroma ? 1 : 2, P.bit_depth, gl, L.line);
+    const short *rec0 = win + (size_t)by * stride + bx;
+    build_ref_line<N, N>([&](int dx, int dy) { return (int)rec0[(ptrdiff_t)dy * stride + dx]; }, avail, chroma ? 1 : 2,
+                         P.bit_depth, gl, L.line);
   }
   __syncthreads();
   if (on && !chroma) smooth_ref_line<N, N>(L.line, L.fline, gl);
