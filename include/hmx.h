@@ -171,7 +171,11 @@ typedef struct {
   hmx_pel *plane[3];
   int stride[3];
 } hmx_pic;
-/* Quantised levels in plane geometry: level of sample (x,y) of plane p at plane[p][y*stride[p]+x]. */
+/* Quantised levels.  stride[p] > 0: plane geometry, level of sample (x,y) of plane p at
+ * plane[p][y*stride[p]+x].  stride[p] == 0 (whole-picture calls only): the reference's own coefficient
+ * layout (TComDataCU::m_pcTrCoeffY/Cb/Cr, TLibCommon/TComDataCU.cpp:117-141): CTU blocks in raster order,
+ * C*C ints each (C = CTU size in that plane, planes padded to whole CTUs); inside a CTU the N x N block
+ * of the transform block whose first 4x4 unit is (ux,uy) starts at 16 * Zorder(ux,uy), row-major. */
 typedef struct {
   hmx_coeff *plane[3];
   int stride[3];
@@ -210,6 +214,15 @@ typedef struct hmx_intra_plan hmx_intra_plan;
 int hmx_intra_plan_create(hmx_ctx *ctx, const hmx_tu *tus, int n_tu, const hmx_pic_param *pp,
                           hmx_intra_plan **plan);
 void hmx_intra_plan_destroy(hmx_ctx *ctx, hmx_intra_plan *plan);
+/* Size of the dependency schedules of a plan: blocks, picture-wide dependency levels (= launches of
+ * the level schedule) and CTU diagonals (= launches of the wave schedule). */
+int hmx_intra_plan_info(const hmx_intra_plan *plan, int *n_blocks, int *n_levels, int *n_diagonals);
+/* Optional stage timing of whole-picture calls (HIP events on the context's stream): layout conversion
+ * in, dependency chain, layout conversion out, of the LAST call issued after hmx_set_timing(ctx, 1). */
+int hmx_set_timing(hmx_ctx *ctx, int enable);
+int hmx_last_call_timing(hmx_ctx *ctx, float *to_tiled_ms, float *chain_ms, float *from_tiled_ms);
+/* Which schedule a whole-picture call with n_pics pictures uses: 1 = level, 0 = wave. */
+int hmx_intra_schedule_for(const hmx_ctx *ctx, int n_pics);
 /* n_pics pictures share one plan (same block structure); org/rec/lev are arrays of n_pics entries. */
 int hmx_frame_intra_encode(hmx_ctx *ctx, const hmx_intra_plan *plan, int n_pics, const hmx_pic *org,
                            const hmx_pic *rec, const hmx_levels *lev);

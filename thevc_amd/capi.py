@@ -107,6 +107,10 @@ def lib():
         L.hmx_intra_plan_create.argtypes = [vp, vp, ci, C.POINTER(PicParam), C.POINTER(vp)]
         L.hmx_intra_plan_destroy.argtypes = [vp, vp]
         L.hmx_intra_plan_destroy.restype = None
+        L.hmx_intra_plan_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+        L.hmx_intra_schedule_for.argtypes = [vp, ci]
+        L.hmx_set_timing.argtypes = [vp, ci]
+        L.hmx_last_call_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.hmx_frame_intra_encode.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(Levels)]
         L.hmx_frame_intra_decode.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Levels)]
         L.hmx_frame_intra_encode_multi.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(Levels)]

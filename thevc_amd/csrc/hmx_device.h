@@ -233,6 +233,7 @@ __device__ __forceinline__ int coef_scan_idx(int N, bool luma, bool intra, int m
 template <int N>
 struct TuLds {
   int tile[N][N + 1];
+  int me[3 * N + 2]; // extended main reference of the angular modes, me[N + k] = refMain[k], k = -N..2N
   int line[4 * N + 2];
   int fline[4 * N + 2];
   unsigned nzmask[2]; // bit g: coefficient group g (scan order) holds a non-zero level
@@ -409,19 +410,65 @@ __device__ __forceinline__ bool use_filtered_refs(int mode, int log2n) { // TCom
   return min(abs(mode - 10), abs(mode - 26)) > thr;
 }
 
-// NC samples of row r of the N x N prediction (TComPrediction.cpp:129-386, 689-730, 1010-1029):
-// p[s] = pred(r, col(s)).  R = reference line (raw or smoothed); top(k) = R[2N+k], left(k) = R[2N-k],
-// k = 0 is the corner.  dc_sum = sum of the N above and N left neighbours (only read for mode 1).
-template <int N, int NC, typename ColFn>
-__device__ __forceinline__ void intra_pred_cols(const int *R, int mode, bool luma, int bit_depth, int r, int dc_sum,
-                                                ColFn col, int *p) {
+// Angular parameters of a mode (TComPrediction.cpp:196-210)
+struct AngParam {
+  bool ver;
+  int angle, inv_angle;
+};
+__device__ __forceinline__ AngParam ang_param(int mode) {
+  AngParam a;
+  a.ver = mode >= 18;
+  const int idx = a.ver ? mode - 26 : 10 - mode, aidx = abs(idx);
+  constexpr int ang_tab[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};
+  constexpr int inv_tab[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};
+  int angle = 0, inv = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++)
+    if (i == aidx) {
+      angle = ang_tab[i];
+      inv = inv_tab[i];
+    }
+  a.angle = idx < 0 ? -angle : angle;
+  a.inv_angle = inv;
+  return a;
+}
+
+// Extended main reference of an angular mode (TComPrediction.cpp:227-258): ME[N + k] = refMain[k].
+// k >= 0: the main reference (above for vertical modes, left for horizontal ones); k < 0 (negative
+// angles only, down to (N*angle)>>5): the side reference projected with the inverse angle.
+// NL lanes of the block fill it together.  R = reference line (top(k) = R[2N+k], left(k) = R[2N-k]).
+template <int N, int NL>
+__device__ __forceinline__ void build_main_ref(const int *R, int *ME, int mode, int gl) {
+  if (mode < 2) return;
+  const AngParam a = ang_param(mode);
+  const int lim = a.angle < 0 ? (N * a.angle) >> 5 : 0, last = a.angle < 0 ? N : 2 * N;
+  for (int e = gl; e <= 3 * N; e += NL) {
+    const int k = e - N;
+    if (k > last || (k < 0 && k <= lim)) continue;
+    int v;
+    if (k >= 0)
+      v = a.ver ? R[2 * N + k] : R[2 * N - k];
+    else {
+      const int j = (128 + (-k) * a.inv_angle) >> 8;
+      v = a.ver ? R[2 * N - j] : R[2 * N + j];
+    }
+    ME[e] = (short)v;
+  }
+}
+
+// NS samples of the N x N prediction (TComPrediction.cpp:129-386, 689-730, 1010-1029):
+// p[s] = pred(row(s), col(s)).  R = reference line (raw or smoothed), ME = extended main reference
+// built from the same line (angular modes), dc_sum = sum of the N above and N left neighbours.
+template <int N, int NS, typename RowFn, typename ColFn>
+__device__ __forceinline__ void intra_pred_samples(const int *R, const int *ME, int mode, bool luma, int bit_depth, int dc_sum,
+                                                   RowFn row, ColFn col, int *p) {
   constexpr int LOG2N = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
   const int *top = R + 2 * N; // top[k]; left(k) = R[2N - k]
   if (mode == 0) { // planar, closed form of the accumulators
-    int left = R[2 * N - (r + 1)], tr = top[N + 1], bl = R[2 * N - (N + 1)];
+    const int tr = top[N + 1], bl = R[2 * N - (N + 1)];
 #pragma unroll
-    for (int s = 0; s < NC; s++) {
-      const int c = col(s), t = top[c + 1];
+    for (int s = 0; s < NS; s++) {
+      const int r = row(s), c = col(s), t = top[c + 1], left = R[2 * N - (r + 1)];
       int hor = (left << LOG2N) + N + (c + 1) * (tr - left);
       int ver = (t << LOG2N) + (r + 1) * (bl - t);
       p[s] = (short)((hor + ver) >> (LOG2N + 1));
@@ -431,8 +478,8 @@ __device__ __forceinline__ void intra_pred_cols(const int *R, int mode, bool lum
   if (mode == 1) { // DC (+ edge smoothing for luma, any size)
     const int dc = (dc_sum + N) >> (LOG2N + 1);
 #pragma unroll
-    for (int s = 0; s < NC; s++) {
-      const int c = col(s);
+    for (int s = 0; s < NS; s++) {
+      const int r = row(s), c = col(s);
       int v = dc;
       if (luma) {
         if (r == 0) v = c == 0 ? (top[1] + R[2 * N - 1] + 2 * dc + 2) >> 2 : (top[c + 1] + 3 * dc + 2) >> 2;
@@ -442,52 +489,32 @@ __device__ __forceinline__ void intra_pred_cols(const int *R, int mode, bool lum
     }
     return;
   }
-  const bool ver = mode >= 18;
-  const int idx = ver ? mode - 26 : 10 - mode;
-  const int aidx = abs(idx);
-  constexpr int ang_tab[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};
-  constexpr int inv_tab[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};
-  int angle = ang_tab[0], inv_angle = 0;
-#pragma unroll
-  for (int i = 0; i < 9; i++)
-    if (i == aidx) {
-      angle = ang_tab[i];
-      inv_angle = inv_tab[i];
-    }
-  if (idx < 0) angle = -angle;
-  // main(i) for i in [-N, 2N]: i >= 0 -> main reference, i < 0 -> projected side reference
-  auto mref = [&](int i) -> int {
-    int k = i >= 0 ? i : (128 + (-i) * inv_angle) >> 8;
-    bool use_top = (i >= 0) == ver;
-    return (short)(use_top ? top[k] : R[2 * N - k]);
-  };
+  const AngParam a = ang_param(mode);
   const int max_v = (1 << bit_depth) - 1;
-  if (angle == 0) {
+  const int *M0 = ME + N; // M0[k] = refMain[k]
+  if (a.angle == 0) {
 #pragma unroll
-    for (int s = 0; s < NC; s++) {
-      const int c = col(s);
-      int v;
-      if (ver) {
-        v = (short)top[c + 1];
-        if (luma && c == 0) v = clip3(0, max_v, v + (((short)R[2 * N - (r + 1)] - (short)top[0]) >> 1));
-      } else {
-        v = (short)R[2 * N - (r + 1)];
-        if (luma && r == 0) v = clip3(0, max_v, v + (((short)top[c + 1] - (short)top[0]) >> 1));
+    for (int s = 0; s < NS; s++) {
+      const int r = row(s), c = col(s);
+      // main-frame coordinates: k = distance from the main reference, l = position along it
+      const int k = a.ver ? r : c, l = a.ver ? c : r;
+      int v = M0[l + 1];
+      if (luma && l == 0) { // edge filter on the first column of the main frame (:280-286)
+        const int side_k1 = a.ver ? R[2 * N - (k + 1)] : top[k + 1];
+        v = clip3(0, max_v, v + (((short)side_k1 - (short)top[0]) >> 1));
       }
       p[s] = v;
     }
     return;
   }
 #pragma unroll
-  for (int s = 0; s < NC; s++) {
-    const int c = col(s);
-    // main-frame coordinates (k = distance from the main reference, l = position along it)
-    int k = ver ? r : c, l = ver ? c : r;
-    int pos = (k + 1) * angle;
-    int di = pos >> 5, df = pos & 31;
-    int i = l + di + 1;
-    int a = mref(i);
-    p[s] = df ? (short)(((32 - df) * a + df * mref(i + 1) + 16) >> 5) : a;
+  for (int s = 0; s < NS; s++) {
+    const int r = row(s), c = col(s);
+    const int k = a.ver ? r : c, l = a.ver ? c : r;
+    const int pos = (k + 1) * a.angle, di = pos >> 5, df = pos & 31;
+    const int i = l + di + 1;
+    const int m0 = M0[i];
+    p[s] = df ? (short)(((32 - df) * m0 + df * M0[i + 1] + 16) >> 5) : m0;
   }
 }
 

@@ -269,7 +269,10 @@ template <int N>
 __device__ __forceinline__ void intra_pred_block(TuLds<N> &L, int gl, int mode, bool luma, const PicDev &P, int *p) {
   const int *R = (luma && use_filtered_refs(mode, Log2<N>::v)) ? L.fline : L.line;
   const int dcs = dc_sum_block<N, N>(L, gl); // shuffles: every lane of the wave executes this
-  intra_pred_cols<N, N>(R, mode, luma, P.bit_depth, gl, dcs, [](int s) { return s; }, p);
+  build_main_ref<N, N>(R, L.me, mode, gl);
+  wave_sync();
+  intra_pred_samples<N, N>(R, L.me, mode, luma, P.bit_depth, dcs, [&](int) { return gl; }, [](int s) { return s; }, p);
+  wave_sync(); // L.me is rebuilt by the next call (mode fan-out)
 }
 
 // row access helpers (a block row inside a plane is not guaranteed to be more than 2-byte aligned)

@@ -180,7 +180,8 @@ struct FrameArgs {
   PicDev P;
 };
 
-#define HMX_WAVE_SMEM (4 * (int)sizeof(TuLds<16>))
+#define HMX_WAVE_SMEM 7680 /* max(4 * sizeof(TuLds<16>), sizeof(Lane4Lds), ...) - checked below */
+static_assert(4 * sizeof(TuLds<16>) <= HMX_WAVE_SMEM, "per-wave LDS scratch");
 static_assert(16 * sizeof(TuLds<4>) <= HMX_WAVE_SMEM && 8 * sizeof(TuLds<8>) <= HMX_WAVE_SMEM &&
                   sizeof(TuLds<32>) <= HMX_WAVE_SMEM,
               "per-wave LDS scratch");
@@ -243,6 +244,204 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const PicWork &W, co
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 4x4 blocks, one LANE per block (64 blocks per wave).  Everything a 4x4 block needs fits one lane's
+// registers: the two transposes of the separable transform are register renaming, sign-bit hiding
+// runs in every lane instead of one lane in four, and no lane idles while its group waits.
+// Only the reference line goes through LDS (the angular modes index it at run time).
+// ---------------------------------------------------------------------------------------------
+struct Lane4Lds {
+  int line[64][17]; // line[lane][p], p = 0..16 as in build_ref_line (odd stride: conflict-free)
+  int me[64][13];   // extended main reference per lane (3N+1 entries)
+};
+static_assert(sizeof(Lane4Lds) <= HMX_WAVE_SMEM, "per-wave LDS scratch");
+
+__device__ __forceinline__ int scan4_pos(int scan_idx, int i) { // raster position of scan entry i of a 4x4 block
+  constexpr unsigned char dg[16] = {0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15};
+  const int hor = i, ver = ((i & 3) << 2) | (i >> 2);
+  return scan_idx == 1 ? hor : (scan_idx == 2 ? ver : dg[i]);
+}
+
+template <bool ENC>
+__device__ __forceinline__ void wave_chain_4_lane(char *smem, const PicWork &W, const PicDev &P, const FTu *tus, int count) {
+  Lane4Lds &LS = *reinterpret_cast<Lane4Lds *>(smem);
+  const int lane = threadIdx.x;
+  const int B = P.bit_depth, mx = (1 << B) - 1, tshift = 15 - B - 2;
+  for (int base = 0; base < count; base += 64) {
+    const int i = base + lane;
+    const bool active = i < count;
+    if (!active) continue; // a lane works alone: nothing below needs the other lanes
+    const FTu ft = tus[i];
+    const hmx_tu t = ft.t;
+    const int pl = t.plane, x = t.x, y = t.y, mode = t.mode;
+    const bool luma = pl == 0, ts = t.flags & HMX_TU_TRANSFORM_SKIP;
+    const unsigned avail = ft.avail_lo; // 4n+1 <= 9 units
+    const TiledPlane &R = W.rec[pl];
+    const size_t b0 = tile_base(R.ctu_w, R.clog, x, y);
+    int v[16];
+    if (ENC) {
+      const i4v o0 = *reinterpret_cast<const i4v *>(W.org[pl].p + b0), o1 = *reinterpret_cast<const i4v *>(W.org[pl].p + b0 + 8);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        v[2 * k] = (short)(o0[k] & 0xffff), v[2 * k + 1] = o0[k] >> 16;
+        v[8 + 2 * k] = (short)(o1[k] & 0xffff), v[8 + 2 * k + 1] = o1[k] >> 16;
+      }
+    }
+    // ---- reference line (fillReferenceSamples): sequential padding is natural inside one lane
+    int *line = LS.line[lane];
+    {
+      const int ul = luma ? 2 : 1, n = 4 >> ul; // unit = 4 (luma) / 2 (chroma) samples
+      if (avail == 0) {
+#pragma unroll
+        for (int p = 0; p <= 16; p++) line[p] = 1 << (B - 1);
+      } else {
+        // first pass: fetch what is available; second: pad in line order
+        int carry = 0;
+        bool have = false;
+        // value for a leading unavailable run = first sample of the first available unit
+        const int u0 = __ffs(avail) - 1;
+        const int p0 = u0 < 2 * n ? (u0 << ul) : (u0 == 2 * n ? 8 : 9 + ((u0 - 2 * n - 1) << ul));
+        const int lead = p0 < 8 ? (int)R.p[taddr(R, x - 1, y + 7 - p0)]
+                                : (p0 == 8 ? (int)R.p[taddr(R, x - 1, y - 1)] : (int)R.p[taddr(R, x + p0 - 9, y - 1)]);
+#pragma unroll
+        for (int p = 0; p <= 16; p++) {
+          const int u = p < 8 ? (p >> ul) : (p == 8 ? 2 * n : 2 * n + 1 + ((p - 9) >> ul));
+          int val;
+          if ((avail >> u) & 1) {
+            val = p < 8 ? (int)R.p[taddr(R, x - 1, y + 7 - p)] : (p == 8 ? (int)R.p[taddr(R, x - 1, y - 1)] : (int)R.p[taddr(R, x + p - 9, y - 1)]);
+            have = true;
+          } else {
+            val = have ? carry : lead;
+          }
+          // an unavailable unit copies the LAST sample of the previous unit: carry only moves at unit ends
+          carry = val;
+          line[p] = val;
+        }
+      }
+    }
+    // ---- prediction (4x4 never uses the smoothed line)
+    int pred[16];
+    {
+      int dcs = 0;
+#pragma unroll
+      for (int k = 1; k <= 4; k++) dcs += line[8 + k] + line[8 - k];
+      int *me = LS.me[lane];
+      build_main_ref<4, 1>(line, me, mode, 0);
+      intra_pred_samples<4, 16>(line, me, mode, luma, B, dcs, [](int s) { return s >> 2; }, [](int s) { return s & 3; }, pred);
+    }
+    int *lev_ptr = W.lev[pl];
+    const bool zlev = W.lev_stride[pl] == 0;
+    const size_t l0 = zlev ? b0 : (size_t)y * W.lev_stride[pl] + x;
+    const int lrow = zlev ? 4 : W.lev_stride[pl];
+    int w[16];
+    if (ENC) {
+      int coef[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) v[k] = wrap16(v[k] - pred[k]);
+      if (ts) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) coef[k] = v[k] << tshift; // tshift >= 1 for B <= 12
+      } else {
+        int t1[16];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { // tmp[k][r] = pass1(row r)[k]
+          int yk[4];
+          fwd_pass<4>(v + 4 * r, yk, 1 + (B - 8), luma);
+#pragma unroll
+          for (int k = 0; k < 4; k++) t1[4 * k + r] = yk[k];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) { // coeff[k][r] = pass2(row r of tmp)[k]
+          int yk[4];
+          fwd_pass<4>(t1 + 4 * r, yk, 8, luma);
+#pragma unroll
+          for (int k = 0; k < 4; k++) coef[4 * k + r] = yk[k];
+        }
+      }
+      const QuantDev &qd = P.qd[luma ? 0 : 1];
+      const int qbits = 14 + qd.per_qbits + tshift;
+      int sum = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        int al;
+        w[k] = quant_one<false>(coef[k], qd.q, qbits, qd.rnd_factor, al);
+        sum += al;
+      }
+      if (P.sign_hide && sum >= 2) { // one coefficient group = the whole block; it is "the last group"
+        const int scan_idx = coef_scan_idx(4, luma, true, mode);
+        int ws[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const int p = scan4_pos(scan_idx, k);
+          int sel = 0;
+#pragma unroll
+          for (int q = 0; q < 16; q++) sel = (q == p) ? w[q] : sel;
+          ws[k] = sel;
+        }
+        int nw;
+        const int bi = sbh_decide(ws, true, nw);
+        if (bi >= 0) {
+          int bp = 0;
+#pragma unroll
+          for (int k = 0; k < 16; k++) bp = (k == bi) ? scan4_pos(scan_idx, k) : bp;
+#pragma unroll
+          for (int q = 0; q < 16; q++) w[q] = (q == bp) ? nw : w[q];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        i4v o = {level_of(w[4 * r]), level_of(w[4 * r + 1]), level_of(w[4 * r + 2]), level_of(w[4 * r + 3])};
+        *reinterpret_cast<i4v *>(lev_ptr + l0 + (size_t)r * lrow) = o;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const i4v o = *reinterpret_cast<const i4v *>(lev_ptr + l0 + (size_t)r * lrow);
+        w[4 * r] = o[0], w[4 * r + 1] = o[1], w[4 * r + 2] = o[2], w[4 * r + 3] = o[3];
+      }
+    }
+    // ---- inverse
+    const QuantDev &qd = P.qd[luma ? 0 : 1];
+    int c[16], out[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) c[k] = dequant_one(ENC ? level_of(w[k]) : w[k], qd.iq_scale, 6 - tshift);
+    if (ts) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) out[k] = wrap16((c[k] + (1 << (tshift - 1))) >> tshift);
+    } else {
+      int t1[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) c[k] = wrap16(c[k]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) { // tmp[j][n] = sum_k M[k][n] * c[k][j]
+        int col[4], yn[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) col[k] = c[4 * k + j];
+        inv_pass<4>(col, yn, 7, luma);
+#pragma unroll
+        for (int nn = 0; nn < 4; nn++) t1[4 * j + nn] = yn[nn];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) { // block[j][n] = sum_k M[k][n] * tmp[k][j]
+        int col[4], yn[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) col[k] = t1[4 * k + j];
+        inv_pass<4>(col, yn, 12 - (B - 8), luma);
+#pragma unroll
+        for (int nn = 0; nn < 4; nn++) out[4 * j + nn] = yn[nn];
+      }
+    }
+    i4v r0, r1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      r0[k] = (clip3(0, mx, pred[2 * k] + out[2 * k]) & 0xffff) | (clip3(0, mx, pred[2 * k + 1] + out[2 * k + 1]) << 16);
+      r1[k] = (clip3(0, mx, pred[8 + 2 * k] + out[8 + 2 * k]) & 0xffff) | (clip3(0, mx, pred[8 + 2 * k + 1] + out[8 + 2 * k + 1]) << 16);
+    }
+    *reinterpret_cast<i4v *>(R.p + b0) = r0;
+    *reinterpret_cast<i4v *>(R.p + b0 + 8) = r1;
+  }
+}
+
 template <bool ENC>
 __device__ __forceinline__ void wave_chain_32(char *smem, const PicWork &W, const PicDev &P, const FTu *tus, int count) {
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
@@ -269,7 +468,9 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const PicWork &W, cons
     intra_refs<32, 64>(L, lane, true, [&](int dx, int dy) { return (int)R.p[taddr(R, x + dx, y + dy)]; }, luma, avail, P);
     const int *RL = (luma && use_filtered_refs(t.mode, LG)) ? L.fline : L.line;
     const int dcs = dc_sum_block<32, 64>(L, lane);
-    intra_pred_cols<32, 16>(RL, t.mode, luma, P.bit_depth, r, dcs, [&](int s) { return mrow(s, h); }, pred);
+    build_main_ref<32, 64>(RL, L.me, t.mode, lane);
+    wave_sync();
+    intra_pred_samples<32, 16>(RL, L.me, t.mode, luma, P.bit_depth, dcs, [&](int) { return r; }, [&](int s) { return mrow(s, h); }, pred);
     const bool zlev = W.lev_stride[pl] == 0;
     int *lev0 = W.lev[pl] + (zlev ? b0 + r : (size_t)y * W.lev_stride[pl] + x + r);
     const int lstep = zlev ? 32 : W.lev_stride[pl];
@@ -348,25 +549,32 @@ __global__ __launch_bounds__(256) void k_convert_tiled(const ConvJob *jobs) {
 struct LevelArgs {
   const PicWork *pics;
   int level;
+  // pictures that share one plan: the level's row and block list travel as kernel arguments, so a
+  // wave can fetch its block descriptors without first chasing the picture table (two dependent
+  // memory hops less on the critical path of every launch)
+  int shared;
+  LevelRow row;
+  const FTu *ltus;
   PicDev P;
 };
 template <bool ENC>
 __global__ __launch_bounds__(64, 4) void k_intra_level(LevelArgs A) {
   __shared__ __attribute__((aligned(16))) char smem[HMX_WAVE_SMEM];
   const PicWork &W = A.pics[blockIdx.y];
-  if (A.level >= W.n_levels) return;
-  const LevelRow row = W.ltab[A.level];
+  if (!A.shared && A.level >= W.n_levels) return;
+  const LevelRow row = A.shared ? A.row : W.ltab[A.level];
+  const FTu *ltus = A.shared ? A.ltus : W.ltus;
   int c = blockIdx.x;
 #pragma unroll
   for (int s = 0; s < 4; s++) {
     const int per = s == 3 ? 1 : (16 >> (2 * s)) * 1; // blocks per wave: 16, 8(=64/8), 4, 1
-    const int slots = s == 0 ? 16 : s == 1 ? 8 : s == 2 ? 4 : 1;
+    const int slots = s == 0 ? 64 : s == 1 ? 8 : s == 2 ? 4 : 1;
     (void)per;
     const int chunks = (int)(row.count[s] + slots - 1) / slots;
     if (c < chunks) {
-      const FTu *tus = W.ltus + row.start[s] + (size_t)c * slots;
+      const FTu *tus = ltus + row.start[s] + (size_t)c * slots;
       const int n = min(slots, (int)row.count[s] - c * slots);
-      if (s == 0) wave_chain_valu<4, ENC>(smem, W, A.P, tus, n);
+      if (s == 0) wave_chain_4_lane<ENC>(smem, W, A.P, tus, n);
       else if (s == 1) wave_chain_valu<8, ENC>(smem, W, A.P, tus, n);
       else if (s == 2) wave_chain_valu<16, ENC>(smem, W, A.P, tus, n);
       else wave_chain_32<ENC>(smem, W, A.P, tus, n);
@@ -392,7 +600,7 @@ __global__ __launch_bounds__(64, 4) void k_intra_wave(FrameArgs A) {
     if (sg.new_level) wave_global_sync();
     wave_sync(); // the LDS scratch is re-interpreted per block size
     switch (sg.log2n) {
-    case 2: wave_chain_valu<4, ENC>(smem, W, A.P, tus, sg.count); break;
+    case 2: wave_chain_4_lane<ENC>(smem, W, A.P, tus, sg.count); break;
     case 3: wave_chain_valu<8, ENC>(smem, W, A.P, tus, sg.count); break;
     case 4: wave_chain_valu<16, ENC>(smem, W, A.P, tus, sg.count); break;
     default: wave_chain_32<ENC>(smem, W, A.P, tus, sg.count); break;
@@ -431,6 +639,10 @@ struct hmx_ctx {
   std::vector<GraphEntry> graphs;
   uint64_t graph_clock = 0;
   int level_mode_min_pics = 16;
+  // optional timing of the last whole-picture call: events around the layout conversions and the chain
+  bool timing = false;
+  hipEvent_t tev[4] = {};
+  bool tev_valid = false;
   // level schedule: picture groups run on side streams so that launches of different groups overlap
   static const int kMaxSide = 8;
   hipStream_t side[kMaxSide] = {};
@@ -448,6 +660,7 @@ struct hmx_intra_plan {
   FTu *d_ltus = nullptr;       // level schedule
   LevelRow *d_ltab = nullptr;
   std::vector<uint32_t> level_chunks; // waves needed per level
+  std::vector<LevelRow> h_ltab;       // host copy of the level table
   PicDev P;
   int n_tu = 0;
   int qp = 0, chroma_qp_offset = 0, slice_type = 0;
@@ -566,6 +779,8 @@ extern "C" void hmx_destroy(hmx_ctx *c) {
     hipEventDestroy(c->ev_join[g]);
   }
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  for (int i = 0; i < 4; i++)
+    if (c->tev[i]) hipEventDestroy(c->tev[i]);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -862,7 +1077,7 @@ extern "C" int hmx_intra_plan_create(hmx_ctx *c, const hmx_tu *tus, int n_tu, co
       for (int sidx = 0; sidx < 4; sidx++) {
         ltab[l].start[sidx] = off;
         off += ltab[l].count[sidx];
-        const uint32_t slots = sidx == 0 ? 16 : sidx == 1 ? 8 : sidx == 2 ? 4 : 1;
+        const uint32_t slots = sidx == 0 ? 64 : sidx == 1 ? 8 : sidx == 2 ? 4 : 1;
         chunks += (ltab[l].count[sidx] + slots - 1) / slots;
       }
       level_chunks[l] = chunks;
@@ -890,6 +1105,7 @@ extern "C" int hmx_intra_plan_create(hmx_ctx *c, const hmx_tu *tus, int n_tu, co
   // CTU diagonals d = X + 2Y: (X,Y) needs (X-1,Y), (X-1,Y-1), (X,Y-1), (X+1,Y-1)
   hmx_intra_plan *pl = new hmx_intra_plan;
   pl->level_chunks = level_chunks;
+  pl->h_ltab = ltab;
   pl->P = P;
   pl->n_tu = n_tu;
   pl->qp = pp->qp;
@@ -920,6 +1136,39 @@ extern "C" int hmx_intra_plan_create(hmx_ctx *c, const hmx_tu *tus, int n_tu, co
   }
   *out = pl;
   return HMX_OK;
+}
+
+extern "C" int hmx_set_timing(hmx_ctx *c, int enable) {
+  if (!c) return HMX_ERR_ARG;
+  if (enable && !c->tev[0])
+    for (int i = 0; i < 4; i++) HIPCHK(c, hipEventCreate(&c->tev[i]));
+  c->timing = enable != 0;
+  c->tev_valid = false;
+  return HMX_OK;
+}
+extern "C" int hmx_last_call_timing(hmx_ctx *c, float *to_tiled_ms, float *chain_ms, float *from_tiled_ms) {
+  if (!c || !c->tev_valid) return fail(c, HMX_ERR_ARG, "hmx_last_call_timing: no timed call");
+  HIPCHK(c, hipEventSynchronize(c->tev[3]));
+  float a = 0, b = 0, d = 0;
+  HIPCHK(c, hipEventElapsedTime(&a, c->tev[0], c->tev[1]));
+  HIPCHK(c, hipEventElapsedTime(&b, c->tev[1], c->tev[2]));
+  HIPCHK(c, hipEventElapsedTime(&d, c->tev[2], c->tev[3]));
+  if (to_tiled_ms) *to_tiled_ms = a;
+  if (chain_ms) *chain_ms = b;
+  if (from_tiled_ms) *from_tiled_ms = d;
+  return HMX_OK;
+}
+extern "C" int hmx_intra_plan_info(const hmx_intra_plan *pl, int *n_blocks, int *n_levels, int *n_diagonals) {
+  if (!pl) return HMX_ERR_ARG;
+  if (n_blocks) *n_blocks = pl->n_tu;
+  if (n_levels) *n_levels = (int)pl->level_chunks.size();
+  if (n_diagonals) *n_diagonals = (int)pl->waves.size();
+  return HMX_OK;
+}
+extern "C" int hmx_intra_schedule_for(const hmx_ctx *c, int n_pics) { // 1 = level schedule, 0 = wave schedule
+  bool use_level = n_pics >= c->level_mode_min_pics;
+  if (const char *e = getenv("HMX_INTRA_SCHEDULE")) use_level = e[0] == 'l' ? true : (e[0] == 'w' ? false : use_level);
+  return use_level ? 1 : 0;
 }
 
 extern "C" void hmx_intra_plan_destroy(hmx_ctx *c, hmx_intra_plan *pl) {
@@ -956,10 +1205,18 @@ static int issue_intra_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, 
   const int cw = (p0->P.pic_w + p0->P.ctu - 1) / p0->P.ctu, ch = (p0->P.pic_h + p0->P.ctu - 1) / p0->P.ctu;
   const unsigned luma_tiles = (unsigned)(cw * ch) * (unsigned)((p0->P.ctu / 4) * (p0->P.ctu / 4));
   dim3 cgrid((luma_tiles + 63) / 64, (unsigned)n_pics * 3);
+  const bool tm = c->timing;
+  if (tm) HIPCHK(c, hipEventRecord(c->tev[0], main));
   if (enc) hipLaunchKernelGGL(k_convert_tiled<true>, cgrid, dim3(256), 0, main, d_jobs);
+  if (tm) HIPCHK(c, hipEventRecord(c->tev[1], main));
   int r = issue_chain_launches(c, plans, plan_stride, n_pics, d_work, enc, use_level, groups, main);
   if (r) return r;
+  if (tm) HIPCHK(c, hipEventRecord(c->tev[2], main));
   hipLaunchKernelGGL(k_convert_tiled<false>, cgrid, dim3(256), 0, main, d_jobs + (size_t)n_pics * 3);
+  if (tm) {
+    HIPCHK(c, hipEventRecord(c->tev[3], main));
+    c->tev_valid = true;
+  }
   HIPCHK(c, hipGetLastError());
   return HMX_OK;
 }
@@ -981,7 +1238,7 @@ static int issue_chain_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, 
     }
     size_t n_levels = 0;
     for (int g = 0; g < groups; g++) n_levels = std::max(n_levels, glevels[g]);
-    LevelArgs LA;
+    LevelArgs LA{};
     LA.P = p0->P;
     for (size_t l = 0; l < n_levels; l++)
       for (int g = 0; g < groups; g++) {
@@ -997,6 +1254,11 @@ static int issue_chain_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, 
         if (!chunks) continue;
         LA.pics = d_work + first[g];
         LA.level = (int)l;
+        LA.shared = plan_stride == 0;
+        if (LA.shared) {
+          LA.row = p0->h_ltab[l];
+          LA.ltus = p0->d_ltus;
+        }
         dim3 grid(chunks, (unsigned)(first[g + 1] - first[g]));
         hipStream_t st = groups > 1 ? c->side[g] : main;
         if (enc)
