@@ -534,12 +534,17 @@ __global__ __launch_bounds__(256) void k_convert_tiled(const ConvJob *jobs) {
   if (x >= w || y >= h) return;
   short *tp = T.p + ((size_t)tt << 4) + (r << 2);
   short *pp = plane + (size_t)y * stride + x;
+  const bool vec = ((reinterpret_cast<uintptr_t>(pp) & 7) == 0) && x + 4 <= w; // 8-byte accesses when the plane row allows
   if (TO_TILED) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) tp[k] = pp[k];
+    if (vec)
+      *reinterpret_cast<s4v *>(tp) = *reinterpret_cast<const s4v *>(pp);
+    else
+      for (int k = 0; k < 4 && x + k < w; k++) tp[k] = pp[k];
   } else {
-#pragma unroll
-    for (int k = 0; k < 4; k++) pp[k] = tp[k];
+    if (vec)
+      *reinterpret_cast<s4v *>(pp) = *reinterpret_cast<const s4v *>(tp);
+    else
+      for (int k = 0; k < 4 && x + k < w; k++) pp[k] = tp[k];
   }
 }
 
