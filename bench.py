@@ -31,6 +31,9 @@ WORKLOADS = {
     "ai2160p10": (3840, 2160, 10, 32, "configs[4] All-intra he10 3840x2160 10-bit"),
     "ai2160p8": (3840, 2160, 8, 32, "all-intra main 3840x2160 8-bit (metric's 2160p all-intra, main profile)"),
     "ai1080p8": (1920, 1080, 8, 32, "configs[1] All-intra main 1920x1080 8-bit"),
+    # random access: intra-period segments sharded over ranks, boundary I pictures exchanged over RCCL
+    "ra2160p8": (3840, 2160, 8, 32, "configs[3] Random-access main 3840x2160 8-bit (hierarchical B, IntraPeriod 32, GOP 8)"),
+    "ra1080p8": (1920, 1080, 8, 32, "random-access main 1920x1080 8-bit (configs[2]/[3] shape at 1080p)"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -87,6 +90,55 @@ def whole_job_value(pixels_per_rank_step, steps, world, seconds):
     return pixels_per_rank_step * steps * world / seconds / 1e6
 
 
+def bench_random_access(args, torch, dist, rank, local_rank, world):
+    """configs[3]: one step = every rank codes its intra-period segments (I pictures through the intra
+    chain, B/P pictures through MC + residual transform + reconstruction); boundary I pictures travel
+    between ranks by RCCL send/recv.  Weak scaling: --segments segments PER RANK."""
+    from thevc_amd import capi
+    from thevc_amd import ra_pipeline as ra
+    w, h, B, qp, cfg_name = WORKLOADS[args.workload]
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = capi.Context(bit_depth=B, device=local_rank, stream=stream)
+    n_seg = args.segments * world
+    wl = ra.RAWorkload(w, h, B, qp, n_segments=n_seg, seed=7, n_distinct=4)
+    pipe = ra.RAPipeline(ctx, torch, wl, rank, world, dist if world > 1 else None)
+    n_pics = pipe.load_originals()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pipe.run()
+    fence()
+    t0 = time.perf_counter()
+    px = 0
+    for _ in range(args.steps):
+        px += pipe.run()
+    fence()
+    dt = max_over_ranks(time.perf_counter() - t0, world, "cuda")
+    if world > 1:
+        t = torch.tensor([px], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        px = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "Mpixels/sec transform+pred+MC, 2160p all-intra, 1/2/4/8 MI355X; bit-exact vs HM",
+            "value": round(px / dt / 1e6, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {cfg_name}; {args.segments} segment(s) of 32 pictures per GPU, I pictures through "
+                                   f"the intra chain, B/P pictures MC (50% bi-pred) + residual T/Q + IQ/IT + recon, boundary I pictures "
+                                   f"exchanged by RCCL send/recv", "segments_per_gpu": args.segments, "pictures_per_gpu": n_pics,
+                       "width": w, "height": h, "bit_depth": B, "qp": qp},
+            "roofline": None, "note": "secondary workload (SURVEY.md 8e); the roofline line is reported for the all-intra default"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,6 +147,7 @@ def main():
     ap.add_argument("--workload", default="ai2160p10", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=512, help="pictures per GPU per step (100 MB of HBM each at 2160p)")
     ap.add_argument("--tiling", default="mix", help="mix | 4 | 8 | 16 | 32 (uniform transform size)")
+    ap.add_argument("--segments", type=int, default=1, help="random-access workloads: intra-period segments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check picture 0 against the oracle after the run")
     args = ap.parse_args()
@@ -116,6 +169,8 @@ def main():
 
     from thevc_amd import capi, workload
 
+    if args.workload.startswith("ra"):
+        return bench_random_access(args, torch, dist, rank, local_rank, world)
     w, h, B, qp, cfg_name = WORKLOADS[args.workload]
     h_c = h - (h % 8)  # pictures are coded in multiples of the minimum CU (8): 1080 -> 1072 + cropped row
     tiling = args.tiling if args.tiling == "mix" else int(args.tiling)

@@ -192,6 +192,10 @@ void hmx_tu_list_destroy(hmx_ctx *ctx, hmx_tu_list *list);
  * (device pointer, may be NULL). */
 int hmx_batch_transformNxN(hmx_ctx *ctx, const hmx_tu_list *list, const hmx_pic *resi, const hmx_levels *lev,
                            uint32_t *d_abs_sum, const hmx_pic_param *pp);
+/* The inter residual path in one pass (ENC/TEncSearch.cpp:4526-4990): residual = org - pred
+ * (TComYuv::subtract, TLibCommon/TComYuv.cpp:461-518) fused into transformNxN. */
+int hmx_batch_residual_transformNxN(hmx_ctx *ctx, const hmx_tu_list *list, const hmx_pic *org, const hmx_pic *pred,
+                                    const hmx_levels *lev, uint32_t *d_abs_sum, const hmx_pic_param *pp);
 /* invtransformNxN over a list of blocks (DEC/TDecCu.cpp:791-831): levels -> residual planes `out`;
  * when pred != NULL the reconstruction Clip(pred + resi) is written instead (TComYuv::addClip). */
 int hmx_batch_invtransformNxN(hmx_ctx *ctx, const hmx_tu_list *list, const hmx_levels *lev, const hmx_pic *pred,

@@ -1,0 +1,94 @@
+"""Random-access pipeline (segment sharding + reference-picture exchange): GPU result vs the CPU oracle
+on a small sequence, and the exchange itself rehearsed with gloo at world_size 2 on the CPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_gop_order_and_exchange_plan():
+    from thevc_amd import ra_pipeline as ra
+    assert [o[0] for o in ra.gop_order(8)] == [8, 4, 2, 1, 3, 6, 5, 7]  # cfg/encoder_randomaccess_main.cfg Frame1-8
+    assert ra.gop_order(8)[1] == (4, 0, 8) and ra.gop_order(8)[5] == (6, 4, 8)
+    # 8 segments on 8 ranks: every rank receives exactly one picture, from its right neighbour
+    plan = ra.exchange_plan(8, 8)
+    assert sorted(d for (_, _, d) in plan) == list(range(8))
+    assert all(s == (d + 1) % 8 for (_, s, d) in plan)
+    assert ra.exchange_plan(4, 1) == []  # one rank: nothing travels
+    wl = ra.RAWorkload(128, 64, 8, 32, intra_period=8, gop=4, n_segments=2)
+    jobs = wl.segment_jobs(1)
+    assert [j[0] for j in jobs] == [12, 10, 9, 11, 14, 13, 15] and jobs[4][1:3] == (12, 16)
+
+
+def _exchange_rank(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from thevc_amd import ra_pipeline as ra
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_seg = 5
+    # every I picture k has a known content on its owner, zeros elsewhere
+    pics = {k: [torch.full((6, 8), 100 * k + p, dtype=torch.int16) if k % world == rank else torch.zeros((6, 8), dtype=torch.int16)
+                for p in range(3)] for k in range(n_seg + 1)}
+    ra.run_exchange(dist, rank, world, n_seg, lambda ki: pics[ki])
+    ok = True
+    for k in range(n_seg):  # the owner of segment k must now hold I(k) and I(k+1)
+        if k % world == rank:
+            for ki in (k, k + 1):
+                ok &= all(int(pics[ki][p][0, 0]) == 100 * ki + p for p in range(3))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_reference_picture_exchange_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_exchange_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [8, 10])
+def test_ra_pipeline_vs_oracle(B):
+    import torch
+    import oracle_lib as ol
+    import ra_oracle
+    from thevc_amd import capi
+    from thevc_amd import ra_pipeline as ra
+    w, h, qp = 192, 128, 30
+    wl = ra.RAWorkload(w, h, B, qp, intra_period=8, gop=4, n_segments=2, seed=3)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = capi.Context(bit_depth=B, stream=stream)
+    pipe = ra.RAPipeline(ctx, torch, wl)
+    pipe.load_originals()
+    px = pipe.run()
+    torch.cuda.synchronize()
+    assert px == 17 * w * h  # 3 I pictures + 2 x 7 inter pictures
+    i_recs = {}
+    for k in range(3):
+        rr, _ = ol.o_intra_frame_encode(wl.intra_tus, w, h, B, qp, wl.original(k * 8))
+        got = pipe.rec[k * 8].download()
+        assert all(np.array_equal(got[p], rr[p]) for p in range(3)), ("I picture", k)
+        i_recs[k * 8] = rr
+    for k in range(2):
+        recs = ra_oracle.oracle_segment(wl, k, {p: i_recs[p] for p in (k * 8, k * 8 + 8)})
+        for (poc, _, _, _) in wl.segment_jobs(k):
+            got = pipe.rec[poc].download()
+            for p in range(3):
+                assert np.array_equal(got[p], recs[poc][p]), ("inter picture", poc, p)
+    # the margins of a referenced picture equal the oracle's border extension
+    full = pipe.rec[4].download(with_margins=True)[0]
+    assert (full[:80, 80:80 + w] == full[80, 80:80 + w]).all()
+    ctx.close()

@@ -100,6 +100,8 @@ def lib():
         L.hmx_tu_list_destroy.argtypes = [vp, vp]
         L.hmx_tu_list_destroy.restype = None
         L.hmx_batch_transformNxN.argtypes = [vp, vp, C.POINTER(Pic), C.POINTER(Levels), vp, C.POINTER(PicParam)]
+        L.hmx_batch_residual_transformNxN.argtypes = [vp, vp, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(Levels), vp,
+                                                      C.POINTER(PicParam)]
         L.hmx_batch_invtransformNxN.argtypes = [vp, vp, C.POINTER(Levels), C.POINTER(Pic), C.POINTER(Pic),
                                                 C.POINTER(PicParam)]
         L.hmx_batch_predIntra.argtypes = [vp, vp, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(PicParam), vp, ci,

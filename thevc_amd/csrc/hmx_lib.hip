@@ -66,7 +66,15 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
   int row[N];
 
   if constexpr (OP == OP_TRANSFORM_NXN || OP == OP_XT) {
-    if (active) load_row16<N>(A.a.p[pl] + (size_t)(y + gl) * A.a.s[pl] + x, row);
+    if (active) {
+      load_row16<N>(A.a.p[pl] + (size_t)(y + gl) * A.a.s[pl] + x, row);
+      if (A.have_pred) { // residual = original - prediction (TComYuv::subtract, TComYuv.cpp:461) fused in
+        int pr[N];
+        load_row16<N>(A.b.p[pl] + (size_t)(y + gl) * A.b.s[pl] + x, pr);
+#pragma unroll
+        for (int k = 0; k < N; k++) row[k] = wrap16(row[k] - pr[k]);
+      }
+    }
     int sum = fwd_tq_block<N>(L, gl, active, row, ts, use_dst, luma, scan_idx, OP == OP_TRANSFORM_NXN, A.P);
     if (active) {
       load_row32<N>(&L.tile[gl][0], row);
@@ -939,6 +947,19 @@ extern "C" int hmx_batch_transformNxN(hmx_ctx *c, const hmx_tu_list *l, const hm
   if (!c || !l || !resi || !lev || !pp) return fail(c, HMX_ERR_ARG, "hmx_batch_transformNxN: null argument");
   ListArgs A{};
   A.a = to_dev(resi);
+  A.lev = to_dev(lev);
+  A.abs_sum = d_abs_sum;
+  A.P = make_picdev(c, pp);
+  return run_list(c, OP_TRANSFORM_NXN, l, A);
+}
+
+extern "C" int hmx_batch_residual_transformNxN(hmx_ctx *c, const hmx_tu_list *l, const hmx_pic *org, const hmx_pic *pred,
+                                               const hmx_levels *lev, uint32_t *d_abs_sum, const hmx_pic_param *pp) {
+  if (!c || !l || !org || !pred || !lev || !pp) return fail(c, HMX_ERR_ARG, "hmx_batch_residual_transformNxN: null argument");
+  ListArgs A{};
+  A.a = to_dev(org);
+  A.b = to_dev(pred);
+  A.have_pred = 1;
   A.lev = to_dev(lev);
   A.abs_sum = d_abs_sum;
   A.P = make_picdev(c, pp);

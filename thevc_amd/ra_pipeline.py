@@ -1,0 +1,205 @@
+"""Random-access (hierarchical-B) workload over the block hot path: frame/segment sharding with an
+exchange of boundary reference pictures (BASELINE.json configs[3]).
+
+Structure (cfg/encoder_randomaccess_main.cfg: IntraPeriod 32, GOPSize 8, DecodingRefreshType 1):
+the sequence is cut into intra-period SEGMENTS; segment k = pictures POC 32k+1 .. 32k+31 plus its two
+bounding I pictures POC 32k and 32(k+1).  Segments are independent once those two I pictures are
+reconstructed, so segment k goes to rank k mod G; the only inter-rank traffic is the reconstruction
+(three planes INCLUDING the margins) of I picture 32(k+1), sent by its owner to the owner of segment
+k (ncclSend/ncclRecv through torch.distributed = RCCL over xGMI; the all-intra phase needs none).
+
+Per picture the hot path is:
+  I pictures   whole-picture all-intra chain (hmx_frame_intra_encode)
+  B/P pictures motion compensation of a PU list against resident references with margins
+               (hmx_batch_motionCompensation), residual + transformNxN (hmx_batch_residual_transformNxN),
+               invtransformNxN + reconstruction (hmx_batch_invtransformNxN), border extension
+               (hmx_pic_extend_border) when the picture is referenced later.
+Decisions (block structure, modes, PUs, MVs) are synthetic and seeded; this module is the bench/test
+harness' stand-in for TEncGOP's picture loop, not part of the product library."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi, workload
+
+MARGIN = 80  # g_uiMaxCUWidth + 16, TComPicYuv.cpp:82
+
+
+def gop_order(gop=8):
+    """(offset, ref0_offset, ref1_offset or None) in coding order for one hierarchical GOP."""
+    out = [(gop, 0, None)]
+
+    def rec(lo, hi):
+        if hi - lo < 2:
+            return
+        mid = (lo + hi) // 2
+        out.append((mid, lo, hi))
+        rec(lo, mid)
+        rec(mid, hi)
+
+    rec(0, gop)
+    return out
+
+
+def exchange_plan(n_segments, world):
+    """[(i_picture_index, src_rank, dst_rank)]: I picture k+1 is reconstructed by the owner of segment
+    k+1 and also needed by the owner of segment k."""
+    plan = []
+    for k in range(n_segments):
+        src, dst = (k + 1) % world, k % world
+        if src != dst:
+            plan.append((k + 1, src, dst))
+    return plan
+
+
+def run_exchange(dist, rank, world, n_segments, tensors_of):
+    """Move every boundary I picture from its owner to the owner of the previous segment.
+    tensors_of(i_picture_index) -> list of tensors (planes incl. margins) on this rank."""
+    ops = []
+    for (ki, src, dst) in exchange_plan(n_segments, world):
+        if rank == src:
+            ops += [dist.P2POp(dist.isend, t, dst) for t in tensors_of(ki)]
+        elif rank == dst:
+            ops += [dist.P2POp(dist.irecv, t, src) for t in tensors_of(ki)]
+    if ops:
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+    return len(ops)
+
+
+class TorchPicture:
+    """Three Pel planes with the reference's margins, backed by torch tensors (so that RCCL can move them)."""
+
+    def __init__(self, torch, device, w, h, m=MARGIN):
+        self.w, self.h, self.m = w, h, m
+        self.dims = [(w, h, m), (w // 2, h // 2, m // 2), (w // 2, h // 2, m // 2)]
+        self.t = [torch.zeros((ph + 2 * pm, pw + 2 * pm), dtype=torch.int16, device=device) for (pw, ph, pm) in self.dims]
+
+    def as_pic(self):
+        s = capi.Pic()
+        for p, (pw, ph, pm) in enumerate(self.dims):
+            st = pw + 2 * pm
+            s.plane[p] = self.t[p].data_ptr() + 2 * (pm * st + pm)
+            s.stride[p] = st
+        return s
+
+    def upload(self, torch, planes):
+        for p, (pw, ph, pm) in enumerate(self.dims):
+            self.t[p][pm:pm + ph, pm:pm + pw] = torch.from_numpy(np.ascontiguousarray(planes[p])).to(self.t[p].device)
+
+    def download(self, with_margins=False):
+        out = []
+        for p, (pw, ph, pm) in enumerate(self.dims):
+            a = self.t[p].cpu().numpy()
+            out.append(a if with_margins else a[pm:pm + ph, pm:pm + pw].copy())
+        return out
+
+
+class RAWorkload:
+    """Synthetic decisions shared by the GPU pipeline and the oracle check."""
+
+    def __init__(self, w, h, B, qp, intra_period=32, gop=8, n_segments=1, seed=0, bi_frac=0.5, n_lists=2, n_distinct=0):
+        self.w, self.h, self.B, self.qp = w, h, B, qp
+        self.n_distinct, self._cache = n_distinct, {}  # > 0: cycle that many synthetic originals (large benches)
+        self.ip, self.gop, self.n_segments, self.seed = intra_period, gop, n_segments, seed
+        self.intra_tus = workload.make_tus(seed + 1, w, h, "mix")
+        self.inter = []
+        for i in range(n_lists):
+            tus = workload.make_tus(seed + 10 + i, w, h, "mix", ts_prob=0.0)
+            tus["flags"] = capi.TU_INTER
+            self.inter.append({"tus": tus, "pus_b": workload.make_pus(seed + 20 + i, w, h, n_refs=2, bi_frac=bi_frac),
+                               "pus_p": workload.make_pus(seed + 30 + i, w, h, n_refs=1, bi_frac=0.0)})
+
+    def original(self, poc):
+        key = poc % self.n_distinct if self.n_distinct else poc
+        if key not in self._cache:
+            self._cache[key] = workload.make_planes(self.seed * 1000 + key, self.w, self.h, self.B, "texture")
+            if not self.n_distinct:
+                return self._cache.pop(key)
+        return self._cache[key]
+
+    def segment_jobs(self, k):
+        """Coding order of segment k: (poc, ref0_poc, ref1_poc|None, list_index)."""
+        base = k * self.ip
+        jobs = []
+        for g in range(self.ip // self.gop):
+            for (off, r0, r1) in gop_order(self.gop):
+                poc = base + g * self.gop + off
+                if poc == base + self.ip:
+                    continue  # the next I picture: intra, reconstructed by its owner
+                jobs.append((poc, base + g * self.gop + r0, None if r1 is None else base + g * self.gop + r1, poc % len(self.inter)))
+        return jobs
+
+
+class RAPipeline:
+    def __init__(self, ctx, torch, wl, rank=0, world=1, dist=None):
+        self.ctx, self.torch, self.wl, self.rank, self.world, self.dist = ctx, torch, wl, rank, world, dist
+        self.L = capi.lib()
+        w, h = wl.w, wl.h
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        self.pp_i = capi.PicParam(w, h, wl.qp, 0, capi.I_SLICE, 1)
+        self.pp_b = capi.PicParam(w, h, wl.qp, 0, capi.B_SLICE, 1)
+        self.plan = ctx.intra_plan(wl.intra_tus, self.pp_i)
+        self.lists = [{"tu": ctx.tu_list(d["tus"]), "pus_b": ctx.to_device(d["pus_b"]), "n_b": len(d["pus_b"]),
+                       "pus_p": ctx.to_device(d["pus_p"]), "n_p": len(d["pus_p"])} for d in wl.inter]
+        self.my_segments = [k for k in range(wl.n_segments) if k % world == rank]
+        self.my_i = sorted({k for k in range(wl.n_segments + 1) if k % world == rank})
+        self.rec = {}   # poc -> TorchPicture (reconstruction with margins)
+        self.org = {}   # poc -> TorchPicture (original, no margins needed but same class)
+        self.pred = TorchPicture(torch, self.dev, w, h, 0)
+        self.lev = capi.DevPicture(ctx, w, h, dtype=np.int32)
+        self.lev_i = None
+
+    def _pic(self, store, poc):
+        if poc not in store:
+            store[poc] = TorchPicture(self.torch, self.dev, self.wl.w, self.wl.h, MARGIN if store is self.rec else 0)
+        return store[poc]
+
+    def load_originals(self):
+        """Synthetic originals for every picture this rank codes (resident before the timed region)."""
+        pocs = {k * self.wl.ip for k in self.my_i}
+        for k in self.my_segments:
+            pocs |= {j[0] for j in self.wl.segment_jobs(k)}
+        for poc in sorted(pocs):
+            self._pic(self.org, poc).upload(self.torch, self.wl.original(poc))
+            self._pic(self.rec, poc)
+        for k in self.my_segments:  # landing buffers for the I pictures received from other ranks
+            self._pic(self.rec, (k + 1) * self.wl.ip)
+        n_i = len(self.my_i)
+        self.lev_i = [capi.DevLevelsZ(self.ctx, self.wl.w, self.wl.h) for _ in range(n_i)]
+        return len(pocs)
+
+    def run(self):
+        """One pass: intra pictures, exchange, inter pictures of every owned segment.  Returns pixels coded."""
+        ctx, L, wl = self.ctx, self.L, self.wl
+        w, h = wl.w, wl.h
+        # phase 1: all my I pictures in one whole-picture call, then their borders
+        ipocs = [k * wl.ip for k in self.my_i]
+        n = len(ipocs)
+        if n:
+            org = (capi.Pic * n)(*[self.org[p].as_pic() for p in ipocs])
+            rec = (capi.Pic * n)(*[self.rec[p].as_pic() for p in ipocs])
+            lev = (capi.Levels * n)(*[l.as_pic() for l in self.lev_i])
+            ctx._chk(L.hmx_frame_intra_encode(ctx.h, self.plan, n, org, rec, lev))
+            for p in ipocs:
+                ctx._chk(L.hmx_pic_extend_border(ctx.h, C.byref(self.rec[p].as_pic()), w, h, MARGIN, MARGIN))
+        # phase 2: boundary I pictures travel to the owner of the previous segment (RCCL send/recv)
+        if self.world > 1:
+            run_exchange(self.dist, self.rank, self.world, wl.n_segments, lambda ki: self.rec[ki * wl.ip].t)
+        # phase 3: inter pictures, segment by segment in coding order
+        pixels = n * w * h
+        for k in self.my_segments:
+            for (poc, r0, r1, li) in wl.segment_jobs(k):
+                d = self.lists[li]
+                refs = [self.rec[r0]] + ([self.rec[r1]] if r1 is not None else [])
+                ref_arr = (capi.Pic * len(refs))(*[r.as_pic() for r in refs])
+                pus, npu = (d["pus_b"], d["n_b"]) if r1 is not None else (d["pus_p"], d["n_p"])
+                pred, rec, org = self.pred.as_pic(), self.rec[poc].as_pic(), self.org[poc].as_pic()
+                ctx._chk(L.hmx_batch_motionCompensation(ctx.h, pus.ptr, npu, ref_arr, len(refs), C.byref(pred)))
+                ctx._chk(L.hmx_batch_residual_transformNxN(ctx.h, d["tu"], C.byref(org), C.byref(pred), C.byref(self.lev.as_pic()),
+                                                           None, C.byref(self.pp_b)))
+                ctx._chk(L.hmx_batch_invtransformNxN(ctx.h, d["tu"], C.byref(self.lev.as_pic()), C.byref(pred), C.byref(rec),
+                                                     C.byref(self.pp_b)))
+                ctx._chk(L.hmx_pic_extend_border(ctx.h, C.byref(rec), w, h, MARGIN, MARGIN))
+                pixels += w * h
+        return pixels
