@@ -60,6 +60,12 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise HmxError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        try:
+            # PyTorch ships its own libamdhip64; if libhmx pulls in the system HIP runtime first, a later
+            # torch.cuda initialisation in the same process finds no device.  Load torch's runtime first.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, ci, cu = C.c_void_p, C.c_int, C.c_uint
         L.hmx_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]

@@ -375,11 +375,15 @@ template <int N, int NL, typename Fetch>
 __device__ __forceinline__ void build_ref_line(Fetch fetch, unsigned long long avail, int unit_log2, int bit_depth, int gl,
                                                int *L) {
   const int unit = 1 << unit_log2, n = N >> unit_log2;
-  for (int p = gl; p <= 4 * N; p += NL) {
-    int v;
-    if (avail == 0) {
-      v = 1 << (bit_depth - 1);
-    } else {
+  constexpr int IT = (4 * N + 1 + NL - 1) / NL;
+  // two phases, fully unrolled: every load of this lane is issued before the first one is consumed,
+  // so the gather costs ONE memory round trip instead of one per sample
+  int v[IT];
+#pragma unroll
+  for (int it = 0; it < IT; it++) {
+    const int p = gl + it * NL;
+    v[it] = 1 << (bit_depth - 1);
+    if (p <= 4 * N && avail != 0) {
       int u = p < 2 * N ? (p >> unit_log2) : (p == 2 * N ? 2 * n : 2 * n + 1 + ((p - 2 * N - 1) >> unit_log2));
       int q = p;
       if (!((avail >> u) & 1)) {
@@ -392,9 +396,16 @@ __device__ __forceinline__ void build_ref_line(Fetch fetch, unsigned long long a
           q = u2 < 2 * n ? (u2 << unit_log2) : (u2 == 2 * n ? 2 * N : 2 * N + 1 + ((u2 - 2 * n - 1) << unit_log2));
         }
       }
-      v = q < 2 * N ? fetch(-1, 2 * N - 1 - q) : (q == 2 * N ? fetch(-1, -1) : fetch(q - 2 * N - 1, -1));
+      // one address, one load (q always names an available sample)
+      const int dx = q < 2 * N ? -1 : (q == 2 * N ? -1 : q - 2 * N - 1);
+      const int dy = q < 2 * N ? 2 * N - 1 - q : -1;
+      v[it] = fetch(dx, dy);
     }
-    L[p] = v;
+  }
+#pragma unroll
+  for (int it = 0; it < IT; it++) {
+    const int p = gl + it * NL;
+    if (p <= 4 * N) L[p] = v[it];
   }
 }
 

@@ -295,36 +295,42 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const PicWork &W, 
         v[8 + 2 * k] = (short)(o1[k] & 0xffff), v[8 + 2 * k + 1] = o1[k] >> 16;
       }
     }
-    // ---- reference line (fillReferenceSamples): sequential padding is natural inside one lane
+    // ---- reference line (fillReferenceSamples): sequential padding is natural inside one lane.
+    // All 17 loads are issued unconditionally first (an unavailable position reads the block's own
+    // first sample, a valid address, and the value is dropped): one memory round trip, not 17.
     int *line = LS.line[lane];
     {
       const int ul = luma ? 2 : 1, n = 4 >> ul; // unit = 4 (luma) / 2 (chroma) samples
-      if (avail == 0) {
+      int raw[17];
 #pragma unroll
-        for (int p = 0; p <= 16; p++) line[p] = 1 << (B - 1);
-      } else {
-        // first pass: fetch what is available; second: pad in line order
-        int carry = 0;
-        bool have = false;
-        // value for a leading unavailable run = first sample of the first available unit
-        const int u0 = __ffs(avail) - 1;
-        const int p0 = u0 < 2 * n ? (u0 << ul) : (u0 == 2 * n ? 8 : 9 + ((u0 - 2 * n - 1) << ul));
-        const int lead = p0 < 8 ? (int)R.p[taddr(R, x - 1, y + 7 - p0)]
-                                : (p0 == 8 ? (int)R.p[taddr(R, x - 1, y - 1)] : (int)R.p[taddr(R, x + p0 - 9, y - 1)]);
+      for (int p = 0; p <= 16; p++) {
+        const int u = p < 8 ? (p >> ul) : (p == 8 ? 2 * n : 2 * n + 1 + ((p - 9) >> ul));
+        const bool ok = (avail >> u) & 1;
+        const int dx = !ok ? 0 : (p <= 8 ? -1 : p - 9), dy = !ok ? 0 : (p < 8 ? 7 - p : -1);
+        raw[p] = R.p[taddr(R, x + dx, y + dy)];
+      }
+      const int dc = 1 << (B - 1);
+      int carry = dc;
+      bool have = false;
+      int lead = dc; // value of a leading unavailable run = first sample of the first available unit
 #pragma unroll
-        for (int p = 0; p <= 16; p++) {
-          const int u = p < 8 ? (p >> ul) : (p == 8 ? 2 * n : 2 * n + 1 + ((p - 9) >> ul));
-          int val;
-          if ((avail >> u) & 1) {
-            val = p < 8 ? (int)R.p[taddr(R, x - 1, y + 7 - p)] : (p == 8 ? (int)R.p[taddr(R, x - 1, y - 1)] : (int)R.p[taddr(R, x + p - 9, y - 1)]);
-            have = true;
-          } else {
-            val = have ? carry : lead;
-          }
-          // an unavailable unit copies the LAST sample of the previous unit: carry only moves at unit ends
-          carry = val;
-          line[p] = val;
+      for (int p = 16; p >= 0; p--) {
+        const int u = p < 8 ? (p >> ul) : (p == 8 ? 2 * n : 2 * n + 1 + ((p - 9) >> ul));
+        const bool first_of_unit = p < 8 ? (p & ((1 << ul) - 1)) == 0 : (p == 8 ? true : ((p - 9) & ((1 << ul) - 1)) == 0);
+        if (((avail >> u) & 1) && first_of_unit) lead = raw[p];
+      }
+#pragma unroll
+      for (int p = 0; p <= 16; p++) {
+        const int u = p < 8 ? (p >> ul) : (p == 8 ? 2 * n : 2 * n + 1 + ((p - 9) >> ul));
+        int val;
+        if ((avail >> u) & 1) {
+          val = raw[p];
+          have = true;
+        } else {
+          val = have ? carry : lead; // an unavailable unit repeats the last sample before it
         }
+        carry = val;
+        line[p] = avail ? val : dc;
       }
     }
     // ---- prediction (4x4 never uses the smoothed line)
@@ -651,7 +657,7 @@ struct hmx_ctx {
   };
   std::vector<GraphEntry> graphs;
   uint64_t graph_clock = 0;
-  int level_mode_min_pics = 16;
+  int level_mode_min_pics = 1; // measured: the level schedule is at least as fast as the wave schedule at every batch size
   // optional timing of the last whole-picture call: events around the layout conversions and the chain
   bool timing = false;
   hipEvent_t tev[4] = {};
