@@ -190,32 +190,44 @@ __constant__ ScanTab<8, unsigned char> kScan8 = ScanTab<8, unsigned char>();
 __constant__ ScanTab<16, unsigned char> kScan16 = ScanTab<16, unsigned char>();
 __constant__ ScanTab<32, unsigned short> kScan32 = ScanTab<32, unsigned short>();
 
-// the 16 raster positions of coefficient group g in scan order (one or two 16-byte loads)
+// the 16 raster positions of coefficient group g in scan order, kept PACKED as loaded (one or two
+// 16-byte loads: 4 dwords of bytes, or 8 dwords of halfwords for 32x32) -- they stay live across the
+// sign-hiding decision, so their register footprint matters
 template <int N>
-__device__ __forceinline__ void scan_group(int scan_idx, int g, int *pos) {
-  typedef unsigned u4 __attribute__((ext_vector_type(4)));
-  if constexpr (N == 32) {
-    const u4 *p = reinterpret_cast<const u4 *>(&kScan32.t[scan_idx][g * 16]);
-    const u4 a = p[0], b = p[1];
+struct ScanPos {
+  static constexpr int W = N == 32 ? 8 : 4;
+  unsigned pk[W];
+  __device__ __forceinline__ void load(int scan_idx, int g) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    if constexpr (N == 32) {
+      const u4 *p = reinterpret_cast<const u4 *>(&kScan32.t[scan_idx][g * 16]);
+      const u4 a = p[0], b = p[1];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      pos[2 * q] = a[q] & 0xffff;
-      pos[2 * q + 1] = a[q] >> 16;
-      pos[8 + 2 * q] = b[q] & 0xffff;
-      pos[8 + 2 * q + 1] = b[q] >> 16;
-    }
-  } else {
-    const unsigned char *base = N == 4 ? &kScan4.t[scan_idx][g * 16] : N == 8 ? &kScan8.t[scan_idx][g * 16] : &kScan16.t[scan_idx][g * 16];
-    const u4 a = *reinterpret_cast<const u4 *>(base);
+      for (int q = 0; q < 4; q++) pk[q] = a[q], pk[4 + q] = b[q];
+    } else {
+      const unsigned char *base = N == 4 ? &kScan4.t[scan_idx][g * 16] : N == 8 ? &kScan8.t[scan_idx][g * 16] : &kScan16.t[scan_idx][g * 16];
+      const u4 a = *reinterpret_cast<const u4 *>(base);
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      pos[4 * q] = a[q] & 255;
-      pos[4 * q + 1] = (a[q] >> 8) & 255;
-      pos[4 * q + 2] = (a[q] >> 16) & 255;
-      pos[4 * q + 3] = a[q] >> 24;
+      for (int q = 0; q < 4; q++) pk[q] = a[q];
     }
   }
-}
+  __device__ __forceinline__ int at(int i) const { // i: compile-time constant after unrolling
+    if constexpr (N == 32) return (pk[i >> 1] >> (16 * (i & 1))) & 0xffff;
+    else return (pk[i >> 2] >> (8 * (i & 3))) & 255;
+  }
+  __device__ __forceinline__ int at_dyn(int i) const { // i: run-time index
+    unsigned d = 0;
+    if constexpr (N == 32) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) d = (i >> 1) == q ? pk[q] : d;
+      return (d >> (16 * (i & 1))) & 0xffff;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++) d = (i >> 2) == q ? pk[q] : d;
+      return (d >> (8 * (i & 3))) & 255;
+    }
+  }
+};
 
 // getCoefScanIdx (TComDataCU.cpp:4014-4063); 0 (zigzag) is used as diagonal by xQuant
 __device__ __forceinline__ int coef_scan_idx(int N, bool luma, bool intra, int mode) {

@@ -118,17 +118,19 @@ __device__ __forceinline__ int quant_sbh_block(TuLds<N> &L, int gl, bool active,
   wave_sync();
   constexpr int NG = (N / 4) * (N / 4), PER = (NG + NL - 1) / NL;
   const bool hide = P.sign_hide && sum >= 2; // uniform over the block's lanes
-  int w[PER][16], pos[PER][16];
+  int w[PER][16];
+  ScanPos<N> pos[PER];
   if (hide) {
 #pragma unroll
     for (int q = 0; q < PER; q++) {
       const int g = gl + q * NL;
       if (g < NG) {
-        scan_group<N>(scan_idx, g, pos[q]);
+        pos[q].load(scan_idx, g);
         bool nz = false;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-          w[q][i] = L.tile[pos[q][i] / N][pos[q][i] % N];
+          const int p = pos[q].at(i);
+          w[q][i] = L.tile[p / N][p % N];
           nz |= (w[q][i] & 0xffff) != 0;
         }
         if (nz) atomicOr(&L.nzmask[g >> 5], 1u << (g & 31));
@@ -146,9 +148,7 @@ __device__ __forceinline__ int quant_sbh_block(TuLds<N> &L, int gl, bool active,
         int nw;
         const int bi = sbh_decide(w[q], !higher, nw);
         if (bi >= 0) {
-          int p = 0;
-#pragma unroll
-          for (int i = 0; i < 16; i++) p = (i == bi) ? pos[q][i] : p;
+          const int p = pos[q].at_dyn(bi);
           L.tile[p / N][p % N] = nw;
         }
       }
@@ -355,26 +355,32 @@ __device__ __forceinline__ v4i load_const_operand(const signed char (*tab)[2][16
   return *reinterpret_cast<const v4i *>(&tab[r][h][0]);
 }
 
-// data as the A operand: out[g] = sum_slot data(lane, slot) * konst(col r, slot) + 128 * fix_col (per lane)
+// data as the A operand: out[g] = sum_slot data(lane, slot) * konst(col r, slot) + 128 * fix_col (per lane).
+// The high-byte product is scaled in place and handed to the low-byte MFMA as its accumulator, so one
+// set of 16 accumulator registers carries the whole product.
 __device__ __forceinline__ void mfma_data_a(const int *data, v4i konst, int fix, int *raw) {
   v4i hi, lo;
   split_hi_lo(data, hi, lo);
-  v16i ch = {0}, cl = {0};
-  ch = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, konst, ch, 0, 0, 0);
-  cl = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, konst, cl, 0, 0, 0);
+  v16i c = {0};
+  c = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, konst, c, 0, 0, 0);
 #pragma unroll
-  for (int g = 0; g < 16; g++) raw[g] = 256 * ch[g] + cl[g] + fix;
+  for (int g = 0; g < 16; g++) c[g] = 256 * c[g] + fix;
+  c = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, konst, c, 0, 0, 0);
+#pragma unroll
+  for (int g = 0; g < 16; g++) raw[g] = c[g];
 }
-// data as the B operand; fix[g] = 128 * (row sum of the constant A for the row this accumulator holds)
+// data as the B operand; fix(g) = 128 * (row sum of the constant A for the row this accumulator holds)
 template <typename FixFn>
 __device__ __forceinline__ void mfma_data_b(const int *data, v4i konst, FixFn fix, int *raw) {
   v4i hi, lo;
   split_hi_lo(data, hi, lo);
-  v16i ch = {0}, cl = {0};
-  ch = __builtin_amdgcn_mfma_i32_32x32x32_i8(konst, hi, ch, 0, 0, 0);
-  cl = __builtin_amdgcn_mfma_i32_32x32x32_i8(konst, lo, cl, 0, 0, 0);
+  v16i c = {0};
+  c = __builtin_amdgcn_mfma_i32_32x32x32_i8(konst, hi, c, 0, 0, 0);
 #pragma unroll
-  for (int g = 0; g < 16; g++) raw[g] = 256 * ch[g] + cl[g] + fix(g);
+  for (int g = 0; g < 16; g++) c[g] = 256 * c[g] + fix(g);
+  c = __builtin_amdgcn_mfma_i32_32x32x32_i8(konst, lo, c, 0, 0, 0);
+#pragma unroll
+  for (int g = 0; g < 16; g++) raw[g] = c[g];
 }
 
 // forward 32x32 DCT: x[s] = residual (row r, col mrow(s,h)) -> coef[g] = coefficient (row mrow(g,h), col r)
@@ -398,16 +404,7 @@ __device__ __forceinline__ void inv32_mfma(const int *c, int r, int h, int B, in
   mfma_data_a(c, ti, 128 * kMfma.colsum[r], raw);
 #pragma unroll
   for (int g = 0; g < 16; g++) t[g] = clip3(-32768, 32767, (raw[g] + 64) >> 7);
-  int fix[16];
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const v4i f = *reinterpret_cast<const v4i *>(&kMfma.csp[h][4 * q]);
-    fix[4 * q] = f[0];
-    fix[4 * q + 1] = f[1];
-    fix[4 * q + 2] = f[2];
-    fix[4 * q + 3] = f[3];
-  }
-  mfma_data_b(t, ti, [&](int g) { return fix[g]; }, raw);
+  mfma_data_b(t, ti, [&](int g) { return kMfma.csp[h][g]; }, raw);
 #pragma unroll
   for (int g = 0; g < 16; g++) out[g] = clip3(-32768, 32767, (raw[g] + (1 << (s2 - 1))) >> s2);
 }

@@ -201,12 +201,12 @@ __device__ __forceinline__ size_t lev_row_off(const PicWork &W, int pl, int x, i
                           : tile_base(W.rec[pl].ctu_w, W.rec[pl].clog, x, y) + (size_t)r * N;
 }
 
-template <int N, bool ENC>
+template <int N, bool ENC, bool ONCE = false>
 __device__ __forceinline__ void wave_chain_valu(char *smem, const PicWork &W, const PicDev &P, const FTu *tus, int count) {
   constexpr int SL = 64 / N;
   const int lane = threadIdx.x, slot = lane / N, gl = lane % N;
   TuLds<N> &L = reinterpret_cast<TuLds<N> *>(smem)[slot];
-  for (int base = 0; base < count; base += SL) {
+  for (int base = 0; ONCE ? base < 1 : base < count; base += SL) { // ONCE: the level schedule hands a wave at most one pass
     const int i = base + slot;
     const bool active = i < count;
     const FTu ft = tus[active ? i : 0];
@@ -270,12 +270,12 @@ __device__ __forceinline__ int scan4_pos(int scan_idx, int i) { // raster positi
   return scan_idx == 1 ? hor : (scan_idx == 2 ? ver : dg[i]);
 }
 
-template <bool ENC>
+template <bool ENC, bool ONCE = false>
 __device__ __forceinline__ void wave_chain_4_lane(char *smem, const PicWork &W, const PicDev &P, const FTu *tus, int count) {
   Lane4Lds &LS = *reinterpret_cast<Lane4Lds *>(smem);
   const int lane = threadIdx.x;
   const int B = P.bit_depth, mx = (1 << B) - 1, tshift = 15 - B - 2;
-  for (int base = 0; base < count; base += 64) {
+  for (int base = 0; ONCE ? base < 1 : base < count; base += 64) {
     const int i = base + lane;
     const bool active = i < count;
     if (!active) continue; // a lane works alone: nothing below needs the other lanes
@@ -456,12 +456,12 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const PicWork &W, 
   }
 }
 
-template <bool ENC>
+template <bool ENC, bool ONCE = false>
 __device__ __forceinline__ void wave_chain_32(char *smem, const PicWork &W, const PicDev &P, const FTu *tus, int count) {
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
   TuLds<32> &L = *reinterpret_cast<TuLds<32> *>(smem);
   constexpr int LG = 5;
-  for (int i = 0; i < count; i++) {
+  for (int i = 0; ONCE ? i < 1 : i < count; i++) {
     const FTu ft = tus[i];
     const hmx_tu t = ft.t;
     const int pl = t.plane, x = t.x, y = t.y;
@@ -472,12 +472,11 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const PicWork &W, cons
     // this lane's samples of row r: columns mrow(s,h) = tile column 2*(s>>2)+h, all four samples of the tile row
     const size_t row_off = b0 + ((r & 3) << 2);
     int pred[16], v[16];
+    s4v org4[4]; // kept packed until the residual is formed
     if (ENC) {
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const s4v o = *reinterpret_cast<const s4v *>(W.org[pl].p + row_off + tile_in_block(2 * q + h, r >> 2));
-        v[4 * q] = o[0], v[4 * q + 1] = o[1], v[4 * q + 2] = o[2], v[4 * q + 3] = o[3];
-      }
+      for (int q = 0; q < 4; q++)
+        org4[q] = *reinterpret_cast<const s4v *>(W.org[pl].p + row_off + tile_in_block(2 * q + h, r >> 2));
     }
     intra_refs<32, 64>(L, lane, true, [&](int dx, int dy) { return (int)R.p[taddr(R, x + dx, y + dy)]; }, luma, avail, P);
     const int *RL = (luma && use_filtered_refs(t.mode, LG)) ? L.fline : L.line;
@@ -488,10 +487,14 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const PicWork &W, cons
     const bool zlev = W.lev_stride[pl] == 0;
     int *lev0 = W.lev[pl] + (zlev ? b0 + r : (size_t)y * W.lev_stride[pl] + x + r);
     const int lstep = zlev ? 32 : W.lev_stride[pl];
+    // the prediction is needed again only for the reconstruction: it waits as 8 packed registers
+    unsigned pred2[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) pred2[s] = (unsigned)pred[2 * s] | ((unsigned)pred[2 * s + 1] << 16);
     if (ENC) {
       int coef[16];
 #pragma unroll
-      for (int s = 0; s < 16; s++) v[s] = wrap16(v[s] - pred[s]);
+      for (int s = 0; s < 16; s++) v[s] = wrap16((int)org4[s >> 2][s & 3] - pred[s]);
       fwd32_mfma(v, r, h, P.bit_depth, coef);
       quant_sbh_block<32, 64, 16, false>(
           L, lane, true, coef, [&](int k) { return mrow(k, h); }, [&](int) { return r; }, luma, 0, P);
@@ -513,8 +516,9 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const PicWork &W, cons
     const int mx = (1 << P.bit_depth) - 1;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      s4v o = {(short)clip3(0, mx, pred[4 * q] + out[4 * q]), (short)clip3(0, mx, pred[4 * q + 1] + out[4 * q + 1]),
-               (short)clip3(0, mx, pred[4 * q + 2] + out[4 * q + 2]), (short)clip3(0, mx, pred[4 * q + 3] + out[4 * q + 3])};
+      const int p0 = pred2[2 * q] & 0xffff, p1 = pred2[2 * q] >> 16, p2 = pred2[2 * q + 1] & 0xffff, p3 = pred2[2 * q + 1] >> 16;
+      s4v o = {(short)clip3(0, mx, p0 + out[4 * q]), (short)clip3(0, mx, p1 + out[4 * q + 1]),
+               (short)clip3(0, mx, p2 + out[4 * q + 2]), (short)clip3(0, mx, p3 + out[4 * q + 3])};
       *reinterpret_cast<s4v *>(R.p + row_off + tile_in_block(2 * q + h, r >> 2)) = o;
     }
     wave_sync();
@@ -593,10 +597,10 @@ __global__ __launch_bounds__(64, 4) void k_intra_level(LevelArgs A) {
     if (c < chunks) {
       const FTu *tus = ltus + row.start[s] + (size_t)c * slots;
       const int n = min(slots, (int)row.count[s] - c * slots);
-      if (s == 0) wave_chain_4_lane<ENC>(smem, W, A.P, tus, n);
-      else if (s == 1) wave_chain_valu<8, ENC>(smem, W, A.P, tus, n);
-      else if (s == 2) wave_chain_valu<16, ENC>(smem, W, A.P, tus, n);
-      else wave_chain_32<ENC>(smem, W, A.P, tus, n);
+      if (s == 0) wave_chain_4_lane<ENC, true>(smem, W, A.P, tus, n);
+      else if (s == 1) wave_chain_valu<8, ENC, true>(smem, W, A.P, tus, n);
+      else if (s == 2) wave_chain_valu<16, ENC, true>(smem, W, A.P, tus, n);
+      else wave_chain_32<ENC, true>(smem, W, A.P, tus, n);
       return;
     }
     c -= chunks;
