@@ -273,63 +273,72 @@ __device__ __forceinline__ int quant_one(int c, int q, int qbits, int rnd_factor
   return (level & 0xffff) | ((du << 1 | (c < 0 ? 1 : 0)) << 16);
 }
 
+// w[idx] for a run-time idx: a four-level tree of 15 bit-field inserts (v_bfi_b32 with an all-ones /
+// all-zeros mask per index bit).  Written with masks on purpose: a tree of ?: selects is turned into
+// an indexed private array by the compiler, i.e. scratch memory.
+__device__ __forceinline__ int blend(int m, int t, int f) { return (t & m) | (f & ~m); }
+__device__ __forceinline__ int select16(const int *w, int idx) {
+  int a[8], b[4], c[2];
+  const int m0 = -(idx & 1), m1 = -((idx >> 1) & 1), m2 = -((idx >> 2) & 1), m3 = -((idx >> 3) & 1);
+#pragma unroll
+  for (int k = 0; k < 8; k++) a[k] = blend(m0, w[2 * k + 1], w[2 * k]);
+#pragma unroll
+  for (int k = 0; k < 4; k++) b[k] = blend(m1, a[2 * k + 1], a[2 * k]);
+#pragma unroll
+  for (int k = 0; k < 2; k++) c[k] = blend(m2, b[2 * k + 1], b[2 * k]);
+  return blend(m3, c[1], c[0]);
+}
+
 // signBitHidingHDQ (TComTrQuant.cpp:977-1100) for ONE 16-coefficient group, given its 16 packed words
-// w[] in scan order.  Groups are independent except for the reference's lastCG flag:
-// first_nz_group = this is the highest group in scan order that holds a non-zero level (its
-// candidate loop starts at the last non-zero, not at 15).  Fully unrolled: no run-time indexing.
+// w[] in scan order (level | neg << 16 | deltaU << 17).  Groups are independent except for the
+// reference's lastCG flag: first_nz_group = this is the highest group in scan order that holds a
+// non-zero level (its candidate loop starts at the last non-zero, not at 15).
 // Returns the scan index whose level changes (or -1) and the new packed word.
+//
+// Branch-free restatement.  Lanes of a wave hold different groups, so an early exit saves nothing
+// unless every lane takes it; instead
+//  * one pass gathers three 16-bit masks (non-zero, negative, parity) -> first/last/sign by bit scans;
+//  * the reference's candidate rules become an "invalid" mask built with a handful of mask ops:
+//      zero level below the first non-zero whose sign differs from the hidden sign   (:1050-1064)
+//      the first non-zero itself when |level| = 1 and deltaU <= 0                    (:1040-1043)
+//      positions above the last non-zero in the last group                           (:1017, lastCG)
+//  * the reference scans n = 15..0 keeping the strictly smaller cost, i.e. the minimum of
+//    (cost, -n); cost = -|deltaU| for a non-zero level, -deltaU for a zero level (:1026-1073).
+//    One integer key (cost + 512) << 5 | (15 - n), bit 30 set when invalid, and a min over 16 keys.
+// deltaU lies in [-86, 255] (the rounding offset is at most 171/512 of a step), so the key is positive.
 __device__ __forceinline__ int sbh_decide(const int *w, bool first_nz_group, int &new_word) {
-  int first = 16, last = -1, sum = 0;
+  unsigned nzm = 0, ngm = 0, par = 0;
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    const int q = level_of(w[i]);
-    sum += q;
-    if (q) {
-      first = min(first, i);
-      last = i;
-    }
+    nzm |= ((w[i] & 0xffff) != 0 ? 1u : 0u) << i;
+    ngm |= (((unsigned)w[i] >> 16) & 1u) << i;
+    par ^= (unsigned)w[i];
   }
-  if (last - first < 4) return -1;
-  int q_first = 0;
+  const int first = __builtin_ctz(nzm | 0x10000u), last = 31 - __builtin_clz(nzm | 1u);
+  const unsigned signbit = (ngm >> first) & 1u;
+  const bool hide = nzm != 0 && last - first >= 4 && signbit != (par & 1u);
+  const int wf = select16(w, first & 15);
+  const int qf = level_of(wf);
+  const bool first_unit_down = (qf == 1 || qf == -1) && (wf >> 17) <= 0;
+  unsigned inv = ~nzm & ((1u << first) - 1u) & (ngm ^ (0u - signbit));
+  inv |= first_unit_down ? (1u << first) : 0u;
+  inv |= first_nz_group ? (0xfffffffeu << last) : 0u;
+  unsigned best = 0xffffffffu;
 #pragma unroll
-  for (int i = 0; i < 16; i++) q_first = (i == first) ? level_of(w[i]) : q_first;
-  const int signbit = q_first > 0 ? 0 : 1;
-  if (signbit == (sum & 1)) return -1;
-  const int start = first_nz_group ? last : 15;
-  int best_cost = 0x7fffffff, best_i = -1, best_chg = 0;
-#pragma unroll
-  for (int i = 15; i >= 0; i--) {
-    const int q = level_of(w[i]), dus = w[i] >> 16, du = dus >> 1;
-    int cost = 0x7fffffff, chg = 0;
-    if (q != 0) {
-      if (du > 0) {
-        cost = -du;
-        chg = 1;
-      } else if (!(i == first && abs(q) == 1)) {
-        cost = du;
-        chg = -1;
-      }
-    } else if (i < first) {
-      if ((dus & 1) == signbit) {
-        cost = -du;
-        chg = 1;
-      }
-    } else {
-      cost = -du;
-      chg = 1;
-    }
-    if (i <= start && cost < best_cost) {
-      best_cost = cost;
-      best_chg = chg;
-      best_i = i;
-    }
+  for (int i = 0; i < 16; i++) {
+    const int du = w[i] >> 17;
+    const int cost = (w[i] & 0xffff) != 0 ? min(du, -du) : -du;
+    unsigned key = (unsigned)((cost << 5) + ((512 << 5) | (15 - i)));
+    key |= (inv << (30 - i)) & 0x40000000u;
+    best = min(best, key);
   }
-  int wsel = 0;
-#pragma unroll
-  for (int i = 0; i < 16; i++) wsel = (i == best_i) ? w[i] : wsel;
+  if (!hide || (best & 0x40000000u)) return -1;
+  const int best_i = 15 - (int)(best & 31u);
+  const int wsel = select16(w, best_i);
   const int q = level_of(wsel), neg = (wsel >> 16) & 1;
-  if (q == 32767 || q == -32768) best_chg = -1;
-  const int nq = neg ? q - best_chg : q + best_chg;
+  int chg = (q != 0 && (wsel >> 17) <= 0) ? -1 : 1;
+  if (q == 32767 || q == -32768) chg = -1;
+  const int nq = neg ? q - chg : q + chg;
   new_word = (wsel & 0xffff0000) | (nq & 0xffff);
   return best_i;
 }

@@ -383,21 +383,21 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const PicWork &W, 
       }
       if (P.sign_hide && sum >= 2) { // one coefficient group = the whole block; it is "the last group"
         const int scan_idx = coef_scan_idx(4, luma, true, mode);
+        // the scan differs per lane, but there are only three of them: scan entry k of each is a
+        // compile-time register, so the reorder is two selects per entry
+        constexpr int dg[16] = {0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15};
+        const bool hor = scan_idx == 1, ver = scan_idx == 2;
         int ws[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-          const int p = scan4_pos(scan_idx, k);
-          int sel = 0;
-#pragma unroll
-          for (int q = 0; q < 16; q++) sel = (q == p) ? w[q] : sel;
-          ws[k] = sel;
+          const int d = w[dg[k]], hv = w[k], vv = w[((k & 3) << 2) | (k >> 2)];
+          ws[k] = hor ? hv : (ver ? vv : d);
         }
         int nw;
         const int bi = sbh_decide(ws, true, nw);
         if (bi >= 0) {
-          int bp = 0;
-#pragma unroll
-          for (int k = 0; k < 16; k++) bp = (k == bi) ? scan4_pos(scan_idx, k) : bp;
+          const int bd = (int)((0xfbe7ad369c258140ull >> (4 * bi)) & 15); // dg[bi], one nibble per entry
+          const int bp = hor ? bi : (ver ? (((bi & 3) << 2) | (bi >> 2)) : bd);
 #pragma unroll
           for (int q = 0; q < 16; q++) w[q] = (q == bp) ? nw : w[q];
         }
