@@ -221,6 +221,9 @@ void hmx_intra_plan_destroy(hmx_ctx *ctx, hmx_intra_plan *plan);
 /* Size of the dependency schedules of a plan: blocks, picture-wide dependency levels (= launches of
  * the level schedule) and CTU diagonals (= launches of the wave schedule). */
 int hmx_intra_plan_info(const hmx_intra_plan *plan, int *n_blocks, int *n_levels, int *n_diagonals);
+/* One dependency level of the level schedule: its block counts by transform size (4, 8, 16, 32) and
+ * the wavefronts one picture contributes to that level's launch. */
+int hmx_intra_plan_level(const hmx_intra_plan *plan, int level, uint32_t counts[4], uint32_t *n_waves);
 /* Optional stage timing of whole-picture calls (HIP events on the context's stream): layout conversion
  * in, dependency chain, layout conversion out, of the LAST call issued after hmx_set_timing(ctx, 1). */
 int hmx_set_timing(hmx_ctx *ctx, int enable);

@@ -226,6 +226,50 @@ def test_frame_intra_encode_decode(ctx, pic, tiling, schedule, monkeypatch):
         d.free()
 
 
+@pytest.mark.parametrize("across", ["1", "0"])
+@pytest.mark.parametrize("pic,n_pics", [((64, 64), 70), ((136, 72), 9)])
+def test_frame_intra_many_pictures_one_plan(ctx, pic, n_pics, across, monkeypatch):
+    """Pictures that follow one plan run in SIMD across pictures (one wave = one block of 64/N pictures):
+    more pictures than a wave has slots (70 > 64), a ragged last chunk (9 = 8 + 1 for 8x8 blocks), and the
+    per-picture level kernel (HMX_INTRA_ACROSS=0) must all give the oracle's bits."""
+    monkeypatch.setenv("HMX_INTRA_SCHEDULE", "level")
+    monkeypatch.setenv("HMX_INTRA_ACROSS", across)
+    B = ctx.bit_depth
+    w, h = pic
+    tus = workload.make_tus(21, w, h, "mix")
+    L = capi.lib()
+    pp = capi.PicParam(w, h, 27, 0, capi.I_SLICE, 1)
+    plan = ctx.intra_plan(tus, pp)
+    orgs = [workload.make_planes(100 + i, w, h, B, "texture" if i % 2 else "noise") for i in range(n_pics)]
+    d_org = [capi.DevPicture(ctx, w, h).upload(o) for o in orgs]
+    d_rec = [capi.DevPicture(ctx, w, h).zero() for _ in range(n_pics)]
+    d_lev = [capi.DevLevelsZ(ctx, w, h) if i % 2 else capi.DevPicture(ctx, w, h, dtype=np.int32).zero() for i in range(n_pics)]
+    A = lambda lst, T: (T * n_pics)(*[x.as_pic() for x in lst])
+    ctx._chk(L.hmx_frame_intra_encode(ctx.h, plan, n_pics, A(d_org, capi.Pic), A(d_rec, capi.Pic), A(d_lev, capi.Levels)))
+    ctx.sync()
+    recs = []
+    for i in range(n_pics):
+        rec_ref, lev_ref = _oracle_frame(tus, w, h, B, 27, orgs[i])
+        rec = d_rec[i].download()
+        recs.append(rec)
+        for p in range(3):
+            assert np.array_equal(rec[p], rec_ref[p]), ("recon", i, p)
+        if i % 2 == 0:
+            lev = d_lev[i].download()
+            for p in range(3):
+                assert np.array_equal(lev[p], lev_ref[p]), ("levels", i, p)
+    d_rec2 = [capi.DevPicture(ctx, w, h).zero() for _ in range(n_pics)]
+    ctx._chk(L.hmx_frame_intra_decode(ctx.h, plan, n_pics, A(d_rec2, capi.Pic), A(d_lev, capi.Levels)))
+    ctx.sync()
+    for i in range(n_pics):
+        a = d_rec2[i].download()
+        for p in range(3):
+            assert np.array_equal(a[p], recs[i][p]), ("decode", i, p)
+    L.hmx_intra_plan_destroy(ctx.h, plan)
+    for d in d_org + d_rec + d_rec2 + d_lev:
+        d.free()
+
+
 def test_batch_lists(ctx):
     """transformNxN / invtransformNxN (+recon) / predIntra (+35-mode fan-out) over block lists."""
     O, B, L = ol.oracle(), ctx.bit_depth, capi.lib()

@@ -29,18 +29,26 @@ struct PlanesDev { // one picture: three planes, element strides
 // reference's own coefficient layout (TComDataCU::m_pcTrCoeffY + 16 * partition index).
 struct TiledPlane {
   short *p;
-  int ctu_w; // CTU blocks per row
-  int clog;  // log2 of the CTU size in this plane (6 luma, 5 chroma for CTU 64)
+  int ctu_w;        // CTU blocks per row
+  int clog;         // log2 of the CTU size in this plane (6 luma, 5 chroma for CTU 64)
+  unsigned qstride; // elements from one 8x8 quad (4 tiles = 64 samples = one 128-byte line) to the next
 };
+// The tiled offsets below ("o") address ONE picture: CTU blocks in raster order, tiles in Z-order.
+// In memory consecutive quads of a picture are qstride elements apart: 64 when every picture has its
+// own contiguous slot, 64 * P when P pictures are interleaved quad by quad -- the layout of the
+// across-pictures schedule, where the 64/N lanes-groups of a wave hold the SAME block of consecutive
+// pictures and so touch consecutive 128-byte lines.
+__host__ __device__ __forceinline__ size_t tphys(unsigned qstride, size_t o) { return (o >> 6) * qstride + (o & 63); }
 __host__ __device__ __forceinline__ unsigned spread4(unsigned t) { return (t & 1) | ((t & 2) << 1) | ((t & 4) << 2) | ((t & 8) << 3); }
-// element offset of the 4x4 tile that holds (x,y); ctu block base + Z index * 16
+// offset o of the 4x4 tile that holds (x,y); ctu block base + Z index * 16
 __host__ __device__ __forceinline__ size_t tile_base(int ctu_w, int clog, int x, int y) {
   const int m = (1 << clog) - 1;
   const unsigned tx = (unsigned)(x & m) >> 2, ty = (unsigned)(y & m) >> 2;
   return ((size_t)((y >> clog) * ctu_w + (x >> clog)) << (2 * clog)) + ((spread4(tx) | (spread4(ty) << 1)) << 4);
 }
+// physical element index of sample (x,y)
 __device__ __forceinline__ size_t taddr(const TiledPlane &T, int x, int y) {
-  return tile_base(T.ctu_w, T.clog, x, y) + ((y & 3) << 2) + (x & 3);
+  return tphys(T.qstride, tile_base(T.ctu_w, T.clog, x, y) + ((y & 3) << 2) + (x & 3));
 }
 // offset of tile (q, rr) (tile units) inside an aligned block whose origin tile has Z index z0
 __host__ __device__ __forceinline__ unsigned tile_in_block(unsigned q, unsigned rr) { return (spread4(q) | (spread4(rr) << 1)) << 4; }
@@ -48,12 +56,12 @@ __host__ __device__ __forceinline__ unsigned tile_in_block(unsigned q, unsigned 
 typedef short s4v __attribute__((ext_vector_type(4)));
 typedef int i4v __attribute__((ext_vector_type(4)));
 
-// row r of the aligned N x N block whose first sample is at element offset b0 of a tiled plane
+// row r of the aligned N x N block (N >= 8) whose first sample has offset b0; pb = p + tphys(b0)
 template <int N>
-__device__ __forceinline__ void tload_row(const short *p, size_t b0, int r, int *x) {
+__device__ __forceinline__ void tload_row(const short *pb, unsigned qstride, int r, int *x) {
 #pragma unroll
   for (int q = 0; q < N / 4; q++) {
-    const s4v v = *reinterpret_cast<const s4v *>(p + b0 + tile_in_block(q, r >> 2) + ((r & 3) << 2));
+    const s4v v = *reinterpret_cast<const s4v *>(pb + tphys(qstride, tile_in_block(q, r >> 2) + ((r & 3) << 2)));
     x[4 * q] = v[0];
     x[4 * q + 1] = v[1];
     x[4 * q + 2] = v[2];
@@ -61,11 +69,11 @@ __device__ __forceinline__ void tload_row(const short *p, size_t b0, int r, int 
   }
 }
 template <int N>
-__device__ __forceinline__ void tstore_row(short *p, size_t b0, int r, const int *x) {
+__device__ __forceinline__ void tstore_row(short *pb, unsigned qstride, int r, const int *x) {
 #pragma unroll
   for (int q = 0; q < N / 4; q++) {
     s4v v = {(short)x[4 * q], (short)x[4 * q + 1], (short)x[4 * q + 2], (short)x[4 * q + 3]};
-    *reinterpret_cast<s4v *>(p + b0 + tile_in_block(q, r >> 2) + ((r & 3) << 2)) = v;
+    *reinterpret_cast<s4v *>(pb + tphys(qstride, tile_in_block(q, r >> 2) + ((r & 3) << 2))) = v;
   }
 }
 struct LevelsDev {

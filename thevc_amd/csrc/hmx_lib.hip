@@ -194,32 +194,70 @@ static_assert(16 * sizeof(TuLds<4>) <= HMX_WAVE_SMEM && 8 * sizeof(TuLds<8>) <= 
                   sizeof(TuLds<32>) <= HMX_WAVE_SMEM,
               "per-wave LDS scratch");
 
+// What a block chain needs of the picture it works on, for the plane of its block.
+struct PlaneView {
+  const short *org; // tiled working copy of the original
+  TiledPlane rec;   // tiled working reconstruction
+  int *lev;
+  int lev_stride;   // > 0: plane geometry; 0: the reference's Z-order coefficient layout
+};
+// Two ways a wave finds its work.  "Own": every item of the wave is another block of ONE picture
+// (descriptor i of a list).  "Across": every item is the SAME block of another picture -- pictures that
+// follow one plan (same decisions) run in SIMD across pictures: the descriptor, its mode, position and
+// availability are wave-uniform (scalar registers, no divergent mode branches), and a wave is full
+// whenever the batch holds at least 64/N pictures.
+struct OwnPicture {
+  const PicWork &W;
+  const FTu *tus;
+  __device__ __forceinline__ FTu desc(int i) const { return tus[i]; }
+  __device__ __forceinline__ PlaneView view(int, int pl) const { return PlaneView{W.org[pl].p, W.rec[pl], W.lev[pl], W.lev_stride[pl]}; }
+};
+struct AcrossPictures {
+  const PicWork *pics;
+  const FTu *ft; // the one block this wave works on (wave-uniform address: scalar loads)
+  int pic0, n_pics;
+  const short *pool_org; // pictures interleaved quad by quad (TiledPlane::qstride = 64 * n_pics)
+  short *pool_rec;
+  uint32_t luma_elems, chroma_elems; // plane sizes of one picture (Y, Cb, Cr in this order)
+  int ctu_w, clog_luma;
+  __device__ __forceinline__ FTu desc(int) const { return *ft; }
+  __device__ __forceinline__ PlaneView view(int i, int pl) const {
+    const size_t o = (size_t)((pl > 0 ? luma_elems : 0u) + (pl > 1 ? chroma_elems : 0u)) * n_pics + (size_t)(pic0 + i) * 64;
+    // the table row is read with computed addresses: an indexed member array would live in scratch
+    const char *row = reinterpret_cast<const char *>(&pics[pic0 + i]);
+    int *lv = *reinterpret_cast<int *const *>(row + offsetof(PicWork, lev) + pl * sizeof(int *));
+    const int ls = *reinterpret_cast<const int *>(row + offsetof(PicWork, lev_stride) + pl * sizeof(int));
+    return PlaneView{pool_org + o, TiledPlane{pool_rec + o, ctu_w, pl ? clog_luma - 1 : clog_luma, 64u * n_pics}, lv, ls};
+  }
+};
+
 // element offset of row r of the N x N block at (x,y) in a level buffer
 template <int N>
-__device__ __forceinline__ size_t lev_row_off(const PicWork &W, int pl, int x, int y, int r) {
-  return W.lev_stride[pl] ? (size_t)(y + r) * W.lev_stride[pl] + x
-                          : tile_base(W.rec[pl].ctu_w, W.rec[pl].clog, x, y) + (size_t)r * N;
+__device__ __forceinline__ size_t lev_row_off(const PlaneView &V, int x, int y, int r) {
+  return V.lev_stride ? (size_t)(y + r) * V.lev_stride + x : tile_base(V.rec.ctu_w, V.rec.clog, x, y) + (size_t)r * N;
 }
 
-template <int N, bool ENC, bool ONCE = false>
-__device__ __forceinline__ void wave_chain_valu(char *smem, const PicWork &W, const PicDev &P, const FTu *tus, int count) {
+template <int N, bool ENC, bool ONCE = false, typename SRC>
+__device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, const PicDev &P, int count) {
   constexpr int SL = 64 / N;
   const int lane = threadIdx.x, slot = lane / N, gl = lane % N;
   TuLds<N> &L = reinterpret_cast<TuLds<N> *>(smem)[slot];
   for (int base = 0; ONCE ? base < 1 : base < count; base += SL) { // ONCE: the level schedule hands a wave at most one pass
     const int i = base + slot;
     const bool active = i < count;
-    const FTu ft = tus[active ? i : 0];
+    const FTu ft = src.desc(active ? i : 0);
     const hmx_tu t = ft.t;
     const int pl = t.plane, x = t.x, y = t.y;
     const bool luma = pl == 0, ts = t.flags & HMX_TU_TRANSFORM_SKIP;
     const int scan_idx = coef_scan_idx(N, luma, true, t.mode);
     const unsigned long long avail = (unsigned long long)ft.avail_lo | ((unsigned long long)ft.avail_hi << 32);
-    const TiledPlane &R = W.rec[pl];
+    const PlaneView V = src.view(active ? i : 0, pl);
+    const TiledPlane &R = V.rec;
     const size_t b0 = tile_base(R.ctu_w, R.clog, x, y); // same geometry for org and rec
     int pred[N], row[N];
-    int *lev_row = W.lev[pl] + lev_row_off<N>(W, pl, x, y, gl);
-    if (ENC && active) tload_row<N>(W.org[pl].p, b0, gl, row); // independent of the references
+    int *lev_row = V.lev + lev_row_off<N>(V, x, y, gl);
+    const size_t pb0 = tphys(R.qstride, b0);
+    if (ENC && active) tload_row<N>(V.org + pb0, R.qstride, gl, row); // independent of the references
     intra_refs<N, N>(L, gl, active, [&](int dx, int dy) { return (int)R.p[taddr(R, x + dx, y + dy)]; }, luma, avail, P);
     intra_pred_block<N>(L, gl, t.mode, luma, P, pred);
     if (ENC) {
@@ -247,7 +285,7 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const PicWork &W, co
       const int mx = (1 << P.bit_depth) - 1;
 #pragma unroll
       for (int k = 0; k < N; k++) row[k] = clip3(0, mx, pred[k] + row[k]);
-      tstore_row<N>(R.p, b0, gl, row);
+      tstore_row<N>(R.p + pb0, R.qstride, gl, row);
     }
   }
 }
@@ -270,8 +308,8 @@ __device__ __forceinline__ int scan4_pos(int scan_idx, int i) { // raster positi
   return scan_idx == 1 ? hor : (scan_idx == 2 ? ver : dg[i]);
 }
 
-template <bool ENC, bool ONCE = false>
-__device__ __forceinline__ void wave_chain_4_lane(char *smem, const PicWork &W, const PicDev &P, const FTu *tus, int count) {
+template <bool ENC, bool ONCE = false, typename SRC>
+__device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, const PicDev &P, int count) {
   Lane4Lds &LS = *reinterpret_cast<Lane4Lds *>(smem);
   const int lane = threadIdx.x;
   const int B = P.bit_depth, mx = (1 << B) - 1, tshift = 15 - B - 2;
@@ -279,16 +317,17 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const PicWork &W, 
     const int i = base + lane;
     const bool active = i < count;
     if (!active) continue; // a lane works alone: nothing below needs the other lanes
-    const FTu ft = tus[i];
+    const FTu ft = src.desc(i);
     const hmx_tu t = ft.t;
     const int pl = t.plane, x = t.x, y = t.y, mode = t.mode;
     const bool luma = pl == 0, ts = t.flags & HMX_TU_TRANSFORM_SKIP;
     const unsigned avail = ft.avail_lo; // 4n+1 <= 9 units
-    const TiledPlane &R = W.rec[pl];
-    const size_t b0 = tile_base(R.ctu_w, R.clog, x, y);
+    const PlaneView V = src.view(i, pl);
+    const TiledPlane &R = V.rec;
+    const size_t b0 = tile_base(R.ctu_w, R.clog, x, y), pb0 = tphys(R.qstride, b0); // a tile never straddles quads
     int v[16];
     if (ENC) {
-      const i4v o0 = *reinterpret_cast<const i4v *>(W.org[pl].p + b0), o1 = *reinterpret_cast<const i4v *>(W.org[pl].p + b0 + 8);
+      const i4v o0 = *reinterpret_cast<const i4v *>(V.org + pb0), o1 = *reinterpret_cast<const i4v *>(V.org + pb0 + 8);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         v[2 * k] = (short)(o0[k] & 0xffff), v[2 * k + 1] = o0[k] >> 16;
@@ -343,10 +382,10 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const PicWork &W, 
       build_main_ref<4, 1>(line, me, mode, 0);
       intra_pred_samples<4, 16>(line, me, mode, luma, B, dcs, [](int s) { return s >> 2; }, [](int s) { return s & 3; }, pred);
     }
-    int *lev_ptr = W.lev[pl];
-    const bool zlev = W.lev_stride[pl] == 0;
-    const size_t l0 = zlev ? b0 : (size_t)y * W.lev_stride[pl] + x;
-    const int lrow = zlev ? 4 : W.lev_stride[pl];
+    int *lev_ptr = V.lev;
+    const bool zlev = V.lev_stride == 0;
+    const size_t l0 = zlev ? b0 : (size_t)y * V.lev_stride + x;
+    const int lrow = zlev ? 4 : V.lev_stride;
     int w[16];
     if (ENC) {
       int coef[16];
@@ -451,32 +490,33 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const PicWork &W, 
       r0[k] = (clip3(0, mx, pred[2 * k] + out[2 * k]) & 0xffff) | (clip3(0, mx, pred[2 * k + 1] + out[2 * k + 1]) << 16);
       r1[k] = (clip3(0, mx, pred[8 + 2 * k] + out[8 + 2 * k]) & 0xffff) | (clip3(0, mx, pred[8 + 2 * k + 1] + out[8 + 2 * k + 1]) << 16);
     }
-    *reinterpret_cast<i4v *>(R.p + b0) = r0;
-    *reinterpret_cast<i4v *>(R.p + b0 + 8) = r1;
+    *reinterpret_cast<i4v *>(R.p + pb0) = r0;
+    *reinterpret_cast<i4v *>(R.p + pb0 + 8) = r1;
   }
 }
 
-template <bool ENC, bool ONCE = false>
-__device__ __forceinline__ void wave_chain_32(char *smem, const PicWork &W, const PicDev &P, const FTu *tus, int count) {
+template <bool ENC, bool ONCE = false, typename SRC>
+__device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const PicDev &P, int count) {
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
   TuLds<32> &L = *reinterpret_cast<TuLds<32> *>(smem);
   constexpr int LG = 5;
   for (int i = 0; ONCE ? i < 1 : i < count; i++) {
-    const FTu ft = tus[i];
+    const FTu ft = src.desc(i);
     const hmx_tu t = ft.t;
     const int pl = t.plane, x = t.x, y = t.y;
     const bool luma = pl == 0;
     const unsigned long long avail = (unsigned long long)ft.avail_lo | ((unsigned long long)ft.avail_hi << 32);
-    const TiledPlane &R = W.rec[pl];
+    const PlaneView V = src.view(i, pl);
+    const TiledPlane &R = V.rec;
     const size_t b0 = tile_base(R.ctu_w, R.clog, x, y);
     // this lane's samples of row r: columns mrow(s,h) = tile column 2*(s>>2)+h, all four samples of the tile row
-    const size_t row_off = b0 + ((r & 3) << 2);
+    const size_t row_off = tphys(R.qstride, b0) + ((r & 3) << 2);
     int pred[16], v[16];
     s4v org4[4]; // kept packed until the residual is formed
     if (ENC) {
 #pragma unroll
       for (int q = 0; q < 4; q++)
-        org4[q] = *reinterpret_cast<const s4v *>(W.org[pl].p + row_off + tile_in_block(2 * q + h, r >> 2));
+        org4[q] = *reinterpret_cast<const s4v *>(V.org + row_off + tphys(R.qstride, tile_in_block(2 * q + h, r >> 2)));
     }
     intra_refs<32, 64>(L, lane, true, [&](int dx, int dy) { return (int)R.p[taddr(R, x + dx, y + dy)]; }, luma, avail, P);
     const int *RL = (luma && use_filtered_refs(t.mode, LG)) ? L.fline : L.line;
@@ -484,9 +524,9 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const PicWork &W, cons
     build_main_ref<32, 64>(RL, L.me, t.mode, lane);
     wave_sync();
     intra_pred_samples<32, 16>(RL, L.me, t.mode, luma, P.bit_depth, dcs, [&](int) { return r; }, [&](int s) { return mrow(s, h); }, pred);
-    const bool zlev = W.lev_stride[pl] == 0;
-    int *lev0 = W.lev[pl] + (zlev ? b0 + r : (size_t)y * W.lev_stride[pl] + x + r);
-    const int lstep = zlev ? 32 : W.lev_stride[pl];
+    const bool zlev = V.lev_stride == 0;
+    int *lev0 = V.lev + (zlev ? b0 + r : (size_t)y * V.lev_stride + x + r);
+    const int lstep = zlev ? 32 : V.lev_stride;
     // the prediction is needed again only for the reconstruction: it waits as 8 packed registers
     unsigned pred2[8];
 #pragma unroll
@@ -519,7 +559,7 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const PicWork &W, cons
       const int p0 = pred2[2 * q] & 0xffff, p1 = pred2[2 * q] >> 16, p2 = pred2[2 * q + 1] & 0xffff, p3 = pred2[2 * q + 1] >> 16;
       s4v o = {(short)clip3(0, mx, p0 + out[4 * q]), (short)clip3(0, mx, p1 + out[4 * q + 1]),
                (short)clip3(0, mx, p2 + out[4 * q + 2]), (short)clip3(0, mx, p3 + out[4 * q + 3])};
-      *reinterpret_cast<s4v *>(R.p + row_off + tile_in_block(2 * q + h, r >> 2)) = o;
+      *reinterpret_cast<s4v *>(R.p + row_off + tphys(R.qstride, tile_in_block(2 * q + h, r >> 2))) = o;
     }
     wave_sync();
   }
@@ -550,7 +590,7 @@ __global__ __launch_bounds__(256) void k_convert_tiled(const ConvJob *jobs) {
   }
   const int x = ((ctu % T.ctu_w) << T.clog) + (tx << 2), y = ((ctu / T.ctu_w) << T.clog) + (ty << 2) + r;
   if (x >= w || y >= h) return;
-  short *tp = T.p + ((size_t)tt << 4) + (r << 2);
+  short *tp = T.p + tphys(T.qstride, ((size_t)tt << 4) + (r << 2));
   short *pp = plane + (size_t)y * stride + x;
   const bool vec = ((reinterpret_cast<uintptr_t>(pp) & 7) == 0) && x + 4 <= w; // 8-byte accesses when the plane row allows
   if (TO_TILED) {
@@ -597,13 +637,53 @@ __global__ __launch_bounds__(64, 4) void k_intra_level(LevelArgs A) {
     if (c < chunks) {
       const FTu *tus = ltus + row.start[s] + (size_t)c * slots;
       const int n = min(slots, (int)row.count[s] - c * slots);
-      if (s == 0) wave_chain_4_lane<ENC, true>(smem, W, A.P, tus, n);
-      else if (s == 1) wave_chain_valu<8, ENC, true>(smem, W, A.P, tus, n);
-      else if (s == 2) wave_chain_valu<16, ENC, true>(smem, W, A.P, tus, n);
-      else wave_chain_32<ENC, true>(smem, W, A.P, tus, n);
+      const OwnPicture src{W, tus};
+      if (s == 0) wave_chain_4_lane<ENC, true>(smem, src, A.P, n);
+      else if (s == 1) wave_chain_valu<8, ENC, true>(smem, src, A.P, n);
+      else if (s == 2) wave_chain_valu<16, ENC, true>(smem, src, A.P, n);
+      else wave_chain_32<ENC, true>(smem, src, A.P, n);
       return;
     }
     c -= chunks;
+  }
+}
+
+// Level schedule for pictures that follow ONE plan: a wave takes one block of the level and works
+// it for 64/N pictures at once (see AcrossPictures).  1-D grid: for each size class, count x cpb
+// waves, cpb = picture chunks per block.
+struct AcrossArgs {
+  const PicWork *pics;
+  const FTu *ltus;
+  LevelRow row;
+  int n_pics;
+  uint32_t cpb[4];
+  const short *pool_org;
+  short *pool_rec;
+  size_t pic_elems;
+  uint32_t plane_off[3];
+  int ctu_w, clog;
+  PicDev P;
+};
+template <bool ENC>
+__global__ __launch_bounds__(64, 4) void k_intra_level_across(AcrossArgs A) {
+  __shared__ __attribute__((aligned(16))) char smem[HMX_WAVE_SMEM];
+  uint32_t c = blockIdx.x;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int slots = s == 0 ? 64 : s == 1 ? 8 : s == 2 ? 4 : 1;
+    const uint32_t waves = A.row.count[s] * A.cpb[s];
+    if (c < waves) {
+      const uint32_t blk = c / A.cpb[s], chunk = c - blk * A.cpb[s];
+      const int pic0 = (int)chunk * slots, n = min(slots, A.n_pics - pic0);
+      const AcrossPictures src{A.pics, A.ltus + A.row.start[s] + blk, pic0, A.n_pics, A.pool_org, A.pool_rec,
+                               A.plane_off[1], A.plane_off[2] - A.plane_off[1], A.ctu_w, A.clog};
+      if (s == 0) wave_chain_4_lane<ENC, true>(smem, src, A.P, n);
+      else if (s == 1) wave_chain_valu<8, ENC, true>(smem, src, A.P, n);
+      else if (s == 2) wave_chain_valu<16, ENC, true>(smem, src, A.P, n);
+      else wave_chain_32<ENC, true>(smem, src, A.P, n);
+      return;
+    }
+    c -= waves;
   }
 }
 
@@ -622,11 +702,12 @@ __global__ __launch_bounds__(64, 4) void k_intra_wave(FrameArgs A) {
     // a new dependency level gathers references from the reconstruction written by the previous one
     if (sg.new_level) wave_global_sync();
     wave_sync(); // the LDS scratch is re-interpreted per block size
+    const OwnPicture src{W, tus};
     switch (sg.log2n) {
-    case 2: wave_chain_4_lane<ENC>(smem, W, A.P, tus, sg.count); break;
-    case 3: wave_chain_valu<8, ENC>(smem, W, A.P, tus, sg.count); break;
-    case 4: wave_chain_valu<16, ENC>(smem, W, A.P, tus, sg.count); break;
-    default: wave_chain_32<ENC>(smem, W, A.P, tus, sg.count); break;
+    case 2: wave_chain_4_lane<ENC>(smem, src, A.P, sg.count); break;
+    case 3: wave_chain_valu<8, ENC>(smem, src, A.P, sg.count); break;
+    case 4: wave_chain_valu<16, ENC>(smem, src, A.P, sg.count); break;
+    default: wave_chain_32<ENC>(smem, src, A.P, sg.count); break;
     }
   }
 }
@@ -643,11 +724,12 @@ struct hmx_ctx {
   char *d_scratch = nullptr;
   size_t scratch_bytes = 0;
   // working pictures of the whole-picture path in tiled layout (grow-only pool, one slot per picture)
-  struct TiledSlot {
-    short *org[3];
-    short *rec[3];
-  };
-  std::vector<TiledSlot> tiled;
+  // ONE allocation per direction, picture i at element offset i * tiled_pic_elems, its planes at
+  // tiled_plane_off[]: a wave that works across pictures reaches any picture with a multiply-add
+  short *pool_org = nullptr, *pool_rec = nullptr;
+  int pool_pics = 0;
+  size_t tiled_pic_elems = 0;
+  uint32_t tiled_plane_off[3] = {0, 0, 0};
   int tiled_cw = 0, tiled_ch = 0; // CTU grid the pool was sized for
   ConvJob *d_jobs = nullptr;      // [2][n_pics*3]: to-tiled jobs, then from-tiled jobs
   int jobs_cap = 0;
@@ -661,6 +743,7 @@ struct hmx_ctx {
   };
   std::vector<GraphEntry> graphs;
   uint64_t graph_clock = 0;
+  bool across_call = false;    // the call being issued uses the across-pictures schedule (interleaved pool)
   int level_mode_min_pics = 1; // measured: the level schedule is at least as fast as the wave schedule at every batch size
   // optional timing of the last whole-picture call: events around the layout conversions and the chain
   bool timing = false;
@@ -790,11 +873,8 @@ extern "C" void hmx_destroy(hmx_ctx *c) {
     hipGraphExecDestroy(e.exec);
     hipFree(e.d_work);
   }
-  for (auto &t : c->tiled)
-    for (int p = 0; p < 3; p++) {
-      hipFree(t.org[p]);
-      hipFree(t.rec[p]);
-    }
+  hipFree(c->pool_org);
+  hipFree(c->pool_rec);
   hipFree(c->d_jobs);
   hipFree(c->d_refs);
   for (int g = 0; g < c->n_side; g++) {
@@ -1201,6 +1281,13 @@ extern "C" int hmx_intra_plan_info(const hmx_intra_plan *pl, int *n_blocks, int 
   if (n_diagonals) *n_diagonals = (int)pl->waves.size();
   return HMX_OK;
 }
+extern "C" int hmx_intra_plan_level(const hmx_intra_plan *pl, int level, uint32_t counts[4], uint32_t *n_waves) {
+  if (!pl || level < 0 || level >= (int)pl->h_ltab.size()) return HMX_ERR_ARG;
+  if (counts)
+    for (int s = 0; s < 4; s++) counts[s] = pl->h_ltab[level].count[s];
+  if (n_waves) *n_waves = pl->level_chunks[level];
+  return HMX_OK;
+}
 extern "C" int hmx_intra_schedule_for(const hmx_ctx *c, int n_pics) { // 1 = level schedule, 0 = wave schedule
   bool use_level = n_pics >= c->level_mode_min_pics;
   if (const char *e = getenv("HMX_INTRA_SCHEDULE")) use_level = e[0] == 'l' ? true : (e[0] == 'w' ? false : use_level);
@@ -1274,6 +1361,38 @@ static int issue_chain_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, 
     }
     size_t n_levels = 0;
     for (int g = 0; g < groups; g++) n_levels = std::max(n_levels, glevels[g]);
+    // one plan for every picture: SIMD across pictures (k_intra_level_across)
+    if (c->across_call) {
+      AcrossArgs AA{};
+      AA.pics = d_work;
+      AA.ltus = p0->d_ltus;
+      AA.n_pics = n_pics;
+      for (int s2 = 0; s2 < 4; s2++) {
+        const int slots = s2 == 0 ? 64 : s2 == 1 ? 8 : s2 == 2 ? 4 : 1;
+        AA.cpb[s2] = (uint32_t)((n_pics + slots - 1) / slots);
+      }
+      AA.pool_org = c->pool_org;
+      AA.pool_rec = c->pool_rec;
+      AA.pic_elems = c->tiled_pic_elems;
+      for (int p = 0; p < 3; p++) AA.plane_off[p] = c->tiled_plane_off[p];
+      AA.ctu_w = c->tiled_cw;
+      AA.clog = 0;
+      while ((1 << AA.clog) < p0->P.ctu) AA.clog++;
+      AA.P = p0->P;
+      for (size_t l = 0; l < n_levels; l++) {
+        AA.row = p0->h_ltab[l];
+        uint64_t waves = 0;
+        for (int s2 = 0; s2 < 4; s2++) waves += (uint64_t)AA.row.count[s2] * AA.cpb[s2];
+        if (!waves) continue;
+        if (waves > 0x7fffffffull) return fail(c, HMX_ERR_ARG, "frame_intra: level too large for one launch");
+        if (enc)
+          hipLaunchKernelGGL(k_intra_level_across<true>, dim3((unsigned)waves), dim3(64), 0, main, AA);
+        else
+          hipLaunchKernelGGL(k_intra_level_across<false>, dim3((unsigned)waves), dim3(64), 0, main, AA);
+      }
+      HIPCHK(c, hipGetLastError());
+      return HMX_OK;
+    }
     LevelArgs LA{};
     LA.P = p0->P;
     for (size_t l = 0; l < n_levels; l++)
@@ -1336,26 +1455,39 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
   const int ctu = p0->P.ctu, cw = (p0->P.pic_w + ctu - 1) / ctu, ch = (p0->P.pic_h + ctu - 1) / ctu;
   int clog = 0;
   while ((1 << clog) < ctu) clog++;
-  if (c->tiled_cw != cw || c->tiled_ch != ch) {
+  if (c->tiled_cw != cw || c->tiled_ch != ch || c->pool_pics < n_pics) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (auto &t : c->tiled)
-      for (int p = 0; p < 3; p++) {
-        hipFree(t.org[p]);
-        hipFree(t.rec[p]);
-      }
-    c->tiled.clear();
+    hipFree(c->pool_org);
+    hipFree(c->pool_rec);
+    c->pool_org = c->pool_rec = nullptr;
+    c->pool_pics = 0;
     c->tiled_cw = cw;
     c->tiled_ch = ch;
-  }
-  while ((int)c->tiled.size() < n_pics) {
-    hmx_ctx::TiledSlot t{};
+    size_t off = 0;
     for (int p = 0; p < 3; p++) {
-      const size_t elems = (size_t)cw * ch * ((size_t)ctu * ctu >> (p ? 2 : 0));
-      if (hipMalloc((void **)&t.org[p], elems * 2) != hipSuccess || hipMalloc((void **)&t.rec[p], elems * 2) != hipSuccess)
-        return fail(c, HMX_ERR_NOMEM, "hipMalloc tiled working picture");
+      c->tiled_plane_off[p] = (uint32_t)off;
+      off += (size_t)cw * ch * ((size_t)ctu * ctu >> (p ? 2 : 0));
     }
-    c->tiled.push_back(t);
+    c->tiled_pic_elems = off;
+    if (hipMalloc((void **)&c->pool_org, off * 2 * n_pics) != hipSuccess || hipMalloc((void **)&c->pool_rec, off * 2 * n_pics) != hipSuccess) {
+      hipFree(c->pool_org);
+      c->pool_org = nullptr;
+      return fail(c, HMX_ERR_NOMEM, "hipMalloc tiled working pictures");
+    }
+    c->pool_pics = n_pics;
   }
+  // Two schedules (DESIGN.md section 4): "level" = one launch per picture-wide dependency level,
+  // lane-packed, throughput-oriented; "wave" = one launch per CTU diagonal with autonomous waves.
+  // Pictures that share ONE plan additionally run the level schedule across pictures, on a pool
+  // whose pictures are interleaved quad by quad.
+  bool use_level = n_pics >= c->level_mode_min_pics;
+  if (const char *e = getenv("HMX_INTRA_SCHEDULE")) use_level = e[0] == 'l' ? true : (e[0] == 'w' ? false : use_level);
+  int groups = 1;
+  if (use_level)
+    if (const char *e = getenv("HMX_INTRA_STREAMS")) groups = std::min(std::max(atoi(e), 1), std::min(n_pics, (int)hmx_ctx::kMaxSide));
+  bool across = use_level && plan_stride == 0 && groups == 1;
+  if (const char *e = getenv("HMX_INTRA_ACROSS")) across = across && e[0] != '0';
+  c->across_call = across;
   std::vector<PicWork> hw(n_pics);
   std::vector<ConvJob> jobs((size_t)n_pics * 6);
   for (int i = 0; i < n_pics; i++) {
@@ -1367,8 +1499,10 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
     memset(&hw[i], 0, sizeof(PicWork));
     for (int p = 0; p < 3; p++) {
       const int pclog = p ? clog - 1 : clog, pw = p0->P.pic_w >> (p ? 1 : 0), ph = p0->P.pic_h >> (p ? 1 : 0);
-      hw[i].org[p] = TiledPlane{c->tiled[i].org[p], cw, pclog};
-      hw[i].rec[p] = TiledPlane{c->tiled[i].rec[p], cw, pclog};
+      const size_t base = across ? (size_t)c->tiled_plane_off[p] * n_pics + (size_t)i * 64 : (size_t)i * c->tiled_pic_elems + c->tiled_plane_off[p];
+      const unsigned qstride = across ? 64u * (unsigned)n_pics : 64u;
+      hw[i].org[p] = TiledPlane{c->pool_org + base, cw, pclog, qstride};
+      hw[i].rec[p] = TiledPlane{c->pool_rec + base, cw, pclog, qstride};
       hw[i].lev[p] = lev[i].plane[p];
       hw[i].lev_stride[p] = lev[i].stride[p];
       if (enc) jobs[(size_t)i * 3 + p] = ConvJob{org[i].plane[p], org[i].stride[p], pw, ph, hw[i].org[p]};
@@ -1381,25 +1515,15 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
     hw[i].ltab = pl->d_ltab;
     hw[i].n_levels = (int)pl->level_chunks.size();
   }
-  // Two schedules (DESIGN.md section 4): "level" = one launch per picture-wide dependency level,
-  // lane-packed, throughput-oriented, wants many pictures; "wave" = one launch per CTU diagonal with
-  // autonomous waves, far fewer launches, better for a handful of pictures.
-  bool use_level = n_pics >= c->level_mode_min_pics;
-  if (const char *e = getenv("HMX_INTRA_SCHEDULE")) use_level = e[0] == 'l' ? true : (e[0] == 'w' ? false : use_level);
-  int groups = 1;
-  if (use_level) {
+  if (use_level && groups > 1 && c->n_side < groups) {
     // measured on MI355X: launches of different streams do not overlap usefully (the dispatcher
     // retires ~140k small kernels/s whatever the stream count), so one stream is the default
-    groups = 1;
-    if (const char *e = getenv("HMX_INTRA_STREAMS")) groups = std::min(std::max(atoi(e), 1), std::min(n_pics, (int)hmx_ctx::kMaxSide));
-    if (groups > 1 && c->n_side < groups) {
-      if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-      for (int g = c->n_side; g < groups; g++) {
-        HIPCHK(c, hipStreamCreateWithFlags(&c->side[g], hipStreamNonBlocking));
-        HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming));
-      }
-      c->n_side = groups;
+    if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (int g = c->n_side; g < groups; g++) {
+      HIPCHK(c, hipStreamCreateWithFlags(&c->side[g], hipStreamNonBlocking));
+      HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming));
     }
+    c->n_side = groups;
   }
   // A call is thousands of dependent launches whose arguments depend only on (plans, planes): it is
   // recorded once as a HIP graph and replayed while the same pictures/plans come back (steady-state
@@ -1411,7 +1535,7 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
   };
   mix(hw.data(), sizeof(PicWork) * n_pics);
   mix(jobs.data(), sizeof(ConvJob) * jobs.size());
-  const int flags[4] = {enc, use_level, groups, n_pics};
+  const int flags[5] = {enc, use_level, groups, n_pics, across};
   mix(flags, sizeof(flags));
   for (int i = 0; i < n_pics; i++) {
     const void *pp = plans[i * plan_stride];
