@@ -234,7 +234,9 @@ def main():
         L.hmx_intra_plan_info(plan, C.byref(nb), C.byref(nl), C.byref(nd))
         level_sched = bool(L.hmx_intra_schedule_for(ctx.h, F))
         n_launch = nl.value if level_sched else nd.value  # launches of the dominant kernel per step
-        kernel = "k_intra_level<true>" if level_sched else "k_intra_wave<true>"
+        # one plan for the whole batch -> the level schedule runs across pictures (hmx_lib.hip, frame_intra)
+        across = level_sched and os.environ.get("HMX_INTRA_ACROSS", "1")[0] != "0" and "HMX_INTRA_STREAMS" not in os.environ
+        kernel = ("k_intra_level_across<true>" if across else "k_intra_level<true>") if level_sched else "k_intra_wave<true>"
         traffic = None
         tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tj) and args.workload == "ai2160p10" and args.tiling == "mix" and level_sched:

@@ -38,13 +38,21 @@ struct TiledPlane {
 // own contiguous slot, 64 * P when P pictures are interleaved quad by quad -- the layout of the
 // across-pictures schedule, where the 64/N lanes-groups of a wave hold the SAME block of consecutive
 // pictures and so touch consecutive 128-byte lines.
-__host__ __device__ __forceinline__ size_t tphys(unsigned qstride, size_t o) { return (o >> 6) * qstride + (o & 63); }
+__host__ __device__ __forceinline__ size_t tphys(unsigned qstride, unsigned o) { return (size_t)(o >> 6) * qstride + (o & 63); }
 __host__ __device__ __forceinline__ unsigned spread4(unsigned t) { return (t & 1) | ((t & 2) << 1) | ((t & 4) << 2) | ((t & 8) << 3); }
-// offset o of the 4x4 tile that holds (x,y); ctu block base + Z index * 16
-__host__ __device__ __forceinline__ size_t tile_base(int ctu_w, int clog, int x, int y) {
-  const int m = (1 << clog) - 1;
-  const unsigned tx = (unsigned)(x & m) >> 2, ty = (unsigned)(y & m) >> 2;
-  return ((size_t)((y >> clog) * ctu_w + (x >> clog)) << (2 * clog)) + ((spread4(tx) | (spread4(ty) << 1)) << 4);
+// Z index of tile (tx, ty), both < 16: the two nibbles are spread together (7 operations)
+__host__ __device__ __forceinline__ unsigned zorder_tile(unsigned tx, unsigned ty) {
+  unsigned v = tx | (ty << 8);
+  v = (v | (v << 2)) & 0x3333u;
+  v = (v | (v << 1)) & 0x5555u;
+  return (v | (v >> 7)) & 0xffu;
+}
+// offset o of the 4x4 tile that holds (x,y); ctu block base + Z index * 16.  A picture has fewer than
+// 2^24 samples per plane set, so the offset is 32-bit arithmetic; only tphys() widens.
+__host__ __device__ __forceinline__ unsigned tile_base(int ctu_w, int clog, int x, int y) {
+  const unsigned m = (1u << clog) - 1;
+  const unsigned tx = ((unsigned)x & m) >> 2, ty = ((unsigned)y & m) >> 2;
+  return ((unsigned)((y >> clog) * ctu_w + (x >> clog)) << (2 * clog)) + (zorder_tile(tx, ty) << 4);
 }
 // physical element index of sample (x,y)
 __device__ __forceinline__ size_t taddr(const TiledPlane &T, int x, int y) {

@@ -253,7 +253,7 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, cons
     const unsigned long long avail = (unsigned long long)ft.avail_lo | ((unsigned long long)ft.avail_hi << 32);
     const PlaneView V = src.view(active ? i : 0, pl);
     const TiledPlane &R = V.rec;
-    const size_t b0 = tile_base(R.ctu_w, R.clog, x, y); // same geometry for org and rec
+    const unsigned b0 = tile_base(R.ctu_w, R.clog, x, y); // same geometry for org and rec
     int pred[N], row[N];
     int *lev_row = V.lev + lev_row_off<N>(V, x, y, gl);
     const size_t pb0 = tphys(R.qstride, b0);
@@ -324,7 +324,8 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
     const unsigned avail = ft.avail_lo; // 4n+1 <= 9 units
     const PlaneView V = src.view(i, pl);
     const TiledPlane &R = V.rec;
-    const size_t b0 = tile_base(R.ctu_w, R.clog, x, y), pb0 = tphys(R.qstride, b0); // a tile never straddles quads
+    const unsigned b0 = tile_base(R.ctu_w, R.clog, x, y);
+    const size_t pb0 = tphys(R.qstride, b0); // a tile never straddles quads
     int v[16];
     if (ENC) {
       const i4v o0 = *reinterpret_cast<const i4v *>(V.org + pb0), o1 = *reinterpret_cast<const i4v *>(V.org + pb0 + 8);
@@ -335,18 +336,31 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
       }
     }
     // ---- reference line (fillReferenceSamples): sequential padding is natural inside one lane.
-    // All 17 loads are issued unconditionally first (an unavailable position reads the block's own
-    // first sample, a valid address, and the value is dropped): one memory round trip, not 17.
     int *line = LS.line[lane];
     {
       const int ul = luma ? 2 : 1, n = 4 >> ul; // unit = 4 (luma) / 2 (chroma) samples
+      // The 17 reference samples lie in five neighbour tiles: column 3 of the below-left and left
+      // tiles, sample (3,3) of the corner tile, row 3 of the above and above-right tiles.  One tile
+      // address each; a tile none of whose units is available is replaced by the block's own tile
+      // (a valid address; the availability mask drops the values).  11 loads, one round trip.
       int raw[17];
+      {
+        const unsigned m_bl = (1u << n) - 1, m_lf = m_bl << n, m_c = 1u << (2 * n), m_a = m_bl << (2 * n + 1), m_ar = m_a << n;
+        const bool has_bl = avail & m_bl, has_lf = avail & m_lf, has_c = avail & m_c, has_a = avail & m_a, has_ar = avail & m_ar;
+        const short *t_bl = R.p + (has_bl ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x - 4, y + 4)) : pb0);
+        const short *t_lf = R.p + (has_lf ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x - 4, y)) : pb0);
+        const short *t_c = R.p + (has_c ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x - 4, y - 4)) : pb0);
+        const short *t_a = R.p + (has_a ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x, y - 4)) : pb0);
+        const short *t_ar = R.p + (has_ar ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x + 4, y - 4)) : pb0);
+        const s4v va = *reinterpret_cast<const s4v *>(t_a + 12), var = *reinterpret_cast<const s4v *>(t_ar + 12);
 #pragma unroll
-      for (int p = 0; p <= 16; p++) {
-        const int u = p < 8 ? (p >> ul) : (p == 8 ? 2 * n : 2 * n + 1 + ((p - 9) >> ul));
-        const bool ok = (avail >> u) & 1;
-        const int dx = !ok ? 0 : (p <= 8 ? -1 : p - 9), dy = !ok ? 0 : (p < 8 ? 7 - p : -1);
-        raw[p] = R.p[taddr(R, x + dx, y + dy)];
+        for (int k = 0; k < 4; k++) {
+          raw[k] = t_bl[4 * (3 - k) + 3];     // p = 0..3: (x-1, y+7-p)
+          raw[4 + k] = t_lf[4 * (3 - k) + 3]; // p = 4..7: (x-1, y+7-p)
+          raw[9 + k] = va[k];
+          raw[13 + k] = var[k];
+        }
+        raw[8] = t_c[15];
       }
       const int dc = 1 << (B - 1);
       int carry = dc;
@@ -508,7 +522,7 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const 
     const unsigned long long avail = (unsigned long long)ft.avail_lo | ((unsigned long long)ft.avail_hi << 32);
     const PlaneView V = src.view(i, pl);
     const TiledPlane &R = V.rec;
-    const size_t b0 = tile_base(R.ctu_w, R.clog, x, y);
+    const unsigned b0 = tile_base(R.ctu_w, R.clog, x, y);
     // this lane's samples of row r: columns mrow(s,h) = tile column 2*(s>>2)+h, all four samples of the tile row
     const size_t row_off = tphys(R.qstride, b0) + ((r & 3) << 2);
     int pred[16], v[16];
@@ -572,26 +586,21 @@ struct ConvJob { // one plane of one picture
   int stride, w, h;
   TiledPlane T;
 };
+// A 256-thread workgroup moves a 64 x 16 strip: thread = (row, 4-sample group), so a wave reads
+// four whole 128-byte lines of four plane rows, and writes the rows of 16 tiles (8 half-quads).
+// grid = (picture, strip, plane): consecutive workgroups take the same strip of consecutive pictures,
+// which are consecutive lines of the interleaved pool.
 template <bool TO_TILED>
 __global__ __launch_bounds__(256) void k_convert_tiled(const ConvJob *jobs) {
-  const ConvJob J = jobs[blockIdx.y];
-  short *plane = J.plane;
+  const ConvJob J = jobs[blockIdx.x * 3 + blockIdx.z];
   const int stride = J.stride, w = J.w, h = J.h;
   const TiledPlane T = J.T;
-  const int tiles_per_ctu = 1 << (2 * T.clog - 4);
-  const long long tt = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
-  const int r = threadIdx.x & 3;
-  const int ctu = (int)(tt / tiles_per_ctu), z = (int)(tt % tiles_per_ctu);
-  unsigned tx = 0, ty = 0;
-#pragma unroll
-  for (int b = 0; b < 4; b++) {
-    tx |= ((z >> (2 * b)) & 1) << b;
-    ty |= ((z >> (2 * b + 1)) & 1) << b;
-  }
-  const int x = ((ctu % T.ctu_w) << T.clog) + (tx << 2), y = ((ctu / T.ctu_w) << T.clog) + (ty << 2) + r;
+  const int spr = ((T.ctu_w << T.clog) + 63) >> 6; // strips per row of this plane
+  const int sx = blockIdx.y % spr, sy = blockIdx.y / spr;
+  const int x = (sx << 6) + ((threadIdx.x & 15) << 2), y = (sy << 4) + (threadIdx.x >> 4);
   if (x >= w || y >= h) return;
-  short *tp = T.p + tphys(T.qstride, ((size_t)tt << 4) + (r << 2));
-  short *pp = plane + (size_t)y * stride + x;
+  short *tp = T.p + tphys(T.qstride, tile_base(T.ctu_w, T.clog, x, y) + ((y & 3) << 2));
+  short *pp = J.plane + (size_t)y * stride + x;
   const bool vec = ((reinterpret_cast<uintptr_t>(pp) & 7) == 0) && x + 4 <= w; // 8-byte accesses when the plane row allows
   if (TO_TILED) {
     if (vec)
@@ -1323,11 +1332,10 @@ static int issue_intra_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, 
                                 hipStream_t main) {
   // original planes -> tiled working copies (encode), chain, tiled reconstruction -> caller's planes
   const hmx_intra_plan *p0 = plans[0];
-  const int ctu = 1 << 6; // tiles are counted per luma CTU grid; chroma planes have 1/4 of the tiles
-  (void)ctu;
   const int cw = (p0->P.pic_w + p0->P.ctu - 1) / p0->P.ctu, ch = (p0->P.pic_h + p0->P.ctu - 1) / p0->P.ctu;
-  const unsigned luma_tiles = (unsigned)(cw * ch) * (unsigned)((p0->P.ctu / 4) * (p0->P.ctu / 4));
-  dim3 cgrid((luma_tiles + 63) / 64, (unsigned)n_pics * 3);
+  // 64 x 16 strips of the padded luma plane (the chroma planes need a quarter of them; the rest exit)
+  const unsigned spr = (unsigned)(cw * p0->P.ctu + 63) / 64, rows = (unsigned)(ch * p0->P.ctu + 15) / 16;
+  dim3 cgrid((unsigned)n_pics, spr * rows, 3);
   const bool tm = c->timing;
   if (tm) HIPCHK(c, hipEventRecord(c->tev[0], main));
   if (enc) hipLaunchKernelGGL(k_convert_tiled<true>, cgrid, dim3(256), 0, main, d_jobs);
