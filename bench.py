@@ -46,7 +46,7 @@ def algorithmic_bytes(tus, n_pics):
     return int(((n * n) * 8 + (4 * n + 1) * 2).sum()) * n_pics
 
 
-def cpu_baseline(tus, w, h, B, qp, seconds_target=15.0):
+def cpu_baseline(tus, w, h, B, qp, seconds_target=12.0):
     """Time the CPU path on one picture of the same workload (one thread)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
@@ -61,7 +61,7 @@ def cpu_baseline(tus, w, h, B, qp, seconds_target=15.0):
         fn(tus, w, h, B, qp, org)
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= seconds_target or n >= 8:
+        if dt >= seconds_target or n >= 256:
             break
     return {"value": round(n * w * h / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": kind,
             "sample": f"{n} picture(s) {w}x{h} of the same block structure, single thread, "
@@ -145,7 +145,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="ai2160p10", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames", type=int, default=512, help="pictures per GPU per step (100 MB of HBM each at 2160p)")
+    ap.add_argument("--frames", type=int, default=1024,
+                    help="pictures per GPU per step (150 MB of HBM each at 2160p: planes, levels and the working pool)")
     ap.add_argument("--tiling", default="mix", help="mix | 4 | 8 | 16 | 32 (uniform transform size)")
     ap.add_argument("--segments", type=int, default=1, help="random-access workloads: intra-period segments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -43,6 +43,11 @@ __host__ __device__ constexpr int dst_coef(int k, int n) {
 }
 
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
+// Full-rate integer multiplies (v_mul_i32_i24 / v_mad_i32_i24 / v_mul_u32_u24; the plain 32-bit multiply
+// v_mul_lo_u32 is a quarter-rate instruction).  Both operands must fit 24 bits; the result is the
+// exact low 32 bits of the product.  Every use states why its operands fit.
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+__device__ __forceinline__ unsigned umul24(unsigned a, unsigned b) { return __umul24(a, b); }
 __device__ __forceinline__ int wrap16(int v) { return (int)(short)v; }
 
 // ---------------------------------------------------------------------------------------------
@@ -66,7 +71,7 @@ __device__ __forceinline__ void dct_fwd_raw(const int *x, int *y) {
       y[2 * m] = ye[m];
       int acc = 0;
 #pragma unroll
-      for (int n = 0; n < N / 2; n++) acc += dct_coef(N, 2 * m + 1, n) * o[n];
+      for (int n = 0; n < N / 2; n++) acc += mul24(dct_coef(N, 2 * m + 1, n), o[n]); // |o| < 2^21: sums of int16 inputs
       y[2 * m + 1] = acc;
     }
   }
@@ -86,7 +91,7 @@ __device__ __forceinline__ void dct_inv_raw(const int *c, int *out) {
     for (int n = 0; n < N / 2; n++) {
       int acc = 0;
 #pragma unroll
-      for (int m = 0; m < N / 2; m++) acc += dct_coef(N, 2 * m + 1, n) * c[2 * m + 1];
+      for (int m = 0; m < N / 2; m++) acc += mul24(dct_coef(N, 2 * m + 1, n), c[2 * m + 1]); // c: int16 inputs
       out[n] = ee[n] + acc;
       out[N - 1 - n] = ee[n] - acc;
     }
@@ -102,7 +107,7 @@ __device__ __forceinline__ void fwd_pass(const int *x, int *y, int shift, bool u
     for (int k = 0; k < 4; k++) {
       int acc = 0;
 #pragma unroll
-      for (int n = 0; n < 4; n++) acc += dst_coef(k, n) * x[n];
+      for (int n = 0; n < 4; n++) acc += mul24(dst_coef(k, n), x[n]); // x: int16-range residuals
       y[k] = wrap16((acc + rnd) >> shift);
     }
   } else {
@@ -122,7 +127,7 @@ __device__ __forceinline__ void inv_pass(const int *c, int *y, int shift, bool u
     for (int n = 0; n < 4; n++) {
       int acc = 0;
 #pragma unroll
-      for (int k = 0; k < 4; k++) acc += dst_coef(k, n) * c[k];
+      for (int k = 0; k < 4; k++) acc += mul24(dst_coef(k, n), c[k]); // c: int16 coefficients
       y[n] = clip3(-32768, 32767, (acc + rnd) >> shift);
     }
   } else {
@@ -264,7 +269,7 @@ __device__ __forceinline__ int quant_one(int c, int q, int qbits, int rnd_factor
     l = (int)((t + add) >> qbits);
     du = (int)((t - ((long long)l << qbits)) >> (qbits - 8));
   } else {
-    const unsigned t = (unsigned)abs(c) * (unsigned)q, add = (unsigned)rnd_factor << (qbits - 9);
+    const unsigned t = umul24((unsigned)abs(c), (unsigned)q), add = (unsigned)rnd_factor << (qbits - 9); // |c| <= 2^15, q < 2^15
     l = (int)((t + add) >> qbits);
     du = ((int)t - (l << qbits)) >> (qbits - 8);
   }
@@ -481,7 +486,7 @@ __device__ __forceinline__ void build_main_ref(const int *R, int *ME, int mode, 
     if (k >= 0)
       v = a.ver ? R[2 * N + k] : R[2 * N - k];
     else {
-      const int j = (128 + (-k) * a.inv_angle) >> 8;
+      const int j = (128 + mul24(-k, a.inv_angle)) >> 8; // k >= -32, inv_angle <= 4096
       v = a.ver ? R[2 * N - j] : R[2 * N + j];
     }
     ME[e] = (short)v;
@@ -501,8 +506,8 @@ __device__ __forceinline__ void intra_pred_samples(const int *R, const int *ME, 
 #pragma unroll
     for (int s = 0; s < NS; s++) {
       const int r = row(s), c = col(s), t = top[c + 1], left = R[2 * N - (r + 1)];
-      int hor = (left << LOG2N) + N + (c + 1) * (tr - left);
-      int ver = (t << LOG2N) + (r + 1) * (bl - t);
+      int hor = (left << LOG2N) + N + mul24(c + 1, tr - left); // samples: at most 12 bits
+      int ver = (t << LOG2N) + mul24(r + 1, bl - t);
       p[s] = (short)((hor + ver) >> (LOG2N + 1));
     }
     return;
@@ -543,10 +548,10 @@ __device__ __forceinline__ void intra_pred_samples(const int *R, const int *ME, 
   for (int s = 0; s < NS; s++) {
     const int r = row(s), c = col(s);
     const int k = a.ver ? r : c, l = a.ver ? c : r;
-    const int pos = (k + 1) * a.angle, di = pos >> 5, df = pos & 31;
+    const int pos = mul24(k + 1, a.angle), di = pos >> 5, df = pos & 31; // k < 32, |angle| <= 32
     const int i = l + di + 1;
     const int m0 = M0[i];
-    p[s] = df ? (short)(((32 - df) * m0 + df * M0[i + 1] + 16) >> 5) : m0;
+    p[s] = df ? (short)((mul24(32 - df, m0) + mul24(df, M0[i + 1]) + 16) >> 5) : m0; // samples: at most 12 bits
   }
 }
 

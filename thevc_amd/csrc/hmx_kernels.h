@@ -52,14 +52,33 @@ __host__ __device__ __forceinline__ unsigned zorder_tile(unsigned tx, unsigned t
 __host__ __device__ __forceinline__ unsigned tile_base(int ctu_w, int clog, int x, int y) {
   const unsigned m = (1u << clog) - 1;
   const unsigned tx = ((unsigned)x & m) >> 2, ty = ((unsigned)y & m) >> 2;
-  return ((unsigned)((y >> clog) * ctu_w + (x >> clog)) << (2 * clog)) + (zorder_tile(tx, ty) << 4);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned cidx = (unsigned)__mul24(y >> clog, ctu_w) + (unsigned)(x >> clog); // CTU rows and columns: far below 2^23
+#else
+  const unsigned cidx = (unsigned)((y >> clog) * ctu_w + (x >> clog));
+#endif
+  return (cidx << (2 * clog)) + (zorder_tile(tx, ty) << 4);
 }
 // physical element index of sample (x,y)
 __device__ __forceinline__ size_t taddr(const TiledPlane &T, int x, int y) {
   return tphys(T.qstride, tile_base(T.ctu_w, T.clog, x, y) + ((y & 3) << 2) + (x & 3));
 }
+// physical displacement of offset k RELATIVE to a quad-aligned block start (k < 1024: a block has at most
+// 16 quads): 32-bit, full-rate multiply (quad index < 16, qstride < 2^24)
+template <int N>
+__device__ __forceinline__ unsigned trel(unsigned qstride, unsigned k) {
+  if constexpr (N <= 8) return k; // the whole block is one quad
+  return __umul24(k >> 6, qstride) + (k & 63);
+}
 // offset of tile (q, rr) (tile units) inside an aligned block whose origin tile has Z index z0
 __host__ __device__ __forceinline__ unsigned tile_in_block(unsigned q, unsigned rr) { return (spread4(q) | (spread4(rr) << 1)) << 4; }
+
+// Pointers that were loaded from a table in memory are generic to the compiler, and accesses through
+// them become FLAT instructions; every buffer this library touches is global memory.
+template <typename T>
+__device__ __forceinline__ T *as_global(T *p) {
+  return (T *)(__attribute__((address_space(1))) T *)p;
+}
 
 typedef short s4v __attribute__((ext_vector_type(4)));
 typedef int i4v __attribute__((ext_vector_type(4)));
@@ -69,7 +88,7 @@ template <int N>
 __device__ __forceinline__ void tload_row(const short *pb, unsigned qstride, int r, int *x) {
 #pragma unroll
   for (int q = 0; q < N / 4; q++) {
-    const s4v v = *reinterpret_cast<const s4v *>(pb + tphys(qstride, tile_in_block(q, r >> 2) + ((r & 3) << 2)));
+    const s4v v = *reinterpret_cast<const s4v *>(pb + trel<N>(qstride, tile_in_block(q, r >> 2) + ((r & 3) << 2)));
     x[4 * q] = v[0];
     x[4 * q + 1] = v[1];
     x[4 * q + 2] = v[2];
@@ -81,7 +100,7 @@ __device__ __forceinline__ void tstore_row(short *pb, unsigned qstride, int r, c
 #pragma unroll
   for (int q = 0; q < N / 4; q++) {
     s4v v = {(short)x[4 * q], (short)x[4 * q + 1], (short)x[4 * q + 2], (short)x[4 * q + 3]};
-    *reinterpret_cast<s4v *>(pb + tphys(qstride, tile_in_block(q, r >> 2) + ((r & 3) << 2))) = v;
+    *reinterpret_cast<s4v *>(pb + trel<N>(qstride, tile_in_block(q, r >> 2) + ((r & 3) << 2))) = v;
   }
 }
 struct LevelsDev {
@@ -223,7 +242,9 @@ __device__ __forceinline__ int fwd_tq_block(TuLds<N> &L, int gl, bool active, co
 
 __device__ __forceinline__ int dequant_one(int v, int iq_scale, int dshift) { // :1343-1354, 32-bit product
   int l = clip3(-32768, 32767, v);
-  return clip3(-32768, 32767, (int)((unsigned)l * (unsigned)iq_scale + (1u << (dshift - 1))) >> dshift);
+  // l is int16, iq_scale = g_invQuantScales[rem] << per <= 72 << 14 < 2^23: the low 32 bits of the 24-bit
+  // multiply are the reference's wrapped 32-bit product
+  return clip3(-32768, 32767, (int)((unsigned)mul24(l, iq_scale) + (1u << (dshift - 1))) >> dshift);
 }
 
 // invtransformNxN core: levels in L.tile[row][col] -> residual row gl in out[N].

@@ -210,7 +210,11 @@ struct OwnPicture {
   const PicWork &W;
   const FTu *tus;
   __device__ __forceinline__ FTu desc(int i) const { return tus[i]; }
-  __device__ __forceinline__ PlaneView view(int, int pl) const { return PlaneView{W.org[pl].p, W.rec[pl], W.lev[pl], W.lev_stride[pl]}; }
+  __device__ __forceinline__ PlaneView view(int, int pl) const {
+    TiledPlane r = W.rec[pl];
+    r.p = as_global(r.p);
+    return PlaneView{as_global(W.org[pl].p), r, as_global(W.lev[pl]), W.lev_stride[pl]};
+  }
 };
 struct AcrossPictures {
   const PicWork *pics;
@@ -227,14 +231,15 @@ struct AcrossPictures {
     const char *row = reinterpret_cast<const char *>(&pics[pic0 + i]);
     int *lv = *reinterpret_cast<int *const *>(row + offsetof(PicWork, lev) + pl * sizeof(int *));
     const int ls = *reinterpret_cast<const int *>(row + offsetof(PicWork, lev_stride) + pl * sizeof(int));
-    return PlaneView{pool_org + o, TiledPlane{pool_rec + o, ctu_w, pl ? clog_luma - 1 : clog_luma, 64u * n_pics}, lv, ls};
+    return PlaneView{pool_org + o, TiledPlane{pool_rec + o, ctu_w, pl ? clog_luma - 1 : clog_luma, 64u * n_pics}, as_global(lv), ls};
   }
 };
 
 // element offset of row r of the N x N block at (x,y) in a level buffer
+// (a level plane holds fewer than 2^32 elements; rows and strides are below 2^24: full-rate multiply)
 template <int N>
-__device__ __forceinline__ size_t lev_row_off(const PlaneView &V, int x, int y, int r) {
-  return V.lev_stride ? (size_t)(y + r) * V.lev_stride + x : tile_base(V.rec.ctu_w, V.rec.clog, x, y) + (size_t)r * N;
+__device__ __forceinline__ unsigned lev_row_off(const PlaneView &V, int x, int y, int r) {
+  return V.lev_stride ? __umul24((unsigned)(y + r), (unsigned)V.lev_stride) + x : tile_base(V.rec.ctu_w, V.rec.clog, x, y) + (unsigned)r * N;
 }
 
 template <int N, bool ENC, bool ONCE = false, typename SRC>
@@ -398,7 +403,7 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
     }
     int *lev_ptr = V.lev;
     const bool zlev = V.lev_stride == 0;
-    const size_t l0 = zlev ? b0 : (size_t)y * V.lev_stride + x;
+    const unsigned l0 = zlev ? b0 : __umul24((unsigned)y, (unsigned)V.lev_stride) + x;
     const int lrow = zlev ? 4 : V.lev_stride;
     int w[16];
     if (ENC) {
@@ -458,12 +463,12 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         i4v o = {level_of(w[4 * r]), level_of(w[4 * r + 1]), level_of(w[4 * r + 2]), level_of(w[4 * r + 3])};
-        *reinterpret_cast<i4v *>(lev_ptr + l0 + (size_t)r * lrow) = o;
+        *reinterpret_cast<i4v *>(lev_ptr + l0 + (unsigned)r * (unsigned)lrow) = o;
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const i4v o = *reinterpret_cast<const i4v *>(lev_ptr + l0 + (size_t)r * lrow);
+        const i4v o = *reinterpret_cast<const i4v *>(lev_ptr + l0 + (unsigned)r * (unsigned)lrow);
         w[4 * r] = o[0], w[4 * r + 1] = o[1], w[4 * r + 2] = o[2], w[4 * r + 3] = o[3];
       }
     }
@@ -530,7 +535,7 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const 
     if (ENC) {
 #pragma unroll
       for (int q = 0; q < 4; q++)
-        org4[q] = *reinterpret_cast<const s4v *>(V.org + row_off + tphys(R.qstride, tile_in_block(2 * q + h, r >> 2)));
+        org4[q] = *reinterpret_cast<const s4v *>(V.org + row_off + trel<32>(R.qstride, tile_in_block(2 * q + h, r >> 2)));
     }
     intra_refs<32, 64>(L, lane, true, [&](int dx, int dy) { return (int)R.p[taddr(R, x + dx, y + dy)]; }, luma, avail, P);
     const int *RL = (luma && use_filtered_refs(t.mode, LG)) ? L.fline : L.line;
@@ -539,7 +544,7 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const 
     wave_sync();
     intra_pred_samples<32, 16>(RL, L.me, t.mode, luma, P.bit_depth, dcs, [&](int) { return r; }, [&](int s) { return mrow(s, h); }, pred);
     const bool zlev = V.lev_stride == 0;
-    int *lev0 = V.lev + (zlev ? b0 + r : (size_t)y * V.lev_stride + x + r);
+    int *lev0 = V.lev + (zlev ? b0 + r : __umul24((unsigned)y, (unsigned)V.lev_stride) + x + r);
     const int lstep = zlev ? 32 : V.lev_stride;
     // the prediction is needed again only for the reconstruction: it waits as 8 packed registers
     unsigned pred2[8];
@@ -555,11 +560,11 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const 
 #pragma unroll
       for (int g = 0; g < 16; g++) {
         v[g] = level_of(L.tile[mrow(g, h)][r]);
-        lev0[(size_t)mrow(g, h) * lstep] = v[g];
+        lev0[__umul24((unsigned)mrow(g, h), (unsigned)lstep)] = v[g];
       }
     } else {
 #pragma unroll
-      for (int g = 0; g < 16; g++) v[g] = lev0[(size_t)mrow(g, h) * lstep];
+      for (int g = 0; g < 16; g++) v[g] = lev0[__umul24((unsigned)mrow(g, h), (unsigned)lstep)];
     }
     const int tshift = 15 - P.bit_depth - LG;
     const QuantDev &qd = P.qd[luma ? 0 : 1];
@@ -573,7 +578,7 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const 
       const int p0 = pred2[2 * q] & 0xffff, p1 = pred2[2 * q] >> 16, p2 = pred2[2 * q + 1] & 0xffff, p3 = pred2[2 * q + 1] >> 16;
       s4v o = {(short)clip3(0, mx, p0 + out[4 * q]), (short)clip3(0, mx, p1 + out[4 * q + 1]),
                (short)clip3(0, mx, p2 + out[4 * q + 2]), (short)clip3(0, mx, p3 + out[4 * q + 3])};
-      *reinterpret_cast<s4v *>(R.p + row_off + tphys(R.qstride, tile_in_block(2 * q + h, r >> 2))) = o;
+      *reinterpret_cast<s4v *>(R.p + row_off + trel<32>(R.qstride, tile_in_block(2 * q + h, r >> 2))) = o;
     }
     wave_sync();
   }
