@@ -253,6 +253,27 @@ typedef struct {
 } hmx_pu;
 int hmx_batch_motionCompensation(hmx_ctx *ctx, const hmx_pu *d_pus, int n, const hmx_pic *refs, int n_refs,
                                  const hmx_pic *dst);
+/* One picture's motion compensation in a multi-picture call. */
+typedef struct hmx_mc_job {
+  const hmx_pu *d_pus; /* device */
+  int n_pus;
+  const hmx_pic *refs; /* host array [n_refs]; hmx_pu::ref0/ref1 index it */
+  int n_refs;
+  const hmx_pic *dst;
+} hmx_mc_job;
+/* The batch entry points over SEVERAL pictures in one launch each (grid.y = picture): pictures at the
+ * same position of different intra-period segments are independent, so a random-access
+ * encoder issues one call per GOP position, not one per picture.  The block list (decisions) is shared
+ * by the pictures of a call; planes and levels are arrays of n_pics entries.  d_abs_sum, if not NULL,
+ * holds n_pics * (blocks of the list) sums, picture-major. */
+int hmx_batch_motionCompensation_multi(hmx_ctx *ctx, int n_jobs, const hmx_mc_job *jobs);
+int hmx_batch_residual_transformNxN_multi(hmx_ctx *ctx, const hmx_tu_list *list, int n_pics, const hmx_pic *org,
+                                          const hmx_pic *pred, const hmx_levels *lev, uint32_t *d_abs_sum,
+                                          const hmx_pic_param *pp);
+int hmx_batch_invtransformNxN_multi(hmx_ctx *ctx, const hmx_tu_list *list, int n_pics, const hmx_levels *lev,
+                                    const hmx_pic *pred, const hmx_pic *out, const hmx_pic_param *pp);
+int hmx_pic_extend_border_multi(hmx_ctx *ctx, int n_pics, const hmx_pic *pics, int pic_w, int pic_h, int margin_x,
+                                int margin_y);
 /* TComPicYuv::extendPicBorder (TLibCommon/TComPicYuv.cpp:248-286); margins in luma samples */
 int hmx_pic_extend_border(hmx_ctx *ctx, const hmx_pic *pic, int pic_w, int pic_h, int margin_x, int margin_y);
 /* TComDataCU::clipMv (TLibCommon/TComDataCU.cpp:3505-3517), host helper */

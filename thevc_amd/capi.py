@@ -51,6 +51,10 @@ class Levels(C.Structure):
     _fields_ = [("plane", C.c_void_p * 3), ("stride", C.c_int * 3)]
 
 
+class McJob(C.Structure):  # hmx_mc_job
+    _fields_ = [("d_pus", C.c_void_p), ("n_pus", C.c_int), ("refs", C.POINTER(Pic)), ("n_refs", C.c_int), ("dst", C.POINTER(Pic))]
+
+
 _lib = None
 
 
@@ -126,6 +130,12 @@ def lib():
         L.hmx_frame_intra_decode_multi.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Levels)]
         L.hmx_batch_motionCompensation.argtypes = [vp, vp, ci, C.POINTER(Pic), ci, C.POINTER(Pic)]
         L.hmx_pic_extend_border.argtypes = [vp, C.POINTER(Pic), ci, ci, ci, ci]
+        L.hmx_batch_motionCompensation_multi.argtypes = [vp, ci, C.POINTER(McJob)]
+        L.hmx_batch_residual_transformNxN_multi.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(Levels), vp,
+                                                            C.POINTER(PicParam)]
+        L.hmx_batch_invtransformNxN_multi.argtypes = [vp, vp, ci, C.POINTER(Levels), C.POINTER(Pic), C.POINTER(Pic),
+                                                      C.POINTER(PicParam)]
+        L.hmx_pic_extend_border_multi.argtypes = [vp, ci, C.POINTER(Pic), ci, ci, ci, ci]
         L.hmx_clipMv.argtypes = [C.POINTER(ci), C.POINTER(ci), ci, ci, ci, ci, ci]
         L.hmx_clipMv.restype = None
         _lib = L

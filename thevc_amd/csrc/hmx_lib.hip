@@ -32,9 +32,15 @@ static_assert(64 * sizeof(TuLds<4>) <= HMX_SMEM_BYTES && 32 * sizeof(TuLds<8>) <
 
 enum ListOp { OP_TRANSFORM_NXN, OP_INVTRANSFORM_NXN, OP_XT, OP_XIT, OP_XQUANT, OP_XDEQUANT, OP_PRED };
 
+struct ListPic { // planes of one picture of a multi-picture list call
+  PlanesDev a, b;
+  LevelsDev lev;
+};
 struct ListArgs {
   const DTu *tus;
   int n;
+  const ListPic *pics; // != NULL: grid.y pictures, planes from this table instead of a / b / lev
+  int n_pics, abs_stride;
   PlanesDev a;   // residual in (transform) / prediction in (inverse with recon) / recon (pred)
   PlanesDev b;   // output planes
   LevelsDev lev; // levels / coefficients (Int)
@@ -60,6 +66,13 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
   DTu d = A.tus[active ? i : 0];
   const hmx_tu t = d.t;
   const int pl = t.plane, x = t.x, y = t.y;
+  // blockIdx.y = picture of a multi-picture call (planes from the table); single calls carry theirs inline
+  const ListPic *Q = A.pics ? A.pics + blockIdx.y : nullptr;
+  short *a_p = Q ? Q->a.p[pl] : A.a.p[pl], *b_p = Q ? Q->b.p[pl] : A.b.p[pl];
+  const int a_s = Q ? Q->a.s[pl] : A.a.s[pl], b_s = Q ? Q->b.s[pl] : A.b.s[pl];
+  int *lev_p = Q ? Q->lev.p[pl] : A.lev.p[pl], *lev2_p = A.lev2.p[pl];
+  const int lev_s = Q ? Q->lev.s[pl] : A.lev.s[pl], lev2_s = A.lev2.s[pl];
+  uint32_t *abs_sum = A.abs_sum ? A.abs_sum + (size_t)blockIdx.y * A.abs_stride : nullptr;
   const bool luma = pl == 0, inter = t.flags & HMX_TU_INTER, ts = t.flags & HMX_TU_TRANSFORM_SKIP;
   const bool use_dst = luma && !inter; // uiMode != REG_DCT, only consulted for N == 4
   const int scan_idx = coef_scan_idx(N, luma, !inter, t.mode);
@@ -67,10 +80,10 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
 
   if constexpr (OP == OP_TRANSFORM_NXN || OP == OP_XT) {
     if (active) {
-      load_row16<N>(A.a.p[pl] + (size_t)(y + gl) * A.a.s[pl] + x, row);
+      load_row16<N>(a_p + (size_t)(y + gl) * a_s + x, row);
       if (A.have_pred) { // residual = original - prediction (TComYuv::subtract, TComYuv.cpp:461) fused in
         int pr[N];
-        load_row16<N>(A.b.p[pl] + (size_t)(y + gl) * A.b.s[pl] + x, pr);
+        load_row16<N>(b_p + (size_t)(y + gl) * b_s + x, pr);
 #pragma unroll
         for (int k = 0; k < N; k++) row[k] = wrap16(row[k] - pr[k]);
       }
@@ -82,24 +95,24 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
 #pragma unroll
         for (int k = 0; k < N; k++) row[k] = level_of(row[k]);
       }
-      store_row32<N>(A.lev.p[pl] + (size_t)(y + gl) * A.lev.s[pl] + x, row);
-      if (OP == OP_TRANSFORM_NXN && gl == 0 && A.abs_sum) A.abs_sum[d.idx] = (uint32_t)sum;
+      store_row32<N>(lev_p + (size_t)(y + gl) * lev_s + x, row);
+      if (OP == OP_TRANSFORM_NXN && gl == 0 && abs_sum) abs_sum[d.idx] = (uint32_t)sum;
     }
   } else if constexpr (OP == OP_XQUANT) {
     // Int coefficients in lev -> levels in lev2 (the quantiser half of transformNxN on its own)
-    if (active) load_row32<N>(A.lev.p[pl] + (size_t)(y + gl) * A.lev.s[pl] + x, row);
+    if (active) load_row32<N>(lev_p + (size_t)(y + gl) * lev_s + x, row);
     int sum = quant_sbh_block<N, N, N, true>(
         L, gl, active, row, [&](int) { return gl; }, [&](int k) { return k; }, luma, scan_idx, A.P);
     if (active) {
       load_row32<N>(&L.tile[gl][0], row);
 #pragma unroll
       for (int k = 0; k < N; k++) row[k] = level_of(row[k]);
-      store_row32<N>(A.lev2.p[pl] + (size_t)(y + gl) * A.lev2.s[pl] + x, row);
-      if (gl == 0 && A.abs_sum) A.abs_sum[d.idx] = (uint32_t)sum;
+      store_row32<N>(lev2_p + (size_t)(y + gl) * lev2_s + x, row);
+      if (gl == 0 && abs_sum) abs_sum[d.idx] = (uint32_t)sum;
     }
   } else if constexpr (OP == OP_INVTRANSFORM_NXN || OP == OP_XIT) {
     if (active) {
-      load_row32<N>(A.lev.p[pl] + (size_t)(y + gl) * A.lev.s[pl] + x, row);
+      load_row32<N>(lev_p + (size_t)(y + gl) * lev_s + x, row);
       if (OP == OP_INVTRANSFORM_NXN) { // the tile holds packed words: xDeQuant's input clip happens here
 #pragma unroll
         for (int k = 0; k < N; k++) row[k] = clip3(-32768, 32767, row[k]) & 0xffff;
@@ -111,40 +124,40 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
     if (active) {
       if (A.have_pred) {
         int pr[N];
-        load_row16<N>(A.a.p[pl] + (size_t)(y + gl) * A.a.s[pl] + x, pr);
+        load_row16<N>(a_p + (size_t)(y + gl) * a_s + x, pr);
         const int mx = (1 << A.P.bit_depth) - 1;
 #pragma unroll
         for (int k = 0; k < N; k++) row[k] = clip3(0, mx, pr[k] + row[k]);
       }
-      store_row16<N>(A.b.p[pl] + (size_t)(y + gl) * A.b.s[pl] + x, row);
+      store_row16<N>(b_p + (size_t)(y + gl) * b_s + x, row);
     }
   } else if constexpr (OP == OP_XDEQUANT) {
     constexpr int LG = Log2<N>::v;
     const int tshift = 15 - A.P.bit_depth - LG, dshift = 6 - tshift, dadd = 1 << (dshift - 1);
     const QuantDev &qd = A.P.qd[luma ? 0 : 1];
     if (active) {
-      load_row32<N>(A.lev.p[pl] + (size_t)(y + gl) * A.lev.s[pl] + x, row);
+      load_row32<N>(lev_p + (size_t)(y + gl) * lev_s + x, row);
 #pragma unroll
       for (int k = 0; k < N; k++) {
         int l = clip3(-32768, 32767, row[k]);
         row[k] = clip3(-32768, 32767, (int)((unsigned)l * (unsigned)qd.iq_scale + (unsigned)dadd) >> dshift);
       }
-      store_row32<N>(A.lev2.p[pl] + (size_t)(y + gl) * A.lev2.s[pl] + x, row);
+      store_row32<N>(lev2_p + (size_t)(y + gl) * lev2_s + x, row);
     }
   } else { // OP_PRED
     const int sh = luma ? 0 : 1;
     const unsigned long long avail = active ? intra_avail_mask(x << sh, y << sh, N << sh, A.P) : 0;
-    const short *rec0 = A.a.p[pl] + (size_t)y * A.a.s[pl] + x;
-    const int rst = A.a.s[pl];
+    const short *rec0 = a_p + (size_t)y * a_s + x;
+    const int rst = a_s;
     intra_refs<N, N>(L, gl, active, [&](int dx, int dy) { return (int)rec0[(ptrdiff_t)dy * rst + dx]; }, luma, avail, A.P);
     if (active) {
       if (A.n_modes <= 0) {
         intra_pred_block<N>(L, gl, t.mode, luma, A.P, row);
-        store_row16<N>(A.b.p[pl] + (size_t)(y + gl) * A.b.s[pl] + x, row);
+        store_row16<N>(b_p + (size_t)(y + gl) * b_s + x, row);
       } else {
         for (int m = 0; m < A.n_modes; m++) {
           intra_pred_block<N>(L, gl, A.modes[m], luma, A.P, row);
-          store_row16<N>(A.b.p[pl] + m * A.mode_elems[pl] + (size_t)(y + gl) * A.b.s[pl] + x, row);
+          store_row16<N>(b_p + m * A.mode_elems[pl] + (size_t)(y + gl) * b_s + x, row);
         }
       }
     }
@@ -768,7 +781,10 @@ struct hmx_ctx {
   hipStream_t side[kMaxSide] = {};
   hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {};
   int n_side = 0;
-  PlanesDev *d_refs = nullptr; // [16]
+  // Argument arena: small per-call tables (picture planes, job lists) travel through a pinned host ring
+  // and a device ring by asynchronous copies; the stream is synchronised only when the ring wraps.
+  char *arena_h = nullptr, *arena_d = nullptr;
+  size_t arena_cap = 0, arena_head = 0;
 };
 
 struct hmx_intra_plan {
@@ -890,7 +906,8 @@ extern "C" void hmx_destroy(hmx_ctx *c) {
   hipFree(c->pool_org);
   hipFree(c->pool_rec);
   hipFree(c->d_jobs);
-  hipFree(c->d_refs);
+  if (c->arena_h) hipHostFree(c->arena_h);
+  hipFree(c->arena_d);
   for (int g = 0; g < c->n_side; g++) {
     hipStreamDestroy(c->side[g]);
     hipEventDestroy(c->ev_join[g]);
@@ -954,11 +971,12 @@ template <int OP>
 static int launch_list(hmx_ctx *c, int log2n, const ListArgs &A) {
   if (A.n <= 0) return HMX_OK;
   dim3 blk(256);
+  const unsigned ny = A.pics ? (unsigned)A.n_pics : 1u;
   switch (log2n) {
-  case 2: hipLaunchKernelGGL((k_list<4, OP>), dim3((A.n + Slots<4>::v - 1) / Slots<4>::v), blk, 0, c->stream, A); break;
-  case 3: hipLaunchKernelGGL((k_list<8, OP>), dim3((A.n + Slots<8>::v - 1) / Slots<8>::v), blk, 0, c->stream, A); break;
-  case 4: hipLaunchKernelGGL((k_list<16, OP>), dim3((A.n + Slots<16>::v - 1) / Slots<16>::v), blk, 0, c->stream, A); break;
-  case 5: hipLaunchKernelGGL((k_list<32, OP>), dim3((A.n + Slots<32>::v - 1) / Slots<32>::v), blk, 0, c->stream, A); break;
+  case 2: hipLaunchKernelGGL((k_list<4, OP>), dim3((A.n + Slots<4>::v - 1) / Slots<4>::v, ny), blk, 0, c->stream, A); break;
+  case 3: hipLaunchKernelGGL((k_list<8, OP>), dim3((A.n + Slots<8>::v - 1) / Slots<8>::v, ny), blk, 0, c->stream, A); break;
+  case 4: hipLaunchKernelGGL((k_list<16, OP>), dim3((A.n + Slots<16>::v - 1) / Slots<16>::v, ny), blk, 0, c->stream, A); break;
+  case 5: hipLaunchKernelGGL((k_list<32, OP>), dim3((A.n + Slots<32>::v - 1) / Slots<32>::v, ny), blk, 0, c->stream, A); break;
   default: return fail(c, HMX_ERR_ARG, "unsupported block size");
   }
   HIPCHK(c, hipGetLastError());
@@ -1035,6 +1053,28 @@ static LevelsDev to_dev(const hmx_levels *p) {
   return d;
 }
 
+// device copy of a small host table, valid for the kernels issued after it on the context's stream
+static void *arena_push(hmx_ctx *c, const void *src, size_t bytes) {
+  const size_t kCap = 8u << 20;
+  if (!c->arena_h) {
+    if (hipHostMalloc((void **)&c->arena_h, kCap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (hipMalloc((void **)&c->arena_d, kCap) != hipSuccess) return nullptr;
+    c->arena_cap = kCap;
+  }
+  const size_t raw = bytes;
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bytes > c->arena_cap) return nullptr;
+  if (c->arena_head + bytes > c->arena_cap) { // wrap: everything issued so far has consumed its tables after this
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return nullptr;
+    c->arena_head = 0;
+  }
+  char *h = c->arena_h + c->arena_head, *d = c->arena_d + c->arena_head;
+  memcpy(h, src, raw);
+  if (hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return nullptr;
+  c->arena_head += bytes;
+  return d;
+}
+
 static int run_list(hmx_ctx *c, int op, const hmx_tu_list *l, ListArgs A) {
   for (int s = 0; s < 4; s++) {
     if (!l->cnt[s]) continue;
@@ -1080,6 +1120,40 @@ extern "C" int hmx_batch_invtransformNxN(hmx_ctx *c, const hmx_tu_list *l, const
   A.lev = to_dev(lev);
   A.P = make_picdev(c, pp);
   return run_list(c, OP_INVTRANSFORM_NXN, l, A);
+}
+
+static int run_list_multi(hmx_ctx *c, int op, const hmx_tu_list *l, int n_pics, const hmx_pic *a, const hmx_pic *b,
+                          const hmx_levels *lev, uint32_t *d_abs_sum, const hmx_pic_param *pp, bool have_pred) {
+  std::vector<ListPic> t(n_pics);
+  for (int i = 0; i < n_pics; i++) {
+    t[i].a = to_dev(a ? &a[i] : nullptr);
+    t[i].b = to_dev(b ? &b[i] : nullptr);
+    t[i].lev = to_dev(&lev[i]);
+  }
+  ListArgs A{};
+  A.pics = static_cast<const ListPic *>(arena_push(c, t.data(), sizeof(ListPic) * n_pics));
+  if (!A.pics) return fail(c, HMX_ERR_NOMEM, "argument arena");
+  A.n_pics = n_pics;
+  A.abs_sum = d_abs_sum;
+  A.abs_stride = l->n;
+  A.have_pred = have_pred;
+  A.P = make_picdev(c, pp);
+  return run_list(c, op, l, A);
+}
+
+extern "C" int hmx_batch_residual_transformNxN_multi(hmx_ctx *c, const hmx_tu_list *l, int n_pics, const hmx_pic *org,
+                                                     const hmx_pic *pred, const hmx_levels *lev, uint32_t *d_abs_sum,
+                                                     const hmx_pic_param *pp) {
+  if (!c || !l || !org || !pred || !lev || !pp || n_pics <= 0 || n_pics > 65535)
+    return fail(c, HMX_ERR_ARG, "hmx_batch_residual_transformNxN_multi: bad argument");
+  return run_list_multi(c, OP_TRANSFORM_NXN, l, n_pics, org, pred, lev, d_abs_sum, pp, true);
+}
+
+extern "C" int hmx_batch_invtransformNxN_multi(hmx_ctx *c, const hmx_tu_list *l, int n_pics, const hmx_levels *lev,
+                                               const hmx_pic *pred, const hmx_pic *out, const hmx_pic_param *pp) {
+  if (!c || !l || !out || !lev || !pp || n_pics <= 0 || n_pics > 65535)
+    return fail(c, HMX_ERR_ARG, "hmx_batch_invtransformNxN_multi: bad argument");
+  return run_list_multi(c, OP_INVTRANSFORM_NXN, l, n_pics, pred, out, lev, nullptr, pp, pred != nullptr);
 }
 
 extern "C" int hmx_batch_predIntra(hmx_ctx *c, const hmx_tu_list *l, const hmx_pic *rec, const hmx_pic *pred,
@@ -2088,11 +2162,14 @@ extern "C" int hmx_addAvg(hmx_ctx *c, const hmx_pel *s0, int s0s, const hmx_pel 
 }
 
 // ---- motionCompensation over a PU list: one workgroup per (PU, plane) ----
-struct McArgs {
+struct McJob { // one picture: its prediction units, its reference pictures, its destination planes
   const hmx_pu *pus;
-  int n;
-  const PlanesDev *refs; // [n_refs]
+  int n, ref_off; // refs of this job start at McArgs::refs[ref_off]
   PlanesDev dst;
+};
+struct McArgs {
+  const McJob *jobs;     // [grid.y]
+  const PlanesDev *refs; // all jobs' reference tables, back to back
   int B;
 };
 
@@ -2131,19 +2208,21 @@ __device__ __forceinline__ void mc_one_list(const short *ref, int rs, int mvx, i
 __global__ __launch_bounds__(256) void k_mc(McArgs A) {
   __shared__ short tmp[(64 + 7) * 64];
   __shared__ short pb[2][64 * 64];
+  const McJob J = A.jobs[blockIdx.y];
   const int pu_i = blockIdx.x / 3, pl = blockIdx.x % 3;
-  const hmx_pu u = A.pus[pu_i];
+  if (pu_i >= J.n) return; // jobs of one call may differ in length
+  const hmx_pu u = J.pus[pu_i];
   const int c = pl ? 1 : 0, x = u.x >> c, y = u.y >> c, w = u.w >> c, h = u.h >> c;
   const bool bi = u.ref0 != 255 && u.ref1 != 255;
-  short *d = A.dst.p[pl] + (size_t)y * A.dst.s[pl] + x;
+  short *d = J.dst.p[pl] + (size_t)y * J.dst.s[pl] + x;
   for (int l = 0; l < 2; l++) {
     const int ri = l ? u.ref1 : u.ref0;
     if (ri == 255) continue; // uniform over the workgroup
-    const PlanesDev &R = A.refs[ri];
+    const PlanesDev &R = A.refs[J.ref_off + ri];
     const short *ref = R.p[pl] + (ptrdiff_t)y * R.s[pl] + x;
     const int mvx = l ? u.mv1x : u.mv0x, mvy = l ? u.mv1y : u.mv0y;
     short *out = bi ? pb[l] : d;
-    const int os = bi ? 64 : A.dst.s[pl];
+    const int os = bi ? 64 : J.dst.s[pl];
     if (pl == 0)
       mc_one_list<8>(ref, R.s[pl], mvx, mvy, w, h, bi, A.B, tmp, out, os);
     else
@@ -2153,59 +2232,80 @@ __global__ __launch_bounds__(256) void k_mc(McArgs A) {
   if (bi)
     for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
       int r = i / w, cc = i % w;
-      d[(size_t)r * A.dst.s[pl] + cc] = (short)add_avg(pb[0][r * 64 + cc], pb[1][r * 64 + cc], A.B);
+      d[(size_t)r * J.dst.s[pl] + cc] = (short)add_avg(pb[0][r * 64 + cc], pb[1][r * 64 + cc], A.B);
     }
+}
+
+extern "C" int hmx_batch_motionCompensation_multi(hmx_ctx *c, int n_jobs, const hmx_mc_job *jobs) {
+  if (!c || !jobs || n_jobs <= 0 || n_jobs > 65535) return fail(c, HMX_ERR_ARG, "hmx_batch_motionCompensation_multi: bad argument");
+  std::vector<McJob> hj(n_jobs);
+  std::vector<PlanesDev> hr;
+  int max_n = 0;
+  for (int i = 0; i < n_jobs; i++) {
+    const hmx_mc_job &j = jobs[i];
+    if (j.n_pus < 0 || (j.n_pus > 0 && !j.d_pus) || !j.refs || j.n_refs <= 0 || j.n_refs > 16 || !j.dst)
+      return fail(c, HMX_ERR_ARG, "hmx_batch_motionCompensation_multi: bad job");
+    hj[i] = McJob{j.d_pus, j.n_pus, (int)hr.size(), to_dev(j.dst)};
+    for (int k = 0; k < j.n_refs; k++) hr.push_back(to_dev(&j.refs[k]));
+    max_n = std::max(max_n, j.n_pus);
+  }
+  if (!max_n) return HMX_OK;
+  McArgs A;
+  A.jobs = static_cast<const McJob *>(arena_push(c, hj.data(), sizeof(McJob) * hj.size()));
+  A.refs = static_cast<const PlanesDev *>(arena_push(c, hr.data(), sizeof(PlanesDev) * hr.size()));
+  if (!A.jobs || !A.refs) return fail(c, HMX_ERR_NOMEM, "argument arena");
+  A.B = c->cfg.bit_depth;
+  hipLaunchKernelGGL(k_mc, dim3((unsigned)max_n * 3, (unsigned)n_jobs), dim3(256), 0, c->stream, A);
+  HIPCHK(c, hipGetLastError());
+  return HMX_OK;
 }
 
 extern "C" int hmx_batch_motionCompensation(hmx_ctx *c, const hmx_pu *d_pus, int n, const hmx_pic *refs, int n_refs,
                                             const hmx_pic *dst) {
   if (!c || !d_pus || !refs || !dst || n_refs <= 0 || n_refs > 16) return fail(c, HMX_ERR_ARG, "hmx_batch_motionCompensation: bad argument");
   if (n <= 0) return HMX_OK;
-  if (!c->d_refs && hipMalloc((void **)&c->d_refs, sizeof(PlanesDev) * 16) != hipSuccess)
-    return fail(c, HMX_ERR_NOMEM, "hipMalloc reference table");
-  PlanesDev hr[16];
-  for (int i = 0; i < n_refs; i++) hr[i] = to_dev(&refs[i]);
-  HIPCHK(c, hipMemcpyAsync(c->d_refs, hr, sizeof(PlanesDev) * n_refs, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  McArgs A;
-  A.pus = d_pus;
-  A.n = n;
-  A.refs = c->d_refs;
-  A.dst = to_dev(dst);
-  A.B = c->cfg.bit_depth;
-  hipLaunchKernelGGL(k_mc, dim3((unsigned)n * 3), dim3(256), 0, c->stream, A);
-  HIPCHK(c, hipGetLastError());
-  return HMX_OK;
+  const hmx_mc_job j{d_pus, n, refs, n_refs, dst};
+  return hmx_batch_motionCompensation_multi(c, 1, &j);
 }
 
-// ---- extendPicBorder: left/right first, then whole extended rows up and down ----
-__global__ void k_border_lr(short *org, int stride, int w, int h, int mx) {
+// ---- extendPicBorder (TComPicYuv.cpp:248-286): every margin sample is the nearest picture sample, so
+// one launch covers all margins of all planes of all pictures (no left/right-then-up/down ordering) ----
+__global__ __launch_bounds__(256) void k_border(const PlanesDev *pics, int pic_w, int pic_h, int mx, int my) {
+  const int pl = blockIdx.y % 3;
+  const PlanesDev &D = pics[blockIdx.y / 3];
+  const int sh = pl ? 1 : 0, w = pic_w >> sh, h = pic_h >> sh, bx = mx >> sh, by = my >> sh;
+  const int ww = w + 2 * bx, band = ww * by, side = h * bx;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= h * mx) return;
-  int y = i / mx, k = i % mx + 1;
-  short *row = org + (size_t)y * stride;
-  row[-k] = row[0];
-  row[w - 1 + k] = row[w - 1];
+  int x, y;
+  if (i < band) { // above
+    y = -1 - i / ww, x = i % ww - bx;
+  } else if ((i -= band) < band) { // below
+    y = h + i / ww, x = i % ww - bx;
+  } else if ((i -= band) < side) { // left
+    y = i / bx, x = -1 - i % bx;
+  } else if ((i -= side) < side) { // right
+    y = i / bx, x = w + i % bx;
+  } else
+    return;
+  short *p = D.p[pl];
+  const int s = D.s[pl];
+  p[(ptrdiff_t)y * s + x] = p[(ptrdiff_t)min(max(y, 0), h - 1) * s + min(max(x, 0), w - 1)];
 }
-__global__ void k_border_tb(short *org, int stride, int w, int h, int mx, int my) {
-  const int ww = w + 2 * mx;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ww * my) return;
-  int k = i / ww + 1, x = i % ww - mx;
-  org[-(ptrdiff_t)k * stride + x] = org[x];
-  org[(ptrdiff_t)(h - 1 + k) * stride + x] = org[(ptrdiff_t)(h - 1) * stride + x];
-}
-extern "C" int hmx_pic_extend_border(hmx_ctx *c, const hmx_pic *pic, int pic_w, int pic_h, int mx, int my) {
-  if (!c || !pic || mx < 0 || my < 0) return fail(c, HMX_ERR_ARG, "hmx_pic_extend_border: bad argument");
-  for (int p = 0; p < 3; p++) {
-    const int sh = p ? 1 : 0, w = pic_w >> sh, h = pic_h >> sh, pmx = mx >> sh, pmy = my >> sh;
-    if (pmx) hipLaunchKernelGGL(k_border_lr, dim3((h * pmx + 255) / 256), dim3(256), 0, c->stream, pic->plane[p], pic->stride[p], w, h, pmx);
-    if (pmy)
-      hipLaunchKernelGGL(k_border_tb, dim3(((w + 2 * pmx) * pmy + 255) / 256), dim3(256), 0, c->stream, pic->plane[p],
-                         pic->stride[p], w, h, pmx, pmy);
-  }
+extern "C" int hmx_pic_extend_border_multi(hmx_ctx *c, int n_pics, const hmx_pic *pics, int pic_w, int pic_h, int mx, int my) {
+  if (!c || !pics || n_pics <= 0 || n_pics > 21845 || mx < 0 || my < 0) return fail(c, HMX_ERR_ARG, "hmx_pic_extend_border_multi: bad argument");
+  if (!mx && !my) return HMX_OK;
+  std::vector<PlanesDev> t(n_pics);
+  for (int i = 0; i < n_pics; i++) t[i] = to_dev(&pics[i]);
+  const PlanesDev *d = static_cast<const PlanesDev *>(arena_push(c, t.data(), sizeof(PlanesDev) * n_pics));
+  if (!d) return fail(c, HMX_ERR_NOMEM, "argument arena");
+  const long long total = 2LL * (pic_w + 2 * mx) * my + 2LL * pic_h * mx; // luma margin samples (chroma has fewer)
+  hipLaunchKernelGGL(k_border, dim3((unsigned)((total + 255) / 256), (unsigned)n_pics * 3), dim3(256), 0, c->stream, d, pic_w, pic_h, mx, my);
   HIPCHK(c, hipGetLastError());
   return HMX_OK;
+}
+extern "C" int hmx_pic_extend_border(hmx_ctx *c, const hmx_pic *pic, int pic_w, int pic_h, int mx, int my) {
+  if (!c || !pic) return fail(c, HMX_ERR_ARG, "hmx_pic_extend_border: bad argument");
+  return hmx_pic_extend_border_multi(c, 1, pic, pic_w, pic_h, mx, my);
 }
 
 extern "C" void hmx_clipMv(int *mvx, int *mvy, int cu_x, int cu_y, int pic_w, int pic_h, int ctu) {

@@ -11,9 +11,10 @@ k (ncclSend/ncclRecv through torch.distributed = RCCL over xGMI; the all-intra p
 Per picture the hot path is:
   I pictures   whole-picture all-intra chain (hmx_frame_intra_encode)
   B/P pictures motion compensation of a PU list against resident references with margins
-               (hmx_batch_motionCompensation), residual + transformNxN (hmx_batch_residual_transformNxN),
-               invtransformNxN + reconstruction (hmx_batch_invtransformNxN), border extension
-               (hmx_pic_extend_border) when the picture is referenced later.
+               (hmx_batch_motionCompensation_multi), residual + transformNxN
+               (hmx_batch_residual_transformNxN_multi), invtransformNxN + reconstruction
+               (hmx_batch_invtransformNxN_multi), border extension (hmx_pic_extend_border_multi);
+               the pictures at one GOP position of all segments a rank owns share each call.
 Decisions (block structure, modes, PUs, MVs) are synthetic and seeded; this module is the bench/test
 harness' stand-in for TEncGOP's picture loop, not part of the product library."""
 import ctypes as C
@@ -146,8 +147,10 @@ class RAPipeline:
         self.my_i = sorted({k for k in range(wl.n_segments + 1) if k % world == rank})
         self.rec = {}   # poc -> TorchPicture (reconstruction with margins)
         self.org = {}   # poc -> TorchPicture (original, no margins needed but same class)
-        self.pred = TorchPicture(torch, self.dev, w, h, 0)
-        self.lev = capi.DevPicture(ctx, w, h, dtype=np.int32)
+        # one prediction picture and one level picture per owned segment: pictures at the same GOP position
+        # of different segments are independent and go through every stage in ONE call
+        self.pred = [TorchPicture(torch, self.dev, w, h, 0) for _ in self.my_segments]
+        self.lev = [capi.DevPicture(ctx, w, h, dtype=np.int32) for _ in self.my_segments]
         self.lev_i = None
 
     def _pic(self, store, poc):
@@ -181,25 +184,40 @@ class RAPipeline:
             rec = (capi.Pic * n)(*[self.rec[p].as_pic() for p in ipocs])
             lev = (capi.Levels * n)(*[l.as_pic() for l in self.lev_i])
             ctx._chk(L.hmx_frame_intra_encode(ctx.h, self.plan, n, org, rec, lev))
-            for p in ipocs:
-                ctx._chk(L.hmx_pic_extend_border(ctx.h, C.byref(self.rec[p].as_pic()), w, h, MARGIN, MARGIN))
+            ctx._chk(L.hmx_pic_extend_border_multi(ctx.h, n, rec, w, h, MARGIN, MARGIN))
         # phase 2: boundary I pictures travel to the owner of the previous segment (RCCL send/recv)
         if self.world > 1:
             run_exchange(self.dist, self.rank, self.world, wl.n_segments, lambda ki: self.rec[ki * wl.ip].t)
-        # phase 3: inter pictures, segment by segment in coding order
+        # phase 3: inter pictures in coding order; position j of every owned segment in one call per stage
         pixels = n * w * h
-        for k in self.my_segments:
-            for (poc, r0, r1, li) in wl.segment_jobs(k):
+        S = len(self.my_segments)
+        if not S:
+            return pixels
+        jobs = [wl.segment_jobs(k) for k in self.my_segments]
+        for j in range(len(jobs[0])):
+            groups = {}
+            for si in range(S):
+                poc, r0, r1, li = jobs[si][j]
+                groups.setdefault((li, r1 is None), []).append(si)
+            for (li, is_p), members in groups.items():
                 d = self.lists[li]
-                refs = [self.rec[r0]] + ([self.rec[r1]] if r1 is not None else [])
-                ref_arr = (capi.Pic * len(refs))(*[r.as_pic() for r in refs])
-                pus, npu = (d["pus_b"], d["n_b"]) if r1 is not None else (d["pus_p"], d["n_p"])
-                pred, rec, org = self.pred.as_pic(), self.rec[poc].as_pic(), self.org[poc].as_pic()
-                ctx._chk(L.hmx_batch_motionCompensation(ctx.h, pus.ptr, npu, ref_arr, len(refs), C.byref(pred)))
-                ctx._chk(L.hmx_batch_residual_transformNxN(ctx.h, d["tu"], C.byref(org), C.byref(pred), C.byref(self.lev.as_pic()),
-                                                           None, C.byref(self.pp_b)))
-                ctx._chk(L.hmx_batch_invtransformNxN(ctx.h, d["tu"], C.byref(self.lev.as_pic()), C.byref(pred), C.byref(rec),
-                                                     C.byref(self.pp_b)))
-                ctx._chk(L.hmx_pic_extend_border(ctx.h, C.byref(rec), w, h, MARGIN, MARGIN))
-                pixels += w * h
+                m = len(members)
+                keep = []  # ctypes arrays referenced by pointer from the job table
+                mc = (capi.McJob * m)()
+                pred, rec, org, lev = (capi.Pic * m)(), (capi.Pic * m)(), (capi.Pic * m)(), (capi.Levels * m)()
+                for q, si in enumerate(members):
+                    poc, r0, r1, _ = jobs[si][j]
+                    refs = [self.rec[r0]] + ([self.rec[r1]] if r1 is not None else [])
+                    ref_arr = (capi.Pic * len(refs))(*[t.as_pic() for t in refs])
+                    pred[q], rec[q], org[q] = self.pred[si].as_pic(), self.rec[poc].as_pic(), self.org[poc].as_pic()
+                    lev[q] = self.lev[si].as_pic()
+                    keep.append(ref_arr)
+                    pus, npu = (d["pus_p"], d["n_p"]) if is_p else (d["pus_b"], d["n_b"])
+                    mc[q].d_pus, mc[q].n_pus, mc[q].refs, mc[q].n_refs = pus.ptr, npu, ref_arr, len(refs)
+                    mc[q].dst = C.pointer(pred[q])
+                ctx._chk(L.hmx_batch_motionCompensation_multi(ctx.h, m, mc))
+                ctx._chk(L.hmx_batch_residual_transformNxN_multi(ctx.h, d["tu"], m, org, pred, lev, None, C.byref(self.pp_b)))
+                ctx._chk(L.hmx_batch_invtransformNxN_multi(ctx.h, d["tu"], m, lev, pred, rec, C.byref(self.pp_b)))
+                ctx._chk(L.hmx_pic_extend_border_multi(ctx.h, m, rec, w, h, MARGIN, MARGIN))
+                pixels += m * w * h
         return pixels
