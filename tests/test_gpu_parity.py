@@ -226,6 +226,55 @@ def test_frame_intra_encode_decode(ctx, pic, tiling, schedule, monkeypatch):
         d.free()
 
 
+@pytest.mark.parametrize("B,qp,ctu,sign_hide,cqo", [(12, 51, 64, 1, 0), (8, 0, 64, 1, 0), (10, 51, 32, 0, 0), (8, 22, 16, 1, 3),
+                                                   (12, 4, 64, 0, -5), (10, 37, 32, 1, 12), (8, 51, 64, 1, -12)])
+def test_frame_intra_parameter_corners(B, qp, ctu, sign_hide, cqo):
+    """The corners of the parameter space the reference allows: 12-bit samples, QP 0 and 51, chroma QP offsets
+    through the chroma table's clip, sign hiding off, CTU 32 and 16 (availability and Z-order geometry change),
+    both level layouts, the across-pictures and the per-picture level kernels."""
+    ctx = capi.Context(bit_depth=B, ctu_size=ctu)
+    try:
+        L = capi.lib()
+        w, h, n_pics = 152, 88, 5
+        tus = workload.make_tus(31 + qp, w, h, "mix", ctu=ctu)
+        pp = capi.PicParam(w, h, qp, cqo, capi.I_SLICE, sign_hide)
+        plan = ctx.intra_plan(tus, pp)
+        orgs = [workload.make_planes(200 + i, w, h, B, "texture" if i % 2 else "noise") for i in range(n_pics)]
+        O = ol.oracle()
+        refs = []
+        for o in orgs:
+            cfg = ol.FrameCfg(w, h, ctu, B, qp, cqo, sign_hide)
+            rec = [np.zeros_like(p) for p in o]
+            lev = [np.zeros(p.shape, np.int32) for p in o]
+            P3, I3 = C.c_void_p * 3, C.c_int * 3
+            st = I3(w, w // 2, w // 2)
+            t = np.ascontiguousarray(tus, ol.TU_DTYPE)
+            O.hmo_intra_frame_encode(C.byref(cfg), t.ctypes.data, len(t), P3(*[p.ctypes.data for p in o]), st,
+                                     P3(*[p.ctypes.data for p in rec]), st, P3(*[p.ctypes.data for p in lev]))
+            refs.append((rec, lev))
+        A = lambda lst, T: (T * n_pics)(*[x.as_pic() for x in lst])
+        for multi in (False, True):  # one plan for the call / one plan pointer per picture
+            d_org = [capi.DevPicture(ctx, w, h).upload(o) for o in orgs]
+            d_rec = [capi.DevPicture(ctx, w, h).zero() for _ in range(n_pics)]
+            d_lev = [capi.DevPicture(ctx, w, h, dtype=np.int32).zero() for _ in range(n_pics)]
+            if multi:
+                plans = (C.c_void_p * n_pics)(*[plan.value] * n_pics)
+                ctx._chk(L.hmx_frame_intra_encode_multi(ctx.h, plans, n_pics, A(d_org, capi.Pic), A(d_rec, capi.Pic), A(d_lev, capi.Levels)))
+            else:
+                ctx._chk(L.hmx_frame_intra_encode(ctx.h, plan, n_pics, A(d_org, capi.Pic), A(d_rec, capi.Pic), A(d_lev, capi.Levels)))
+            ctx.sync()
+            for i in range(n_pics):
+                rec, lev = d_rec[i].download(), d_lev[i].download()
+                for p in range(3):
+                    assert np.array_equal(lev[p], refs[i][1][p]), ("levels", multi, i, p)
+                    assert np.array_equal(rec[p], refs[i][0][p]), ("recon", multi, i, p)
+            for d in d_org + d_rec + d_lev:
+                d.free()
+        L.hmx_intra_plan_destroy(ctx.h, plan)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("across", ["1", "0"])
 @pytest.mark.parametrize("pic,n_pics", [((64, 64), 70), ((136, 72), 9)])
 def test_frame_intra_many_pictures_one_plan(ctx, pic, n_pics, across, monkeypatch):
