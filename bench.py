@@ -233,11 +233,12 @@ def main():
         px_step = w * h_c * F
         nb, nl, nd = C.c_int(), C.c_int(), C.c_int()
         L.hmx_intra_plan_info(plan, C.byref(nb), C.byref(nl), C.byref(nd))
-        level_sched = bool(L.hmx_intra_schedule_for(ctx.h, F))
-        n_launch = nl.value if level_sched else nd.value  # launches of the dominant kernel per step
-        # one plan for the whole batch -> the level schedule runs across pictures (hmx_lib.hip, frame_intra)
-        across = level_sched and os.environ.get("HMX_INTRA_ACROSS", "1")[0] != "0" and "HMX_INTRA_STREAMS" not in os.environ
-        kernel = ("k_intra_level_across<true>" if across else "k_intra_level<true>") if level_sched else "k_intra_wave<true>"
+        sched, groups = C.c_int(), C.c_int()
+        L.hmx_last_call_shape(ctx.h, C.byref(sched), C.byref(groups))  # how the library issued the timed calls
+        level_sched = sched.value > 0
+        n_levels = nl.value if level_sched else nd.value   # dependent steps of the chain
+        n_launch = n_levels * groups.value                 # launches of the dominant kernel per step
+        kernel = ["k_intra_wave<true>", "k_intra_level<true>", "k_intra_level_across<true>"][sched.value]
         traffic = None
         tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tj) and args.workload == "ai2160p10" and args.tiling == "mix" and level_sched:
@@ -264,9 +265,13 @@ def main():
                        "pictures_per_gpu": F, "width": w, "height": h_c, "bit_depth": B, "qp": qp, "tiling": str(args.tiling)},
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": kernel, "launches_per_step": n_launch,
+                         # `achieved` is the device-level rate of the chain: the library runs `concurrent_launches`
+                         # picture groups on separate streams, so that many launches of the kernel share the GPU
+                         # at any time and each lasts about chain time / dependency levels
+                         "kernel": kernel, "launches_per_step": n_launch, "concurrent_launches": groups.value,
                          "algorithmic_bytes_per_launch": round(bytes_step / n_launch),
-                         "avg_launch_us": round(tb.value * 1e3 / n_launch, 2),
+                         "avg_launch_us": round(tb.value * 1e3 / n_levels, 2),
+                         "achieved_per_launch": round(bytes_step / n_launch / (tb.value * 1e-3 / n_levels) / 1e9, 2),
                          "step_ms_events": round(kernel_ms / args.steps, 3),
                          "layout_conversion_ms": [round(ta.value, 3), round(tc.value, 3)]},
         }

@@ -224,6 +224,10 @@ int hmx_intra_plan_info(const hmx_intra_plan *plan, int *n_blocks, int *n_levels
 /* One dependency level of the level schedule: its block counts by transform size (4, 8, 16, 32) and
  * the wavefronts one picture contributes to that level's launch. */
 int hmx_intra_plan_level(const hmx_intra_plan *plan, int level, uint32_t counts[4], uint32_t *n_waves);
+/* How the LAST whole-picture call was issued: schedule 0 = CTU-diagonal waves (k_intra_wave), 1 = levels,
+ * one picture per wave (k_intra_level), 2 = levels across pictures (k_intra_level_across); stream_groups =
+ * picture groups whose launches ran concurrently on separate streams (launches per level). */
+int hmx_last_call_shape(const hmx_ctx *ctx, int *schedule, int *stream_groups);
 /* Optional stage timing of whole-picture calls (HIP events on the context's stream): layout conversion
  * in, dependency chain, layout conversion out, of the LAST call issued after hmx_set_timing(ctx, 1). */
 int hmx_set_timing(hmx_ctx *ctx, int enable);

@@ -122,6 +122,7 @@ def lib():
         L.hmx_intra_plan_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
         L.hmx_intra_plan_level.argtypes = [vp, ci, C.POINTER(C.c_uint32 * 4), C.POINTER(C.c_uint32)]
         L.hmx_intra_schedule_for.argtypes = [vp, ci]
+        L.hmx_last_call_shape.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
         L.hmx_set_timing.argtypes = [vp, ci]
         L.hmx_last_call_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.hmx_frame_intra_encode.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(Levels)]

@@ -770,6 +770,7 @@ struct hmx_ctx {
   };
   std::vector<GraphEntry> graphs;
   uint64_t graph_clock = 0;
+  int last_schedule = 0, last_groups = 1; // of the last whole-picture call (hmx_last_call_shape)
   bool across_call = false;    // the call being issued uses the across-pictures schedule (interleaved pool)
   int level_mode_min_pics = 1; // measured: the level schedule is at least as fast as the wave schedule at every batch size
   // optional timing of the last whole-picture call: events around the layout conversions and the chain
@@ -1369,6 +1370,12 @@ extern "C" int hmx_intra_plan_info(const hmx_intra_plan *pl, int *n_blocks, int 
   if (n_diagonals) *n_diagonals = (int)pl->waves.size();
   return HMX_OK;
 }
+extern "C" int hmx_last_call_shape(const hmx_ctx *c, int *schedule, int *stream_groups) {
+  if (!c) return HMX_ERR_ARG;
+  if (schedule) *schedule = c->last_schedule;
+  if (stream_groups) *stream_groups = c->last_groups;
+  return HMX_OK;
+}
 extern "C" int hmx_intra_plan_level(const hmx_intra_plan *pl, int level, uint32_t counts[4], uint32_t *n_waves) {
   if (!pl || level < 0 || level >= (int)pl->h_ltab.size()) return HMX_ERR_ARG;
   if (counts)
@@ -1448,18 +1455,11 @@ static int issue_chain_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, 
     }
     size_t n_levels = 0;
     for (int g = 0; g < groups; g++) n_levels = std::max(n_levels, glevels[g]);
-    // one plan for every picture: SIMD across pictures (k_intra_level_across)
+    // one plan for every picture: SIMD across pictures (k_intra_level_across); every group of pictures
+    // is its own interleave domain of the pool (see frame_intra) and walks the levels on its own stream
     if (c->across_call) {
       AcrossArgs AA{};
-      AA.pics = d_work;
       AA.ltus = p0->d_ltus;
-      AA.n_pics = n_pics;
-      for (int s2 = 0; s2 < 4; s2++) {
-        const int slots = s2 == 0 ? 64 : s2 == 1 ? 8 : s2 == 2 ? 4 : 1;
-        AA.cpb[s2] = (uint32_t)((n_pics + slots - 1) / slots);
-      }
-      AA.pool_org = c->pool_org;
-      AA.pool_rec = c->pool_rec;
       AA.pic_elems = c->tiled_pic_elems;
       for (int p = 0; p < 3; p++) AA.plane_off[p] = c->tiled_plane_off[p];
       AA.ctu_w = c->tiled_cw;
@@ -1468,15 +1468,33 @@ static int issue_chain_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, 
       AA.P = p0->P;
       for (size_t l = 0; l < n_levels; l++) {
         AA.row = p0->h_ltab[l];
-        uint64_t waves = 0;
-        for (int s2 = 0; s2 < 4; s2++) waves += (uint64_t)AA.row.count[s2] * AA.cpb[s2];
-        if (!waves) continue;
-        if (waves > 0x7fffffffull) return fail(c, HMX_ERR_ARG, "frame_intra: level too large for one launch");
-        if (enc)
-          hipLaunchKernelGGL(k_intra_level_across<true>, dim3((unsigned)waves), dim3(64), 0, main, AA);
-        else
-          hipLaunchKernelGGL(k_intra_level_across<false>, dim3((unsigned)waves), dim3(64), 0, main, AA);
+        for (int g = 0; g < groups; g++) {
+          const int np = first[g + 1] - first[g];
+          if (np <= 0) continue;
+          AA.pics = d_work + first[g];
+          AA.n_pics = np;
+          AA.pool_org = c->pool_org + (size_t)first[g] * c->tiled_pic_elems;
+          AA.pool_rec = c->pool_rec + (size_t)first[g] * c->tiled_pic_elems;
+          uint64_t waves = 0;
+          for (int s2 = 0; s2 < 4; s2++) {
+            const int slots = s2 == 0 ? 64 : s2 == 1 ? 8 : s2 == 2 ? 4 : 1;
+            AA.cpb[s2] = (uint32_t)((np + slots - 1) / slots);
+            waves += (uint64_t)AA.row.count[s2] * AA.cpb[s2];
+          }
+          if (!waves) continue;
+          if (waves > 0x7fffffffull) return fail(c, HMX_ERR_ARG, "frame_intra: level too large for one launch");
+          hipStream_t st = groups > 1 ? c->side[g] : main;
+          if (enc)
+            hipLaunchKernelGGL(k_intra_level_across<true>, dim3((unsigned)waves), dim3(64), 0, st, AA);
+          else
+            hipLaunchKernelGGL(k_intra_level_across<false>, dim3((unsigned)waves), dim3(64), 0, st, AA);
+        }
       }
+      if (groups > 1)
+        for (int g = 0; g < groups; g++) {
+          HIPCHK(c, hipEventRecord(c->ev_join[g], c->side[g]));
+          HIPCHK(c, hipStreamWaitEvent(main, c->ev_join[g], 0));
+        }
       HIPCHK(c, hipGetLastError());
       return HMX_OK;
     }
@@ -1569,12 +1587,17 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
   // whose pictures are interleaved quad by quad.
   bool use_level = n_pics >= c->level_mode_min_pics;
   if (const char *e = getenv("HMX_INTRA_SCHEDULE")) use_level = e[0] == 'l' ? true : (e[0] == 'w' ? false : use_level);
-  int groups = 1;
+  bool across = use_level && plan_stride == 0;
+  if (const char *e = getenv("HMX_INTRA_ACROSS")) across = across && e[0] != '0';
+  // Picture groups on separate streams: the launches of two groups overlap, which hides part of the
+  // per-level latency floor once each group still fills its waves (measured: +4 % at 512 pictures, +10 % at
+  // 1024, +13 % at 1400 with two groups; four or more are slower, and so is any split of the per-picture kernel)
+  int groups = across && n_pics >= 384 ? 2 : 1;
   if (use_level)
     if (const char *e = getenv("HMX_INTRA_STREAMS")) groups = std::min(std::max(atoi(e), 1), std::min(n_pics, (int)hmx_ctx::kMaxSide));
-  bool across = use_level && plan_stride == 0 && groups == 1;
-  if (const char *e = getenv("HMX_INTRA_ACROSS")) across = across && e[0] != '0';
   c->across_call = across;
+  c->last_schedule = !use_level ? 0 : (across ? 2 : 1);
+  c->last_groups = groups;
   std::vector<PicWork> hw(n_pics);
   std::vector<ConvJob> jobs((size_t)n_pics * 6);
   for (int i = 0; i < n_pics; i++) {
@@ -1586,8 +1609,15 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
     memset(&hw[i], 0, sizeof(PicWork));
     for (int p = 0; p < 3; p++) {
       const int pclog = p ? clog - 1 : clog, pw = p0->P.pic_w >> (p ? 1 : 0), ph = p0->P.pic_h >> (p ? 1 : 0);
-      const size_t base = across ? (size_t)c->tiled_plane_off[p] * n_pics + (size_t)i * 64 : (size_t)i * c->tiled_pic_elems + c->tiled_plane_off[p];
-      const unsigned qstride = across ? 64u * (unsigned)n_pics : 64u;
+      // across: the pictures of a group [g0, g1) are interleaved among themselves, groups one after another
+      int g0 = 0, g1 = n_pics;
+      if (across && groups > 1) {
+        const int g = (int)(((long long)(i + 1) * groups - 1) / n_pics); // the g with first[g] <= i < first[g+1]
+        g0 = (int)((long long)n_pics * g / groups), g1 = (int)((long long)n_pics * (g + 1) / groups);
+      }
+      const size_t base = across ? (size_t)g0 * c->tiled_pic_elems + (size_t)c->tiled_plane_off[p] * (g1 - g0) + (size_t)(i - g0) * 64
+                                 : (size_t)i * c->tiled_pic_elems + c->tiled_plane_off[p];
+      const unsigned qstride = across ? 64u * (unsigned)(g1 - g0) : 64u;
       hw[i].org[p] = TiledPlane{c->pool_org + base, cw, pclog, qstride};
       hw[i].rec[p] = TiledPlane{c->pool_rec + base, cw, pclog, qstride};
       hw[i].lev[p] = lev[i].plane[p];
