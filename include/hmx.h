@@ -264,6 +264,9 @@ typedef struct hmx_mc_job {
   const hmx_pic *refs; /* host array [n_refs]; hmx_pu::ref0/ref1 index it */
   int n_refs;
   const hmx_pic *dst;
+  int pic_w, pic_h;    /* luma picture size; when > 0 the PUs are scattered into a 4x4-cell map and the
+                          prediction runs one lane per cell of the picture (full waves whatever the PU sizes);
+                          0: one wave per PU */
 } hmx_mc_job;
 /* The batch entry points over SEVERAL pictures in one launch each (grid.y = picture): pictures at the
  * same position of different intra-period segments are independent, so a random-access
@@ -274,6 +277,13 @@ int hmx_batch_motionCompensation_multi(hmx_ctx *ctx, int n_jobs, const hmx_mc_jo
 int hmx_batch_residual_transformNxN_multi(hmx_ctx *ctx, const hmx_tu_list *list, int n_pics, const hmx_pic *org,
                                           const hmx_pic *pred, const hmx_levels *lev, uint32_t *d_abs_sum,
                                           const hmx_pic_param *pp);
+/* The encoder's inter block chain in one pass per block (xEstimateResidualQT's transformNxN followed by
+ * invtransformNxN and TComYuv::addClip, TLibEncoder/TEncSearch.cpp:4890-4990): residual org - pred, T, Q
+ * (levels out), IQ, IT, rec = Clip(pred + resi).  Same results as hmx_batch_residual_transformNxN_multi
+ * followed by hmx_batch_invtransformNxN_multi. */
+int hmx_batch_residual_transform_recon_multi(hmx_ctx *ctx, const hmx_tu_list *list, int n_pics, const hmx_pic *org,
+                                             const hmx_pic *pred, const hmx_levels *lev, const hmx_pic *rec,
+                                             uint32_t *d_abs_sum, const hmx_pic_param *pp);
 int hmx_batch_invtransformNxN_multi(hmx_ctx *ctx, const hmx_tu_list *list, int n_pics, const hmx_levels *lev,
                                     const hmx_pic *pred, const hmx_pic *out, const hmx_pic_param *pp);
 int hmx_pic_extend_border_multi(hmx_ctx *ctx, int n_pics, const hmx_pic *pics, int pic_w, int pic_h, int margin_x,

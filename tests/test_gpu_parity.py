@@ -437,6 +437,19 @@ def test_batch_motion_compensation(ctx):
         O.hmo_mc_frame(t.ctypes.data, len(t), B, ptrs, rs, P3(*[d.ctypes.data for d in dst]), I3(w, w // 2, w // 2))
         for p in range(3):
             assert np.array_equal(got[p], dst[p]), ("mc", bi_frac, p)
+        # the multi-picture entry point with the picture size given: cell-map path, two jobs in one call
+        d_dst2 = [capi.DevPicture(ctx, w, h).zero() for _ in range(2)]
+        dst_pics = (capi.Pic * 2)(*[d.as_pic() for d in d_dst2])
+        jobs = (capi.McJob * 2)()
+        for q in range(2):
+            jobs[q].d_pus, jobs[q].n_pus, jobs[q].refs, jobs[q].n_refs = d_pus.ptr, len(pus), ref_arr, n_refs
+            jobs[q].dst, jobs[q].pic_w, jobs[q].pic_h = C.pointer(dst_pics[q]), w, h
+        ctx._chk(L.hmx_batch_motionCompensation_multi(ctx.h, 2, jobs))
+        ctx.sync()
+        for q in range(2):
+            got2 = d_dst2[q].download()
+            for p in range(3):
+                assert np.array_equal(got2[p], dst[p]), ("mc multi", bi_frac, q, p)
 
 
 @pytest.mark.parametrize("schedule", ["wave", "level"])

@@ -60,8 +60,9 @@ def test_reference_picture_exchange_gloo():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("B", [8, 10])
-def test_ra_pipeline_vs_oracle(B):
+def test_ra_pipeline_vs_oracle(B, fused):
     import torch
     import oracle_lib as ol
     import ra_oracle
@@ -71,7 +72,7 @@ def test_ra_pipeline_vs_oracle(B):
     wl = ra.RAWorkload(w, h, B, qp, intra_period=8, gop=4, n_segments=2, seed=3)
     stream = torch.cuda.current_stream().cuda_stream
     ctx = capi.Context(bit_depth=B, stream=stream)
-    pipe = ra.RAPipeline(ctx, torch, wl)
+    pipe = ra.RAPipeline(ctx, torch, wl, fused=fused)  # one-pass inter chain / the two reference-shaped calls
     pipe.load_originals()
     px = pipe.run()
     torch.cuda.synchronize()

@@ -52,7 +52,8 @@ class Levels(C.Structure):
 
 
 class McJob(C.Structure):  # hmx_mc_job
-    _fields_ = [("d_pus", C.c_void_p), ("n_pus", C.c_int), ("refs", C.POINTER(Pic)), ("n_refs", C.c_int), ("dst", C.POINTER(Pic))]
+    _fields_ = [("d_pus", C.c_void_p), ("n_pus", C.c_int), ("refs", C.POINTER(Pic)), ("n_refs", C.c_int), ("dst", C.POINTER(Pic)),
+                ("pic_w", C.c_int), ("pic_h", C.c_int)]
 
 
 _lib = None
@@ -134,6 +135,8 @@ def lib():
         L.hmx_batch_motionCompensation_multi.argtypes = [vp, ci, C.POINTER(McJob)]
         L.hmx_batch_residual_transformNxN_multi.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(Levels), vp,
                                                             C.POINTER(PicParam)]
+        L.hmx_batch_residual_transform_recon_multi.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(Levels),
+                                                               C.POINTER(Pic), vp, C.POINTER(PicParam)]
         L.hmx_batch_invtransformNxN_multi.argtypes = [vp, vp, ci, C.POINTER(Levels), C.POINTER(Pic), C.POINTER(Pic),
                                                       C.POINTER(PicParam)]
         L.hmx_pic_extend_border_multi.argtypes = [vp, ci, C.POINTER(Pic), ci, ci, ci, ci]

@@ -30,11 +30,12 @@ static_assert(64 * sizeof(TuLds<4>) <= HMX_SMEM_BYTES && 32 * sizeof(TuLds<8>) <
                   4 * sizeof(TuLds<32>) <= HMX_SMEM_BYTES,
               "LDS scratch");
 
-enum ListOp { OP_TRANSFORM_NXN, OP_INVTRANSFORM_NXN, OP_XT, OP_XIT, OP_XQUANT, OP_XDEQUANT, OP_PRED };
+enum ListOp { OP_TRANSFORM_NXN, OP_INVTRANSFORM_NXN, OP_XT, OP_XIT, OP_XQUANT, OP_XDEQUANT, OP_PRED, OP_TRANSFORM_RECON };
 
 struct ListPic { // planes of one picture of a multi-picture list call
   PlanesDev a, b;
   LevelsDev lev;
+  PlanesDev rec; // OP_TRANSFORM_RECON: reconstruction out
 };
 struct ListArgs {
   const DTu *tus;
@@ -78,25 +79,34 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
   const int scan_idx = coef_scan_idx(N, luma, !inter, t.mode);
   int row[N];
 
-  if constexpr (OP == OP_TRANSFORM_NXN || OP == OP_XT) {
+  if constexpr (OP == OP_TRANSFORM_NXN || OP == OP_XT || OP == OP_TRANSFORM_RECON) {
+    int pr[N];
     if (active) {
       load_row16<N>(a_p + (size_t)(y + gl) * a_s + x, row);
       if (A.have_pred) { // residual = original - prediction (TComYuv::subtract, TComYuv.cpp:461) fused in
-        int pr[N];
         load_row16<N>(b_p + (size_t)(y + gl) * b_s + x, pr);
 #pragma unroll
         for (int k = 0; k < N; k++) row[k] = wrap16(row[k] - pr[k]);
       }
     }
-    int sum = fwd_tq_block<N>(L, gl, active, row, ts, use_dst, luma, scan_idx, OP == OP_TRANSFORM_NXN, A.P);
+    int sum = fwd_tq_block<N>(L, gl, active, row, ts, use_dst, luma, scan_idx, OP != OP_XT, A.P);
     if (active) {
       load_row32<N>(&L.tile[gl][0], row);
-      if (OP == OP_TRANSFORM_NXN) {
+      if (OP != OP_XT) {
 #pragma unroll
         for (int k = 0; k < N; k++) row[k] = level_of(row[k]);
       }
       store_row32<N>(lev_p + (size_t)(y + gl) * lev_s + x, row);
-      if (OP == OP_TRANSFORM_NXN && gl == 0 && abs_sum) abs_sum[d.idx] = (uint32_t)sum;
+      if (OP != OP_XT && gl == 0 && abs_sum) abs_sum[d.idx] = (uint32_t)sum;
+    }
+    if constexpr (OP == OP_TRANSFORM_RECON) { // the packed words are still in the tile: IQ, IT, Clip(pred + resi) in the same pass
+      inv_tq_block<N>(L, gl, active, ts, use_dst, luma, true, A.P, row);
+      if (active) {
+        const int mx = (1 << A.P.bit_depth) - 1;
+#pragma unroll
+        for (int k = 0; k < N; k++) row[k] = clip3(0, mx, pr[k] + row[k]);
+        store_row16<N>(Q->rec.p[pl] + (size_t)(y + gl) * Q->rec.s[pl] + x, row);
+      }
     }
   } else if constexpr (OP == OP_XQUANT) {
     // Int coefficients in lev -> levels in lev2 (the quantiser half of transformNxN on its own)
@@ -784,6 +794,8 @@ struct hmx_ctx {
   int n_side = 0;
   // Argument arena: small per-call tables (picture planes, job lists) travel through a pinned host ring
   // and a device ring by asynchronous copies; the stream is synchronised only when the ring wraps.
+  int *d_mcmap = nullptr; // cell -> PU maps of the last motion-compensation call
+  size_t mcmap_cap = 0;
   char *arena_h = nullptr, *arena_d = nullptr;
   size_t arena_cap = 0, arena_head = 0;
 };
@@ -909,6 +921,7 @@ extern "C" void hmx_destroy(hmx_ctx *c) {
   hipFree(c->d_jobs);
   if (c->arena_h) hipHostFree(c->arena_h);
   hipFree(c->arena_d);
+  hipFree(c->d_mcmap);
   for (int g = 0; g < c->n_side; g++) {
     hipStreamDestroy(c->side[g]);
     hipEventDestroy(c->ev_join[g]);
@@ -992,6 +1005,7 @@ static int launch_op(hmx_ctx *c, int op, int log2n, const ListArgs &A) {
   case OP_XIT: return launch_list<OP_XIT>(c, log2n, A);
   case OP_XQUANT: return launch_list<OP_XQUANT>(c, log2n, A);
   case OP_XDEQUANT: return launch_list<OP_XDEQUANT>(c, log2n, A);
+  case OP_TRANSFORM_RECON: return launch_list<OP_TRANSFORM_RECON>(c, log2n, A);
   default: return launch_list<OP_PRED>(c, log2n, A);
   }
 }
@@ -1124,12 +1138,14 @@ extern "C" int hmx_batch_invtransformNxN(hmx_ctx *c, const hmx_tu_list *l, const
 }
 
 static int run_list_multi(hmx_ctx *c, int op, const hmx_tu_list *l, int n_pics, const hmx_pic *a, const hmx_pic *b,
-                          const hmx_levels *lev, uint32_t *d_abs_sum, const hmx_pic_param *pp, bool have_pred) {
+                          const hmx_levels *lev, uint32_t *d_abs_sum, const hmx_pic_param *pp, bool have_pred,
+                          const hmx_pic *rec = nullptr) {
   std::vector<ListPic> t(n_pics);
   for (int i = 0; i < n_pics; i++) {
     t[i].a = to_dev(a ? &a[i] : nullptr);
     t[i].b = to_dev(b ? &b[i] : nullptr);
     t[i].lev = to_dev(&lev[i]);
+    t[i].rec = to_dev(rec ? &rec[i] : nullptr);
   }
   ListArgs A{};
   A.pics = static_cast<const ListPic *>(arena_push(c, t.data(), sizeof(ListPic) * n_pics));
@@ -1148,6 +1164,14 @@ extern "C" int hmx_batch_residual_transformNxN_multi(hmx_ctx *c, const hmx_tu_li
   if (!c || !l || !org || !pred || !lev || !pp || n_pics <= 0 || n_pics > 65535)
     return fail(c, HMX_ERR_ARG, "hmx_batch_residual_transformNxN_multi: bad argument");
   return run_list_multi(c, OP_TRANSFORM_NXN, l, n_pics, org, pred, lev, d_abs_sum, pp, true);
+}
+
+extern "C" int hmx_batch_residual_transform_recon_multi(hmx_ctx *c, const hmx_tu_list *l, int n_pics, const hmx_pic *org,
+                                                       const hmx_pic *pred, const hmx_levels *lev, const hmx_pic *rec,
+                                                       uint32_t *d_abs_sum, const hmx_pic_param *pp) {
+  if (!c || !l || !org || !pred || !lev || !rec || !pp || n_pics <= 0 || n_pics > 65535)
+    return fail(c, HMX_ERR_ARG, "hmx_batch_residual_transform_recon_multi: bad argument");
+  return run_list_multi(c, OP_TRANSFORM_RECON, l, n_pics, org, pred, lev, d_abs_sum, pp, true, rec);
 }
 
 extern "C" int hmx_batch_invtransformNxN_multi(hmx_ctx *c, const hmx_tu_list *l, int n_pics, const hmx_levels *lev,
@@ -2191,11 +2215,13 @@ extern "C" int hmx_addAvg(hmx_ctx *c, const hmx_pel *s0, int s0s, const hmx_pel 
   return down2d(c, dst, ds, dd, 2, w, h);
 }
 
-// ---- motionCompensation over a PU list: one workgroup per (PU, plane) ----
+// ---- motionCompensation over PU lists ----
 struct McJob { // one picture: its prediction units, its reference pictures, its destination planes
   const hmx_pu *pus;
   int n, ref_off; // refs of this job start at McArgs::refs[ref_off]
   PlanesDev dst;
+  int *map;       // cell -> PU index (-1: none), cw x ch cells of 4x4 luma samples; NULL: one wave per PU
+  int cw, ch;
 };
 struct McArgs {
   const McJob *jobs;     // [grid.y]
@@ -2203,67 +2229,150 @@ struct McArgs {
   int B;
 };
 
-// prediction of one list into out[] (dense w x h, stride 64): xPredInterLumaBlk / ChromaBlk, :554-642
+// One interpolated sample from NTAP values already in registers (v[NTAP/2 - 1] is the co-located one):
+// the arithmetic of interp_sample.
 template <int NTAP>
-__device__ __forceinline__ void mc_one_list(const short *ref, int rs, int mvx, int mvy, int w, int h, bool bi, int B, short *tmp,
-                                            short *out, int os) {
-  constexpr int SH = NTAP == 8 ? 2 : 3, MASK = (1 << SH) - 1, HALF = NTAP / 2;
+__device__ __forceinline__ int interp_core(const int *v, const int *taps, int frac, bool first, bool last, int B) {
+  const int head = 14 - B, maxv = (1 << B) - 1;
+  if (frac == 0) {
+    const int x = v[NTAP / 2 - 1];
+    if (first == last) return x;
+    if (first) return wrap16(wrap16(x << head) - 8192);
+    const int off = wrap16(8192 + (head ? (1 << (head - 1)) : 0));
+    return clip3(0, maxv, wrap16((x + off) >> head));
+  }
+  int shift = 6, offset;
+  if (last) {
+    shift += first ? 0 : head;
+    offset = (1 << (shift - 1)) + (first ? 0 : 8192 << 6);
+  } else {
+    shift -= first ? head : 0;
+    offset = first ? -(8192 << shift) : 0;
+  }
+  int sum = 0;
+#pragma unroll
+  for (int t = 0; t < NTAP; t++) sum += v[t] * taps[t];
+  const int r = wrap16((sum + offset) >> shift);
+  return last ? clip3(0, maxv, r) : r;
+}
+
+// Prediction of one list for a W x W cell (4x4 luma, 2x2 chroma) whose first sample is `ref` in the
+// reference plane: xPredInterLumaBlk / ChromaBlk (:554-642) restricted to the cell.  The reference's
+// two-stage filtering is position-wise (every output is the vertical filter of horizontally filtered
+// rows), so cutting a PU into cells gives the same samples.
+template <int NTAP, int W>
+__device__ __forceinline__ void mc_cell(const short *ref, int rs, int mvx, int mvy, bool bi, int B, int *out) {
+  constexpr int SH = NTAP == 8 ? 2 : 3, MASK = (1 << SH) - 1, HALF = NTAP / 2, R = W + NTAP - 1;
   ref += (mvx >> SH) + (ptrdiff_t)(mvy >> SH) * rs;
   const int xf = mvx & MASK, yf = mvy & MASK;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  if (yf == 0) {
-    for (int i = tid; i < w * h; i += nt) {
-      int r = i / w, cc = i % w;
-      out[r * os + cc] = (short)interp_sample<NTAP>(ref + (ptrdiff_t)r * rs + cc, 1, xf, true, !bi, B);
+  int tx[NTAP], ty[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; t++) {
+    tx[t] = NTAP == 8 ? luma_tap(xf, t) : chroma_tap(xf, t);
+    ty[t] = NTAP == 8 ? luma_tap(yf, t) : chroma_tap(yf, t);
+  }
+  if (yf == 0) { // horizontal only (or plain copy)
+#pragma unroll
+    for (int r = 0; r < W; r++) {
+      int row[R];
+#pragma unroll
+      for (int k = 0; k < R; k++) row[k] = ref[(ptrdiff_t)r * rs + k - (HALF - 1)];
+#pragma unroll
+      for (int c = 0; c < W; c++) out[r * W + c] = interp_core<NTAP>(row + c, tx, xf, true, !bi, B);
     }
-  } else if (xf == 0) {
-    for (int i = tid; i < w * h; i += nt) {
-      int r = i / w, cc = i % w;
-      out[r * os + cc] = (short)interp_sample<NTAP>(ref + (ptrdiff_t)r * rs + cc, rs, yf, true, !bi, B);
+  } else if (xf == 0) { // vertical only
+#pragma unroll
+    for (int c = 0; c < W; c++) {
+      int col[R];
+#pragma unroll
+      for (int k = 0; k < R; k++) col[k] = ref[(ptrdiff_t)(k - (HALF - 1)) * rs + c];
+#pragma unroll
+      for (int r = 0; r < W; r++) out[r * W + c] = interp_core<NTAP>(col + r, ty, yf, true, !bi, B);
     }
-  } else {
-    const int th = h + NTAP - 1;
-    for (int i = tid; i < w * th; i += nt) {
-      int r = i / w, cc = i % w;
-      tmp[r * 64 + cc] = (short)interp_sample<NTAP>(ref + (ptrdiff_t)(r - (HALF - 1)) * rs + cc, 1, xf, true, false, B);
+  } else { // horizontal into 14-bit intermediates for W + NTAP - 1 rows, then vertical
+    int tmp[R][W];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int row[R];
+#pragma unroll
+      for (int k = 0; k < R; k++) row[k] = ref[(ptrdiff_t)(r - (HALF - 1)) * rs + k - (HALF - 1)];
+#pragma unroll
+      for (int c = 0; c < W; c++) tmp[r][c] = interp_core<NTAP>(row + c, tx, xf, true, false, B);
     }
-    __syncthreads();
-    for (int i = tid; i < w * h; i += nt) {
-      int r = i / w, cc = i % w;
-      out[r * os + cc] = (short)interp_sample<NTAP>(tmp + (r + HALF - 1) * 64 + cc, 64, yf, false, !bi, B);
+#pragma unroll
+    for (int c = 0; c < W; c++) {
+      int col[R];
+#pragma unroll
+      for (int k = 0; k < R; k++) col[k] = tmp[k][c];
+#pragma unroll
+      for (int r = 0; r < W; r++) out[r * W + c] = interp_core<NTAP>(col + r, ty, yf, false, !bi, B);
     }
   }
 }
 
-__global__ __launch_bounds__(256) void k_mc(McArgs A) {
-  __shared__ short tmp[(64 + 7) * 64];
-  __shared__ short pb[2][64 * 64];
-  const McJob J = A.jobs[blockIdx.y];
-  const int pu_i = blockIdx.x / 3, pl = blockIdx.x % 3;
-  if (pu_i >= J.n) return; // jobs of one call may differ in length
-  const hmx_pu u = J.pus[pu_i];
-  const int c = pl ? 1 : 0, x = u.x >> c, y = u.y >> c, w = u.w >> c, h = u.h >> c;
+// prediction of one plane's cell from both lists (+ addAvg) into dst
+template <int NTAP, int W>
+__device__ __forceinline__ void mc_cell_plane(const McArgs &A, const McJob &J, const hmx_pu &u, int pl, int x, int y) {
   const bool bi = u.ref0 != 255 && u.ref1 != 255;
-  short *d = J.dst.p[pl] + (size_t)y * J.dst.s[pl] + x;
-  for (int l = 0; l < 2; l++) {
-    const int ri = l ? u.ref1 : u.ref0;
-    if (ri == 255) continue; // uniform over the workgroup
-    const PlanesDev &R = A.refs[J.ref_off + ri];
-    const short *ref = R.p[pl] + (ptrdiff_t)y * R.s[pl] + x;
-    const int mvx = l ? u.mv1x : u.mv0x, mvy = l ? u.mv1y : u.mv0y;
-    short *out = bi ? pb[l] : d;
-    const int os = bi ? 64 : J.dst.s[pl];
-    if (pl == 0)
-      mc_one_list<8>(ref, R.s[pl], mvx, mvy, w, h, bi, A.B, tmp, out, os);
-    else
-      mc_one_list<4>(ref, R.s[pl], mvx, mvy, w, h, bi, A.B, tmp, out, os);
-    __syncthreads();
+  int p0[W * W], p1[W * W];
+  const int sc = NTAP == 8 ? 1 : 1; // chroma MVs are the luma MVs in eighth-pel units (4:2:0)
+  (void)sc;
+  if (u.ref0 != 255) {
+    const PlanesDev &R = A.refs[J.ref_off + u.ref0];
+    mc_cell<NTAP, W>(R.p[pl] + (ptrdiff_t)y * R.s[pl] + x, R.s[pl], u.mv0x, u.mv0y, bi, A.B, p0);
   }
-  if (bi)
-    for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
-      int r = i / w, cc = i % w;
-      d[(size_t)r * J.dst.s[pl] + cc] = (short)add_avg(pb[0][r * 64 + cc], pb[1][r * 64 + cc], A.B);
-    }
+  if (u.ref1 != 255) {
+    const PlanesDev &R = A.refs[J.ref_off + u.ref1];
+    mc_cell<NTAP, W>(R.p[pl] + (ptrdiff_t)y * R.s[pl] + x, R.s[pl], u.mv1x, u.mv1y, bi, A.B, bi ? p1 : p0);
+  }
+  short *d = J.dst.p[pl] + (size_t)y * J.dst.s[pl] + x;
+#pragma unroll
+  for (int r = 0; r < W; r++)
+#pragma unroll
+    for (int c = 0; c < W; c++) d[(size_t)r * J.dst.s[pl] + c] = (short)(bi ? add_avg(p0[r * W + c], p1[r * W + c], A.B) : p0[r * W + c]);
+}
+
+// Two ways to hand cells to lanes.  With the picture size known (hmx_mc_job::pic_w/pic_h) a scatter pass
+// writes each PU's index into a cell map and the prediction kernel runs one lane per cell of the PICTURE:
+// every wave is full whatever the PU sizes.  Without it, one wave per PU, its lanes looping over the
+// PU's cells (an 8x4 PU keeps 2 of 64 lanes busy).  A cell reads its (W+7)^2 / (W+3)^2 reference samples
+// straight from the margin-extended reference planes (the caches absorb the overlap between neighbouring
+// cells); nothing is staged, nothing synchronises.
+__global__ __launch_bounds__(64) void k_mc_map(McArgs A) {
+  const McJob J = A.jobs[blockIdx.y];
+  if ((int)blockIdx.x >= J.n) return;
+  const hmx_pu u = J.pus[blockIdx.x];
+  if (u.ref0 == 255 && u.ref1 == 255) return;
+  const int cw = u.w >> 2, cells = cw * (u.h >> 2);
+  for (int i = threadIdx.x; i < cells; i += 64) {
+    const int cx = (u.x >> 2) + i % cw, cy = (u.y >> 2) + i / cw;
+    if (cx < J.cw && cy < J.ch) J.map[(size_t)cy * J.cw + cx] = (int)blockIdx.x;
+  }
+}
+__global__ __launch_bounds__(256) void k_mc_cells(McArgs A) {
+  const McJob J = A.jobs[blockIdx.y];
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  if (cell >= J.cw * J.ch) return;
+  const int pi = J.map[cell];
+  if (pi < 0) return;
+  const hmx_pu u = J.pus[pi];
+  const int x = (cell % J.cw) << 2, y = (cell / J.cw) << 2;
+  mc_cell_plane<8, 4>(A, J, u, 0, x, y);
+  mc_cell_plane<4, 2>(A, J, u, 1, x >> 1, y >> 1);
+  mc_cell_plane<4, 2>(A, J, u, 2, x >> 1, y >> 1);
+}
+__global__ __launch_bounds__(64) void k_mc(McArgs A) {
+  const McJob J = A.jobs[blockIdx.y];
+  if ((int)blockIdx.x >= J.n) return; // jobs of one call may differ in length
+  const hmx_pu u = J.pus[blockIdx.x];
+  if (u.ref0 == 255 && u.ref1 == 255) return;
+  const int cw = u.w >> 2, cells = cw * (u.h >> 2);
+  for (int i = threadIdx.x; i < cells; i += 64) {
+    const int x = u.x + ((i % cw) << 2), y = u.y + ((i / cw) << 2);
+    mc_cell_plane<8, 4>(A, J, u, 0, x, y);
+    mc_cell_plane<4, 2>(A, J, u, 1, x >> 1, y >> 1);
+    mc_cell_plane<4, 2>(A, J, u, 2, x >> 1, y >> 1);
+  }
 }
 
 extern "C" int hmx_batch_motionCompensation_multi(hmx_ctx *c, int n_jobs, const hmx_mc_job *jobs) {
@@ -2271,21 +2380,54 @@ extern "C" int hmx_batch_motionCompensation_multi(hmx_ctx *c, int n_jobs, const 
   std::vector<McJob> hj(n_jobs);
   std::vector<PlanesDev> hr;
   int max_n = 0;
+  size_t map_cells = 0, max_cells = 0;
+  bool mapped = true;
   for (int i = 0; i < n_jobs; i++) {
     const hmx_mc_job &j = jobs[i];
-    if (j.n_pus < 0 || (j.n_pus > 0 && !j.d_pus) || !j.refs || j.n_refs <= 0 || j.n_refs > 16 || !j.dst)
+    if (j.n_pus < 0 || (j.n_pus > 0 && !j.d_pus) || !j.refs || j.n_refs <= 0 || j.n_refs > 16 || !j.dst || j.pic_w < 0 || j.pic_h < 0)
       return fail(c, HMX_ERR_ARG, "hmx_batch_motionCompensation_multi: bad job");
-    hj[i] = McJob{j.d_pus, j.n_pus, (int)hr.size(), to_dev(j.dst)};
+    hj[i] = McJob{j.d_pus, j.n_pus, (int)hr.size(), to_dev(j.dst), nullptr, (j.pic_w + 3) / 4, (j.pic_h + 3) / 4};
     for (int k = 0; k < j.n_refs; k++) hr.push_back(to_dev(&j.refs[k]));
     max_n = std::max(max_n, j.n_pus);
+    const size_t cells = (size_t)hj[i].cw * hj[i].ch;
+    mapped = mapped && cells > 0;
+    map_cells += cells;
+    max_cells = std::max(max_cells, cells);
   }
   if (!max_n) return HMX_OK;
+  if (mapped) { // cell maps of all jobs, back to back, in a grow-only scratch buffer
+    if (map_cells > c->mcmap_cap) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      hipFree(c->d_mcmap);
+      c->d_mcmap = nullptr;
+      c->mcmap_cap = 0;
+      if (hipMalloc((void **)&c->d_mcmap, map_cells * sizeof(int)) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc cell map");
+      c->mcmap_cap = map_cells;
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_mcmap, 0xff, map_cells * sizeof(int), c->stream));
+    size_t off = 0;
+    for (int i = 0; i < n_jobs; i++) {
+      hj[i].map = c->d_mcmap + off;
+      off += (size_t)hj[i].cw * hj[i].ch;
+    }
+  }
+  // both tables in one copy
+  const size_t jb = (sizeof(McJob) * hj.size() + 255) & ~(size_t)255;
+  std::vector<char> blob(jb + sizeof(PlanesDev) * hr.size());
+  memcpy(blob.data(), hj.data(), sizeof(McJob) * hj.size());
+  memcpy(blob.data() + jb, hr.data(), sizeof(PlanesDev) * hr.size());
+  char *d = static_cast<char *>(arena_push(c, blob.data(), blob.size()));
+  if (!d) return fail(c, HMX_ERR_NOMEM, "argument arena");
   McArgs A;
-  A.jobs = static_cast<const McJob *>(arena_push(c, hj.data(), sizeof(McJob) * hj.size()));
-  A.refs = static_cast<const PlanesDev *>(arena_push(c, hr.data(), sizeof(PlanesDev) * hr.size()));
-  if (!A.jobs || !A.refs) return fail(c, HMX_ERR_NOMEM, "argument arena");
+  A.jobs = reinterpret_cast<const McJob *>(d);
+  A.refs = reinterpret_cast<const PlanesDev *>(d + jb);
   A.B = c->cfg.bit_depth;
-  hipLaunchKernelGGL(k_mc, dim3((unsigned)max_n * 3, (unsigned)n_jobs), dim3(256), 0, c->stream, A);
+  if (mapped) {
+    hipLaunchKernelGGL(k_mc_map, dim3((unsigned)max_n, (unsigned)n_jobs), dim3(64), 0, c->stream, A);
+    hipLaunchKernelGGL(k_mc_cells, dim3((unsigned)((max_cells + 255) / 256), (unsigned)n_jobs), dim3(256), 0, c->stream, A);
+  } else {
+    hipLaunchKernelGGL(k_mc, dim3((unsigned)max_n, (unsigned)n_jobs), dim3(64), 0, c->stream, A);
+  }
   HIPCHK(c, hipGetLastError());
   return HMX_OK;
 }
@@ -2294,7 +2436,7 @@ extern "C" int hmx_batch_motionCompensation(hmx_ctx *c, const hmx_pu *d_pus, int
                                             const hmx_pic *dst) {
   if (!c || !d_pus || !refs || !dst || n_refs <= 0 || n_refs > 16) return fail(c, HMX_ERR_ARG, "hmx_batch_motionCompensation: bad argument");
   if (n <= 0) return HMX_OK;
-  const hmx_mc_job j{d_pus, n, refs, n_refs, dst};
+  const hmx_mc_job j{d_pus, n, refs, n_refs, dst, 0, 0}; // picture size unknown here: one wave per PU
   return hmx_batch_motionCompensation_multi(c, 1, &j);
 }
 

@@ -12,8 +12,7 @@ Per picture the hot path is:
   I pictures   whole-picture all-intra chain (hmx_frame_intra_encode)
   B/P pictures motion compensation of a PU list against resident references with margins
                (hmx_batch_motionCompensation_multi), residual + transformNxN
-               (hmx_batch_residual_transformNxN_multi), invtransformNxN + reconstruction
-               (hmx_batch_invtransformNxN_multi), border extension (hmx_pic_extend_border_multi);
+               (hmx_batch_residual_transform_recon_multi = residual, T, Q, IQ, IT, reconstruction in one pass), border extension (hmx_pic_extend_border_multi);
                the pictures at one GOP position of all segments a rank owns share each call.
 Decisions (block structure, modes, PUs, MVs) are synthetic and seeded; this module is the bench/test
 harness' stand-in for TEncGOP's picture loop, not part of the product library."""
@@ -133,8 +132,9 @@ class RAWorkload:
 
 
 class RAPipeline:
-    def __init__(self, ctx, torch, wl, rank=0, world=1, dist=None):
+    def __init__(self, ctx, torch, wl, rank=0, world=1, dist=None, fused=True):
         self.ctx, self.torch, self.wl, self.rank, self.world, self.dist = ctx, torch, wl, rank, world, dist
+        self.fused = fused
         self.L = capi.lib()
         w, h = wl.w, wl.h
         self.dev = torch.device("cuda", torch.cuda.current_device())
@@ -215,9 +215,13 @@ class RAPipeline:
                     pus, npu = (d["pus_p"], d["n_p"]) if is_p else (d["pus_b"], d["n_b"])
                     mc[q].d_pus, mc[q].n_pus, mc[q].refs, mc[q].n_refs = pus.ptr, npu, ref_arr, len(refs)
                     mc[q].dst = C.pointer(pred[q])
+                    mc[q].pic_w, mc[q].pic_h = w, h
                 ctx._chk(L.hmx_batch_motionCompensation_multi(ctx.h, m, mc))
-                ctx._chk(L.hmx_batch_residual_transformNxN_multi(ctx.h, d["tu"], m, org, pred, lev, None, C.byref(self.pp_b)))
-                ctx._chk(L.hmx_batch_invtransformNxN_multi(ctx.h, d["tu"], m, lev, pred, rec, C.byref(self.pp_b)))
+                if self.fused:
+                    ctx._chk(L.hmx_batch_residual_transform_recon_multi(ctx.h, d["tu"], m, org, pred, lev, rec, None, C.byref(self.pp_b)))
+                else:  # the two reference-shaped calls (kept for the parity test of both routes)
+                    ctx._chk(L.hmx_batch_residual_transformNxN_multi(ctx.h, d["tu"], m, org, pred, lev, None, C.byref(self.pp_b)))
+                    ctx._chk(L.hmx_batch_invtransformNxN_multi(ctx.h, d["tu"], m, lev, pred, rec, C.byref(self.pp_b)))
                 ctx._chk(L.hmx_pic_extend_border_multi(ctx.h, m, rec, w, h, MARGIN, MARGIN))
                 pixels += m * w * h
         return pixels
