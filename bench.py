@@ -8,8 +8,9 @@ region starts.  Weak scaling: every rank (one process per GPU) owns its own batc
 (IntraPeriod 1 => pictures are independent, no data-path collective).
 
     python bench.py --gpus N --steps K --warmup W [--workload ai2160p10|ai2160p8|ai1080p8] [--frames F]
+    python bench.py --workload ra2160p8|ra1080p8|ldp1080p8 [--segments S]     (secondary workloads)
 
-Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (k_intra_wave) against the
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (k_intra_level_across) against the
 HBM peak with ALGORITHMIC bytes; `cpu_baseline` times the reference's own CPU
 functions (oracle/_ref, kind "reference") or, if that library is absent, the CPU oracle (kind "port")
 on a bounded sample of the same workload, rank 0 at N=1 only.
@@ -33,7 +34,9 @@ WORKLOADS = {
     "ai1080p8": (1920, 1080, 8, 32, "configs[1] All-intra main 1920x1080 8-bit"),
     # random access: intra-period segments sharded over ranks, boundary I pictures exchanged over RCCL
     "ra2160p8": (3840, 2160, 8, 32, "configs[3] Random-access main 3840x2160 8-bit (hierarchical B, IntraPeriod 32, GOP 8)"),
-    "ra1080p8": (1920, 1080, 8, 32, "random-access main 1920x1080 8-bit (configs[2]/[3] shape at 1080p)"),
+    "ra1080p8": (1920, 1080, 8, 32, "random-access main 1920x1080 8-bit (configs[3] shape at 1080p)"),
+    # low-delay P: a strict chain inside a sequence, so a rank batches over independent sequences (replicas)
+    "ldp1080p8": (1920, 1080, 8, 32, "configs[2] Low-delay-P main 1920x1080 8-bit, 64 pictures per sequence"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -100,7 +103,9 @@ def bench_random_access(args, torch, dist, rank, local_rank, world):
     stream = torch.cuda.current_stream().cuda_stream
     ctx = capi.Context(bit_depth=B, device=local_rank, stream=stream)
     n_seg = args.segments * world
-    wl = ra.RAWorkload(w, h, B, qp, n_segments=n_seg, seed=7, n_distinct=4)
+    ldp = args.workload.startswith("ldp")
+    wl = ra.RAWorkload(w, h, B, qp, n_segments=n_seg, seed=7, n_distinct=4, structure="ldp" if ldp else "ra",
+                       intra_period=64 if ldp else 32)
     pipe = ra.RAPipeline(ctx, torch, wl, rank, world, dist if world > 1 else None)
     n_pics = pipe.load_originals()
 
@@ -128,9 +133,12 @@ def bench_random_access(args, torch, dist, rank, local_rank, world):
             "value": round(px / dt / 1e6, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {cfg_name}; {args.segments} segment(s) of 32 pictures per GPU, I pictures through "
-                                   f"the intra chain, B/P pictures MC (50% bi-pred) + residual T/Q + IQ/IT + recon, boundary I pictures "
-                                   f"exchanged by RCCL send/recv", "segments_per_gpu": args.segments, "pictures_per_gpu": n_pics,
+            "config": {"workload": (f"{args.workload}: {cfg_name}; {args.segments} independent sequence(s) per GPU, I picture through the "
+                                    f"intra chain, P pictures (each references the previous one) MC + residual T/Q + IQ/IT + recon; "
+                                    f"no exchange between sequences" if ldp else
+                                    f"{args.workload}: {cfg_name}; {args.segments} segment(s) of 32 pictures per GPU, I pictures through "
+                                    f"the intra chain, B/P pictures MC (50% bi-pred) + residual T/Q + IQ/IT + recon, boundary I pictures "
+                                    f"exchanged by RCCL send/recv"), "segments_per_gpu": args.segments, "pictures_per_gpu": n_pics,
                        "width": w, "height": h, "bit_depth": B, "qp": qp},
             "roofline": None, "note": "secondary workload (SURVEY.md 8e); the roofline line is reported for the all-intra default"}), flush=True)
     if world > 1:
@@ -148,7 +156,9 @@ def main():
     ap.add_argument("--frames", type=int, default=1024,
                     help="pictures per GPU per step (150 MB of HBM each at 2160p: planes, levels and the working pool)")
     ap.add_argument("--tiling", default="mix", help="mix | 4 | 8 | 16 | 32 (uniform transform size)")
-    ap.add_argument("--segments", type=int, default=1, help="random-access workloads: intra-period segments per GPU")
+    ap.add_argument("--segments", type=int, default=16,
+                    help="random-access workloads: intra-period segments (32 pictures each) per GPU; the I pictures of all "
+                         "segments share one whole-picture call, so few segments are dominated by its 4844 dependent launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check picture 0 against the oracle after the run")
     args = ap.parse_args()
@@ -170,7 +180,7 @@ def main():
 
     from thevc_amd import capi, workload
 
-    if args.workload.startswith("ra"):
+    if args.workload.startswith(("ra", "ldp")):
         return bench_random_access(args, torch, dist, rank, local_rank, world)
     w, h, B, qp, cfg_name = WORKLOADS[args.workload]
     h_c = h - (h % 8)  # pictures are coded in multiples of the minimum CU (8): 1080 -> 1072 + cropped row

@@ -93,3 +93,33 @@ def test_ra_pipeline_vs_oracle(B, fused):
     full = pipe.rec[4].download(with_margins=True)[0]
     assert (full[:80, 80:80 + w] == full[80, 80:80 + w]).all()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_ldp_pipeline_vs_oracle():
+    """Low-delay P (configs[2]): independent sequences, every P picture references the previous one; the
+    pipeline batches position j of all sequences into one call per stage."""
+    import torch
+    import oracle_lib as ol
+    import ra_oracle
+    from thevc_amd import capi
+    from thevc_amd import ra_pipeline as ra
+    w, h, qp, B, ip = 192, 128, 33, 8, 5
+    wl = ra.RAWorkload(w, h, B, qp, intra_period=ip, n_segments=3, seed=5, structure="ldp")
+    assert wl.segment_jobs(1) == [(ip + i, ip + i - 1, None, (ip + i) % 2) for i in range(1, ip)]
+    ctx = capi.Context(bit_depth=B, stream=torch.cuda.current_stream().cuda_stream)
+    pipe = ra.RAPipeline(ctx, torch, wl)
+    pipe.load_originals()
+    px = pipe.run()
+    torch.cuda.synchronize()
+    assert px == 3 * ip * w * h
+    for k in range(3):
+        rr, _ = ol.o_intra_frame_encode(wl.intra_tus, w, h, B, qp, wl.original(k * ip))
+        got = pipe.rec[k * ip].download()
+        assert all(np.array_equal(got[p], rr[p]) for p in range(3)), ("I picture", k)
+        recs = ra_oracle.oracle_segment(wl, k, {k * ip: rr})
+        for (poc, _, _, _) in wl.segment_jobs(k):
+            got = pipe.rec[poc].download()
+            for p in range(3):
+                assert np.array_equal(got[p], recs[poc][p]), ("P picture", poc, p)
+    ctx.close()

@@ -98,7 +98,13 @@ class TorchPicture:
 class RAWorkload:
     """Synthetic decisions shared by the GPU pipeline and the oracle check."""
 
-    def __init__(self, w, h, B, qp, intra_period=32, gop=8, n_segments=1, seed=0, bi_frac=0.5, n_lists=2, n_distinct=0):
+    def __init__(self, w, h, B, qp, intra_period=32, gop=8, n_segments=1, seed=0, bi_frac=0.5, n_lists=2, n_distinct=0,
+                 structure="ra"):
+        """structure "ra": hierarchical-B segments between I pictures (encoder_randomaccess_main.cfg);
+        "ldp": low-delay P (encoder_lowdelay_P_main.cfg) -- every segment is an independent SEQUENCE of
+        intra_period pictures, one I picture then P pictures that each reference the previous picture, so
+        nothing crosses segments and a rank only batches over the sequences it owns (replicas)."""
+        self.structure = structure
         self.w, self.h, self.B, self.qp = w, h, B, qp
         self.n_distinct, self._cache = n_distinct, {}  # > 0: cycle that many synthetic originals (large benches)
         self.ip, self.gop, self.n_segments, self.seed = intra_period, gop, n_segments, seed
@@ -122,6 +128,8 @@ class RAWorkload:
         """Coding order of segment k: (poc, ref0_poc, ref1_poc|None, list_index)."""
         base = k * self.ip
         jobs = []
+        if self.structure == "ldp":
+            return [(base + i, base + i - 1, None, (base + i) % len(self.inter)) for i in range(1, self.ip)]
         for g in range(self.ip // self.gop):
             for (off, r0, r1) in gop_order(self.gop):
                 poc = base + g * self.gop + off
@@ -144,7 +152,8 @@ class RAPipeline:
         self.lists = [{"tu": ctx.tu_list(d["tus"]), "pus_b": ctx.to_device(d["pus_b"]), "n_b": len(d["pus_b"]),
                        "pus_p": ctx.to_device(d["pus_p"]), "n_p": len(d["pus_p"])} for d in wl.inter]
         self.my_segments = [k for k in range(wl.n_segments) if k % world == rank]
-        self.my_i = sorted({k for k in range(wl.n_segments + 1) if k % world == rank})
+        last = wl.n_segments + (0 if wl.structure == "ldp" else 1)  # "ra": the closing I picture of the last segment
+        self.my_i = sorted({k for k in range(last) if k % world == rank})
         self.rec = {}   # poc -> TorchPicture (reconstruction with margins)
         self.org = {}   # poc -> TorchPicture (original, no margins needed but same class)
         # one prediction picture and one level picture per owned segment: pictures at the same GOP position
@@ -166,8 +175,9 @@ class RAPipeline:
         for poc in sorted(pocs):
             self._pic(self.org, poc).upload(self.torch, self.wl.original(poc))
             self._pic(self.rec, poc)
-        for k in self.my_segments:  # landing buffers for the I pictures received from other ranks
-            self._pic(self.rec, (k + 1) * self.wl.ip)
+        if self.wl.structure == "ra":
+            for k in self.my_segments:  # landing buffers for the I pictures received from other ranks
+                self._pic(self.rec, (k + 1) * self.wl.ip)
         n_i = len(self.my_i)
         self.lev_i = [capi.DevLevelsZ(self.ctx, self.wl.w, self.wl.h) for _ in range(n_i)]
         return len(pocs)
@@ -186,7 +196,7 @@ class RAPipeline:
             ctx._chk(L.hmx_frame_intra_encode(ctx.h, self.plan, n, org, rec, lev))
             ctx._chk(L.hmx_pic_extend_border_multi(ctx.h, n, rec, w, h, MARGIN, MARGIN))
         # phase 2: boundary I pictures travel to the owner of the previous segment (RCCL send/recv)
-        if self.world > 1:
+        if self.world > 1 and wl.structure == "ra":
             run_exchange(self.dist, self.rank, self.world, wl.n_segments, lambda ki: self.rec[ki * wl.ip].t)
         # phase 3: inter pictures in coding order; position j of every owned segment in one call per stage
         pixels = n * w * h
