@@ -10,6 +10,7 @@
  */
 #include "hmx_oracle.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -308,6 +309,396 @@ void hmo_xQuant(const int32_t *src, int32_t *dst, int N, int B, const hmo_quant_
   }
   *ac_sum = sum;
   if (cfg->sign_hide && sum >= 2) sign_bit_hiding(dst, src, hmo_scan(cfg->scan_idx, lg), deltaU, N);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Rate-distortion optimised quantisation (COM/TComTrQuant.cpp:1719-2305)
+ *
+ * Restated as three phases over per-scan-position records:
+ *   A. reverse scan: candidate level per coefficient (the quantised value or one below, whichever
+ *      costs less in D + lambda*R under the running c1/c2/Rice context state), per-group decision to
+ *      zero a whole coefficient group;
+ *   B. choice of the last significant position (scan backwards while levels are <= 1);
+ *   C. sign-bit hiding with rate-aware costs.
+ * All costs are doubles evaluated in the reference's operation order (no fused multiply-add).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  const hmo_est_bits *e;
+  double lambda;
+} rdoq_rates;
+
+static int rdoq_base_level(unsigned c1i, unsigned c2i) { return c1i < 8 ? (2 + (c2i < 1)) : 1; }
+
+/* rate of coding |level| beyond the significance flag, as a double-valued COST (xGetICRateCost :2508) */
+static double rdoq_level_cost(const rdoq_rates *r, unsigned lvl, unsigned ctx1, unsigned ctx2, unsigned rice, unsigned c1i,
+                              unsigned c2i) {
+  double rate = 32768; /* the sign: one equiprobable bin */
+  unsigned base = (unsigned)rdoq_base_level(c1i, c2i);
+  if (lvl >= base) {
+    unsigned sym = lvl - base, len;
+    if (sym < (3u << rice)) {
+      len = sym >> rice;
+      rate += (double)((len + 1 + rice) << 15);
+    } else {
+      len = rice;
+      sym -= 3u << rice;
+      while (sym >= (1u << len)) sym -= 1u << (len++);
+      rate += (double)((3 + len + 1 - rice + len) << 15);
+    }
+    if (c1i < 8) {
+      rate += r->e->greater1[ctx1][1];
+      if (c2i < 1) rate += r->e->greater2[ctx2][1];
+    }
+  } else if (lvl == 1) {
+    rate += r->e->greater1[ctx1][0];
+  } else { /* lvl == 2 */
+    rate += r->e->greater1[ctx1][1];
+    rate += r->e->greater2[ctx2][0];
+  }
+  return r->lambda * rate;
+}
+
+/* integer rate of |level| (xGetICRate :2577): used only for the sign-hiding deltas */
+static int rdoq_level_rate(const rdoq_rates *r, unsigned lvl, unsigned ctx1, unsigned ctx2, unsigned rice, unsigned c1i,
+                           unsigned c2i) {
+  static const unsigned range[5] = {7, 14, 26, 46, 78}, prefix[5] = {8, 7, 6, 5, 4};
+  int rate = 0;
+  unsigned base = (unsigned)rdoq_base_level(c1i, c2i);
+  if (lvl >= base) {
+    unsigned sym = lvl - base, max_vlc = range[rice];
+    if (sym > max_vlc) {
+      unsigned a = sym - max_vlc;
+      int egs = 1;
+      for (unsigned m = 2; a >= m; m <<= 1) egs += 2;
+      rate += egs << 15;
+      sym = sym < max_vlc + 1 ? sym : max_vlc + 1;
+    }
+    unsigned pre = (uint16_t)(sym >> rice) + 1;
+    unsigned bins = (pre < prefix[rice] ? pre : prefix[rice]) + rice;
+    rate += (int)((uint16_t)bins << 15);
+    if (c1i < 8) {
+      rate += r->e->greater1[ctx1][1];
+      if (c2i < 1) rate += r->e->greater2[ctx2][1];
+    }
+  } else if (lvl == 0) {
+    return 0;
+  } else if (lvl == 1) {
+    rate += r->e->greater1[ctx1][0];
+  } else {
+    rate += r->e->greater1[ctx1][1];
+    rate += r->e->greater2[ctx2][0];
+  }
+  return rate;
+}
+
+/* significance context of a coefficient (getSigCtxInc :2349, REMOVAL_8x2_2x8_CG branch) */
+static int rdoq_sig_ctx(int pattern, int scan_idx, int px, int py, int log2n, int is_luma) {
+  static const int map4[16] = {0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8};
+  if (px + py == 0) return 0;
+  if (log2n == 2) return map4[4 * py + px];
+  int offset = log2n == 3 ? (scan_idx == HMO_SCAN_DIAG ? 9 : 15) : (is_luma ? 21 : 12);
+  int sx = px & 3, sy = py & 3, cnt;
+  if (pattern == 0)
+    cnt = sx + sy <= 2 ? (sx + sy == 0 ? 2 : 1) : 0;
+  else if (pattern == 1)
+    cnt = sy <= 1 ? (sy == 0 ? 2 : 1) : 0;
+  else if (pattern == 2)
+    cnt = sx <= 1 ? (sx == 0 ? 2 : 1) : 0;
+  else
+    cnt = 2;
+  return ((is_luma && ((px >> 2) + (py >> 2)) > 0) ? 3 : 0) + offset + cnt;
+}
+
+static double rdoq_last_cost(const rdoq_rates *r, unsigned px, unsigned py) { /* xGetRateLast :2652 */
+  static const unsigned grp[32] = {0, 1, 2, 3, 4, 4, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 9};
+  unsigned cx = grp[px], cy = grp[py];
+  double cost = r->e->last_x[cx] + r->e->last_y[cy];
+  if (cx > 3) cost += 32768.0 * ((cx - 2) >> 1);
+  if (cy > 3) cost += 32768.0 * ((cy - 2) >> 1);
+  return r->lambda * cost;
+}
+
+void hmo_xRateDistOptQuant(const int32_t *src, int32_t *dst, int N, int B, const hmo_rdoq_cfg *cfg,
+                           const hmo_est_bits *est, uint32_t *abs_sum) {
+  const int lg = ilog2(N), nn = N * N, G = N / 4, n_cg = nn >> 4;
+  const int tshift = 15 - B - lg, qbits = 14 + cfg->per + tshift, inc = B - 8;
+  const int q = hmo_quant_scale(cfg->rem);
+  const int scan_idx = cfg->scan_idx == HMO_SCAN_ZIGZAG ? HMO_SCAN_DIAG : cfg->scan_idx; /* :1770-1774 */
+  const uint32_t *scan = hmo_scan(scan_idx, lg);
+  const rdoq_rates R = {est, cfg->lambda};
+  /* flat error scale (setErrScaleCoeff :2794-2818) */
+  double err_scale = (double)(1 << 15);
+  err_scale = err_scale * ldexp(1.0, -2 * tshift); /* pow(2.0, -2.0 * iTransformShift): an exact power of two */
+  err_scale = err_scale / (double)q / (double)q / (double)(1 << (2 * inc));
+
+  static double cost_coded[1024], cost_sig[1024], cost_zero[1024], cost_cg_sig[64];
+  static int rate_up[1024], rate_down[1024], sig_delta[1024], delta_u[1024];
+  unsigned cg_flag[64];
+  memset(cost_coded, 0, sizeof(double) * nn);
+  memset(cost_sig, 0, sizeof(double) * nn);
+  memset(rate_up, 0, sizeof(int) * nn);
+  memset(rate_down, 0, sizeof(int) * nn);
+  memset(sig_delta, 0, sizeof(int) * nn);
+  memset(delta_u, 0, sizeof(int) * nn);
+  memset(cost_cg_sig, 0, sizeof(cost_cg_sig));
+  memset(cg_flag, 0, sizeof(cg_flag));
+  for (int i = 0; i < nn; i++) dst[i] = 0;
+
+  double uncoded = 0, base = 0;
+  int last_pos = -1, last_cg = -1;
+  unsigned ctx_set = 0, rice = 0, c1i = 0, c2i = 0;
+  int c1 = 1, c2 = 0;
+
+  /* ---- phase A ---- */
+  for (int cg = n_cg - 1; cg >= 0; cg--) {
+    /* the group's position in the grid of groups: from its first scan entry */
+    const unsigned p0 = scan[cg * 16], gx = (p0 & (N - 1)) >> 2, gy = (p0 >> lg) >> 2, gpos = gy * G + gx;
+    double s_sig = 0, s_sig0 = 0, s_coded = 0, s_uncoded = 0;
+    int nnz_before0 = 0;
+    int pattern = -1; /* calcPatternSigCtx :2315 */
+    if (N != 4) {
+      unsigned right = gx < (unsigned)G - 1 ? cg_flag[gy * G + gx + 1] != 0 : 0;
+      unsigned lower = gy < (unsigned)G - 1 ? cg_flag[(gy + 1) * G + gx] != 0 : 0;
+      pattern = (int)(right + (lower << 1));
+    }
+    for (int k = 15; k >= 0; k--) {
+      const int sp = cg * 16 + k;
+      const unsigned bp = scan[sp];
+      int64_t wide = (int64_t)abs(src[bp]) * q;
+      const int64_t cap = (int64_t)2147483647 - ((int64_t)1 << (qbits - 1));
+      const int ld = (int)(wide < cap ? wide : cap); /* "level double": |c| * q */
+      const unsigned max_lvl = (unsigned)((ld + (1 << (qbits - 1))) >> qbits);
+      const double e0 = (double)ld;
+      cost_zero[sp] = e0 * e0 * err_scale;
+      uncoded += cost_zero[sp];
+      dst[bp] = (int32_t)max_lvl;
+      if (max_lvl > 0 && last_pos < 0) {
+        last_pos = sp;
+        ctx_set = (sp < 16 || !cfg->is_luma) ? 0 : 2;
+        last_cg = cg;
+      }
+      if (last_pos >= 0) {
+        const unsigned ctx1 = 4 * ctx_set + (unsigned)c1, ctx2 = ctx_set + (unsigned)c2;
+        const int is_last = sp == last_pos;
+        unsigned ctx_sig = 0;
+        if (!is_last) ctx_sig = (unsigned)rdoq_sig_ctx(pattern, scan_idx, (int)(bp & (N - 1)), (int)(bp >> lg), lg, cfg->is_luma);
+        /* best level among {max_lvl, max_lvl - 1 (>= 1)} and, when allowed, zero (xGetCodedLevel :2446) */
+        unsigned best = 0;
+        double sig1 = 0;
+        int decided = 0;
+        if (!is_last && max_lvl < 3) {
+          cost_sig[sp] = R.lambda * est->sig[ctx_sig][0];
+          cost_coded[sp] = cost_zero[sp] + cost_sig[sp];
+          if (max_lvl == 0) decided = 1;
+        } else {
+          cost_coded[sp] = 1.7e+308;
+        }
+        if (!decided) {
+          if (!is_last) sig1 = R.lambda * est->sig[ctx_sig][1];
+          const unsigned lo = max_lvl > 1 ? max_lvl - 1 : 1;
+          for (int l = (int)max_lvl; l >= (int)lo; l--) {
+            const double d = (double)(ld - (l << qbits));
+            double cst = d * d * err_scale + rdoq_level_cost(&R, (unsigned)l, ctx1, ctx2, rice, c1i, c2i);
+            cst += sig1;
+            if (cst < cost_coded[sp]) {
+              best = (unsigned)l;
+              cost_coded[sp] = cst;
+              cost_sig[sp] = sig1;
+            }
+          }
+        }
+        if (!is_last) sig_delta[bp] = est->sig[ctx_sig][1] - est->sig[ctx_sig][0];
+        delta_u[bp] = (ld - ((int)best << qbits)) >> (qbits - 8);
+        if (best > 0) {
+          const int now = rdoq_level_rate(&R, best, ctx1, ctx2, rice, c1i, c2i);
+          rate_up[bp] = rdoq_level_rate(&R, best + 1, ctx1, ctx2, rice, c1i, c2i) - now;
+          rate_down[bp] = rdoq_level_rate(&R, best - 1, ctx1, ctx2, rice, c1i, c2i) - now;
+        } else {
+          rate_up[bp] = est->greater1[ctx1][0];
+        }
+        dst[bp] = (int32_t)best;
+        base += cost_coded[sp];
+        /* context state for the next (lower) scan position (:1952-2003) */
+        if (best >= (unsigned)rdoq_base_level(c1i, c2i) && best > 3u * (1u << rice)) rice = rice + 1 < 4 ? rice + 1 : 4;
+        if (best >= 1) c1i++;
+        if (best > 1) {
+          c1 = 0;
+          c2 += (c2 < 2);
+          c2i++;
+        } else if (c1 < 3 && c1 > 0 && best) {
+          c1++;
+        }
+        if ((sp % 16 == 0) && sp > 0) {
+          c2 = 0;
+          rice = 0;
+          c1i = 0;
+          c2i = 0;
+          ctx_set = (sp == 16 || !cfg->is_luma) ? 0 : 2;
+          if (c1 == 0) ctx_set++;
+          c1 = 1;
+        }
+      } else {
+        base += cost_zero[sp];
+      }
+      s_sig += cost_sig[sp];
+      if (k == 0) s_sig0 = cost_sig[sp];
+      if (dst[bp]) {
+        cg_flag[gpos] = 1;
+        s_coded += cost_coded[sp] - cost_sig[sp];
+        s_uncoded += cost_zero[sp];
+        if (k != 0) nnz_before0++;
+      }
+    }
+    /* whole-group decision (:2022-2086) */
+    if (last_cg >= 0) {
+      if (cg) {
+        unsigned right = gx < (unsigned)G - 1 ? cg_flag[gy * G + gx + 1] != 0 : 0;
+        unsigned lower = gy < (unsigned)G - 1 ? cg_flag[(gy + 1) * G + gx] != 0 : 0;
+        const unsigned cctx = right || lower; /* getSigCoeffGroupCtxInc :2707 */
+        if (cg_flag[gpos] == 0) {
+          base += R.lambda * est->sig_cg[cctx][0] - s_sig;
+          cost_cg_sig[cg] = R.lambda * est->sig_cg[cctx][0];
+        } else if (cg < last_cg) {
+          if (nnz_before0 == 0) {
+            base -= s_sig0;
+            s_sig -= s_sig0;
+          }
+          double zero_cost = base;
+          base += R.lambda * est->sig_cg[cctx][1];
+          zero_cost += R.lambda * est->sig_cg[cctx][0];
+          cost_cg_sig[cg] = R.lambda * est->sig_cg[cctx][1];
+          zero_cost += s_uncoded;
+          zero_cost -= s_coded;
+          zero_cost -= s_sig;
+          if (zero_cost < base) {
+            cg_flag[gpos] = 0;
+            base = zero_cost;
+            cost_cg_sig[cg] = R.lambda * est->sig_cg[cctx][0];
+            for (int k = 15; k >= 0; k--) {
+              const int sp = cg * 16 + k;
+              const unsigned bp = scan[sp];
+              if (dst[bp]) {
+                dst[bp] = 0;
+                cost_coded[sp] = cost_zero[sp];
+                cost_sig[sp] = 0;
+              }
+            }
+          }
+        }
+      } else {
+        cg_flag[gpos] = 1;
+      }
+    }
+  }
+  if (last_pos < 0) return;
+
+  /* ---- phase B: last position ---- */
+  double best_cost;
+  if (cfg->root_cbf) {
+    best_cost = uncoded + R.lambda * est->root_cbf[0][0];
+    base += R.lambda * est->root_cbf[0][1];
+  } else {
+    best_cost = uncoded + R.lambda * est->cbf[cfg->cbf_ctx][0];
+    base += R.lambda * est->cbf[cfg->cbf_ctx][1];
+  }
+  int best_last_p1 = 0, found = 0;
+  for (int cg = last_cg; cg >= 0 && !found; cg--) {
+    const unsigned p0 = scan[cg * 16], gpos = ((p0 >> lg) >> 2) * G + ((p0 & (N - 1)) >> 2);
+    base -= cost_cg_sig[cg];
+    if (!cg_flag[gpos]) continue;
+    for (int k = 15; k >= 0; k--) {
+      const int sp = cg * 16 + k;
+      if (sp > last_pos) continue;
+      const unsigned bp = scan[sp];
+      if (dst[bp]) {
+        const unsigned py = bp >> lg, px = bp & (N - 1);
+        const double lc = scan_idx == HMO_SCAN_VER ? rdoq_last_cost(&R, py, px) : rdoq_last_cost(&R, px, py);
+        const double total = base + lc - cost_sig[sp];
+        if (total < best_cost) {
+          best_last_p1 = sp + 1;
+          best_cost = total;
+        }
+        if (dst[bp] > 1) {
+          found = 1;
+          break;
+        }
+        base -= cost_coded[sp];
+        base += cost_zero[sp];
+      } else {
+        base -= cost_sig[sp];
+      }
+    }
+  }
+  for (int sp = 0; sp < best_last_p1; sp++) {
+    const unsigned bp = scan[sp];
+    const int l = dst[bp];
+    *abs_sum += (uint32_t)l;
+    dst[bp] = src[bp] < 0 ? -l : l;
+  }
+  for (int sp = best_last_p1; sp <= last_pos; sp++) dst[scan[sp]] = 0;
+
+  /* ---- phase C: sign-bit hiding with rate-aware costs (:2203-2304) ---- */
+  if (!(cfg->sign_hide && *abs_sum >= 2)) return;
+  const int invq = hmo_inv_quant_scale(cfg->rem);
+  const int64_t rd_factor =
+      (int64_t)((double)invq * (double)invq * (double)(1 << (2 * cfg->per)) / cfg->lambda / 16 / (double)(1 << (2 * inc)) + 0.5);
+  int seen_last = -1;
+  for (int sub = (nn - 1) >> 4; sub >= 0; sub--) {
+    const int o = sub << 4;
+    int first = 16, lastnz = -1, sum = 0;
+    for (int n = 15; n >= 0; n--)
+      if (dst[scan[n + o]]) {
+        lastnz = n;
+        break;
+      }
+    for (int n = 0; n < 16; n++)
+      if (dst[scan[n + o]]) {
+        first = n;
+        break;
+      }
+    for (int n = first; n <= lastnz; n++) sum += dst[scan[n + o]];
+    if (lastnz >= 0 && seen_last == -1) seen_last = 1;
+    if (lastnz - first >= 4) {
+      const unsigned signbit = dst[scan[o + first]] > 0 ? 0 : 1;
+      if (signbit != (unsigned)(sum & 1)) {
+        int64_t min_cost = INT64_MAX, cur = INT64_MAX;
+        int min_pos = -1, final_change = 0, change = 0;
+        for (int n = (seen_last == 1 ? lastnz : 15); n >= 0; n--) {
+          const unsigned bp = scan[n + o];
+          if (dst[bp] != 0) {
+            const int64_t up = rd_factor * (-delta_u[bp]) + rate_up[bp];
+            int64_t down = rd_factor * (delta_u[bp]) + rate_down[bp] - (abs(dst[bp]) == 1 ? ((1 << 15) + sig_delta[bp]) : 0);
+            if (seen_last == 1 && lastnz == n && abs(dst[bp]) == 1) down -= (4 << 15);
+            if (up < down) {
+              cur = up;
+              change = 1;
+            } else {
+              change = -1;
+              cur = (n == first && abs(dst[bp]) == 1) ? INT64_MAX : down;
+            }
+          } else {
+            cur = rd_factor * (-(abs(delta_u[bp]))) + (1 << 15) + rate_up[bp] + sig_delta[bp];
+            change = 1;
+            if (n < first) {
+              const unsigned s = src[bp] >= 0 ? 0 : 1;
+              if (s != signbit) cur = INT64_MAX;
+            }
+          }
+          if (cur < min_cost) {
+            min_cost = cur;
+            final_change = change;
+            min_pos = (int)bp;
+          }
+        }
+        /* the reference tests the flat quantiser coefficient (never +-32768) here (:2290): no effect */
+        if (src[min_pos] >= 0)
+          dst[min_pos] += final_change;
+        else
+          dst[min_pos] -= final_change;
+      }
+    }
+    if (seen_last == 1) seen_last = 0;
+  }
 }
 
 /* Flat de-quantiser (COM/TComTrQuant.cpp:1343-1354). */

@@ -70,6 +70,34 @@ int hmo_coef_scan_idx(int N, int is_luma, int is_intra, int dir_mode);
 void hmo_xQuant(const int32_t *src, int32_t *dst, int N, int B, const hmo_quant_cfg *cfg,
                 uint32_t *ac_sum);
 void hmo_xDeQuant(const int32_t *src, int32_t *dst, int N, int B, int per, int rem);
+
+/* Rate-distortion optimised quantisation, xRateDistOptQuant (COM/TComTrQuant.cpp:1719-2305) with its
+ * helpers (:2315-2735), flat scaling (setErrScaleCoeff :2794-2818), as compiled in the reference
+ * (REMOVE_NSQT, REMOVAL_8x2_2x8_CG, REMOVE_NUM_GREATER1, COEF_REMAIN_BIN_REDUCTION 3, C1FLAG_NUMBER 8,
+ * C2FLAG_NUMBER 1).  Bit estimates are an INPUT: the table TEncSbac::estBit prepares for the block's size
+ * and texture type (estBitsSbacStruct, COM/TComTrQuant.h:59-72, same field order, 1/32768 bit units). */
+typedef struct {
+  int32_t sig_cg[2][2];    /* significantCoeffGroupBits */
+  int32_t sig[42][2];      /* significantBits */
+  int32_t last_x[32], last_y[32];
+  int32_t greater1[24][2]; /* m_greaterOneBits */
+  int32_t greater2[6][2];  /* m_levelAbsBits */
+  int32_t cbf[15][2];      /* blockCbpBits */
+  int32_t root_cbf[4][2];  /* blockRootCbpBits */
+  int32_t scan_zigzag[2], scan_nonzigzag[2];
+} hmo_est_bits;
+typedef struct {
+  int per, rem;      /* m_cQP of the block's texture type */
+  int is_luma;       /* eTType == TEXT_LUMA */
+  int is_intra;      /* pcCU->isIntra */
+  int scan_idx;      /* getCoefScanIdx (HMO_SCAN_*; ZIGZAG is treated as DIAG) */
+  int root_cbf;      /* 1: inter luma block with transform index 0 -> blockRootCbpBits[0] (:2139-2144) */
+  int cbf_ctx;       /* otherwise: index into blockCbpBits, texture offset included (:2147-2150) */
+  int sign_hide;     /* PPS SignHideFlag */
+  double lambda;     /* m_dLambda */
+} hmo_rdoq_cfg;
+void hmo_xRateDistOptQuant(const int32_t *src, int32_t *dst, int N, int B, const hmo_rdoq_cfg *cfg,
+                           const hmo_est_bits *est, uint32_t *abs_sum);
 /* transformNxN / invtransformNxN without the TComDataCU plumbing (COM/TComTrQuant.cpp:1373-1450) */
 void hmo_transformNxN(const int16_t *resi, int stride, int32_t *level, int N, int B, unsigned mode,
                       int transform_skip, int bypass, const hmo_quant_cfg *cfg, uint32_t *abs_sum);

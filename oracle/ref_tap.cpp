@@ -86,6 +86,7 @@ int ref_init(int bit_depth, int pic_w, int pic_h, int sign_hide) {
   S->sps.setMaxTrSize(32);
   S->sps.setQpBDOffsetY(6 * (bit_depth - 8));
   S->sps.setQpBDOffsetC(6 * (bit_depth - 8));
+  S->tq.setFlatScalingList(); // the error-scale tables of RDOQ depend on the bit depth set above
   S->pps.setSignHideFlag(sign_hide);
   S->pps.setConstrainedIntraPred(false);
   S->pps.setSPS(&S->sps);
@@ -190,6 +191,38 @@ void ref_transformNxN(int qpy, int slice_type /*0 B,1 P,2 I*/, int ttype, int is
   Int *arl = NULL;
   UInt sum = 0;
   S->tq.transformNxN(cu, resi, stride, level, arl, N, N, sum, (TextType)ttype, 0, ts != 0);
+  *abs_sum = sum;
+}
+// xRateDistOptQuant with a caller-supplied bit-estimate table (what TEncSbac::estBit would have left in
+// m_pcEstBitsSbac for this block size / texture type) and Lagrange multiplier.
+int ref_sizeof_estbits() { return (int)sizeof(estBitsSbacStruct); }
+int ref_cbf_ctx(int ttype, int tr_idx) {
+  TComDataCU *cu = S->pic->getCU(0);
+  int ctx = (int)cu->getCtxQtCbf(0, (TextType)ttype, (UInt)tr_idx);
+  return (ttype ? TEXT_CHROMA : ttype) * NUM_QT_CBF_CTX + ctx;
+}
+void ref_xRateDistOptQuant(int qpy, int slice_type, int ttype, int is_intra, int dir_mode, int tr_idx, double lambda,
+                           const int *est_blob, int *coef, int *level, int N, unsigned *abs_sum) {
+  TComDataCU *cu = S->pic->getCU(0);
+  TComSlice *sl = S->pic->getSlice(0);
+  sl->setSliceType((SliceType)slice_type);
+  sl->setSliceQp(qpy);
+  sl->setSliceQpBase(qpy);
+  cu->m_pcSlice = sl;
+  cu->m_pePredMode[0] = is_intra ? MODE_INTRA : MODE_INTER;
+  cu->m_puhLumaIntraDir[0] = (UChar)dir_mode;
+  cu->m_puhChromaIntraDir[0] = (UChar)dir_mode;
+  cu->m_puhDepth[0] = 0;
+  cu->m_puhTrIdx[0] = (UChar)tr_idx;
+  cu->m_CUTransquantBypass[0] = false;
+  Int bd = (ttype == 0) ? S->sps.getQpBDOffsetY() : S->sps.getQpBDOffsetC();
+  S->tq.setQPforQuant(qpy, (TextType)ttype, bd, 0);
+  memcpy(S->tq.m_pcEstBitsSbac, est_blob, sizeof(estBitsSbacStruct));
+  S->tq.m_dLambda = lambda;
+  static Int arl_buf[32 * 32];
+  Int *arl = arl_buf;
+  UInt sum = 0;
+  S->tq.xRateDistOptQuant(cu, coef, level, arl, N, N, sum, (TextType)ttype, 0);
   *abs_sum = sum;
 }
 void ref_invtransformNxN(int qpy, int ttype, int bypass, unsigned mode, short *resi, unsigned stride,

@@ -28,6 +28,40 @@ class Qp(C.Structure):
     _fields_ = [("qp", ci), ("per", ci), ("rem", ci)]
 
 
+class EstBits(C.Structure):  # hmo_est_bits == estBitsSbacStruct (COM/TComTrQuant.h:59-72), 1/32768 bit
+    _fields_ = [("sig_cg", (C.c_int32 * 2) * 2), ("sig", (C.c_int32 * 2) * 42), ("last_x", C.c_int32 * 32),
+                ("last_y", C.c_int32 * 32), ("greater1", (C.c_int32 * 2) * 24), ("greater2", (C.c_int32 * 2) * 6),
+                ("cbf", (C.c_int32 * 2) * 15), ("root_cbf", (C.c_int32 * 2) * 4), ("scan_zigzag", C.c_int32 * 2),
+                ("scan_nonzigzag", C.c_int32 * 2)]
+
+
+class RdoqCfg(C.Structure):  # hmo_rdoq_cfg
+    _fields_ = [("per", ci), ("rem", ci), ("is_luma", ci), ("is_intra", ci), ("scan_idx", ci), ("root_cbf", ci),
+                ("cbf_ctx", ci), ("sign_hide", ci), ("lam", C.c_double)]
+
+
+def make_est_bits(rng):
+    """A plausible CABAC bit-estimate table: every context holds a probability p of the bin being 1;
+    bits[0] = -log2(1-p), bits[1] = -log2(p) in 1/32768 bit (TEncBinCABAC's entropy-bits scale)."""
+    e = EstBits()
+
+    def pair(dst):
+        p = float(rng.uniform(0.03, 0.97))
+        dst[0] = int(round(-np.log2(1 - p) * 32768))
+        dst[1] = int(round(-np.log2(p) * 32768))
+
+    for name, n in (("sig_cg", 2), ("sig", 42), ("greater1", 24), ("greater2", 6), ("cbf", 15), ("root_cbf", 4)):
+        arr = getattr(e, name)
+        for i in range(n):
+            pair(arr[i])
+    for i in range(32):  # cumulative cost of the truncated-unary last-position prefix
+        e.last_x[i] = int(rng.integers(8000, 60000) * (1 + i // 4))
+        e.last_y[i] = int(rng.integers(8000, 60000) * (1 + i // 4))
+    pair(e.scan_zigzag)
+    pair(e.scan_nonzigzag)
+    return e
+
+
 class FrameCfg(C.Structure):
     _fields_ = [("pic_w", ci), ("pic_h", ci), ("ctu", ci), ("B", ci), ("qp", ci),
                 ("chroma_qp_offset", ci), ("sign_hide", ci)]
@@ -70,6 +104,8 @@ def oracle():
         L.hmo_setQPforQuant.restype = Qp
         L.hmo_coef_scan_idx.argtypes = [ci, ci, ci, ci]
         L.hmo_xQuant.argtypes = [i32p, i32p, ci, ci, C.POINTER(QuantCfg), C.POINTER(C.c_uint32)]
+        L.hmo_xRateDistOptQuant.argtypes = [i32p, i32p, ci, ci, C.POINTER(RdoqCfg), C.POINTER(EstBits), C.POINTER(C.c_uint32)]
+        L.hmo_xRateDistOptQuant.restype = None
         L.hmo_xDeQuant.argtypes = [i32p, i32p, ci, ci, ci, ci]
         L.hmo_transformNxN.argtypes = [i16p, ci, i32p, ci, ci, cu, ci, ci, C.POINTER(QuantCfg),
                                        C.POINTER(C.c_uint32)]
@@ -220,3 +256,25 @@ def r_intra_frame_encode(tus, w, h, B, qp, org, sign_hide=1):
     R.ref_intra_frame_encode(t.ctypes.data, len(t), qp, o[0], o[1], o[2], rec[0].reshape(-1), rec[1].reshape(-1),
                              rec[2].reshape(-1), lev[0].reshape(-1), lev[1].reshape(-1), lev[2].reshape(-1))
     return rec, lev
+
+
+def o_rdoq(coef, N, B, cfg, est):
+    coef = np.ascontiguousarray(coef, np.int32).reshape(-1)
+    lvl = np.zeros(N * N, np.int32)
+    s = C.c_uint32(0)
+    oracle().hmo_xRateDistOptQuant(coef, lvl, N, B, C.byref(cfg), C.byref(est), C.byref(s))
+    return lvl.reshape(N, N), s.value
+
+
+def r_rdoq(coef, N, qpy, slice_type, ttype, is_intra, dir_mode, tr_idx, lam, est):
+    """the compiled reference's xRateDistOptQuant; ref().ref_init(B, ...) must have been called"""
+    R = ref()
+    R.ref_xRateDistOptQuant.argtypes = [ci, ci, ci, ci, ci, ci, C.c_double, C.POINTER(EstBits), i32p, i32p, ci,
+                                        C.POINTER(C.c_uint32)]
+    R.ref_xRateDistOptQuant.restype = None
+    assert R.ref_sizeof_estbits() == C.sizeof(EstBits)
+    coef = np.ascontiguousarray(coef, np.int32).reshape(-1).copy()
+    lvl = np.zeros(N * N, np.int32)
+    s = C.c_uint32(0)
+    R.ref_xRateDistOptQuant(qpy, slice_type, ttype, is_intra, dir_mode, tr_idx, lam, C.byref(est), coef, lvl, N, C.byref(s))
+    return lvl.reshape(N, N), s.value

@@ -175,6 +175,47 @@ def test_transformNxN_flat_quant_sbh(B, N):
     assert n_changed > 5  # the SBH path was exercised
 
 
+@pytest.mark.parametrize("N", [4, 8, 16, 32])
+def test_xRateDistOptQuant(B, N):
+    """RDOQ (the quantiser of every shipped cfg): the oracle's restatement vs the reference's
+    xRateDistOptQuant on transform coefficients of random residuals, with random CABAC bit-estimate tables,
+    Lagrange multipliers, QPs, texture types, scans (intra direction), intra/inter and both cbf branches."""
+    R, O = ol.ref(), ol.oracle()
+    rng = np.random.default_rng(900 + N + B)
+    bd = 6 * (B - 8)
+    mx = (1 << B) - 1
+    n_nonzero = n_differs_from_flat = 0
+    for it in range(120):
+        ttype = (0, 2, 3)[it % 3] if N < 32 else 0
+        is_intra = it % 4 != 3
+        mode = int(rng.integers(0, 35))
+        tr_idx = int(rng.integers(0, 2))
+        qpy = int(rng.choice([10, 22, 27, 32, 37, 45]))
+        slice_type = 2 if is_intra else [1, 0][it % 2]
+        lam = float(rng.choice([3.0, 17.5, 58.0, 140.25, 900.0]))
+        amp = int(rng.choice([4, 20, 60, 200, mx, mx]))
+        resi = rng.integers(-amp, amp + 1, N * N).astype(np.int16)
+        coef = np.zeros(N * N, np.int32)
+        tmode = mode if (ttype == 0 and is_intra) else REG_DCT
+        O.hmo_xT(tmode, resi, N, coef, N, B)
+        est = ol.make_est_bits(rng)
+        la, sa = ol.r_rdoq(coef, N, qpy, slice_type, ttype, int(is_intra), mode, tr_idx, lam, est)
+        q = O.hmo_setQPforQuant(qpy, int(ttype != 0), bd, 0)
+        scan = O.hmo_coef_scan_idx(N, int(ttype == 0), int(is_intra), mode)
+        root = int((not is_intra) and ttype == 0 and tr_idx == 0)
+        cfg = ol.RdoqCfg(q.per, q.rem, int(ttype == 0), int(is_intra), scan, root, R.ref_cbf_ctx(ttype, tr_idx), 1, lam)
+        lb, sb = ol.o_rdoq(coef, N, B, cfg, est)
+        assert np.array_equal(la, lb), (it, N, B, np.argwhere(la != lb)[:4])
+        assert sa == sb
+        n_nonzero += int(sa > 0)
+        fc = ol.quant_cfg(q.per, q.rem, intra_slice=int(slice_type == 2), sign_hide=1, scan_idx=scan)
+        lf = np.zeros(N * N, np.int32)
+        sf = C.c_uint32(0)
+        O.hmo_xQuant(coef, lf, N, B, C.byref(fc), C.byref(sf))
+        n_differs_from_flat += int(not np.array_equal(lf.reshape(N, N), lb))
+    assert n_nonzero >= 30 and n_differs_from_flat >= 15, (n_nonzero, n_differs_from_flat)  # the RD decisions were exercised
+
+
 def _rand_flags(rng, n, kind):
     total = 4 * n + 1
     if kind == 0:
