@@ -100,6 +100,33 @@ int hmx_xITransformSkip(hmx_ctx *ctx, const int32_t *coef, hmx_pel *resi, unsign
 /* xQuant, flat path + signBitHidingHDQ (TComTrQuant.cpp:1102-1270, 977-1100); ac_sum accumulates */
 int hmx_xQuant(hmx_ctx *ctx, const int32_t *src, hmx_coeff *dst, int w, int h, uint32_t *ac_sum,
                int text_type, const hmx_quant_param *qp);
+/* xRateDistOptQuant (TComTrQuant.cpp:1719-2305), the quantiser transformNxN selects when RDOQ is on
+ * (:1122-1128; every shipped cfg).  It reads CABAC bit estimates that TEncSbac::estBit leaves in
+ * m_pcEstBitsSbac for the block's size and texture type (estBitsSbacStruct, TComTrQuant.h:59-72; same
+ * field order here, 1/32768 bit) and the Lagrange multiplier m_dLambda: both are inputs. */
+typedef struct hmx_est_bits {
+  int32_t significantCoeffGroupBits[2][2];
+  int32_t significantBits[42][2];
+  int32_t lastXBits[32];
+  int32_t lastYBits[32];
+  int32_t greaterOneBits[24][2];
+  int32_t levelAbsBits[6][2];
+  int32_t blockCbpBits[15][2];
+  int32_t blockRootCbpBits[4][2];
+  int32_t scanZigzag[2];
+  int32_t scanNonZigzag[2];
+} hmx_est_bits;
+typedef struct hmx_rdoq_param {
+  hmx_qp qp;       /* m_cQP */
+  int sign_hide;   /* PPS getSignHideFlag() */
+  int is_intra;    /* pcCU->isIntra(uiAbsPartIdx) */
+  int dir_mode;    /* intra direction used by getCoefScanIdx */
+  int root_cbf;    /* 1: inter luma block with transform index 0 -> blockRootCbpBits[0] (:2139-2144) */
+  int cbf_ctx;     /* otherwise the index into blockCbpBits, texture offset included (:2147-2150) */
+  double lambda;   /* m_dLambda */
+} hmx_rdoq_param;
+int hmx_xRateDistOptQuant(hmx_ctx *ctx, const int32_t *src, hmx_coeff *dst, int w, int h, uint32_t *abs_sum,
+                          int text_type, const hmx_rdoq_param *rp, const hmx_est_bits *est);
 /* xDeQuant, flat path (TComTrQuant.cpp:1272-1355) */
 int hmx_xDeQuant(hmx_ctx *ctx, const hmx_coeff *src, int32_t *dst, int w, int h, const hmx_qp *qp);
 /* transformNxN (TComTrQuant.cpp:1373-1426): uiMode is derived as the reference does
@@ -200,6 +227,17 @@ int hmx_batch_residual_transformNxN(hmx_ctx *ctx, const hmx_tu_list *list, const
  * when pred != NULL the reconstruction Clip(pred + resi) is written instead (TComYuv::addClip). */
 int hmx_batch_invtransformNxN(hmx_ctx *ctx, const hmx_tu_list *list, const hmx_levels *lev, const hmx_pic *pred,
                               const hmx_pic *out, const hmx_pic_param *pp);
+/* RDOQ over a list of blocks (host list): Int coefficients in `coef` (plane geometry, e.g. the output of the
+ * xT drop-in or of a batch transform without quantisation) -> levels in `lev`; d_abs_sum[i] (device, may be
+ * NULL) receives block i's absolute sum.  side[i] carries what the reference reads from the CU for block i
+ * and which bit-estimate table (est[side[i].est_idx], host array) applies.  One lane per block. */
+typedef struct hmx_rdoq_side {
+  uint16_t est_idx;
+  uint8_t root_cbf, cbf_ctx;
+} hmx_rdoq_side;
+int hmx_batch_xRateDistOptQuant(hmx_ctx *ctx, const hmx_tu *tus, const hmx_rdoq_side *side, int n, const hmx_levels *coef,
+                                const hmx_levels *lev, uint32_t *d_abs_sum, const hmx_pic_param *pp,
+                                const hmx_est_bits *est, int n_est, double lambda_luma, double lambda_chroma);
 /* Intra prediction of a list of blocks from a reconstructed picture (all neighbours are read
  * from rec as it is: the caller guarantees the dependency order).  Output in plane geometry of
  * `pred`.  HOT LOOP A shape (ENC/TEncSearch.cpp:2534): d_modes != NULL evaluates modes[0..n_modes) for

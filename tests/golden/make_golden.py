@@ -74,6 +74,42 @@ def quant(R, B, rng):
     return out
 
 
+def rdoq(R, B, rng):
+    """xRateDistOptQuant of the compiled reference: coefficients (the reference's own xT of random residuals),
+    a random CABAC bit-estimate table and Lagrange multiplier per case -> levels and their absolute sum."""
+    out = {}
+    mx = (1 << B) - 1
+    for N in (4, 8, 16, 32):
+        par, lam_l, est_l, coef_l, lev_l, sum_l = [], [], [], [], [], []
+        for it in range(16):
+            ttype = (0, 2, 3)[it % 3] if N < 32 else 0
+            is_intra = int(it % 4 != 3)
+            mode = int(rng.integers(0, 35))
+            tr_idx = int(rng.integers(0, 2))
+            qpy = int(rng.choice([10, 22, 27, 32, 37, 45]))
+            st = 2 if is_intra else (1, 0)[it % 2]
+            lam = float(rng.choice([3.0, 17.5, 58.0, 140.25, 900.0]))
+            amp = int(rng.choice([20, 60, 200, mx, mx]))
+            resi = rng.integers(-amp, amp + 1, N * N).astype(np.int16)
+            coef = np.zeros(N * N, np.int32)
+            R.ref_xT(mode if (ttype == 0 and is_intra) else REG_DCT, resi, N, coef, N)
+            est = ol.make_est_bits(rng)
+            lev, s = ol.r_rdoq(coef, N, qpy, st, ttype, is_intra, mode, tr_idx, lam, est)
+            par.append((qpy, st, ttype, is_intra, mode, tr_idx, R.ref_cbf_ctx(ttype, tr_idx)))
+            lam_l.append(lam)
+            est_l.append(np.frombuffer(bytes(est), np.int32).copy())
+            coef_l.append(coef)
+            lev_l.append(lev.reshape(-1))
+            sum_l.append(s)
+        out[f"r{N}_par"] = np.array(par, np.int32)
+        out[f"r{N}_lambda"] = np.array(lam_l, np.float64)
+        out[f"r{N}_est"] = np.stack(est_l)
+        out[f"r{N}_coef"] = np.stack(coef_l)
+        out[f"r{N}_lev"] = np.stack(lev_l)
+        out[f"r{N}_sum"] = np.array(sum_l, np.uint32)
+    return out
+
+
 def intra(R, B, rng):
     """initAdiPattern on a real picture + all 35 modes, luma and chroma."""
     out = {}
@@ -187,6 +223,11 @@ def frame(R, B, qp, pic, tiling, seed):
 def main():
     assert ol.have_ref(), "build oracle/_ref first: bash oracle/build_ref.sh"
     R = ol.ref()
+    if sys.argv[1:] == ["rdoq"]:  # added after the first set: generate only the RDOQ vectors
+        for B in (8, 10):
+            R.ref_init(B, 416, 240, 1)
+            np.savez_compressed(os.path.join(HERE, f"rdoq_b{B}.npz"), **rdoq(R, B, np.random.default_rng(4048 + B)))
+        return
     for B in (8, 10):
         R.ref_init(B, 416, 240, 1)
         rng = np.random.default_rng(2024 + B)

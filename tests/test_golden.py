@@ -51,6 +51,26 @@ def test_oracle_quant(B):
             assert np.array_equal(r.reshape(-1), g[f"q{N}_inv"][k])
 
 
+def _rdoq_case(O, B, N, par, lam, est_words):
+    qpy, st, ttype, is_intra, mode, tr_idx, cbf_ctx = (int(v) for v in par)
+    q = O.hmo_setQPforQuant(qpy, int(ttype != 0), 6 * (B - 8), 0)
+    scan = O.hmo_coef_scan_idx(N, int(ttype == 0), is_intra, mode)
+    root = int((not is_intra) and ttype == 0 and tr_idx == 0)
+    cfg = ol.RdoqCfg(q.per, q.rem, int(ttype == 0), is_intra, scan, root, cbf_ctx, 1, float(lam))
+    est = ol.EstBits.from_buffer_copy(np.ascontiguousarray(est_words, np.int32).tobytes())
+    return cfg, est
+
+
+@pytest.mark.parametrize("B", [8, 10])
+def test_oracle_rdoq(B):
+    g, O = load(f"rdoq_b{B}.npz"), ol.oracle()
+    for N in (4, 8, 16, 32):
+        for k, par in enumerate(g[f"r{N}_par"]):
+            cfg, est = _rdoq_case(O, B, N, par, g[f"r{N}_lambda"][k], g[f"r{N}_est"][k])
+            lev, s = ol.o_rdoq(g[f"r{N}_coef"][k], N, B, cfg, est)
+            assert np.array_equal(lev.reshape(-1), g[f"r{N}_lev"][k]) and s == g[f"r{N}_sum"][k], (N, k)
+
+
 @pytest.mark.parametrize("B", [8, 10])
 def test_oracle_intra(B):
     g, O = load(f"intra_b{B}.npz"), ol.oracle()
@@ -254,3 +274,20 @@ def test_gpu_frame(name, B):
         assert np.array_equal(lev[p], g["lev_" + k].astype(np.int32)), k
     L.hmx_intra_plan_destroy(ctx.h, plan)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_rdoq(gctx):
+    """libhmx's xRateDistOptQuant drop-in vs the reference's vectors (coefficients, bit estimates, lambda in)."""
+    from thevc_amd import capi
+    B = gctx.bit_depth
+    g, O = load(f"rdoq_b{B}.npz"), ol.oracle()
+    for N in (4, 8, 16, 32):
+        for k, par in enumerate(g[f"r{N}_par"]):
+            qpy, st, ttype, is_intra, mode, tr_idx, cbf_ctx = (int(v) for v in par)
+            qp = capi.qp_for(qpy, ttype, B)
+            root = int((not is_intra) and ttype == 0 and tr_idx == 0)
+            rp = capi.RdoqParam(qp, 1, is_intra, mode, root, cbf_ctx, float(g[f"r{N}_lambda"][k]))
+            est = capi.EstBits.from_buffer_copy(np.ascontiguousarray(g[f"r{N}_est"][k], np.int32).tobytes())
+            lev, s = gctx.xRateDistOptQuant(g[f"r{N}_coef"][k], N, ttype, rp, est)
+            assert np.array_equal(lev, g[f"r{N}_lev"][k]) and s == g[f"r{N}_sum"][k], (N, k)

@@ -510,3 +510,56 @@ def test_frame_intra_zorder_levels(ctx, pic, tiling, schedule, monkeypatch):
     rec2 = d_rec2.download()
     assert all(np.array_equal(rec2[p], rr[p]) for p in range(3))
     L.hmx_intra_plan_destroy(ctx.h, plan)
+
+
+def test_rdoq_batch_vs_oracle(ctx):
+    """RDOQ over a block list (one lane per block): coefficients of random residuals in level-plane geometry,
+    several bit-estimate tables, luma and chroma QPs and lambdas, intra scans and inter blocks, both cbf
+    branches -> levels and absolute sums bit-exact with the oracle (doubles in the reference's order)."""
+    B, L, O = ctx.bit_depth, capi.lib(), ol.oracle()
+    rng = np.random.default_rng(77 + B)
+    w, h, qp, cqo = 128, 96, 30, 2
+    tus = workload.make_tus(17, w, h, "mix")
+    inter = rng.random(len(tus)) < 0.3
+    tus["flags"] = np.where(inter, capi.TU_INTER, 0).astype(np.uint8)
+    n = len(tus)
+    n_est = 5
+    ests = [ol.make_est_bits(rng) for _ in range(n_est)]
+    est_arr = (capi.EstBits * n_est)(*[capi.EstBits.from_buffer_copy(bytes(e)) for e in ests])
+    side = (capi.RdoqSide * n)()
+    coef = [np.zeros((h, w), np.int32), np.zeros((h // 2, w // 2), np.int32), np.zeros((h // 2, w // 2), np.int32)]
+    mx = (1 << B) - 1
+    for i, t in enumerate(tus):
+        N, p, x, y = 1 << int(t["log2n"]), int(t["plane"]), int(t["x"]), int(t["y"])
+        amp = int(rng.choice([20, 60, 200, mx]))
+        resi = rng.integers(-amp, amp + 1, N * N).astype(np.int16)
+        c = np.zeros(N * N, np.int32)
+        tmode = int(t["mode"]) if (p == 0 and not inter[i]) else REG_DCT
+        O.hmo_xT(tmode, resi, N, c, N, B)
+        coef[p][y:y + N, x:x + N] = c.reshape(N, N)
+        side[i].est_idx = int(rng.integers(0, n_est))
+        side[i].root_cbf = int(inter[i] and p == 0 and rng.random() < 0.5)
+        side[i].cbf_ctx = int(rng.integers(0, 5)) + (5 if p else 0)
+    lam = (41.5, 33.25)
+    d_coef = capi.DevPicture(ctx, w, h, dtype=np.int32).upload(coef)
+    d_lev = capi.DevPicture(ctx, w, h, dtype=np.int32).zero()
+    d_sum = ctx.alloc(4 * n)
+    pp = capi.PicParam(w, h, qp, cqo, capi.I_SLICE, 1)
+    t_c = np.ascontiguousarray(tus, capi.TU_DTYPE)
+    ctx._chk(L.hmx_batch_xRateDistOptQuant(ctx.h, t_c.ctypes.data, side, n, C.byref(d_coef.as_pic()), C.byref(d_lev.as_pic()),
+                                           d_sum.ptr, C.byref(pp), est_arr, n_est, lam[0], lam[1]))
+    ctx.sync()
+    lev = d_lev.download()
+    sums = d_sum.download(np.uint32, n)
+    n_nz = 0
+    for i, t in enumerate(tus):
+        N, p, x, y = 1 << int(t["log2n"]), int(t["plane"]), int(t["x"]), int(t["y"])
+        q = O.hmo_setQPforQuant(qp, int(p != 0), 6 * (B - 8), cqo if p else 0)
+        scan = O.hmo_coef_scan_idx(N, int(p == 0), int(not inter[i]), int(t["mode"]))
+        cfg = ol.RdoqCfg(q.per, q.rem, int(p == 0), int(not inter[i]), scan, side[i].root_cbf, side[i].cbf_ctx, 1, lam[1 if p else 0])
+        lo, so = ol.o_rdoq(coef[p][y:y + N, x:x + N], N, B, cfg, ests[side[i].est_idx])
+        assert np.array_equal(lev[p][y:y + N, x:x + N], lo), ("levels", i, N, p)
+        assert int(sums[i]) == so, ("abs_sum", i)
+        n_nz += int(so > 0)
+    assert n_nz > n // 4
+    d_coef.free(), d_lev.free(), d_sum.free()

@@ -38,6 +38,11 @@ class QuantParam(C.Structure):
                 ("is_intra", C.c_int), ("dir_mode", C.c_int)]
 
 
+class RdoqParam(C.Structure):  # hmx_rdoq_param
+    _fields_ = [("qp", Qp), ("sign_hide", C.c_int), ("is_intra", C.c_int), ("dir_mode", C.c_int), ("root_cbf", C.c_int),
+                ("cbf_ctx", C.c_int), ("lam", C.c_double)]
+
+
 class PicParam(C.Structure):
     _fields_ = [("pic_w", C.c_int), ("pic_h", C.c_int), ("qp", C.c_int), ("chroma_qp_offset", C.c_int),
                 ("slice_type", C.c_int), ("sign_hide", C.c_int)]
@@ -49,6 +54,17 @@ class Pic(C.Structure):
 
 class Levels(C.Structure):
     _fields_ = [("plane", C.c_void_p * 3), ("stride", C.c_int * 3)]
+
+
+class EstBits(C.Structure):  # hmx_est_bits == estBitsSbacStruct (TComTrQuant.h:59-72)
+    _fields_ = [("significantCoeffGroupBits", (C.c_int32 * 2) * 2), ("significantBits", (C.c_int32 * 2) * 42),
+                ("lastXBits", C.c_int32 * 32), ("lastYBits", C.c_int32 * 32), ("greaterOneBits", (C.c_int32 * 2) * 24),
+                ("levelAbsBits", (C.c_int32 * 2) * 6), ("blockCbpBits", (C.c_int32 * 2) * 15),
+                ("blockRootCbpBits", (C.c_int32 * 2) * 4), ("scanZigzag", C.c_int32 * 2), ("scanNonZigzag", C.c_int32 * 2)]
+
+
+class RdoqSide(C.Structure):  # hmx_rdoq_side
+    _fields_ = [("est_idx", C.c_uint16), ("root_cbf", C.c_uint8), ("cbf_ctx", C.c_uint8)]
 
 
 class McJob(C.Structure):  # hmx_mc_job
@@ -133,6 +149,9 @@ def lib():
         L.hmx_batch_motionCompensation.argtypes = [vp, vp, ci, C.POINTER(Pic), ci, C.POINTER(Pic)]
         L.hmx_pic_extend_border.argtypes = [vp, C.POINTER(Pic), ci, ci, ci, ci]
         L.hmx_batch_motionCompensation_multi.argtypes = [vp, ci, C.POINTER(McJob)]
+        L.hmx_xRateDistOptQuant.argtypes = [vp, vp, vp, ci, ci, C.POINTER(C.c_uint32), ci, C.POINTER(RdoqParam), C.POINTER(EstBits)]
+        L.hmx_batch_xRateDistOptQuant.argtypes = [vp, vp, C.POINTER(RdoqSide), ci, C.POINTER(Levels), C.POINTER(Levels), vp,
+                                                  C.POINTER(PicParam), C.POINTER(EstBits), ci, C.c_double, C.c_double]
         L.hmx_batch_residual_transformNxN_multi.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(Levels), vp,
                                                             C.POINTER(PicParam)]
         L.hmx_batch_residual_transform_recon_multi.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(Levels),
@@ -257,6 +276,13 @@ class Context:
         dst = np.zeros(n * n, np.int32)
         s = C.c_uint32(ac_sum)
         self._chk(lib().hmx_xQuant(self.h, _hp(src), _hp(dst), n, n, C.byref(s), text_type, C.byref(qparam)))
+        return dst, s.value
+
+    def xRateDistOptQuant(self, src, n, text_type, rparam, est, abs_sum=0):
+        src = np.ascontiguousarray(src, np.int32)
+        dst = np.zeros(n * n, np.int32)
+        s = C.c_uint32(abs_sum)
+        self._chk(lib().hmx_xRateDistOptQuant(self.h, _hp(src), _hp(dst), n, n, C.byref(s), text_type, C.byref(rparam), C.byref(est)))
         return dst, s.value
 
     def xDeQuant(self, src, n, qp):

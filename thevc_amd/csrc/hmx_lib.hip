@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "hmx_kernels.h"
+#include "hmx_rdoq.h"
 
 using namespace hmx;
 
@@ -794,6 +795,11 @@ struct hmx_ctx {
   int n_side = 0;
   // Argument arena: small per-call tables (picture planes, job lists) travel through a pinned host ring
   // and a device ring by asynchronous copies; the stream is synchronised only when the ring wraps.
+  double *rdoq_wd = nullptr; // RDOQ per-lane records (hmx_rdoq.h), sized for rdoq_T lanes
+  int *rdoq_wi = nullptr;
+  RdoqBlock *rdoq_blocks = nullptr;
+  EstBitsDev *rdoq_est = nullptr;
+  int rdoq_T = 0, rdoq_est_cap = 0;
   int *d_mcmap = nullptr; // cell -> PU maps of the last motion-compensation call
   size_t mcmap_cap = 0;
   char *arena_h = nullptr, *arena_d = nullptr;
@@ -922,6 +928,10 @@ extern "C" void hmx_destroy(hmx_ctx *c) {
   if (c->arena_h) hipHostFree(c->arena_h);
   hipFree(c->arena_d);
   hipFree(c->d_mcmap);
+  hipFree(c->rdoq_wd);
+  hipFree(c->rdoq_wi);
+  hipFree(c->rdoq_blocks);
+  hipFree(c->rdoq_est);
   for (int g = 0; g < c->n_side; g++) {
     hipStreamDestroy(c->side[g]);
     hipEventDestroy(c->ev_join[g]);
@@ -1922,6 +1932,129 @@ extern "C" int hmx_xQuant(hmx_ctx *c, const int32_t *src, hmx_coeff *dst, int w,
   return r;
 }
 
+// ---- rate-distortion optimised quantisation (hmx_rdoq.h) ----
+static_assert(sizeof(hmx_est_bits) == sizeof(EstBitsDev), "hmx_est_bits mirrors estBitsSbacStruct");
+static const int kRdoqChunk = 16384; // lanes per launch: 41 KB of records each
+
+static int rdoq_scan_index(int n, bool luma, bool intra, int mode) { // getCoefScanIdx (TComDataCU.cpp:4014): 0 diag, 1 hor, 2 ver
+  if (!intra) return 0;
+  const bool multi = luma ? (n == 4 || n == 8) : (n == 4);
+  if (!multi) return 0;
+  if (abs(mode - 26) < 5) return 1;
+  if (abs(mode - 10) < 5) return 2;
+  return 0;
+}
+
+// the per-call constants; the two quotients are formed here, in the reference's operation order
+static void rdoq_constants(RdoqArgs &A, int B, const hmx_qp qp[2], const double lambda[2]) {
+#pragma clang fp contract(off)
+  const int inc = B - 8;
+  for (int t = 0; t < 2; t++) {
+    A.per[t] = qp[t].per;
+    A.rem[t] = qp[t].rem;
+    A.q[t] = kQuantScales[qp[t].rem];
+    A.lambda[t] = lambda[t];
+    for (int lg = 2; lg <= 5; lg++) { // setErrScaleCoeff, TComTrQuant.cpp:2794-2818 (flat quantiser coefficients)
+      const int tshift = 15 - B - lg;
+      double e = (double)(1 << 15);
+      e = e * ldexp(1.0, -2 * tshift);
+      e = e / (double)A.q[t] / (double)A.q[t] / (double)(1 << (2 * inc));
+      A.err_scale[t][lg - 2] = e;
+    }
+    const int iq = kInvQuantScales[qp[t].rem];
+    A.rd_factor[t] = (long long)((double)iq * (double)iq * (double)(1 << (2 * qp[t].per)) / lambda[t] / 16 / (double)(1 << (2 * inc)) + 0.5); // :2205
+  }
+  A.bit_depth = B;
+}
+
+static int rdoq_launch(hmx_ctx *c, RdoqArgs A, const std::vector<RdoqBlock> &blocks, const hmx_est_bits *est, int n_est) {
+  if (n_est > c->rdoq_est_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(c->rdoq_est);
+    c->rdoq_est = nullptr;
+    c->rdoq_est_cap = 0;
+    if (hipMalloc((void **)&c->rdoq_est, sizeof(EstBitsDev) * n_est) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc bit-estimate tables");
+    c->rdoq_est_cap = n_est;
+  }
+  if (!c->rdoq_wd) {
+    const size_t T = kRdoqChunk;
+    if (hipMalloc((void **)&c->rdoq_wd, sizeof(double) * (3 * 1024 + 64) * T) != hipSuccess ||
+        hipMalloc((void **)&c->rdoq_wi, sizeof(int) * 4 * 1024 * T) != hipSuccess ||
+        hipMalloc((void **)&c->rdoq_blocks, sizeof(RdoqBlock) * T) != hipSuccess)
+      return fail(c, HMX_ERR_NOMEM, "hipMalloc RDOQ workspace");
+    c->rdoq_T = (int)T;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->rdoq_est, est, sizeof(EstBitsDev) * n_est, hipMemcpyHostToDevice, c->stream));
+  A.est = c->rdoq_est;
+  A.wd = c->rdoq_wd;
+  A.wi = c->rdoq_wi;
+  A.T = c->rdoq_T;
+  A.blocks = c->rdoq_blocks;
+  for (size_t o = 0; o < blocks.size(); o += kRdoqChunk) {
+    const int n = (int)std::min(blocks.size() - o, (size_t)kRdoqChunk);
+    HIPCHK(c, hipMemcpyAsync(c->rdoq_blocks, blocks.data() + o, sizeof(RdoqBlock) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // pageable source
+    A.n = n;
+    hipLaunchKernelGGL(k_rdoq, dim3((n + 63) / 64), dim3(64), 0, c->stream, A);
+    HIPCHK(c, hipGetLastError());
+  }
+  return HMX_OK;
+}
+
+extern "C" int hmx_xRateDistOptQuant(hmx_ctx *c, const int32_t *src, hmx_coeff *dst, int w, int h, uint32_t *abs_sum, int text_type,
+                                     const hmx_rdoq_param *rp, const hmx_est_bits *est) {
+  if (!c || !src || !dst || !rp || !est || !abs_sum || !size_ok(w, h) || !(rp->lambda > 0))
+    return fail(c, HMX_ERR_ARG, "hmx_xRateDistOptQuant: unsupported size, null or non-positive lambda");
+  Scratch s{c};
+  int *d_in = s.take<int>(w * h), *d_out = s.take<int>(w * h);
+  uint32_t *d_sum = s.take<uint32_t>(1);
+  int r = up2d(c, d_in, src, 4, w, h, w);
+  if (r) return r;
+  RdoqArgs A{};
+  const hmx_qp qps[2] = {rp->qp, rp->qp};
+  const double lam[2] = {rp->lambda, rp->lambda};
+  rdoq_constants(A, c->cfg.bit_depth, qps, lam);
+  A.sign_hide = rp->sign_hide;
+  const bool luma = text_type == HMX_TEXT_LUMA;
+  std::vector<RdoqBlock> b(1);
+  b[0] = RdoqBlock{d_in, d_out, w, w, d_sum, (unsigned char)ilog2i(w), (unsigned char)luma,
+                   (unsigned char)rdoq_scan_index(w, luma, rp->is_intra != 0, rp->dir_mode), (unsigned char)(rp->root_cbf != 0),
+                   (unsigned char)rp->cbf_ctx, 0, 0};
+  if ((r = rdoq_launch(c, A, b, est, 1))) return r;
+  uint32_t hs = 0;
+  HIPCHK(c, hipMemcpyAsync(&hs, d_sum, 4, hipMemcpyDeviceToHost, c->stream));
+  r = down2d(c, dst, w, d_out, 4, w, h);
+  *abs_sum += hs; // uiAbsSum accumulates (:2187)
+  return r;
+}
+
+extern "C" int hmx_batch_xRateDistOptQuant(hmx_ctx *c, const hmx_tu *tus, const hmx_rdoq_side *side, int n, const hmx_levels *coef,
+                                           const hmx_levels *lev, uint32_t *d_abs_sum, const hmx_pic_param *pp,
+                                           const hmx_est_bits *est, int n_est, double lambda_luma, double lambda_chroma) {
+  if (!c || !tus || !side || n <= 0 || !coef || !lev || !pp || !est || n_est <= 0 || !(lambda_luma > 0) || !(lambda_chroma > 0))
+    return fail(c, HMX_ERR_ARG, "hmx_batch_xRateDistOptQuant: bad argument");
+  RdoqArgs A{};
+  const int bd = 6 * (c->cfg.bit_depth - 8);
+  const hmx_qp qps[2] = {hmx_setQPforQuant(pp->qp, HMX_TEXT_LUMA, bd, 0), hmx_setQPforQuant(pp->qp, HMX_TEXT_CHROMA, bd, pp->chroma_qp_offset)};
+  const double lam[2] = {lambda_luma, lambda_chroma};
+  rdoq_constants(A, c->cfg.bit_depth, qps, lam);
+  A.sign_hide = pp->sign_hide;
+  std::vector<RdoqBlock> b(n);
+  for (int i = 0; i < n; i++) {
+    const hmx_tu &t = tus[i];
+    if (t.plane > 2 || t.log2n < 2 || t.log2n > 5 || side[i].est_idx >= n_est || side[i].cbf_ctx >= 15)
+      return fail(c, HMX_ERR_ARG, "hmx_batch_xRateDistOptQuant: bad block");
+    const int p = t.plane, N = 1 << t.log2n;
+    const bool luma = p == 0, intra = !(t.flags & HMX_TU_INTER);
+    b[i] = RdoqBlock{coef->plane[p] + (size_t)t.y * coef->stride[p] + t.x,
+                     lev->plane[p] + (size_t)t.y * lev->stride[p] + t.x,
+                     coef->stride[p], lev->stride[p], d_abs_sum ? d_abs_sum + i : nullptr, t.log2n, (unsigned char)luma,
+                     (unsigned char)rdoq_scan_index(N, luma, intra, t.mode), side[i].root_cbf, side[i].cbf_ctx,
+                     (unsigned char)(luma ? 0 : 1), side[i].est_idx};
+  }
+  return rdoq_launch(c, A, b, est, n_est);
+}
+
 extern "C" int hmx_xDeQuant(hmx_ctx *c, const hmx_coeff *src, int32_t *dst, int w, int h, const hmx_qp *qp) {
   if (!c || !src || !dst || !qp || !size_ok(w, h)) return fail(c, HMX_ERR_ARG, "hmx_xDeQuant: unsupported size or null");
   Scratch s{c};
@@ -2399,6 +2532,10 @@ extern "C" int hmx_batch_motionCompensation_multi(hmx_ctx *c, int n_jobs, const 
     if (map_cells > c->mcmap_cap) {
       HIPCHK(c, hipStreamSynchronize(c->stream));
       hipFree(c->d_mcmap);
+  hipFree(c->rdoq_wd);
+  hipFree(c->rdoq_wi);
+  hipFree(c->rdoq_blocks);
+  hipFree(c->rdoq_est);
       c->d_mcmap = nullptr;
       c->mcmap_cap = 0;
       if (hipMalloc((void **)&c->d_mcmap, map_cells * sizeof(int)) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc cell map");

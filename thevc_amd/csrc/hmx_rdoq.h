@@ -1,0 +1,460 @@
+// hmx_rdoq.h - rate-distortion optimised quantisation on the device.
+//
+// TComTrQuant::xRateDistOptQuant (TLibCommon/TComTrQuant.cpp:1719-2305) with xGetCodedLevel :2446,
+// xGetICRateCost :2508, xGetICRate :2577, xGetRateLast :2652, getSigCtxInc :2349, calcPatternSigCtx :2315,
+// getSigCoeffGroupCtxInc :2707, flat error scale setErrScaleCoeff :2794, as the reference is compiled
+// (REMOVE_NSQT, REMOVAL_8x2_2x8_CG, REMOVE_NUM_GREATER1, COEF_REMAIN_BIN_REDUCTION 3, C1FLAG_NUMBER 8,
+// C2FLAG_NUMBER 1).  Same three phases as the oracle's restatement:
+//   A. reverse scan: per coefficient the cheaper of {quantised level, one below, (zero)} in D + lambda*R under
+//      the running c1/c2/Rice context state; per coefficient group the decision to zero the whole group;
+//   B. the last significant position;
+//   C. sign-bit hiding with rate-aware costs.
+// The running context state makes a block sequential, so the work item is ONE LANE PER BLOCK; blocks are
+// independent.  Per-position records live in a global workspace interleaved by lane (record i of lane t at
+// i * T + t): lanes of a wave walk the same positions, so the accesses coalesce.
+//
+// Costs are IEEE doubles evaluated in the reference's order.  Fused multiply-add would round differently:
+// contraction is switched off for this file, and the two quotients (error scale, sign-hiding factor) are
+// formed on the host.
+#pragma once
+#include "hmx_device.h"
+
+#pragma clang fp contract(off)
+
+namespace hmx {
+
+struct EstBitsDev { // estBitsSbacStruct (TComTrQuant.h:59-72), 1/32768 bit
+  int sig_cg[2][2];
+  int sig[42][2];
+  int last_x[32], last_y[32];
+  int greater1[24][2];
+  int greater2[6][2];
+  int cbf[15][2];
+  int root_cbf[4][2];
+  int scan_zigzag[2], scan_nonzigzag[2];
+};
+
+struct RdoqBlock { // one block of a launch
+  const int *src;  // coefficients (Int), row stride src_stride
+  int *dst;        // levels out
+  int src_stride, dst_stride;
+  uint32_t *abs_sum; // may be NULL
+  unsigned char log2n, is_luma, scan_idx /* 0 diag, 1 hor, 2 ver */, root_cbf, cbf_ctx, plane_type /* 0 luma, 1 chroma QP */;
+  unsigned short est_idx;
+};
+
+struct RdoqArgs {
+  const RdoqBlock *blocks;
+  int n;
+  const EstBitsDev *est; // tables, RdoqBlock::est_idx selects
+  // workspace, n_threads = T lanes: doubles [3 * 1024 + 64] * T, ints [4 * 1024] * T
+  double *wd;
+  int *wi;
+  int T;
+  int bit_depth, sign_hide;
+  int per[2], rem[2], q[2];
+  double lambda[2];
+  double err_scale[2][4]; // [plane type][log2n - 2]: 2^15 * 2^(-2 tshift) / q / q / 2^(2 inc)
+  long long rd_factor[2]; // (Int64)(invq * invq * 2^(2 per) / lambda / 16 / 2^(2 inc) + 0.5)
+};
+
+__device__ __forceinline__ int rdoq_base_level(unsigned c1i, unsigned c2i) { return c1i < 8 ? (2 + (c2i < 1)) : 1; }
+
+// rate of |level| beyond the significance flag as a COST (xGetICRateCost)
+__device__ __forceinline__ double rdoq_level_cost(const EstBitsDev &e, double lambda, unsigned lvl, unsigned ctx1, unsigned ctx2,
+                                                  unsigned rice, unsigned c1i, unsigned c2i) {
+  double rate = 32768;
+  const unsigned base = (unsigned)rdoq_base_level(c1i, c2i);
+  if (lvl >= base) {
+    unsigned sym = lvl - base, len;
+    if (sym < (3u << rice)) {
+      len = sym >> rice;
+      rate += (double)((len + 1 + rice) << 15);
+    } else {
+      len = rice;
+      sym -= 3u << rice;
+      while (sym >= (1u << len)) sym -= 1u << (len++);
+      rate += (double)((3 + len + 1 - rice + len) << 15);
+    }
+    if (c1i < 8) {
+      rate += e.greater1[ctx1][1];
+      if (c2i < 1) rate += e.greater2[ctx2][1];
+    }
+  } else if (lvl == 1) {
+    rate += e.greater1[ctx1][0];
+  } else {
+    rate += e.greater1[ctx1][1];
+    rate += e.greater2[ctx2][0];
+  }
+  return lambda * rate;
+}
+
+// integer rate of |level| (xGetICRate): only for the sign-hiding deltas
+__device__ __forceinline__ int rdoq_level_rate(const EstBitsDev &e, unsigned lvl, unsigned ctx1, unsigned ctx2, unsigned rice,
+                                               unsigned c1i, unsigned c2i) {
+  int rate = 0;
+  const unsigned base = (unsigned)rdoq_base_level(c1i, c2i);
+  if (lvl >= base) {
+    unsigned sym = lvl - base;
+    const unsigned max_vlc = rice == 0 ? 7u : rice == 1 ? 14u : rice == 2 ? 26u : rice == 3 ? 46u : 78u;
+    const unsigned pre_max = 8u - rice;
+    if (sym > max_vlc) {
+      const unsigned a = sym - max_vlc;
+      int egs = 1;
+      for (unsigned m = 2; a >= m; m <<= 1) egs += 2;
+      rate += egs << 15;
+      sym = min(sym, max_vlc + 1);
+    }
+    const unsigned pre = ((sym >> rice) & 0xffffu) + 1;
+    const unsigned bins = min(pre, pre_max) + rice;
+    rate += (int)((bins & 0xffffu) << 15);
+    if (c1i < 8) {
+      rate += e.greater1[ctx1][1];
+      if (c2i < 1) rate += e.greater2[ctx2][1];
+    }
+  } else if (lvl == 0) {
+    return 0;
+  } else if (lvl == 1) {
+    rate += e.greater1[ctx1][0];
+  } else {
+    rate += e.greater1[ctx1][1];
+    rate += e.greater2[ctx2][0];
+  }
+  return rate;
+}
+
+// significance context (getSigCtxInc, REMOVAL_8x2_2x8_CG branch); scan_idx 0 = diagonal
+__device__ __forceinline__ int rdoq_sig_ctx(int pattern, int scan_idx, int px, int py, int log2n, bool is_luma) {
+  if (px + py == 0) return 0;
+  if (log2n == 2) {
+    const unsigned long long map4 = 0x8877886654325410ull; // {0,1,4,5, 2,3,4,5, 6,6,8,8, 7,7,8,8}, one nibble each
+    return (int)((map4 >> (4 * (4 * py + px))) & 15);
+  }
+  const int offset = log2n == 3 ? (scan_idx == 0 ? 9 : 15) : (is_luma ? 21 : 12);
+  const int sx = px & 3, sy = py & 3;
+  int cnt;
+  if (pattern == 0)
+    cnt = sx + sy <= 2 ? (sx + sy == 0 ? 2 : 1) : 0;
+  else if (pattern == 1)
+    cnt = sy <= 1 ? (sy == 0 ? 2 : 1) : 0;
+  else if (pattern == 2)
+    cnt = sx <= 1 ? (sx == 0 ? 2 : 1) : 0;
+  else
+    cnt = 2;
+  return ((is_luma && ((px >> 2) + (py >> 2)) > 0) ? 3 : 0) + offset + cnt;
+}
+
+__device__ __forceinline__ unsigned rdoq_group_idx(unsigned p) { // g_uiGroupIdx
+  return p < 4 ? p : p < 6 ? 4 : p < 8 ? 5 : p < 12 ? 6 : p < 16 ? 7 : p < 24 ? 8 : 9;
+}
+__device__ __forceinline__ double rdoq_last_cost(const EstBitsDev &e, double lambda, unsigned px, unsigned py) {
+  const unsigned cx = rdoq_group_idx(px), cy = rdoq_group_idx(py);
+  double cost = e.last_x[cx] + e.last_y[cy];
+  if (cx > 3) cost += 32768.0 * ((cx - 2) >> 1);
+  if (cy > 3) cost += 32768.0 * ((cy - 2) >> 1);
+  return lambda * cost;
+}
+
+__device__ __forceinline__ unsigned rdoq_scan_pos(int log2n, int scan_idx, int sp) {
+  return log2n == 2 ? kScan4.t[scan_idx][sp] : log2n == 3 ? kScan8.t[scan_idx][sp] : log2n == 4 ? kScan16.t[scan_idx][sp] : kScan32.t[scan_idx][sp];
+}
+
+__global__ __launch_bounds__(64) void k_rdoq(RdoqArgs A) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= A.n) return;
+  const RdoqBlock K = A.blocks[tid];
+  const EstBitsDev &E = A.est[K.est_idx];
+  const size_t T = (size_t)A.T;
+  // workspace records of this lane
+  double *cost_coded = A.wd + tid, *cost_sig = A.wd + 1024 * T + tid, *cost_zero = A.wd + 2048 * T + tid, *cost_cg_sig = A.wd + 3072 * T + tid;
+  int *rate_up = A.wi + tid, *rate_down = A.wi + 1024 * T + tid, *sig_delta = A.wi + 2048 * T + tid, *delta_u = A.wi + 3072 * T + tid;
+#define WS(a, i) a[(size_t)(i) * T]
+  const int lg = K.log2n, N = 1 << lg, nn = N * N, G = N >> 2, n_cg = nn >> 4;
+  const int pt = K.plane_type, B = A.bit_depth;
+  const int tshift = 15 - B - lg, qbits = 14 + A.per[pt] + tshift;
+  const int q = A.q[pt], scan_idx = K.scan_idx;
+  const bool is_luma = K.is_luma;
+  const double lambda = A.lambda[pt], err_scale = A.err_scale[pt][lg - 2];
+  const int *src = K.src;
+  int *dst = K.dst;
+  const int ss = K.src_stride, ds = K.dst_stride;
+#define SRC(bp) src[((bp) >> lg) * ss + ((bp) & (N - 1))]
+#define DST(bp) dst[((bp) >> lg) * ds + ((bp) & (N - 1))]
+  for (int i = 0; i < nn; i++) {
+    WS(cost_coded, i) = 0;
+    WS(cost_sig, i) = 0;
+    WS(rate_up, i) = 0;
+    WS(rate_down, i) = 0;
+    WS(sig_delta, i) = 0;
+    WS(delta_u, i) = 0;
+    DST(i) = 0;
+  }
+  for (int i = 0; i < 64; i++) WS(cost_cg_sig, i) = 0;
+  unsigned long long cg_flag = 0; // bit gpos
+  double uncoded = 0, base = 0;
+  int last_pos = -1, last_cg = -1;
+  unsigned ctx_set = 0, rice = 0, c1i = 0, c2i = 0;
+  int c1 = 1, c2 = 0;
+  uint32_t abs_sum = 0;
+
+  // ---- phase A ----
+  for (int cg = n_cg - 1; cg >= 0; cg--) {
+    const unsigned p0 = rdoq_scan_pos(lg, scan_idx, cg * 16), gx = (p0 & (N - 1)) >> 2, gy = (p0 >> lg) >> 2, gpos = gy * G + gx;
+    const unsigned right = gx < (unsigned)G - 1 ? (unsigned)((cg_flag >> (gy * G + gx + 1)) & 1) : 0u;
+    const unsigned lower = gy < (unsigned)G - 1 ? (unsigned)((cg_flag >> ((gy + 1) * G + gx)) & 1) : 0u;
+    const int pattern = N == 4 ? -1 : (int)(right + (lower << 1));
+    double s_sig = 0, s_sig0 = 0, s_coded = 0, s_uncoded = 0;
+    int nnz_before0 = 0;
+    for (int k = 15; k >= 0; k--) {
+      const int sp = cg * 16 + k;
+      const unsigned bp = rdoq_scan_pos(lg, scan_idx, sp);
+      const long long wide = (long long)abs(SRC(bp)) * q, cap = 2147483647ll - (1ll << (qbits - 1));
+      const int ld = (int)(wide < cap ? wide : cap);
+      const unsigned max_lvl = (unsigned)((ld + (1 << (qbits - 1))) >> qbits);
+      const double e0 = (double)ld;
+      const double cz = e0 * e0 * err_scale;
+      WS(cost_zero, sp) = cz;
+      uncoded += cz;
+      int out_level = (int)max_lvl;
+      double cc = 0, cs = 0; // cost_coded / cost_sig of this position
+      if (max_lvl > 0 && last_pos < 0) {
+        last_pos = sp;
+        ctx_set = (sp < 16 || !is_luma) ? 0 : 2;
+        last_cg = cg;
+      }
+      if (last_pos >= 0) {
+        const unsigned ctx1 = 4 * ctx_set + (unsigned)c1, ctx2 = ctx_set + (unsigned)c2;
+        const bool is_last = sp == last_pos;
+        unsigned ctx_sig = 0;
+        if (!is_last) ctx_sig = (unsigned)rdoq_sig_ctx(pattern, scan_idx, (int)(bp & (N - 1)), (int)(bp >> lg), lg, is_luma);
+        unsigned best = 0;
+        double sig1 = 0;
+        bool decided = false;
+        if (!is_last && max_lvl < 3) {
+          cs = lambda * E.sig[ctx_sig][0];
+          cc = cz + cs;
+          if (max_lvl == 0) decided = true;
+        } else {
+          cc = 1.7e+308;
+        }
+        if (!decided) {
+          if (!is_last) sig1 = lambda * E.sig[ctx_sig][1];
+          const unsigned lo = max_lvl > 1 ? max_lvl - 1 : 1;
+          for (int l = (int)max_lvl; l >= (int)lo; l--) {
+            const double d = (double)(ld - (l << qbits));
+            double cst = d * d * err_scale + rdoq_level_cost(E, lambda, (unsigned)l, ctx1, ctx2, rice, c1i, c2i);
+            cst += sig1;
+            if (cst < cc) {
+              best = (unsigned)l;
+              cc = cst;
+              cs = sig1;
+            }
+          }
+        }
+        if (!is_last) WS(sig_delta, bp) = E.sig[ctx_sig][1] - E.sig[ctx_sig][0];
+        WS(delta_u, bp) = (ld - ((int)best << qbits)) >> (qbits - 8);
+        if (best > 0) {
+          const int now = rdoq_level_rate(E, best, ctx1, ctx2, rice, c1i, c2i);
+          WS(rate_up, bp) = rdoq_level_rate(E, best + 1, ctx1, ctx2, rice, c1i, c2i) - now;
+          WS(rate_down, bp) = rdoq_level_rate(E, best - 1, ctx1, ctx2, rice, c1i, c2i) - now;
+        } else {
+          WS(rate_up, bp) = E.greater1[ctx1][0];
+        }
+        out_level = (int)best;
+        base += cc;
+        if (best >= (unsigned)rdoq_base_level(c1i, c2i) && best > 3u * (1u << rice)) rice = min(rice + 1, 4u);
+        if (best >= 1) c1i++;
+        if (best > 1) {
+          c1 = 0;
+          c2 += (c2 < 2);
+          c2i++;
+        } else if (c1 < 3 && c1 > 0 && best) {
+          c1++;
+        }
+        if ((sp & 15) == 0 && sp > 0) {
+          c2 = 0;
+          rice = 0;
+          c1i = 0;
+          c2i = 0;
+          ctx_set = (sp == 16 || !is_luma) ? 0 : 2;
+          if (c1 == 0) ctx_set++;
+          c1 = 1;
+        }
+      } else {
+        base += cz;
+      }
+      WS(cost_coded, sp) = cc;
+      WS(cost_sig, sp) = cs;
+      DST(bp) = out_level;
+      s_sig += cs;
+      if (k == 0) s_sig0 = cs;
+      if (out_level) {
+        cg_flag |= 1ull << gpos;
+        s_coded += cc - cs;
+        s_uncoded += cz;
+        if (k != 0) nnz_before0++;
+      }
+    }
+    if (last_cg >= 0) {
+      if (cg) {
+        const unsigned r2 = gx < (unsigned)G - 1 ? (unsigned)((cg_flag >> (gy * G + gx + 1)) & 1) : 0u;
+        const unsigned l2 = gy < (unsigned)G - 1 ? (unsigned)((cg_flag >> ((gy + 1) * G + gx)) & 1) : 0u;
+        const unsigned cctx = (r2 || l2) ? 1u : 0u;
+        if (!((cg_flag >> gpos) & 1)) {
+          base += lambda * E.sig_cg[cctx][0] - s_sig;
+          WS(cost_cg_sig, cg) = lambda * E.sig_cg[cctx][0];
+        } else if (cg < last_cg) {
+          if (nnz_before0 == 0) {
+            base -= s_sig0;
+            s_sig -= s_sig0;
+          }
+          double zero_cost = base;
+          base += lambda * E.sig_cg[cctx][1];
+          zero_cost += lambda * E.sig_cg[cctx][0];
+          WS(cost_cg_sig, cg) = lambda * E.sig_cg[cctx][1];
+          zero_cost += s_uncoded;
+          zero_cost -= s_coded;
+          zero_cost -= s_sig;
+          if (zero_cost < base) {
+            cg_flag &= ~(1ull << gpos);
+            base = zero_cost;
+            WS(cost_cg_sig, cg) = lambda * E.sig_cg[cctx][0];
+            for (int k = 15; k >= 0; k--) {
+              const int sp = cg * 16 + k;
+              const unsigned bp = rdoq_scan_pos(lg, scan_idx, sp);
+              if (DST(bp)) {
+                DST(bp) = 0;
+                WS(cost_coded, sp) = WS(cost_zero, sp);
+                WS(cost_sig, sp) = 0;
+              }
+            }
+          }
+        }
+      } else {
+        cg_flag |= 1ull << gpos;
+      }
+    }
+  }
+  if (last_pos < 0) {
+    if (K.abs_sum) *K.abs_sum = 0;
+    return;
+  }
+
+  // ---- phase B: last position ----
+  double best_cost;
+  if (K.root_cbf) {
+    best_cost = uncoded + lambda * E.root_cbf[0][0];
+    base += lambda * E.root_cbf[0][1];
+  } else {
+    best_cost = uncoded + lambda * E.cbf[K.cbf_ctx][0];
+    base += lambda * E.cbf[K.cbf_ctx][1];
+  }
+  int best_last_p1 = 0;
+  bool found = false;
+  for (int cg = last_cg; cg >= 0 && !found; cg--) {
+    const unsigned p0 = rdoq_scan_pos(lg, scan_idx, cg * 16), gpos = ((p0 >> lg) >> 2) * G + ((p0 & (N - 1)) >> 2);
+    base -= WS(cost_cg_sig, cg);
+    if (!((cg_flag >> gpos) & 1)) continue;
+    for (int k = 15; k >= 0; k--) {
+      const int sp = cg * 16 + k;
+      if (sp > last_pos) continue;
+      const unsigned bp = rdoq_scan_pos(lg, scan_idx, sp);
+      const int lv = DST(bp);
+      if (lv) {
+        const unsigned py = bp >> lg, px = bp & (N - 1);
+        const double lc = scan_idx == 2 ? rdoq_last_cost(E, lambda, py, px) : rdoq_last_cost(E, lambda, px, py);
+        const double total = base + lc - WS(cost_sig, sp);
+        if (total < best_cost) {
+          best_last_p1 = sp + 1;
+          best_cost = total;
+        }
+        if (lv > 1) {
+          found = true;
+          break;
+        }
+        base -= WS(cost_coded, sp);
+        base += WS(cost_zero, sp);
+      } else {
+        base -= WS(cost_sig, sp);
+      }
+    }
+  }
+  for (int sp = 0; sp < best_last_p1; sp++) {
+    const unsigned bp = rdoq_scan_pos(lg, scan_idx, sp);
+    const int l = DST(bp);
+    abs_sum += (uint32_t)l;
+    DST(bp) = SRC(bp) < 0 ? -l : l;
+  }
+  for (int sp = best_last_p1; sp <= last_pos; sp++) DST(rdoq_scan_pos(lg, scan_idx, sp)) = 0;
+  if (K.abs_sum) *K.abs_sum = abs_sum;
+
+  // ---- phase C: sign-bit hiding with rate-aware costs (:2203-2304) ----
+  if (!(A.sign_hide && abs_sum >= 2)) return;
+  const long long rd_factor = A.rd_factor[pt];
+  const long long kMax = 0x7fffffffffffffffll;
+  int seen_last = -1;
+  for (int sub = (nn - 1) >> 4; sub >= 0; sub--) {
+    const int o = sub << 4;
+    int first = 16, lastnz = -1, sum = 0;
+    for (int n = 15; n >= 0; n--)
+      if (DST(rdoq_scan_pos(lg, scan_idx, n + o))) {
+        lastnz = n;
+        break;
+      }
+    for (int n = 0; n < 16; n++)
+      if (DST(rdoq_scan_pos(lg, scan_idx, n + o))) {
+        first = n;
+        break;
+      }
+    for (int n = first; n <= lastnz; n++) sum += DST(rdoq_scan_pos(lg, scan_idx, n + o));
+    if (lastnz >= 0 && seen_last == -1) seen_last = 1;
+    if (lastnz - first >= 4) {
+      const unsigned signbit = DST(rdoq_scan_pos(lg, scan_idx, o + first)) > 0 ? 0u : 1u;
+      if (signbit != (unsigned)(sum & 1)) {
+        long long min_cost = kMax, cur = kMax;
+        int min_pos = -1, final_change = 0, change = 0;
+        for (int n = (seen_last == 1 ? lastnz : 15); n >= 0; n--) {
+          const unsigned bp = rdoq_scan_pos(lg, scan_idx, n + o);
+          const int lv = DST(bp), du = WS(delta_u, bp), ru = WS(rate_up, bp);
+          if (lv != 0) {
+            const long long up = rd_factor * (-du) + ru;
+            long long down = rd_factor * (du) + WS(rate_down, bp) - (abs(lv) == 1 ? ((1 << 15) + WS(sig_delta, bp)) : 0);
+            if (seen_last == 1 && lastnz == n && abs(lv) == 1) down -= (4 << 15);
+            if (up < down) {
+              cur = up;
+              change = 1;
+            } else {
+              change = -1;
+              cur = (n == first && abs(lv) == 1) ? kMax : down;
+            }
+          } else {
+            cur = rd_factor * (-(long long)(abs(du))) + (1 << 15) + ru + WS(sig_delta, bp);
+            change = 1;
+            if (n < first) {
+              const unsigned s = SRC(bp) >= 0 ? 0u : 1u;
+              if (s != signbit) cur = kMax;
+            }
+          }
+          if (cur < min_cost) {
+            min_cost = cur;
+            final_change = change;
+            min_pos = (int)bp;
+          }
+        }
+        // (the reference's test of the flat quantiser coefficient against +-32768, :2290, never fires)
+        if (min_pos >= 0) {
+          if (SRC(min_pos) >= 0)
+            DST(min_pos) += final_change;
+          else
+            DST(min_pos) -= final_change;
+        }
+      }
+    }
+    if (seen_last == 1) seen_last = 0;
+  }
+#undef WS
+#undef SRC
+#undef DST
+}
+
+} // namespace hmx

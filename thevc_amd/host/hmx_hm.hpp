@@ -18,6 +18,7 @@ typedef int TCoeff;
 typedef int Int;
 typedef unsigned UInt;
 typedef bool Bool;
+typedef double Double;
 enum TextType { TEXT_LUMA = 0, TEXT_CHROMA = 1, TEXT_CHROMA_U = 2, TEXT_CHROMA_V = 3 };
 static const UInt REG_DCT = 65535;
 
@@ -97,11 +98,30 @@ public:
   void xDeQuant(const TCoeff *pSrc, Int *pDes, Int iWidth, Int iHeight, Int /*scalingListType*/) {
     m_c.check(hmx_xDeQuant(m_c.get(), pSrc, pDes, iWidth, iHeight, &m_qp.qp), "xDeQuant");
   }
+  // xRateDistOptQuant (TComTrQuant.cpp:1719): m_pcEstBitsSbac and m_dLambda are members here too (setLambda,
+  // TComTrQuant.h:155; the table is filled by the entropy coder's estBit); transform index and cbf context, which
+  // the reference reads from pcCU, come through setRdoqBlockState()
+  hmx_est_bits *m_pcEstBitsSbac = &m_estBits;
+  void setLambda(Double dLambda) { m_dLambda = dLambda; }
+  void setRdoqBlockState(Bool rootCbf, Int cbfCtx) {
+    m_rootCbf = rootCbf;
+    m_cbfCtx = cbfCtx;
+  }
+  void xRateDistOptQuant(Int *plSrcCoeff, TCoeff *piDstCoeff, UInt uiWidth, UInt uiHeight, UInt &uiAbsSum, TextType eTType) {
+    hmx_rdoq_param rp{m_qp.qp, m_qp.sign_hide, m_qp.is_intra, m_qp.dir_mode, m_rootCbf, m_cbfCtx, m_dLambda};
+    uint32_t s = uiAbsSum;
+    m_c.check(hmx_xRateDistOptQuant(m_c.get(), plSrcCoeff, piDstCoeff, (int)uiWidth, (int)uiHeight, &s, eTType, &rp, m_pcEstBitsSbac),
+              "xRateDistOptQuant");
+    uiAbsSum = s;
+  }
   const hmx_qp &qp() const { return m_qp.qp; }
 
 private:
   Context &m_c;
   hmx_quant_param m_qp;
+  hmx_est_bits m_estBits{};
+  Double m_dLambda = 1.0;
+  int m_rootCbf = 0, m_cbfCtx = 0;
 };
 
 // TComPattern + TComPrediction, intra part (TComPattern.cpp:213-366, TComPrediction.cpp:338-386)
