@@ -2052,6 +2052,9 @@ extern "C" int hmx_batch_xRateDistOptQuant(hmx_ctx *c, const hmx_tu *tus, const 
                      (unsigned char)rdoq_scan_index(N, luma, intra, t.mode), side[i].root_cbf, side[i].cbf_ctx,
                      (unsigned char)(luma ? 0 : 1), side[i].est_idx};
   }
+  // a block is one lane and its cost grows with its size: lanes of a wave should hold blocks of one size,
+  // the long ones first
+  std::stable_sort(b.begin(), b.end(), [](const RdoqBlock &x, const RdoqBlock &y) { return x.log2n > y.log2n; });
   return rdoq_launch(c, A, b, est, n_est);
 }
 
