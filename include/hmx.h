@@ -154,6 +154,15 @@ int hmx_predIntraLumaAng(hmx_ctx *ctx, const int32_t *adi, unsigned dir_mode, hm
                          int w, int h);
 int hmx_predIntraChromaAng(hmx_ctx *ctx, const int32_t *adi, unsigned dir_mode, hmx_pel *pred, unsigned stride,
                            int w, int h);
+/* The protected building blocks of the two wrappers (TComPrediction.cpp:129-167, 190-336, 689-730), named by
+ * the north star.  `adi` is ONE (2w+1) x (2w+1) border buffer (raw or smoothed: the reference's callers choose
+ * by passing a pointer; the reference's pSrc is its cell (1,1)).  xPredIntraAng: dir_mode 1 = DC from the
+ * sides flagged available (no edge smoothing: xDCPredFiltering is the wrapper's), 2..34 angular, `filter` =
+ * bFilter (edge filter of the pure vertical / horizontal modes). */
+int hmx_predIntraGetPredValDC(hmx_ctx *ctx, const int32_t *adi, int w, int h, int above, int left, hmx_pel *dc);
+int hmx_xPredIntraPlanar(hmx_ctx *ctx, const int32_t *adi, hmx_pel *pred, unsigned stride, int w, int h);
+int hmx_xPredIntraAng(hmx_ctx *ctx, const int32_t *adi, hmx_pel *pred, unsigned stride, int w, int h, unsigned dir_mode,
+                      int above, int left, int filter);
 
 /* ------------------------------------------------------------------------------------------------
  * Scalar drop-ins, TComInterpolationFilter (TLibCommon/TComInterpolationFilter.cpp:323-415) and

@@ -874,6 +874,17 @@ int hmo_use_filtered_refs(int mode, int log2n) { /* COM/TComPattern.cpp:49-56, 5
  * Intra prediction.  src points at buffer cell (1,1) like the reference (ptrSrc+sw+1), so
  * top(k) = src[k - stride - 1] (k=0 is the corner) and left(k) = src[(k-1)*stride - 1].
  * ---------------------------------------------------------------------------------------- */
+int16_t hmo_predIntraGetPredValDC(const int32_t *src, int ss, int N, int above, int left) {
+  int sum = 0;
+  if (above)
+    for (int i = 0; i < N; i++) sum += src[i - ss];
+  if (left)
+    for (int i = 0; i < N; i++) sum += src[i * ss - 1];
+  if (above && left) return (int16_t)((sum + N) / (2 * N));
+  if (above || left) return (int16_t)((sum + N / 2) / N);
+  return (int16_t)src[-1]; /* the default value the reference samples were filled with */
+}
+
 void hmo_xPredIntraAng(const int32_t *src, int ss, int16_t *dst, int ds, int N, int mode,
                        int filter_edge, int B) {
   static const int ang_tab[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};

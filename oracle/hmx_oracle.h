@@ -120,6 +120,8 @@ int hmo_use_filtered_refs(int mode, int log2n); /* getPredictorPtr decision */
 /* ---- intra prediction (COM/TComPrediction.cpp:129-386, 689-730, 1010-1029) ---- */
 void hmo_xPredIntraAng(const int32_t *src, int src_stride, int16_t *dst, int dst_stride, int N,
                        int mode, int filter_edge, int B);
+/* predIntraGetPredValDC (COM/TComPrediction.cpp:129-167): src points at buffer cell (1,1) */
+int16_t hmo_predIntraGetPredValDC(const int32_t *src, int src_stride, int N, int above, int left);
 void hmo_xPredIntraPlanar(const int32_t *src, int src_stride, int16_t *dst, int dst_stride, int N);
 void hmo_xDCPredFiltering(const int32_t *src, int src_stride, int16_t *dst, int dst_stride, int N);
 void hmo_predIntraLumaAng(const int32_t *adi, int mode, int16_t *dst, int dst_stride, int N, int B);

@@ -313,6 +313,21 @@ void ref_predIntraChromaAng(const int *adi, int mode, short *dst, unsigned strid
                              true);
 }
 
+// the protected building blocks named by the north star, on a caller-supplied border buffer
+int ref_predIntraGetPredValDC(const int *adi, int N, int above, int left) {
+  int W = 2 * N + 1;
+  return S->pred.predIntraGetPredValDC(const_cast<int *>(adi) + W + 1, W, N, N, above != 0, left != 0);
+}
+void ref_xPredIntraAng(const int *adi, int N, int mode, int above, int left, int filter, short *dst) {
+  int W = 2 * N + 1;
+  Pel *d = dst;
+  S->pred.xPredIntraAng(const_cast<int *>(adi) + W + 1, W, d, N, N, N, mode, above != 0, left != 0, filter != 0);
+}
+void ref_xPredIntraPlanar(const int *adi, int N, short *dst) {
+  int W = 2 * N + 1;
+  S->pred.xPredIntraPlanar(const_cast<int *>(adi) + W + 1, W, dst, N, N, N);
+}
+
 // ---- inter ----
 void ref_filterHorLuma(short *s, int ss, short *d, int ds, int w, int h, int frac, int last) {
   S->filt.filterHorLuma(s, ss, d, ds, w, h, frac, last != 0);

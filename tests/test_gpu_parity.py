@@ -563,3 +563,27 @@ def test_rdoq_batch_vs_oracle(ctx):
         n_nz += int(so > 0)
     assert n_nz > n // 4
     d_coef.free(), d_lev.free(), d_sum.free()
+
+
+def test_intra_building_blocks(ctx):
+    """predIntraGetPredValDC / xPredIntraPlanar / xPredIntraAng drop-ins on random border buffers vs the oracle."""
+    O, B = ol.oracle(), ctx.bit_depth
+    O.hmo_predIntraGetPredValDC.restype = C.c_int16
+    rng = np.random.default_rng(61 + B)
+    for N in (4, 8, 16, 32):
+        W = 2 * N + 1
+        adi = rng.integers(0, 1 << B, W * W).astype(np.int32)
+        src = ol.ptr(adi, W + 1)
+        for above in (0, 1):
+            for left in (0, 1):
+                want = O.hmo_predIntraGetPredValDC(src, W, N, above, left)
+                assert ctx.predIntraGetPredValDC(adi, N, above, left) == want, (N, above, left)
+                got = ctx.xPredIntraAng(adi, N, 1, above, left, 0)
+                assert (got == want).all(), ("dc fill", N, above, left)
+        ref = np.zeros(N * N, np.int16)
+        O.hmo_xPredIntraPlanar(src, W, ref.ctypes.data_as(C.c_void_p), N, N)
+        assert np.array_equal(ctx.xPredIntraPlanar(adi, N), ref), ("planar", N)
+        for mode in range(2, 35):
+            for filt in (0, 1):
+                O.hmo_xPredIntraAng(src, W, ref.ctypes.data_as(C.c_void_p), N, N, mode, filt, B)
+                assert np.array_equal(ctx.xPredIntraAng(adi, N, mode, 1, 1, filt), ref), ("ang", N, mode, filt)

@@ -359,6 +359,35 @@ def test_interpolation_filters(B):
                     assert np.array_equal(a, b), ("ver", chroma, frac, first, last)
 
 
+def test_intra_building_blocks(B):
+    """The protected building blocks named by the north star, on random border buffers:
+    predIntraGetPredValDC with every (above, left) combination, xPredIntraPlanar, xPredIntraAng with and
+    without the edge filter (modes 2..34; DC with both sides as initAdiPattern always flags them)."""
+    R, O = ol.ref(), ol.oracle()
+    O.hmo_predIntraGetPredValDC.restype = C.c_int16
+    R.ref_predIntraGetPredValDC.restype = C.c_int
+    rng = np.random.default_rng(1500 + B)
+    for N in (4, 8, 16, 32):
+        W = 2 * N + 1
+        for it in range(6):
+            adi = rng.integers(0, 1 << B, W * W).astype(np.int32)
+            src = ol.ptr(adi, W + 1)
+            for above in (0, 1):
+                for left in (0, 1):
+                    a = R.ref_predIntraGetPredValDC(adi.ctypes.data_as(C.c_void_p), N, above, left)
+                    b = O.hmo_predIntraGetPredValDC(src, W, N, above, left)
+                    assert a == b, (N, above, left)
+            pa, pb = np.zeros(N * N, np.int16), np.zeros(N * N, np.int16)
+            R.ref_xPredIntraPlanar(adi.ctypes.data_as(C.c_void_p), N, pa.ctypes.data_as(C.c_void_p))
+            O.hmo_xPredIntraPlanar(src, W, pb.ctypes.data_as(C.c_void_p), N, N)
+            assert np.array_equal(pa, pb), ("planar", N)
+            for mode in range(1, 35):
+                for filt in (0, 1):
+                    R.ref_xPredIntraAng(adi.ctypes.data_as(C.c_void_p), N, mode, 1, 1, filt, pa.ctypes.data_as(C.c_void_p))
+                    O.hmo_xPredIntraAng(src, W, pb.ctypes.data_as(C.c_void_p), N, N, mode, filt, B)
+                    assert np.array_equal(pa, pb), ("ang", N, mode, filt)
+
+
 def test_pred_inter_blocks_and_border():
     R, O = ol.ref(), ol.oracle()
     for B in (8, 10):

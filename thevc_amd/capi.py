@@ -118,6 +118,9 @@ def lib():
         L.hmx_initAdiPattern.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
         L.hmx_predIntraLumaAng.argtypes = [vp, vp, cu, vp, cu, ci, ci]
         L.hmx_predIntraChromaAng.argtypes = [vp, vp, cu, vp, cu, ci, ci]
+        L.hmx_predIntraGetPredValDC.argtypes = [vp, vp, ci, ci, ci, ci, C.POINTER(C.c_int16)]
+        L.hmx_xPredIntraPlanar.argtypes = [vp, vp, vp, cu, ci, ci]
+        L.hmx_xPredIntraAng.argtypes = [vp, vp, vp, cu, ci, ci, cu, ci, ci, ci]
         for n in ("hmx_filterHorLuma", "hmx_filterHorChroma"):
             getattr(L, n).argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci]
         for n in ("hmx_filterVerLuma", "hmx_filterVerChroma"):
@@ -323,6 +326,24 @@ class Context:
         adi = np.ascontiguousarray(adi, np.int32)
         pred = np.zeros(n * stride, np.int16)
         self._chk(lib().hmx_predIntraChromaAng(self.h, _hp(adi), mode, _hp(pred), stride, n, n))
+        return pred
+
+    def predIntraGetPredValDC(self, adi, n, above, left):
+        adi = np.ascontiguousarray(adi, np.int32)
+        dc = C.c_int16(0)
+        self._chk(lib().hmx_predIntraGetPredValDC(self.h, _hp(adi), n, n, above, left, C.byref(dc)))
+        return dc.value
+
+    def xPredIntraPlanar(self, adi, n):
+        adi = np.ascontiguousarray(adi, np.int32)
+        pred = np.zeros(n * n, np.int16)
+        self._chk(lib().hmx_xPredIntraPlanar(self.h, _hp(adi), _hp(pred), n, n, n))
+        return pred
+
+    def xPredIntraAng(self, adi, n, mode, above=1, left=1, filt=0):
+        adi = np.ascontiguousarray(adi, np.int32)
+        pred = np.zeros(n * n, np.int16)
+        self._chk(lib().hmx_xPredIntraAng(self.h, _hp(adi), _hp(pred), n, n, n, mode, above, left, filt))
         return pred
 
     def filter(self, name, src, src_off, ss, ds, w, h, frac, is_first=None, is_last=1):

@@ -302,9 +302,11 @@ __device__ __forceinline__ int dc_sum_block(const TuLds<N> &L, int gl) {
   return group_sum(s, NL);
 }
 
+// luma: edge filters of the angular/DC modes (bFilter) and, unless raw_line, the smoothed reference line
+// where getPredictorPtr picks it
 template <int N>
-__device__ __forceinline__ void intra_pred_block(TuLds<N> &L, int gl, int mode, bool luma, const PicDev &P, int *p) {
-  const int *R = (luma && use_filtered_refs(mode, Log2<N>::v)) ? L.fline : L.line;
+__device__ __forceinline__ void intra_pred_block(TuLds<N> &L, int gl, int mode, bool luma, const PicDev &P, int *p, bool raw_line = false) {
+  const int *R = (luma && !raw_line && use_filtered_refs(mode, Log2<N>::v)) ? L.fline : L.line;
   const int dcs = dc_sum_block<N, N>(L, gl); // shuffles: every lane of the wave executes this
   build_main_ref<N, N>(R, L.me, mode, gl);
   wave_sync();

@@ -2170,8 +2170,30 @@ __global__ __launch_bounds__(64) void k_adi(const short *win, int stride, int bx
   }
 }
 
+// predIntraGetPredValDC (TComPrediction.cpp:129-167) on a border buffer; fill >= 0: write it to n*n samples
+__global__ void k_dcval(const int *adi, int n, int above, int left, int *out, short *fill) {
+  const int W = 2 * n + 1;
+  const int *src = adi + W + 1;
+  int sum = 0;
+  if (above)
+    for (int i = 0; i < n; i++) sum += src[i - W];
+  if (left)
+    for (int i = 0; i < n; i++) sum += src[i * W - 1];
+  int dc;
+  if (above && left)
+    dc = (sum + n) / (2 * n);
+  else if (above || left)
+    dc = (sum + n / 2) / n;
+  else
+    dc = src[-1];
+  dc = (short)dc;
+  if (out) *out = dc;
+  if (fill)
+    for (int i = 0; i < n * n; i++) fill[i] = (short)dc;
+}
+
 template <int N>
-__global__ __launch_bounds__(64) void k_pred_adi(const int *adi, int mode, int luma, PicDev P, short *pred) {
+__global__ __launch_bounds__(64) void k_pred_adi(const int *adi, int mode, int luma, PicDev P, short *pred, int raw_line = 0) {
   __shared__ TuLds<N> L;
   const int gl = threadIdx.x;
   constexpr int W = 2 * N + 1;
@@ -2185,7 +2207,7 @@ __global__ __launch_bounds__(64) void k_pred_adi(const int *adi, int mode, int l
   __syncthreads();
   if (gl < N) {
     int row[N];
-    intra_pred_block<N>(L, gl, mode, luma != 0, P, row);
+    intra_pred_block<N>(L, gl, mode, luma != 0, P, row, raw_line != 0);
     store_row16<N>(pred + gl * N, row);
   }
 }
@@ -2216,7 +2238,7 @@ extern "C" int hmx_initAdiPattern(hmx_ctx *c, const hmx_pel *rec, int stride, in
 }
 
 static int pred_from_adi(hmx_ctx *c, const int32_t *adi, unsigned mode, hmx_pel *pred, unsigned stride, int w, int h,
-                         int luma) {
+                         int luma, int raw_line = 0) {
   if (!c || !adi || !pred || !size_ok(w, h) || mode > 34) return fail(c, HMX_ERR_ARG, "predIntra: unsupported size/mode or null");
   const int W = 2 * w + 1;
   Scratch s{c};
@@ -2227,10 +2249,10 @@ static int pred_from_adi(hmx_ctx *c, const int32_t *adi, unsigned mode, hmx_pel 
   hmx_pic_param pp{1 << 14, 1 << 14, 0, 0, HMX_I_SLICE, 0};
   PicDev P = make_picdev(c, &pp);
   switch (w) {
-  case 4: hipLaunchKernelGGL(k_pred_adi<4>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred); break;
-  case 8: hipLaunchKernelGGL(k_pred_adi<8>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred); break;
-  case 16: hipLaunchKernelGGL(k_pred_adi<16>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred); break;
-  default: hipLaunchKernelGGL(k_pred_adi<32>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred); break;
+  case 4: hipLaunchKernelGGL(k_pred_adi<4>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred, raw_line); break;
+  case 8: hipLaunchKernelGGL(k_pred_adi<8>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred, raw_line); break;
+  case 16: hipLaunchKernelGGL(k_pred_adi<16>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred, raw_line); break;
+  default: hipLaunchKernelGGL(k_pred_adi<32>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred, raw_line); break;
   }
   HIPCHK(c, hipGetLastError());
   return down2d(c, pred, stride, d_pred, 2, w, h);
@@ -2242,6 +2264,51 @@ extern "C" int hmx_predIntraLumaAng(hmx_ctx *c, const int32_t *adi, unsigned mod
 extern "C" int hmx_predIntraChromaAng(hmx_ctx *c, const int32_t *adi, unsigned mode, hmx_pel *pred, unsigned stride, int w,
                                       int h) {
   return pred_from_adi(c, adi, mode, pred, stride, w, h, 0);
+}
+
+// The protected building blocks of the two wrappers above, named by the north star.  `adi` is ONE
+// (2w+1) x (2w+1) border buffer (the caller chose raw or smoothed, as the reference's callers do by
+// passing a pointer); the reference's pSrc is its cell (1,1).
+extern "C" int hmx_predIntraGetPredValDC(hmx_ctx *c, const int32_t *adi, int w, int h, int above, int left, hmx_pel *dc) {
+  if (!c || !adi || !dc || !size_ok(w, h)) return fail(c, HMX_ERR_ARG, "hmx_predIntraGetPredValDC: unsupported size or null");
+  const int W = 2 * w + 1;
+  Scratch s{c};
+  int *d_adi = s.take<int>((size_t)W * W), *d_out = s.take<int>(1);
+  int r = hmx_upload(c, d_adi, adi, sizeof(int) * W * W);
+  if (r) return r;
+  hipLaunchKernelGGL(k_dcval, dim3(1), dim3(1), 0, c->stream, d_adi, w, above, left, d_out, (short *)nullptr);
+  HIPCHK(c, hipGetLastError());
+  int v = 0;
+  r = hmx_download(c, &v, d_out, sizeof(int));
+  *dc = (hmx_pel)v;
+  return r;
+}
+extern "C" int hmx_xPredIntraPlanar(hmx_ctx *c, const int32_t *adi, hmx_pel *pred, unsigned stride, int w, int h) {
+  return pred_from_adi(c, adi, 0, pred, stride, w, h, 0); // planar has no luma-only step: the chroma path on the given buffer
+}
+extern "C" int hmx_xPredIntraAng(hmx_ctx *c, const int32_t *adi, hmx_pel *pred, unsigned stride, int w, int h, unsigned dir_mode,
+                                 int above, int left, int filter) {
+  if (!c || !adi || !pred || !size_ok(w, h) || dir_mode < 1 || dir_mode > 34)
+    return fail(c, HMX_ERR_ARG, "hmx_xPredIntraAng: unsupported size, null or mode outside 1..34");
+  if (dir_mode == 1) { // DC from the sides flagged available; no edge smoothing here (xDCPredFiltering is the wrapper's)
+    const int W = 2 * w + 1;
+    Scratch s{c};
+    int *d_adi = s.take<int>((size_t)W * W);
+    short *d_pred = s.take<short>((size_t)w * h);
+    int r = hmx_upload(c, d_adi, adi, sizeof(int) * W * W);
+    if (r) return r;
+    hipLaunchKernelGGL(k_dcval, dim3(1), dim3(1), 0, c->stream, d_adi, w, above, left, (int *)nullptr, d_pred);
+    HIPCHK(c, hipGetLastError());
+    return down2d(c, pred, stride, d_pred, 2, w, h);
+  }
+  if (!filter) return pred_from_adi(c, adi, dir_mode, pred, stride, w, h, 0);
+  // bFilter: the luma edge filter of the pure vertical / horizontal modes, on the buffer as given.  The luma
+  // kernel expects the smoothed copy behind the raw one; it is told not to select it.
+  const int W = 2 * w + 1;
+  std::vector<int32_t> two((size_t)2 * W * W);
+  memcpy(two.data(), adi, sizeof(int32_t) * W * W);
+  memcpy(two.data() + (size_t)W * W, adi, sizeof(int32_t) * W * W);
+  return pred_from_adi(c, two.data(), dir_mode, pred, stride, w, h, 1, 1);
 }
 
 // =============================================================================================
