@@ -83,6 +83,40 @@ public:
                                   uiHeight, &m_qp.qp, useTransformSkip),
               "invtransformNxN");
   }
+  // invRecurTransformNxN (TComTrQuant.cpp:1452-1529): the walk over the transform quadtree of an inter CU.
+  // What the reference asks pcCU becomes a view over the per-partition arrays TComDataCU stores (one entry per
+  // 4x4 luma partition in z-order): transform index, coded-block flags of THIS texture, transform-skip flags.
+  struct CuTransformTree {
+    const unsigned char *trIdx;         // getTransformIdx
+    const unsigned char *cbf;           // getCbf(eTxt): bit d = flag at transform depth d
+    const unsigned char *transformSkip; // getTransformSkip(eTxt), may be null
+    UInt cuDepth;                       // getDepth
+    UInt maxCuWidth;                    // SPS getMaxCUWidth (64)
+    UInt numPartInLCU;                  // getPic()->getNumPartInCU() (256 for a 64x64 LCU of 4x4 partitions)
+    UInt totalNumPart;                  // getTotalNumPart(): partitions of this CU
+    Bool transquantBypass;
+  };
+  void invRecurTransformNxN(const CuTransformTree &cu, UInt uiAbsPartIdx, TextType eTxt, Pel *rpcResidual, UInt uiAddr,
+                            UInt uiStride, UInt uiWidth, UInt uiHeight, UInt uiMaxTrMode, UInt uiTrMode, TCoeff *rpcCoeff) {
+    if (!((cu.cbf[uiAbsPartIdx] >> uiTrMode) & 1)) return; // nothing coded below this node
+    if (uiTrMode == cu.trIdx[uiAbsPartIdx]) {               // a leaf (convertTransIdx is the identity, TComDataCU.cpp:3520)
+      const UInt depth = cu.cuDepth + uiTrMode;
+      if (eTxt != TEXT_LUMA && (cu.maxCuWidth >> depth) == 4) {
+        // four 4x4 luma leaves share one 4x4 chroma block, carried by the first of them (:1467-1476)
+        const UInt quarter = cu.numPartInLCU >> ((depth - 1) << 1);
+        if (uiAbsPartIdx % quarter) return;
+        uiWidth <<= 1;
+        uiHeight <<= 1;
+      }
+      const Bool ts = cu.transformSkip && cu.transformSkip[uiAbsPartIdx];
+      invtransformNxN(cu.transquantBypass, eTxt, HMX_REG_DCT, rpcResidual + uiAddr, uiStride, rpcCoeff, uiWidth, uiHeight, 0, ts);
+      return;
+    }
+    const UInt half_w = uiWidth >> 1, half_h = uiHeight >> 1, parts = cu.totalNumPart >> ((uiTrMode + 1) << 1);
+    for (UInt q = 0; q < 4; q++) // z-order: coefficients and partitions advance together
+      invRecurTransformNxN(cu, uiAbsPartIdx + q * parts, eTxt, rpcResidual, uiAddr + (q & 1) * half_w + (q >> 1) * half_h * uiStride,
+                           uiStride, half_w, half_h, uiMaxTrMode, uiTrMode + 1, rpcCoeff + q * half_w * half_h);
+  }
   // private members of the reference, named by the north star
   void xT(UInt uiMode, Pel *piBlkResi, UInt uiStride, Int *psCoeff, Int iWidth, Int iHeight) {
     m_c.check(hmx_xT(m_c.get(), uiMode, piBlkResi, uiStride, psCoeff, iWidth, iHeight), "xT");
