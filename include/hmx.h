@@ -165,6 +165,16 @@ int hmx_xPredIntraAng(hmx_ctx *ctx, const int32_t *adi, hmx_pel *pred, unsigned 
                       int above, int left, int filter);
 
 /* ------------------------------------------------------------------------------------------------
+ * Scalar drop-ins, TComRdCost (TLibCommon/TComRdCost.cpp): calcHAD :404-450 (same argument order) and
+ * getDistPart(piCur, iCurStride, piOrg, iOrgStride, w, h, false, DF_SSE) :452-478 -> xGetSSE* :1313-1657
+ * (the IBDI_DISTORTION 0 variant: per-sample (diff^2) >> 2*bitIncrement).  w, h <= 64.
+ * ---------------------------------------------------------------------------------------------- */
+int hmx_calcHAD(hmx_ctx *ctx, const hmx_pel *pi0, int stride0, const hmx_pel *pi1, int stride1, int w, int h,
+                uint32_t *satd);
+int hmx_getSSE(hmx_ctx *ctx, const hmx_pel *cur, int cur_stride, const hmx_pel *org, int org_stride, int w, int h,
+               uint32_t *sse);
+
+/* ------------------------------------------------------------------------------------------------
  * Scalar drop-ins, TComInterpolationFilter (TLibCommon/TComInterpolationFilter.cpp:323-415) and
  * TComYuv::addAvg (TLibCommon/TComYuv.cpp:520-581).  src must be readable 3 (luma) / 1 (chroma)
  * samples before and 4 / 2 after the block in the filtered direction, as in the reference.
@@ -256,6 +266,13 @@ int hmx_batch_predIntra(hmx_ctx *ctx, const hmx_tu_list *list, const hmx_pic *re
                         const hmx_pic_param *pp, const uint8_t *d_modes, int n_modes,
                         const size_t mode_plane_elems[3]);
 
+/* The mode pre-selection of estIntraPredQT (TLibEncoder/TEncSearch.cpp:2509-2540) without writing the
+ * candidates: for every block and every mode of d_modes (NULL: the block's own mode, n_modes = 1) predict
+ * from `rec` and cost against `org` with TComRdCost::calcHAD (TLibCommon/TComRdCost.cpp:404-450: Hadamard
+ * SATD over 8x8 sub-blocks, 4x4 for 4x4 blocks).  d_satd[(block index in the list's creation order) * n_modes
+ * + k] (device).  The 35 predictions stay in registers: 35x less write traffic than hmx_batch_predIntra. */
+int hmx_batch_predIntra_cost(hmx_ctx *ctx, const hmx_tu_list *list, const hmx_pic *rec, const hmx_pic *org,
+                             const hmx_pic_param *pp, const uint8_t *d_modes, int n_modes, uint32_t *d_satd);
 /* Whole-picture all-intra reconstruction from decisions: for every block, refs <- recon, predict,
  * residual, T, Q, IQ, IT, recon (ENC/TEncSearch.cpp:1006-1165 with RDOQ off; DEC/TDecCu.cpp:469-687 for
  * the decode direction).  Blocks are given per picture in coding order on the HOST; the library

@@ -748,6 +748,47 @@ void hmo_invtransformNxN(int bypass, unsigned mode, int16_t *resi, int stride, c
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Distortion.  The sum of |coefficients| of a 2-D Hadamard transform does not depend on the order or
+ * the signs of the transform's rows, so the butterflies below are the plain Walsh-Hadamard ones.
+ * ---------------------------------------------------------------------------------------- */
+static void wht(int *v, int n, int stride) {
+  for (int half = 1; half < n; half <<= 1)
+    for (int i = 0; i < n; i += 2 * half)
+      for (int j = i; j < i + half; j++) {
+        int a = v[j * stride], b = v[(j + half) * stride];
+        v[j * stride] = a + b;
+        v[(j + half) * stride] = a - b;
+      }
+}
+static uint32_t had_block(const int16_t *org, int so, const int16_t *cur, int sc, int n) {
+  int d[64], sum = 0;
+  for (int r = 0; r < n; r++)
+    for (int k = 0; k < n; k++) d[r * n + k] = org[r * so + k] - cur[r * sc + k];
+  for (int r = 0; r < n; r++) wht(d + r * n, n, 1);
+  for (int k = 0; k < n; k++) wht(d + k, n, n);
+  for (int i = 0; i < n * n; i++) sum += abs(d[i]);
+  return (uint32_t)(n == 8 ? (sum + 2) >> 2 : (sum + 1) >> 1); /* :1865, :1747 */
+}
+uint32_t hmo_calcHAD(const int16_t *org, int so, const int16_t *cur, int sc, int w, int h, int B) {
+  const int n = (w % 8 == 0 && h % 8 == 0) ? 8 : 4;
+  uint32_t sum = 0;
+  for (int y = 0; y < h; y += n)
+    for (int x = 0; x < w; x += n) sum += had_block(org + y * so + x, so, cur + y * sc + x, sc, n);
+  return sum >> (B - 8);
+}
+uint32_t hmo_getSSE(const int16_t *org, int so, const int16_t *cur, int sc, int w, int h, int B) {
+  /* the variant compiled with IBDI_DISTORTION 0 (COM/TComRdCost.cpp:1313-1657): per-sample square, then >> 2*inc */
+  const unsigned shift = (unsigned)(B - 8) << 1;
+  uint32_t sum = 0;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      int t = org[y * so + x] - cur[y * sc + x];
+      sum += (uint32_t)((t * t) >> shift);
+    }
+  return sum;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Intra reference samples
  * ---------------------------------------------------------------------------------------- */
 static inline unsigned zorder(unsigned cx, unsigned cy) { /* g_auiRasterToZscan for a unit */

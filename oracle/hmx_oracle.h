@@ -128,6 +128,11 @@ void hmo_predIntraLumaAng(const int32_t *adi, int mode, int16_t *dst, int dst_st
 void hmo_predIntraChromaAng(const int32_t *adi, int mode, int16_t *dst, int dst_stride, int N,
                             int B);
 
+/* ---- distortion (COM/TComRdCost.cpp): calcHAD :404-450 (Hadamard SATD over 8x8 sub-blocks when both sizes are
+ *      multiples of 8, else 4x4; xCalcHADs4x4 :1684, xCalcHADs8x8 :1778), xGetSSE* :1313-1657 (the IBDI_DISTORTION 0 variant) ---- */
+uint32_t hmo_calcHAD(const int16_t *org, int so, const int16_t *cur, int sc, int w, int h, int B);
+uint32_t hmo_getSSE(const int16_t *org, int so, const int16_t *cur, int sc, int w, int h, int B);
+
 /* ---- inter prediction (COM/TComInterpolationFilter.cpp, COM/TComPrediction.cpp:554-642,
  *      COM/TComYuv.cpp:401-581, COM/TComPicYuv.cpp:248-286) ---- */
 void hmo_filterHorLuma(const int16_t *src, int ss, int16_t *dst, int ds, int w, int h, int frac,

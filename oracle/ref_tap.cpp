@@ -14,6 +14,7 @@
 #include "TLibCommon/TComPic.h"
 #include "TLibCommon/TComPicYuv.h"
 #include "TLibCommon/TComPrediction.h"
+#include "TLibCommon/TComRdCost.h"
 #include "TLibCommon/TComRom.h"
 #include "TLibCommon/TComSlice.h"
 #include "TLibCommon/TComTrQuant.h"
@@ -43,6 +44,7 @@ struct State {
   TComPrediction pred;
   TComPattern pattern;
   TComInterpolationFilter filt;
+  TComRdCost rd;
   TComSPS sps;
   TComPPS pps;
   TComPic *pic = nullptr;
@@ -76,6 +78,7 @@ int ref_init(int bit_depth, int pic_w, int pic_h, int sign_hide) {
     S->tq.setFlatScalingList();
     S->tq.setUseScalingList(false);
     S->pred.initTempBuff();
+    S->rd.init();
     S->sub.create(256, 64, 64, false, 4, true);
     for (int i = 0; i < 3; i++) S->yuv[i].create(64, 64);
     S->rom = true;
@@ -326,6 +329,12 @@ void ref_xPredIntraAng(const int *adi, int N, int mode, int above, int left, int
 void ref_xPredIntraPlanar(const int *adi, int N, short *dst) {
   int W = 2 * N + 1;
   S->pred.xPredIntraPlanar(const_cast<int *>(adi) + W + 1, W, dst, N, N, N);
+}
+
+// ---- distortion ----
+unsigned ref_calcHAD(short *org, int so, short *cur, int sc, int w, int h) { return S->rd.calcHAD(org, so, cur, sc, w, h); }
+unsigned ref_getDistPart(short *cur, int sc, short *org, int so, int w, int h, int hads) {
+  return S->rd.getDistPart(cur, sc, org, so, w, h, false, hads ? DF_HADS : DF_SSE);
 }
 
 // ---- inter ----

@@ -388,8 +388,52 @@ def test_batch_lists(ctx):
         for m in range(35):
             ref = ol.o_intra_pred(flat[0], w, x, y, N, m, B, w, h, False)
             assert np.array_equal(cand[m, y:y + N, x:x + N], ref), (t, m)
+    # the same fan-out costed in place: calcHAD(original, prediction) for every (block, mode), nothing written back
+    O = ol.oracle()
+    O.hmo_calcHAD.restype = C.c_uint32
+    orgp = workload.make_planes(91, w, h, B, "texture")
+    d_orgp = capi.DevPicture(ctx, w, h).upload(orgp)
+    d_cost = ctx.alloc(4 * len(luma) * 35)
+    ctx._chk(L.hmx_batch_predIntra_cost(ctx.h, lst3, C.byref(d_pred.as_pic()), C.byref(d_orgp.as_pic()), C.byref(pp), d_modes.ptr, 35, d_cost.ptr))
+    ctx.sync()
+    cost = d_cost.download(np.uint32).reshape(len(luma), 35)
+    for i, t in enumerate(luma):
+        N, x, y = 1 << int(t["log2n"]), int(t["x"]), int(t["y"])
+        ob = np.ascontiguousarray(orgp[0][y:y + N, x:x + N])
+        for m in range(0, 35, 3) if i % 7 else range(35):
+            pb = np.ascontiguousarray(ol.o_intra_pred(flat[0], w, x, y, N, m, B, w, h, False))
+            want = O.hmo_calcHAD(ob.ctypes.data_as(C.c_void_p), N, pb.ctypes.data_as(C.c_void_p), N, N, N, B)
+            assert cost[i, m] == want, ("satd", i, N, m)
+    # chroma and the block's own mode (d_modes NULL), all sizes
+    d_cost2 = ctx.alloc(4 * len(tus2))
+    ctx._chk(L.hmx_batch_predIntra_cost(ctx.h, lst2, C.byref(d_pred.as_pic()), C.byref(d_orgp.as_pic()), C.byref(pp), None, 0, d_cost2.ptr))
+    ctx.sync()
+    cost2 = d_cost2.download(np.uint32)
+    for i, t in enumerate(tus2):
+        N, p, x, y = 1 << int(t["log2n"]), int(t["plane"]), int(t["x"]), int(t["y"])
+        ob = np.ascontiguousarray(orgp[p][y:y + N, x:x + N])
+        pb = np.ascontiguousarray(got[p][y:y + N, x:x + N])
+        assert cost2[i] == O.hmo_calcHAD(ob.ctypes.data_as(C.c_void_p), N, pb.ctypes.data_as(C.c_void_p), N, N, N, B), ("satd own mode", i)
     for l in (lst, lst2, lst3):
         L.hmx_tu_list_destroy(ctx.h, l)
+
+
+def test_distortion_dropins(ctx):
+    """calcHAD / getDistPart(SSE) drop-ins vs the oracle over block shapes incl. non-square ones."""
+    O, B, L = ol.oracle(), ctx.bit_depth, capi.lib()
+    O.hmo_calcHAD.restype = O.hmo_getSSE.restype = C.c_uint32
+    rng = np.random.default_rng(33 + B)
+    mx = (1 << B) - 1
+    for (w, h) in ((4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (8, 4), (16, 8), (12, 16), (64, 32)):
+        so, sc = w + 3, w + 1
+        org = rng.integers(0, mx + 1, so * h).astype(np.int16)
+        cur = rng.integers(0, mx + 1, sc * h).astype(np.int16)
+        po, pc = org.ctypes.data_as(C.c_void_p), cur.ctypes.data_as(C.c_void_p)
+        v = C.c_uint32(0)
+        ctx._chk(L.hmx_calcHAD(ctx.h, po, so, pc, sc, w, h, C.byref(v)))
+        assert v.value == O.hmo_calcHAD(po, so, pc, sc, w, h, B), ("calcHAD", w, h)
+        ctx._chk(L.hmx_getSSE(ctx.h, pc, sc, po, so, w, h, C.byref(v)))
+        assert v.value == O.hmo_getSSE(po, so, pc, sc, w, h, B), ("SSE", w, h)
 
 
 def test_batch_motion_compensation(ctx):

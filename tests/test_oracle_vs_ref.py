@@ -388,6 +388,28 @@ def test_intra_building_blocks(B):
                     assert np.array_equal(pa, pb), ("ang", N, mode, filt)
 
 
+def test_distortion(B):
+    """calcHAD (what estIntraPredQT costs a prediction with) and getDistPart SSE / HADS over block shapes."""
+    R, O = ol.ref(), ol.oracle()
+    O.hmo_calcHAD.restype = O.hmo_getSSE.restype = C.c_uint32
+    R.ref_calcHAD.restype = R.ref_getDistPart.restype = C.c_uint
+    rng = np.random.default_rng(1700 + B)
+    mx = (1 << B) - 1
+    for (w, h) in ((4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (8, 4), (4, 8), (16, 8), (16, 4), (12, 16), (32, 8), (64, 32)):
+        for it in range(4):
+            so, sc = w + int(rng.integers(0, 5)), w + int(rng.integers(0, 5))
+            org = rng.integers(0, mx + 1, so * h).astype(np.int16)
+            amp = int(rng.choice([3, 30, mx]))
+            cur = np.clip(org.reshape(h, so)[:, :w].astype(np.int32) + rng.integers(-amp, amp + 1, (h, w)), 0, mx).astype(np.int16)
+            curp = np.zeros(sc * h, np.int16)
+            curp.reshape(h, sc)[:, :w] = cur
+            po, pc = org.ctypes.data_as(C.c_void_p), curp.ctypes.data_as(C.c_void_p)
+            assert R.ref_calcHAD(po, so, pc, sc, w, h) == O.hmo_calcHAD(po, so, pc, sc, w, h, B), ("calcHAD", w, h)
+            assert R.ref_getDistPart(pc, sc, po, so, w, h, 0) == O.hmo_getSSE(po, so, pc, sc, w, h, B), ("SSE", w, h)
+            if w % 4 == 0 and h % 4 == 0 and (w == h or (w % 8 == 0 and h % 8 == 0)):
+                assert R.ref_getDistPart(pc, sc, po, so, w, h, 1) == O.hmo_calcHAD(po, so, pc, sc, w, h, B), ("HADS", w, h)
+
+
 def test_pred_inter_blocks_and_border():
     R, O = ol.ref(), ol.oracle()
     for B in (8, 10):

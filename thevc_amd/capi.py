@@ -118,6 +118,9 @@ def lib():
         L.hmx_initAdiPattern.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
         L.hmx_predIntraLumaAng.argtypes = [vp, vp, cu, vp, cu, ci, ci]
         L.hmx_predIntraChromaAng.argtypes = [vp, vp, cu, vp, cu, ci, ci]
+        L.hmx_calcHAD.argtypes = [vp, vp, ci, vp, ci, ci, ci, C.POINTER(C.c_uint32)]
+        L.hmx_getSSE.argtypes = [vp, vp, ci, vp, ci, ci, ci, C.POINTER(C.c_uint32)]
+        L.hmx_batch_predIntra_cost.argtypes = [vp, vp, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(PicParam), vp, ci, vp]
         L.hmx_predIntraGetPredValDC.argtypes = [vp, vp, ci, ci, ci, ci, C.POINTER(C.c_int16)]
         L.hmx_xPredIntraPlanar.argtypes = [vp, vp, vp, cu, ci, ci]
         L.hmx_xPredIntraAng.argtypes = [vp, vp, vp, cu, ci, ci, cu, ci, ci, ci]

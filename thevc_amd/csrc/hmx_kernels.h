@@ -314,6 +314,50 @@ __device__ __forceinline__ void intra_pred_block(TuLds<N> &L, int gl, int mode, 
   wave_sync(); // L.me is rebuilt by the next call (mode fan-out)
 }
 
+// calcHAD of an N x N block (TComRdCost.cpp:404-450): Hadamard SATD over its 8x8 sub-blocks (4x4 for N = 4),
+// each rounded on its own ((sum+2)>>2, (sum+1)>>1), summed.  Lane gl holds row gl of org - cur in d[]; all
+// lanes of the block return the block's sum (before calcHAD's final >> bit increment).  The sum of magnitudes
+// of a 2-D Hadamard transform does not depend on the order or signs of its rows: plain Walsh-Hadamard steps.
+template <int S>
+__device__ __forceinline__ void wht_regs(int *v) {
+#pragma unroll
+  for (int half = 1; half < S; half <<= 1)
+#pragma unroll
+    for (int i = 0; i < S; i += 2 * half)
+#pragma unroll
+      for (int j = i; j < i + half; j++) {
+        const int a = v[j], b = v[j + half];
+        v[j] = a + b;
+        v[j + half] = a - b;
+      }
+}
+template <int N>
+__device__ __forceinline__ int satd_block(TuLds<N> &L, int gl, const int *d) {
+  constexpr int S = N >= 8 ? 8 : 4, RND = S == 8 ? 2 : 1;
+  int t[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) t[k] = d[k];
+#pragma unroll
+  for (int c = 0; c < N; c += S) wht_regs<S>(t + c); // horizontal, per sub-block row
+#pragma unroll
+  for (int k = 0; k < N; k++) L.tile[gl][k] = t[k];
+  wave_sync();
+#pragma unroll
+  for (int r = 0; r < N; r++) t[r] = L.tile[r][gl]; // column gl
+  wave_sync();
+  int total = 0;
+#pragma unroll
+  for (int c = 0; c < N; c += S) { // vertical, per sub-block column; then the sub-block's S columns are S lanes
+    wht_regs<S>(t + c);
+    int s = 0;
+#pragma unroll
+    for (int r = 0; r < S; r++) s += abs(t[c + r]);
+    s = group_sum(s, S);
+    total += (s + RND) >> RND;
+  }
+  return group_sum((gl % S) == 0 ? total : 0, N);
+}
+
 // row access helpers (a block row inside a plane is not guaranteed to be more than 2-byte aligned)
 template <int N>
 __device__ __forceinline__ void load_row16(const short *src, int *x) {

@@ -49,6 +49,8 @@ struct ListArgs {
   LevelsDev lev2;
   uint32_t *abs_sum;
   int have_pred;
+  PlanesDev org;        // OP_PRED with cost: the original the predictions are costed against
+  uint32_t *cost;       // OP_PRED: calcHAD of every (block, mode), [block idx][n_modes]; NULL = none
   const uint8_t *modes; // OP_PRED fan-out
   int n_modes;
   size_t mode_elems[3];
@@ -162,13 +164,17 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
     const int rst = a_s;
     intra_refs<N, N>(L, gl, active, [&](int dx, int dy) { return (int)rec0[(ptrdiff_t)dy * rst + dx]; }, luma, avail, A.P);
     if (active) {
-      if (A.n_modes <= 0) {
-        intra_pred_block<N>(L, gl, t.mode, luma, A.P, row);
-        store_row16<N>(b_p + (size_t)(y + gl) * b_s + x, row);
-      } else {
-        for (int m = 0; m < A.n_modes; m++) {
-          intra_pred_block<N>(L, gl, A.modes[m], luma, A.P, row);
-          store_row16<N>(b_p + m * A.mode_elems[pl] + (size_t)(y + gl) * b_s + x, row);
+      int org_row[N];
+      if (A.cost) load_row16<N>(A.org.p[pl] + (size_t)(y + gl) * A.org.s[pl] + x, org_row);
+      const int nm = A.n_modes <= 0 ? 1 : A.n_modes;
+      for (int m = 0; m < nm; m++) {
+        intra_pred_block<N>(L, gl, A.n_modes <= 0 ? (int)t.mode : (int)A.modes[m], luma, A.P, row);
+        if (b_p) store_row16<N>(b_p + (A.n_modes <= 0 ? 0 : m * A.mode_elems[pl]) + (size_t)(y + gl) * b_s + x, row);
+        if (A.cost) { // the prediction never leaves the registers: estIntraPredQT's calcHAD(org, pred) fused in
+#pragma unroll
+          for (int k = 0; k < N; k++) row[k] = org_row[k] - row[k];
+          const int satd = satd_block<N>(L, gl, row);
+          if (gl == 0) A.cost[(size_t)d.idx * nm + m] = (uint32_t)satd >> (A.P.bit_depth - 8);
         }
       }
     }
@@ -1202,6 +1208,20 @@ extern "C" int hmx_batch_predIntra(hmx_ctx *c, const hmx_tu_list *l, const hmx_p
   A.modes = d_modes;
   A.n_modes = d_modes ? n_modes : 0;
   for (int i = 0; i < 3; i++) A.mode_elems[i] = mode_plane_elems ? mode_plane_elems[i] : 0;
+  return run_list(c, OP_PRED, l, A);
+}
+
+extern "C" int hmx_batch_predIntra_cost(hmx_ctx *c, const hmx_tu_list *l, const hmx_pic *rec, const hmx_pic *org,
+                                        const hmx_pic_param *pp, const uint8_t *d_modes, int n_modes, uint32_t *d_satd) {
+  if (!c || !l || !rec || !org || !pp || !d_satd || (d_modes && (n_modes <= 0 || n_modes > 35)))
+    return fail(c, HMX_ERR_ARG, "hmx_batch_predIntra_cost: bad argument");
+  ListArgs A{};
+  A.a = to_dev(rec);
+  A.org = to_dev(org);
+  A.cost = d_satd;
+  A.P = make_picdev(c, pp);
+  A.modes = d_modes;
+  A.n_modes = d_modes ? n_modes : 0;
   return run_list(c, OP_PRED, l, A);
 }
 
@@ -2309,6 +2329,73 @@ extern "C" int hmx_xPredIntraAng(hmx_ctx *c, const int32_t *adi, hmx_pel *pred, 
   memcpy(two.data(), adi, sizeof(int32_t) * W * W);
   memcpy(two.data() + (size_t)W * W, adi, sizeof(int32_t) * W * W);
   return pred_from_adi(c, two.data(), dir_mode, pred, stride, w, h, 1, 1);
+}
+
+// ---- distortion drop-ins (TComRdCost.cpp): calcHAD :404-450, getDistPart(DF_SSE) -> xGetSSE* :1313-1657 ----
+// one thread per 8x8 / 4x4 sub-block (HAD) or per row (SSE); partial sums by atomicAdd
+__global__ void k_dist(const short *org, int so, const short *cur, int sc, int w, int h, int inc, int hads, unsigned *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (hads) {
+    const int n = (w % 8 == 0 && h % 8 == 0) ? 8 : 4, bw = w / n, nb = bw * (h / n);
+    if (i >= nb) return;
+    const short *o = org + (size_t)(i / bw) * n * so + (i % bw) * n, *c = cur + (size_t)(i / bw) * n * sc + (i % bw) * n;
+    int d[64];
+    for (int r = 0; r < n; r++)
+      for (int k = 0; k < n; k++) d[r * 8 + k] = o[r * so + k] - c[r * sc + k];
+    int sum = 0;
+    if (n == 8) {
+      for (int r = 0; r < 8; r++) wht_regs<8>(d + r * 8);
+      for (int k = 0; k < 8; k++) {
+        int col[8];
+        for (int r = 0; r < 8; r++) col[r] = d[r * 8 + k];
+        wht_regs<8>(col);
+        for (int r = 0; r < 8; r++) sum += abs(col[r]);
+      }
+      sum = (sum + 2) >> 2;
+    } else {
+      for (int r = 0; r < 4; r++) wht_regs<4>(d + r * 8);
+      for (int k = 0; k < 4; k++) {
+        int col[4];
+        for (int r = 0; r < 4; r++) col[r] = d[r * 8 + k];
+        wht_regs<4>(col);
+        for (int r = 0; r < 4; r++) sum += abs(col[r]);
+      }
+      sum = (sum + 1) >> 1;
+    }
+    atomicAdd(out, (unsigned)sum);
+  } else {
+    if (i >= h) return;
+    unsigned sum = 0;
+    for (int k = 0; k < w; k++) {
+      const int t = org[(size_t)i * so + k] - cur[(size_t)i * sc + k];
+      sum += (unsigned)((t * t) >> (2 * inc));
+    }
+    atomicAdd(out, sum);
+  }
+}
+static int dist_scalar(hmx_ctx *c, const hmx_pel *org, int so, const hmx_pel *cur, int sc, int w, int h, int hads, uint32_t *out) {
+  if (!c || !org || !cur || !out || w <= 0 || h <= 0 || w > 64 || h > 64 || (hads && ((w | h) & 3)))
+    return fail(c, HMX_ERR_ARG, "distortion: unsupported size or null");
+  Scratch s{c};
+  short *d_o = s.take<short>((size_t)w * h), *d_c = s.take<short>((size_t)w * h);
+  unsigned *d_out = s.take<unsigned>(1);
+  int r = up2d(c, d_o, org, 2, w, h, so);
+  if (!r) r = up2d(c, d_c, cur, 2, w, h, sc);
+  if (r) return r;
+  HIPCHK(c, hipMemsetAsync(d_out, 0, 4, c->stream));
+  const int items = hads ? (w / 4) * (h / 4) : h;
+  hipLaunchKernelGGL(k_dist, dim3((items + 63) / 64), dim3(64), 0, c->stream, d_o, w, d_c, w, w, h, c->cfg.bit_depth - 8, hads, d_out);
+  HIPCHK(c, hipGetLastError());
+  unsigned v = 0;
+  r = hmx_download(c, &v, d_out, 4);
+  *out = hads ? v >> (c->cfg.bit_depth - 8) : v; // calcHAD returns uiSum >> g_uiBitIncrement (:449)
+  return r;
+}
+extern "C" int hmx_calcHAD(hmx_ctx *c, const hmx_pel *pi0, int stride0, const hmx_pel *pi1, int stride1, int w, int h, uint32_t *satd) {
+  return dist_scalar(c, pi0, stride0, pi1, stride1, w, h, 1, satd);
+}
+extern "C" int hmx_getSSE(hmx_ctx *c, const hmx_pel *cur, int cur_stride, const hmx_pel *org, int org_stride, int w, int h, uint32_t *sse) {
+  return dist_scalar(c, org, org_stride, cur, cur_stride, w, h, 0, sse);
 }
 
 // =============================================================================================

@@ -178,6 +178,26 @@ private:
   Context &m_c;
 };
 
+// TComRdCost, the two distortion entry points next to the path (TComRdCost.cpp:404-478)
+class TComRdCost {
+public:
+  explicit TComRdCost(Context &c) : m_c(c) {}
+  UInt calcHAD(Pel *pi0, Int iStride0, Pel *pi1, Int iStride1, Int iWidth, Int iHeight) {
+    uint32_t v = 0;
+    m_c.check(hmx_calcHAD(m_c.get(), pi0, iStride0, pi1, iStride1, iWidth, iHeight, &v), "calcHAD");
+    return v;
+  }
+  // getDistPart(..., bWeighted = false, DF_SSE)
+  UInt getDistPart(Pel *piCur, Int iCurStride, Pel *piOrg, Int iOrgStride, UInt uiBlkWidth, UInt uiBlkHeight) {
+    uint32_t v = 0;
+    m_c.check(hmx_getSSE(m_c.get(), piCur, iCurStride, piOrg, iOrgStride, (int)uiBlkWidth, (int)uiBlkHeight, &v), "getDistPart");
+    return v;
+  }
+
+private:
+  Context &m_c;
+};
+
 // TComInterpolationFilter (TComInterpolationFilter.cpp:323-415): identical signatures
 class TComInterpolationFilter {
 public:
