@@ -321,6 +321,18 @@ typedef struct {
 } hmx_pu;
 int hmx_batch_motionCompensation(hmx_ctx *ctx, const hmx_pu *d_pus, int n, const hmx_pic *refs, int n_refs,
                                  const hmx_pic *dst);
+/* Planar 4:2:0 YUV frames, the format either side of the path (TLibVideoIO/TVideoIOYuv.cpp:226-480, SURVEY.md
+ * 8f rank 4).  d_file (device) holds one frame as the file does: 8-bit or 16-bit little-endian samples, Y then
+ * Cb then Cr.  unpack = TVideoIOYuv::read: the file's (w_full - pad_x) x (h_full - pad_y) samples are padded to
+ * the right and below by replication and every sample is scaled from file_bits to the context's bit depth
+ * (<< when deeper; (v + half) >> s clipped to [0, 2^bits - 1] when shallower).  pack = TVideoIOYuv::write:
+ * scaled the other way, the top-left (w - crop_right) x (h - crop_bottom) samples stored.
+ * hmx_yuv_frame_bytes(w, h, file_bits) = size of a frame of w x h samples. */
+size_t hmx_yuv_frame_bytes(int w, int h, int file_bits);
+int hmx_yuv_unpack(hmx_ctx *ctx, const void *d_file, int file_bits, const hmx_pic *dst, int w_full, int h_full, int pad_x,
+                   int pad_y);
+int hmx_yuv_pack(hmx_ctx *ctx, const hmx_pic *src, int w, int h, int crop_right, int crop_bottom, int file_bits, void *d_file);
+
 /* One picture's motion compensation in a multi-picture call. */
 typedef struct hmx_mc_job {
   const hmx_pu *d_pus; /* device */

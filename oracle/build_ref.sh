@@ -41,6 +41,7 @@ for f in "$SRC"/TLibCommon/*.cpp; do
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 gcc -O2 -w -fPIC -c "$SRC/libmd5/libmd5.c" -o "$OUT/obj/libmd5.o"
+$CXX $FLAGS -c "$SRC/TLibVideoIO/TVideoIOYuv.cpp" -o "$OUT/obj/TVideoIOYuv.o"
 $CXX $FLAGS -I"$HERE" -c "$HERE/ref_tap.cpp" -o "$OUT/obj/ref_tap.o"
 $CXX -shared -o "$OUT/libhmref.so" "$OUT"/obj/*.o
 echo "build_ref: wrote $OUT/libhmref.so"

@@ -1267,3 +1267,48 @@ void hmo_mc_frame(const hmo_pu *pus, int n_pu, int B, const int16_t *const *ref_
     }
   }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Planar YUV frames (VIO/TVideoIOYuv.cpp)
+ * ---------------------------------------------------------------------------------------- */
+static int16_t yuv_rescale(int16_t v, int shift, int bits) { /* scalePlane :62-127: shift > 0 multiplies */
+  if (shift == 0) return v;
+  if (shift > 0) return (int16_t)(v << shift);
+  int16_t r = (int16_t)((v + (int16_t)(1 << (-shift - 1))) >> -shift);
+  int maxv = (1 << bits) - 1;
+  return (int16_t)(r < 0 ? 0 : (r > maxv ? maxv : r));
+}
+void hmo_yuv_unpack(const uint8_t *file, int file_bits, int internal_bits, int w_full, int h_full, int pad_x, int pad_y,
+                    int16_t *const planes[3], const int strides[3]) {
+  const int wide = file_bits > 8, shift = internal_bits - file_bits;
+  for (int p = 0; p < 3; p++) {
+    const int c = p ? 1 : 0, wf = w_full >> c, hf = h_full >> c, px = pad_x >> c, py = pad_y >> c, w = wf - px, h = hf - py;
+    int16_t *d = planes[p];
+    const int st = strides[p];
+    for (int y = 0; y < hf; y++)
+      for (int x = 0; x < wf; x++) {
+        const int sx = x < w ? x : w - 1, sy = y < h ? y : h - 1; /* readPlane :226-275 */
+        const uint8_t *s = file + ((size_t)sy * w + sx) * (wide ? 2 : 1);
+        const int16_t v = wide ? (int16_t)((s[1] << 8) | s[0]) : (int16_t)s[0];
+        d[y * st + x] = yuv_rescale(v, shift, internal_bits);
+      }
+    file += (size_t)w * h * (wide ? 2 : 1);
+  }
+}
+void hmo_yuv_pack(const int16_t *const planes[3], const int strides[3], int w, int h, int crop_right, int crop_bottom,
+                  int internal_bits, int file_bits, uint8_t *file) {
+  const int wide = file_bits > 8, shift = file_bits - internal_bits; /* write() scales by -m_bitdepthShift :421-436 */
+  int ww = w - crop_right, hh = h - crop_bottom;
+  for (int p = 0; p < 3; p++) {
+    if (p == 1) ww >>= 1, hh >>= 1;
+    for (int y = 0; y < hh; y++)
+      for (int x = 0; x < ww; x++) {
+        const int16_t v = yuv_rescale(planes[p][y * strides[p] + x], shift, file_bits);
+        if (wide) {
+          *file++ = (uint8_t)(v & 0xff);
+          *file++ = (uint8_t)((v >> 8) & 0xff);
+        } else
+          *file++ = (uint8_t)v;
+      }
+  }
+}

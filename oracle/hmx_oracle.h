@@ -199,6 +199,17 @@ typedef struct {
 void hmo_mc_frame(const hmo_pu *pus, int n_pu, int B, const int16_t *const *ref_planes /*[nref*3]*/,
                   const int *ref_strides /*[3]*/, int16_t *const dst[3], const int dst_stride[3]);
 
+/* ---- planar 4:2:0 YUV frames as the reference reads and writes them (VIO/TVideoIOYuv.cpp:226-480):
+ *      8-bit or 16-bit little-endian samples, Y then Cb then Cr; on read the active area is padded to the
+ *      right and below by replication and the whole padded plane is scaled to the internal bit depth
+ *      (<< when deeper; (v + half) >> s clipped to [0, 2^bits - 1] when shallower, CLIP_TO_709_RANGE 0);
+ *      on write the planes are scaled the other way and the top-left (w - crop_right) x (h - crop_bottom)
+ *      samples are stored ---- */
+void hmo_yuv_unpack(const uint8_t *file, int file_bits, int internal_bits, int w_full, int h_full, int pad_x, int pad_y,
+                    int16_t *const planes[3], const int strides[3]);
+void hmo_yuv_pack(const int16_t *const planes[3], const int strides[3], int w, int h, int crop_right, int crop_bottom,
+                  int internal_bits, int file_bits, uint8_t *file);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@
 #include "TLibCommon/TComSlice.h"
 #include "TLibCommon/TComTrQuant.h"
 #include "TLibCommon/TComYuv.h"
+#include "TLibVideoIO/TVideoIOYuv.h"
 #undef private
 #undef protected
 
@@ -329,6 +330,44 @@ void ref_xPredIntraAng(const int *adi, int N, int mode, int above, int left, int
 void ref_xPredIntraPlanar(const int *adi, int N, short *dst) {
   int W = 2 * N + 1;
   S->pred.xPredIntraPlanar(const_cast<int *>(adi) + W + 1, W, dst, N, N, N);
+}
+
+// ---- planar YUV files (TLibVideoIO/TVideoIOYuv.cpp): one frame in, one frame out ----
+// read: the file holds (w_full - pad_x) x (h_full - pad_y) samples; planes come back dense w_full x h_full
+int ref_yuv_read(const char *path, int file_bits, int internal_bits, int w_full, int h_full, int pad_x, int pad_y, short *y,
+                 short *cb, short *cr) {
+  TVideoIOYuv io;
+  io.open(const_cast<char *>(path), false, file_bits, internal_bits);
+  TComPicYuv pic;
+  pic.create(w_full, h_full, 64, 64, 4);
+  Int pad[2] = {pad_x, pad_y};
+  bool ok = io.read(&pic, pad);
+  io.close();
+  if (ok) {
+    for (int j = 0; j < h_full; j++) memcpy(y + j * w_full, pic.getLumaAddr() + j * pic.getStride(), 2 * w_full);
+    for (int j = 0; j < h_full / 2; j++) {
+      memcpy(cb + j * (w_full / 2), pic.getCbAddr() + j * pic.getCStride(), w_full);
+      memcpy(cr + j * (w_full / 2), pic.getCrAddr() + j * pic.getCStride(), w_full);
+    }
+  }
+  pic.destroy();
+  return ok ? 1 : 0;
+}
+int ref_yuv_write(const char *path, int file_bits, int internal_bits, int w, int h, int crop_right, int crop_bottom, const short *y,
+                  const short *cb, const short *cr) {
+  TVideoIOYuv io;
+  io.open(const_cast<char *>(path), true, file_bits, internal_bits);
+  TComPicYuv pic;
+  pic.create(w, h, 64, 64, 4);
+  for (int j = 0; j < h; j++) memcpy(pic.getLumaAddr() + j * pic.getStride(), y + j * w, 2 * w);
+  for (int j = 0; j < h / 2; j++) {
+    memcpy(pic.getCbAddr() + j * pic.getCStride(), cb + j * (w / 2), w);
+    memcpy(pic.getCrAddr() + j * pic.getCStride(), cr + j * (w / 2), w);
+  }
+  bool ok = io.write(&pic, 0, crop_right, 0, crop_bottom);
+  io.close();
+  pic.destroy();
+  return ok ? 1 : 0;
 }
 
 // ---- distortion ----

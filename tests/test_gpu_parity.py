@@ -631,3 +631,47 @@ def test_intra_building_blocks(ctx):
             for filt in (0, 1):
                 O.hmo_xPredIntraAng(src, W, ref.ctypes.data_as(C.c_void_p), N, N, mode, filt, B)
                 assert np.array_equal(ctx.xPredIntraAng(adi, N, mode, 1, 1, filt), ref), ("ang", N, mode, filt)
+
+
+def test_yuv_files_on_device(ctx, tmp_path):
+    """hmx_yuv_unpack / hmx_yuv_pack (through thevc_amd.yuvio, real files) vs the oracle's TVideoIOYuv restatement:
+    8- and 16-bit files, scaling up and down to the context's bit depth, right/bottom padding, cropping."""
+    from thevc_amd import yuvio
+    O, B = ol.oracle(), ctx.bit_depth
+    rng = np.random.default_rng(5 + B)
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
+    for file_bits in (8, 10, 12):
+        w, h, px, py = 72, 40, 24, 8
+        wf, hf = w + px, h + py
+        wide = file_bits > 8
+        frames = []
+        path = str(tmp_path / f"in{file_bits}.yuv")
+        with open(path, "wb") as f:
+            for k in range(3):
+                vals = rng.integers(0, 1 << file_bits, w * h * 3 // 2)
+                raw = vals.astype("<u2").tobytes() if wide else vals.astype(np.uint8).tobytes()
+                frames.append(np.frombuffer(raw, np.uint8))
+                f.write(raw)
+        rd = yuvio.YuvReader(ctx, path, w, h, file_bits)
+        wr = yuvio.YuvWriter(ctx, str(tmp_path / f"out{file_bits}.yuv"), file_bits)
+        pic = capi.DevPicture(ctx, wf, hf)
+        rd.skip_frames(1)
+        want_bytes = b""
+        for k in (1, 2):
+            assert rd.read(pic, px, py)
+            ctx.sync()
+            got = pic.download()
+            oy, ocb, ocr = np.zeros((hf, wf), np.int16), np.zeros((hf // 2, wf // 2), np.int16), np.zeros((hf // 2, wf // 2), np.int16)
+            O.hmo_yuv_unpack(frames[k].ctypes.data_as(C.c_void_p), file_bits, B, wf, hf, px, py,
+                             P3(oy.ctypes.data, ocb.ctypes.data, ocr.ctypes.data), I3(wf, wf // 2, wf // 2))
+            for p, o in enumerate((oy, ocb, ocr)):
+                assert np.array_equal(got[p], o), ("unpack", file_bits, k, p)
+            wr.write(pic, wf, hf, px, py)
+            mine = np.zeros(w * h * 3 // 2 * (2 if wide else 1), np.uint8)
+            O.hmo_yuv_pack(P3(oy.ctypes.data, ocb.ctypes.data, ocr.ctypes.data), I3(wf, wf // 2, wf // 2), wf, hf, px, py, B,
+                           file_bits, mine.ctypes.data_as(C.c_void_p))
+            want_bytes += mine.tobytes()
+        assert not rd.read(pic, px, py)  # end of file
+        rd.close(), wr.close()
+        assert open(str(tmp_path / f"out{file_bits}.yuv"), "rb").read() == want_bytes, ("pack", file_bits)
+        pic.free()

@@ -495,3 +495,38 @@ def test_whole_picture_intra_encode(pic, tiling, B, qp):
         for p in range(3):
             assert np.array_equal(lo[p], lr[p]), ("levels", kind, p)
             assert np.array_equal(ro[p], rr[p]), ("recon", kind, p)
+
+
+def test_yuv_files(tmp_path):
+    """TVideoIOYuv::read / write through real files: 8- and 16-bit samples, bit-depth scaling both ways,
+    right/bottom padding on read, cropping on write."""
+    R, O = ol.ref(), ol.oracle()
+    R.ref_init(8, 416, 240, 1)
+    rng = np.random.default_rng(77)
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
+    for (file_bits, int_bits) in ((8, 8), (8, 10), (10, 10), (10, 8), (12, 10), (8, 12)):
+        w, h, px, py = 40, 24, 8, 8  # active area in the file; padded to 48 x 32
+        wf, hf = w + px, h + py
+        wide = file_bits > 8
+        n = w * h * 3 // 2
+        vals = rng.integers(0, 1 << file_bits, n)
+        raw = vals.astype("<u2").tobytes() if wide else vals.astype(np.uint8).tobytes()
+        path = str(tmp_path / f"in_{file_bits}_{int_bits}.yuv")
+        open(path, "wb").write(raw)
+        ry, rcb, rcr = np.zeros(wf * hf, np.int16), np.zeros(wf * hf // 4, np.int16), np.zeros(wf * hf // 4, np.int16)
+        assert R.ref_yuv_read(path.encode(), file_bits, int_bits, wf, hf, px, py, ry.ctypes.data_as(C.c_void_p),
+                              rcb.ctypes.data_as(C.c_void_p), rcr.ctypes.data_as(C.c_void_p)) == 1
+        oy, ocb, ocr = np.zeros_like(ry), np.zeros_like(rcb), np.zeros_like(rcr)
+        buf = np.frombuffer(raw, np.uint8)
+        O.hmo_yuv_unpack(buf.ctypes.data_as(C.c_void_p), file_bits, int_bits, wf, hf, px, py,
+                         P3(oy.ctypes.data, ocb.ctypes.data, ocr.ctypes.data), I3(wf, wf // 2, wf // 2))
+        assert np.array_equal(ry, oy) and np.array_equal(rcb, ocb) and np.array_equal(rcr, ocr), (file_bits, int_bits)
+        # write the padded picture back, cropping the padding away
+        out = str(tmp_path / f"out_{file_bits}_{int_bits}.yuv")
+        assert R.ref_yuv_write(out.encode(), file_bits, int_bits, wf, hf, px, py, ry.ctypes.data_as(C.c_void_p),
+                               rcb.ctypes.data_as(C.c_void_p), rcr.ctypes.data_as(C.c_void_p)) == 1
+        ref_bytes = np.frombuffer(open(out, "rb").read(), np.uint8)
+        mine = np.zeros(len(ref_bytes), np.uint8)
+        O.hmo_yuv_pack(P3(oy.ctypes.data, ocb.ctypes.data, ocr.ctypes.data), I3(wf, wf // 2, wf // 2), wf, hf, px, py, int_bits,
+                       file_bits, mine.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(ref_bytes, mine), ("write", file_bits, int_bits)

@@ -2774,6 +2774,65 @@ extern "C" int hmx_pic_extend_border(hmx_ctx *c, const hmx_pic *pic, int pic_w, 
   return hmx_pic_extend_border_multi(c, 1, pic, pic_w, pic_h, mx, my);
 }
 
+// ---- planar 4:2:0 YUV frames (TLibVideoIO/TVideoIOYuv.cpp:226-480) ----
+// A frame travels as the bytes of the file (1 or 2 bytes per sample, Y then Cb then Cr): half or a quarter of
+// the PCIe traffic of int16 planes; widening, bit-depth scaling and the right/bottom padding happen in HBM.
+__device__ __forceinline__ short yuv_rescale(short v, int shift, int bits) { // scalePlane :62-127
+  if (shift == 0) return v;
+  if (shift > 0) return (short)(v << shift);
+  const short r = (short)((v + (short)(1 << (-shift - 1))) >> -shift);
+  return (short)min(max((int)r, 0), (1 << bits) - 1);
+}
+__global__ __launch_bounds__(256) void k_yuv_unpack(const unsigned char *file, int wide, int shift, int bits, int w_full, int h_full,
+                                                    int pad_x, int pad_y, PlanesDev D) {
+  const int p = blockIdx.y, c = p ? 1 : 0;
+  const int wf = w_full >> c, hf = h_full >> c, w = wf - (pad_x >> c), h = hf - (pad_y >> c);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= wf * hf) return;
+  const int x = i % wf, y = i / wf, sx = min(x, w - 1), sy = min(y, h - 1); // readPlane :226-275: replicate right, then down
+  const size_t luma = (size_t)(w_full - pad_x) * (h_full - pad_y), chroma = (size_t)w * h;
+  const size_t plane_off = (p == 0 ? 0 : luma + (p == 2 ? chroma : 0)) * (wide ? 2 : 1);
+  const unsigned char *s = file + plane_off + ((size_t)sy * w + sx) * (wide ? 2 : 1);
+  const short v = wide ? (short)((s[1] << 8) | s[0]) : (short)s[0];
+  D.p[p][(size_t)y * D.s[p] + x] = yuv_rescale(v, shift, bits);
+}
+__global__ __launch_bounds__(256) void k_yuv_pack(PlanesDev S, int wide, int shift, int bits, int ww, int hh, unsigned char *file) {
+  const int p = blockIdx.y, c = p ? 1 : 0, w = ww >> c, h = hh >> c;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w * h) return;
+  const int x = i % w, y = i / w;
+  const size_t luma = (size_t)ww * hh, chroma = (size_t)w * h;
+  unsigned char *d = file + ((p == 0 ? 0 : luma + (p == 2 ? chroma : 0)) + (size_t)i) * (wide ? 2 : 1);
+  const short v = yuv_rescale(S.p[p][(size_t)y * S.s[p] + x], shift, bits);
+  if (wide) {
+    d[0] = (unsigned char)(v & 0xff);
+    d[1] = (unsigned char)((v >> 8) & 0xff);
+  } else
+    d[0] = (unsigned char)v;
+}
+extern "C" size_t hmx_yuv_frame_bytes(int w, int h, int file_bits) { return (size_t)w * h * 3 / 2 * (file_bits > 8 ? 2 : 1); }
+extern "C" int hmx_yuv_unpack(hmx_ctx *c, const void *d_file, int file_bits, const hmx_pic *dst, int w_full, int h_full, int pad_x,
+                              int pad_y) {
+  if (!c || !d_file || !dst || file_bits < 8 || file_bits > 16 || w_full <= 0 || h_full <= 0 || (w_full & 1) || (h_full & 1) ||
+      pad_x < 0 || pad_y < 0 || (pad_x & 1) || (pad_y & 1) || pad_x >= w_full || pad_y >= h_full)
+    return fail(c, HMX_ERR_ARG, "hmx_yuv_unpack: bad argument");
+  hipLaunchKernelGGL(k_yuv_unpack, dim3((unsigned)(((size_t)w_full * h_full + 255) / 256), 3), dim3(256), 0, c->stream,
+                     static_cast<const unsigned char *>(d_file), file_bits > 8 ? 1 : 0, c->cfg.bit_depth - file_bits, c->cfg.bit_depth,
+                     w_full, h_full, pad_x, pad_y, to_dev(dst));
+  HIPCHK(c, hipGetLastError());
+  return HMX_OK;
+}
+extern "C" int hmx_yuv_pack(hmx_ctx *c, const hmx_pic *src, int w, int h, int crop_right, int crop_bottom, int file_bits, void *d_file) {
+  if (!c || !d_file || !src || file_bits < 8 || file_bits > 16 || crop_right < 0 || crop_bottom < 0 || crop_right >= w ||
+      crop_bottom >= h || ((w - crop_right) & 1) || ((h - crop_bottom) & 1))
+    return fail(c, HMX_ERR_ARG, "hmx_yuv_pack: bad argument");
+  const int ww = w - crop_right, hh = h - crop_bottom;
+  hipLaunchKernelGGL(k_yuv_pack, dim3((unsigned)(((size_t)ww * hh + 255) / 256), 3), dim3(256), 0, c->stream, to_dev(src),
+                     file_bits > 8 ? 1 : 0, file_bits - c->cfg.bit_depth, file_bits, ww, hh, static_cast<unsigned char *>(d_file));
+  HIPCHK(c, hipGetLastError());
+  return HMX_OK;
+}
+
 extern "C" void hmx_clipMv(int *mvx, int *mvy, int cu_x, int cu_y, int pic_w, int pic_h, int ctu) {
   const int hmax = (pic_w + 8 - cu_x - 1) << 2, hmin = (-ctu - 8 - cu_x + 1) * 4; // TComDataCU.cpp:3505-3517
   const int vmax = (pic_h + 8 - cu_y - 1) << 2, vmin = (-ctu - 8 - cu_y + 1) * 4;
