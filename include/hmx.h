@@ -321,6 +321,19 @@ typedef struct {
 } hmx_pu;
 int hmx_batch_motionCompensation(hmx_ctx *ctx, const hmx_pu *d_pus, int n, const hmx_pic *refs, int n_refs,
                                  const hmx_pic *dst);
+/* Deblocking filter, the application part (TLibCommon/TComLoopFilter.cpp:571-922: xEdgeFilterLuma, xEdgeFilterChroma,
+ * the pel filters, the strong/weak decision), in place on a reconstructed picture whose size
+ * is a multiple of 8.  Maps (device) hold one entry per 4x4 luma unit in raster order: d_bs_ver[u] = boundary
+ * strength 0..2 of the vertical edge on the unit's LEFT side, d_bs_hor[u] = of the horizontal edge on its TOP side
+ * (what xGetBoundaryStrengthSingle :444 leaves in m_aapucBS; 0 on the picture boundary); d_qp[u] = the unit's luma
+ * QP (TComDataCU::getQP); d_no_filter[u] != 0 (may be NULL) keeps a unit's samples: IPCM with
+ * pcm_loop_filter_disable (:609-614).  (The reference's lossless flags are ORed into variables that stay set for
+ * the rest of a CU's edge, :616-617; that CU-shaped stickiness is not reproduced.)  Edges on the 8x8 luma grid
+ * are filtered, chroma on its own 8x8 grid for strength 2; all vertical edges, then all horizontal ones. */
+int hmx_deblock_picture(hmx_ctx *ctx, const hmx_pic *rec, int pic_w, int pic_h, const uint8_t *d_bs_ver,
+                        const uint8_t *d_bs_hor, const int8_t *d_qp, const uint8_t *d_no_filter, int beta_offset_div2,
+                        int tc_offset_div2);
+
 /* Planar 4:2:0 YUV frames, the format either side of the path (TLibVideoIO/TVideoIOYuv.cpp:226-480, SURVEY.md
  * 8f rank 4).  d_file (device) holds one frame as the file does: 8-bit or 16-bit little-endian samples, Y then
  * Cb then Cr.  unpack = TVideoIOYuv::read: the file's (w_full - pad_x) x (h_full - pad_y) samples are padded to

@@ -1312,3 +1312,88 @@ void hmo_yuv_pack(const int16_t *const planes[3], const int strides[3], int w, i
       }
   }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Deblocking filter application (COM/TComLoopFilter.cpp:571-922)
+ * ---------------------------------------------------------------------------------------- */
+static const uint8_t dbk_tc[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                   2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
+static const uint8_t dbk_beta[52] = {0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15,
+                                     16, 17, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
+
+/* one luma segment: 4 lines across an edge; s = sample Q0 of line 0, `across` = step over the edge, `along` = step to the next line */
+static void dbk_luma_segment(int16_t *s, int across, int along, int bs, int qp, int B, int boff, int toff, int p_off, int q_off) {
+  const int scale = 1 << (B - 8), maxv = (1 << B) - 1;
+  const int tc = dbk_tc[clip3(0, 53, qp + 2 * (bs - 1) + (toff << 1))] * scale;
+  const int beta = dbk_beta[clip3(0, 51, qp + (boff << 1))] * scale;
+  const int side = (beta + (beta >> 1)) >> 3, cut = tc * 10;
+#define PX(line, k) s[(line) * along + (k) * across] /* k = -4..3: P3..P0, Q0..Q3 */
+  const int dp0 = abs(PX(0, -3) - 2 * PX(0, -2) + PX(0, -1)), dq0 = abs(PX(0, 0) - 2 * PX(0, 1) + PX(0, 2));
+  const int dp3 = abs(PX(3, -3) - 2 * PX(3, -2) + PX(3, -1)), dq3 = abs(PX(3, 0) - 2 * PX(3, 1) + PX(3, 2));
+  const int d0 = dp0 + dq0, d3 = dp3 + dq3, dp = dp0 + dp3, dq = dq0 + dq3, d = d0 + d3;
+  if (d >= beta) return;
+  const int fp = dp < side, fq = dq < side;
+  int strong = 1;
+  for (int e = 0; e < 2; e++) { /* xUseStrongFiltering on lines 0 and 3 */
+    const int line = e ? 3 : 0, dd = 2 * (e ? d3 : d0);
+    const int ds = abs(PX(line, -4) - PX(line, -1)) + abs(PX(line, 3) - PX(line, 0));
+    strong = strong && (ds < (beta >> 3)) && (dd < (beta >> 2)) && (abs(PX(line, -1) - PX(line, 0)) < ((tc * 5 + 1) >> 1));
+  }
+  for (int l = 0; l < 4; l++) {
+    const int m0 = PX(l, -4), m1 = PX(l, -3), m2 = PX(l, -2), m3 = PX(l, -1), m4 = PX(l, 0), m5 = PX(l, 1), m6 = PX(l, 2), m7 = PX(l, 3);
+    int n1 = m1, n2 = m2, n3 = m3, n4 = m4, n5 = m5, n6 = m6;
+    if (strong) {
+      n3 = clip3(m3 - 2 * tc, m3 + 2 * tc, (m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3);
+      n4 = clip3(m4 - 2 * tc, m4 + 2 * tc, (m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3);
+      n2 = clip3(m2 - 2 * tc, m2 + 2 * tc, (m1 + m2 + m3 + m4 + 2) >> 2);
+      n5 = clip3(m5 - 2 * tc, m5 + 2 * tc, (m3 + m4 + m5 + m6 + 2) >> 2);
+      n1 = clip3(m1 - 2 * tc, m1 + 2 * tc, (2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3);
+      n6 = clip3(m6 - 2 * tc, m6 + 2 * tc, (m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3);
+    } else {
+      int delta = (9 * (m4 - m3) - 3 * (m5 - m2) + 8) >> 4;
+      if (abs(delta) < cut) {
+        delta = clip3(-tc, tc, delta);
+        n3 = clip3(0, maxv, m3 + delta);
+        n4 = clip3(0, maxv, m4 - delta);
+        const int tc2 = tc >> 1;
+        if (fp) n2 = clip3(0, maxv, m2 + clip3(-tc2, tc2, ((((m1 + m3 + 1) >> 1) - m2 + delta) >> 1)));
+        if (fq) n5 = clip3(0, maxv, m5 + clip3(-tc2, tc2, ((((m6 + m4 + 1) >> 1) - m5 - delta) >> 1)));
+      }
+    }
+    if (!p_off) PX(l, -1) = (int16_t)n3, PX(l, -2) = (int16_t)n2, PX(l, -3) = (int16_t)n1;
+    if (!q_off) PX(l, 0) = (int16_t)n4, PX(l, 1) = (int16_t)n5, PX(l, 2) = (int16_t)n6;
+  }
+#undef PX
+}
+static void dbk_chroma_line(int16_t *s, int across, int tc, int maxv, int p_off, int q_off) {
+  const int m2 = s[-2 * across], m3 = s[-across], m4 = s[0], m5 = s[across];
+  const int delta = clip3(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
+  if (!p_off) s[-across] = (int16_t)clip3(0, maxv, m3 + delta);
+  if (!q_off) s[0] = (int16_t)clip3(0, maxv, m4 - delta);
+}
+void hmo_deblock_picture(int16_t *const planes[3], const int strides[3], int pic_w, int pic_h, int B, const uint8_t *bs_ver,
+                         const uint8_t *bs_hor, const int8_t *qp, const uint8_t *no_filter, int boff, int toff) {
+  const int uw = pic_w / 4, uh = pic_h / 4, scale = 1 << (B - 8), maxv = (1 << B) - 1;
+  for (int dir = 0; dir < 2; dir++) {
+    const uint8_t *bs = dir ? bs_hor : bs_ver;
+    for (int uy = 0; uy < uh; uy++)
+      for (int ux = 0; ux < uw; ux++) {
+        const int u = uy * uw + ux, b = bs[u];
+        if (!b || ((dir ? uy : ux) & 1)) continue; /* the 8x8 luma grid */
+        const int up = dir ? u - uw : u - 1;       /* the unit on the P side */
+        const int pn = no_filter ? no_filter[up] : 0, qn = no_filter ? no_filter[u] : 0;
+        const int q_avg = (qp[up] + qp[u] + 1) >> 1;
+        int16_t *y0 = planes[0] + (4 * uy) * strides[0] + 4 * ux;
+        dbk_luma_segment(y0, dir ? strides[0] : 1, dir ? 1 : strides[0], b, q_avg, B, boff, toff, pn, qn);
+        if (b > 1 && !((dir ? uy : ux) & 3)) { /* chroma: its own 8x8 grid, strength 2 only (:709-712, :740) */
+          const int qc = hmo_chroma_scale(clip3(0, 51, q_avg));
+          const int tc = dbk_tc[clip3(0, 53, qc + 2 * (b - 1) + (toff << 1))] * scale;
+          for (int p = 1; p < 3; p++)
+            for (int k = 0; k < 2; k++) {
+              int16_t *c0 = planes[p] + (2 * uy) * strides[p] + 2 * ux;
+              dbk_chroma_line(c0 + k * (dir ? 1 : strides[p]), dir ? strides[p] : 1, tc, maxv, pn, qn);
+            }
+        }
+      }
+  }
+}

@@ -199,6 +199,18 @@ typedef struct {
 void hmo_mc_frame(const hmo_pu *pus, int n_pu, int B, const int16_t *const *ref_planes /*[nref*3]*/,
                   const int *ref_strides /*[3]*/, int16_t *const dst[3], const int dst_stride[3]);
 
+/* ---- deblocking filter, application part (COM/TComLoopFilter.cpp:571-922: xEdgeFilterLuma, xEdgeFilterChroma,
+ *      xPelFilterLuma/Chroma, xUseStrongFiltering, xCalcDP/DQ, tables :54-62).  Boundary strengths are an INPUT
+ *      (xGetBoundaryStrengthSingle :444 derives them from modes, cbf and motion): per 4x4 luma unit in raster
+ *      order, bs_ver[u] = strength of the vertical edge on the unit's LEFT side, bs_hor[u] = of the horizontal
+ *      edge on its TOP side (0 = no edge); only edges on the 8x8 luma grid are filtered (chroma: on its own
+ *      8x8 grid, strength 2 only).  qp[u] = the unit's luma QP (TComDataCU::getQP); no_filter[u] != 0 marks
+ *      IPCM-with-filter-disabled or lossless units (may be NULL).  All vertical edges of the picture, then all
+ *      horizontal ones (loopFilterPic :153-201). ---- */
+void hmo_deblock_picture(int16_t *const planes[3], const int strides[3], int pic_w, int pic_h, int B, const uint8_t *bs_ver,
+                         const uint8_t *bs_hor, const int8_t *qp, const uint8_t *no_filter, int beta_offset_div2,
+                         int tc_offset_div2);
+
 /* ---- planar 4:2:0 YUV frames as the reference reads and writes them (VIO/TVideoIOYuv.cpp:226-480):
  *      8-bit or 16-bit little-endian samples, Y then Cb then Cr; on read the active area is padded to the
  *      right and below by replication and the whole padded plane is scaled to the internal bit depth

@@ -10,6 +10,7 @@
 #define protected public
 #include "TLibCommon/TComDataCU.h"
 #include "TLibCommon/TComInterpolationFilter.h"
+#include "TLibCommon/TComLoopFilter.h"
 #include "TLibCommon/TComPattern.h"
 #include "TLibCommon/TComPic.h"
 #include "TLibCommon/TComPicYuv.h"
@@ -330,6 +331,57 @@ void ref_xPredIntraAng(const int *adi, int N, int mode, int above, int left, int
 void ref_xPredIntraPlanar(const int *adi, int N, short *dst) {
   int W = 2 * N + 1;
   S->pred.xPredIntraPlanar(const_cast<int *>(adi) + W + 1, W, dst, N, N, N);
+}
+
+// ---- deblocking, application part: the reference's own edge filters driven with caller-supplied boundary strengths.
+// The picture set by ref_init / ref_set_recon must be a whole number of 64x64 LCUs.  Maps are per 4x4 luma unit,
+// raster order: bs_ver[u] = strength of the edge on the unit's left side, bs_hor[u] = on its top side.  Every LCU is
+// driven as ONE depth-0 CU, edge by edge, as xDeblockCU does (all vertical edges of the picture, then all horizontal).
+void ref_deblock_picture(const unsigned char *bs_ver, const unsigned char *bs_hor, const signed char *qp, const unsigned char *no_filter,
+                         int beta_off_div2, int tc_off_div2, short *y, short *cb, short *cr) {
+  TComPic *pic = S->pic;
+  const int w = S->pic_w, h = S->pic_h, uw = w / 4, lw = w / 64, lh = h / 64;
+  static TComLoopFilter *lf = nullptr;
+  if (!lf) {
+    lf = new TComLoopFilter;
+    lf->create(4);
+  }
+  lf->setCfg(true, 0, beta_off_div2, tc_off_div2, true);
+  TComSlice *sl = pic->getSlice(0);
+  sl->setLFCrossSliceBoundaryFlag(true);
+  // no_filter is driven through the IPCM + pcm_loop_filter_disable path (:609-614), where the P/Q flags are re-read
+  // for every unit; the lossless path ORs them into flags that stay set for the rest of the CU's edge (:616-617)
+  S->sps.setUsePCM(no_filter != NULL);
+  S->sps.setPCMFilterDisableFlag(no_filter != NULL);
+  S->pps.setTransquantBypassEnableFlag(false);
+  for (int a = 0; a < lw * lh; a++) {
+    TComDataCU *cu = pic->getCU(a);
+    cu->initCU(pic, a);
+    const int lx = (a % lw) * 16, ly = (a / lw) * 16;
+    for (int r = 0; r < 256; r++) {
+      const int z = g_auiRasterToZscan[r], u = (ly + r / 16) * uw + lx + r % 16;
+      cu->m_phQP[z] = qp[u];
+      cu->m_pbIPCMFlag[z] = no_filter ? no_filter[u] != 0 : false;
+      cu->m_CUTransquantBypass[z] = false;
+    }
+  }
+  for (int dir = 0; dir < 2; dir++)
+    for (int a = 0; a < lw * lh; a++) {
+      TComDataCU *cu = pic->getCU(a);
+      const int lx = (a % lw) * 16, ly = (a / lw) * 16;
+      const unsigned char *bs = dir ? bs_hor : bs_ver;
+      for (int r = 0; r < 256; r++) lf->m_aapucBS[dir][g_auiRasterToZscan[r]] = bs[(ly + r / 16) * uw + lx + r % 16];
+      for (int e = 0; e < 16; e += 2) {
+        lf->xEdgeFilterLuma(cu, 0, 0, dir, e);
+        if (e % 4 == 0) lf->xEdgeFilterChroma(cu, 0, 0, dir, e);
+      }
+    }
+  TComPicYuv *r = pic->getPicYuvRec();
+  for (int j = 0; j < h; j++) memcpy(y + j * w, r->getLumaAddr() + j * r->getStride(), 2 * w);
+  for (int j = 0; j < h / 2; j++) {
+    memcpy(cb + j * (w / 2), r->getCbAddr() + j * r->getCStride(), w);
+    memcpy(cr + j * (w / 2), r->getCrAddr() + j * r->getCStride(), w);
+  }
 }
 
 // ---- planar YUV files (TLibVideoIO/TVideoIOYuv.cpp): one frame in, one frame out ----

@@ -110,6 +110,33 @@ def rdoq(R, B, rng):
     return out
 
 
+def deblock(R, B, rng):
+    """The reference's deblocking edge filters on a 128x64 picture, driven with random boundary strengths."""
+    w, h = 128, 64
+    R.ref_init(B, w, h, 1)
+    mx = (1 << B) - 1
+    uw, uh = w // 4, h // 4
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    out = {}
+    for k, (boff, toff, use_nof) in enumerate([(0, 0, 0), (1, -2, 1)]):
+        ramp = (np.arange(w)[None, :] // 8 + np.arange(h)[:, None] // 8) * (2 << (B - 8))
+        y = np.clip(rng.integers(0, 24 << (B - 8), (h // 8, w // 8)).repeat(8, 0).repeat(8, 1) + rng.integers(-2, 3, (h, w)) + (90 << (B - 8)) + ramp, 0, mx).astype(np.int16)
+        cb = np.clip(rng.integers(0, mx // 4, (h // 16, w // 16)).repeat(8, 0).repeat(8, 1) + rng.integers(0, 5, (h // 2, w // 2)), 0, mx).astype(np.int16)
+        cr = np.clip(rng.integers(0, mx // 4, (h // 16, w // 16)).repeat(8, 0).repeat(8, 1) + rng.integers(0, 5, (h // 2, w // 2)), 0, mx).astype(np.int16)
+        bs_v, bs_h = rng.integers(0, 3, (uh, uw)).astype(np.uint8), rng.integers(0, 3, (uh, uw)).astype(np.uint8)
+        bs_v[:, 0] = 0
+        bs_h[0, :] = 0
+        qp = rng.integers(20, 46, (uh // 2, uw // 2)).repeat(2, 0).repeat(2, 1).astype(np.int8)
+        nof = (rng.random((uh // 2, uw // 2)) < 0.1).repeat(2, 0).repeat(2, 1).astype(np.uint8)
+        R.ref_set_recon(y.reshape(-1), cb.reshape(-1), cr.reshape(-1))
+        ry, rcb, rcr = np.zeros_like(y), np.zeros_like(cb), np.zeros_like(cr)
+        R.ref_deblock_picture(vp(bs_v), vp(bs_h), vp(qp), vp(nof) if use_nof else None, boff, toff, vp(ry), vp(rcb), vp(rcr))
+        assert (ry != y).sum() > 100
+        out.update({f"d{k}_par": np.array([boff, toff, use_nof], np.int32), f"d{k}_y": y, f"d{k}_cb": cb, f"d{k}_cr": cr,
+                    f"d{k}_bsv": bs_v, f"d{k}_bsh": bs_h, f"d{k}_qp": qp, f"d{k}_nof": nof, f"d{k}_oy": ry, f"d{k}_ocb": rcb, f"d{k}_ocr": rcr})
+    return out
+
+
 def intra(R, B, rng):
     """initAdiPattern on a real picture + all 35 modes, luma and chroma."""
     out = {}
@@ -227,6 +254,10 @@ def main():
         for B in (8, 10):
             R.ref_init(B, 416, 240, 1)
             np.savez_compressed(os.path.join(HERE, f"rdoq_b{B}.npz"), **rdoq(R, B, np.random.default_rng(4048 + B)))
+        return
+    if sys.argv[1:] == ["deblock"]:
+        for B in (8, 10):
+            np.savez_compressed(os.path.join(HERE, f"deblock_b{B}.npz"), **deblock(R, B, np.random.default_rng(6072 + B)))
         return
     for B in (8, 10):
         R.ref_init(B, 416, 240, 1)

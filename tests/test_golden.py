@@ -71,6 +71,28 @@ def test_oracle_rdoq(B):
             assert np.array_equal(lev.reshape(-1), g[f"r{N}_lev"][k]) and s == g[f"r{N}_sum"][k], (N, k)
 
 
+def _deblock_case(g, k):
+    par = g[f"d{k}_par"]
+    ins = [np.ascontiguousarray(g[f"d{k}_{n}"]) for n in ("y", "cb", "cr", "bsv", "bsh", "qp", "nof")]
+    outs = [g[f"d{k}_{n}"] for n in ("oy", "ocb", "ocr")]
+    return int(par[0]), int(par[1]), int(par[2]), ins, outs
+
+
+@pytest.mark.parametrize("B", [8, 10])
+def test_oracle_deblock(B):
+    g, O = load(f"deblock_b{B}.npz"), ol.oracle()
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    for k in range(2):
+        boff, toff, use_nof, (y, cb, cr, bsv, bsh, qp, nof), outs = _deblock_case(g, k)
+        h, w = y.shape
+        y, cb, cr = y.copy(), cb.copy(), cr.copy()
+        O.hmo_deblock_picture(P3(y.ctypes.data, cb.ctypes.data, cr.ctypes.data), I3(w, w // 2, w // 2), w, h, B, vp(bsv), vp(bsh), vp(qp),
+                              vp(nof) if use_nof else None, boff, toff)
+        for a, b in zip((y, cb, cr), outs):
+            assert np.array_equal(a, b), k
+
+
 @pytest.mark.parametrize("B", [8, 10])
 def test_oracle_intra(B):
     g, O = load(f"intra_b{B}.npz"), ol.oracle()
@@ -291,3 +313,25 @@ def test_gpu_rdoq(gctx):
             est = capi.EstBits.from_buffer_copy(np.ascontiguousarray(g[f"r{N}_est"][k], np.int32).tobytes())
             lev, s = gctx.xRateDistOptQuant(g[f"r{N}_coef"][k], N, ttype, rp, est)
             assert np.array_equal(lev, g[f"r{N}_lev"][k]) and s == g[f"r{N}_sum"][k], (N, k)
+
+
+@pytest.mark.gpu
+def test_gpu_deblock(gctx):
+    """hmx_deblock_picture vs the reference's edge filters (golden), luma and chroma, with and without no-filter units."""
+    from thevc_amd import capi
+    B, L = gctx.bit_depth, capi.lib()
+    g = load(f"deblock_b{B}.npz")
+    for k in range(2):
+        boff, toff, use_nof, (y, cb, cr, bsv, bsh, qp, nof), outs = _deblock_case(g, k)
+        h, w = y.shape
+        pic = capi.DevPicture(gctx, w, h).upload([y, cb, cr])
+        d = [gctx.to_device(a) for a in (bsv, bsh, qp, nof)]
+        p = pic.as_pic()
+        gctx._chk(L.hmx_deblock_picture(gctx.h, C.byref(p), w, h, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr if use_nof else None, boff, toff))
+        gctx.sync()
+        got = pic.download()
+        for a, b in zip(got, outs):
+            assert np.array_equal(a, b), k
+        pic.free()
+        for x in d:
+            x.free()

@@ -675,3 +675,40 @@ def test_yuv_files_on_device(ctx, tmp_path):
         rd.close(), wr.close()
         assert open(str(tmp_path / f"out{file_bits}.yuv"), "rb").read() == want_bytes, ("pack", file_bits)
         pic.free()
+
+
+def test_deblock_picture_vs_oracle(ctx):
+    """The deblocking application over a 416x240 picture (not a multiple of the CTU size: the device path has no
+    LCU structure), random boundary strengths, per-8x8 QPs, no-filter units, non-zero beta/tc offsets."""
+    O, B, L = ol.oracle(), ctx.bit_depth, capi.lib()
+    rng = np.random.default_rng(818 + B)
+    w, h = 416, 240
+    mx = (1 << B) - 1
+    uw, uh = w // 4, h // 4
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    for (boff, toff, use_nof) in ((0, 0, 0), (2, -1, 1), (-4, 4, 1)):
+        ramp = (np.arange(w)[None, :] // 8 + np.arange(h)[:, None] // 8) * (1 << (B - 8))
+        y = np.clip(rng.integers(0, 30 << (B - 8), (h // 8, w // 8)).repeat(8, 0).repeat(8, 1) + rng.integers(-2, 3, (h, w)) + (60 << (B - 8)) + ramp, 0, mx).astype(np.int16)
+        cb = np.clip(rng.integers(0, mx // 3, (h // 16, w // 16)).repeat(8, 0).repeat(8, 1) + rng.integers(0, 6, (h // 2, w // 2)), 0, mx).astype(np.int16)
+        cr = np.clip(rng.integers(0, mx // 3, (h // 16, w // 16)).repeat(8, 0).repeat(8, 1) + rng.integers(0, 6, (h // 2, w // 2)), 0, mx).astype(np.int16)
+        bsv, bsh = rng.integers(0, 3, (uh, uw)).astype(np.uint8), rng.integers(0, 3, (uh, uw)).astype(np.uint8)
+        bsv[:, 0] = 0
+        bsh[0, :] = 0
+        qp = rng.integers(10, 52, (uh // 2, uw // 2)).repeat(2, 0).repeat(2, 1).astype(np.int8)
+        nof = (rng.random((uh // 2, uw // 2)) < 0.15).repeat(2, 0).repeat(2, 1).astype(np.uint8)
+        pic = capi.DevPicture(ctx, w, h).upload([y, cb, cr])
+        d = [ctx.to_device(a) for a in (bsv, bsh, qp, nof)]
+        p = pic.as_pic()
+        ctx._chk(L.hmx_deblock_picture(ctx.h, C.byref(p), w, h, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr if use_nof else None, boff, toff))
+        ctx.sync()
+        got = pic.download()
+        oy, ocb, ocr = y.copy(), cb.copy(), cr.copy()
+        O.hmo_deblock_picture(P3(oy.ctypes.data, ocb.ctypes.data, ocr.ctypes.data), I3(w, w // 2, w // 2), w, h, B, vp(bsv), vp(bsh), vp(qp),
+                              vp(nof) if use_nof else None, boff, toff)
+        for a, b in zip(got, (oy, ocb, ocr)):
+            assert np.array_equal(a, b), (boff, toff, use_nof)
+        assert (oy != y).sum() > 1000 and (ocb != cb).sum() > 100
+        pic.free()
+        for x in d:
+            x.free()

@@ -530,3 +530,50 @@ def test_yuv_files(tmp_path):
         O.hmo_yuv_pack(P3(oy.ctypes.data, ocb.ctypes.data, ocr.ctypes.data), I3(wf, wf // 2, wf // 2), wf, hf, px, py, int_bits,
                        file_bits, mine.ctypes.data_as(C.c_void_p))
         assert np.array_equal(ref_bytes, mine), ("write", file_bits, int_bits)
+
+
+def _deblock_inputs(rng, w, h, B, smooth):
+    """A picture with block-edge steps (so that all three decisions - off, weak, strong - occur) and random
+    boundary-strength / QP / lossless maps per 4x4 unit."""
+    mx = (1 << B) - 1
+    uw, uh = w // 4, h // 4
+    base = rng.integers(0, mx + 1, (h // 8, w // 8)).astype(np.int32)
+    y = np.kron(base, np.ones((8, 8), np.int32)) if smooth else rng.integers(0, mx + 1, (h, w)).astype(np.int32)
+    y = np.clip(y + rng.integers(-3, 4, (h, w)) * (1 << (B - 8)), 0, mx).astype(np.int16)
+    if smooth:  # pull neighbouring blocks together so that steps fall below beta / tc for many edges
+        ramp = (np.arange(w)[None, :] // 8 + np.arange(h)[:, None] // 8) * (2 << (B - 8))
+        y = np.clip((y.astype(np.int32) // 8) + 100 * (1 << (B - 8)) + ramp, 0, mx).astype(np.int16)
+    cb = np.clip(rng.integers(0, mx + 1, (h // 16, w // 16)).repeat(8, 0).repeat(8, 1) // (4 if smooth else 1) + rng.integers(0, 5, (h // 2, w // 2)), 0, mx).astype(np.int16)
+    cr = np.clip(rng.integers(0, mx + 1, (h // 16, w // 16)).repeat(8, 0).repeat(8, 1) // (4 if smooth else 1) + rng.integers(0, 5, (h // 2, w // 2)), 0, mx).astype(np.int16)
+    bs_v = rng.integers(0, 3, (uh, uw)).astype(np.uint8)
+    bs_h = rng.integers(0, 3, (uh, uw)).astype(np.uint8)
+    bs_v[:, 0] = 0  # no edge on the picture boundary
+    bs_h[0, :] = 0
+    qp = rng.integers(18, 48, (uh // 2, uw // 2)).repeat(2, 0).repeat(2, 1).astype(np.int8)  # QP per 8x8
+    nof = (rng.random((uh // 2, uw // 2)) < 0.1).repeat(2, 0).repeat(2, 1).astype(np.uint8)
+    return y, cb, cr, bs_v, bs_h, qp, nof
+
+
+def test_deblock_application():
+    """The deblocking edge filters (xEdgeFilterLuma / xEdgeFilterChroma and the pel filters) of the reference,
+    driven with random boundary strengths per 4x4 unit, vs the oracle's picture-level restatement."""
+    R, O = ol.ref(), ol.oracle()
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    for B in (8, 10):
+        w, h = 192, 128
+        R.ref_init(B, w, h, 1)
+        rng = np.random.default_rng(2100 + B)
+        changed = 0
+        for it, (boff, toff, smooth, use_nof) in enumerate([(0, 0, True, False), (0, 0, False, False), (2, -1, True, True), (-3, 3, True, False)]):
+            y, cb, cr, bs_v, bs_h, qp, nof = _deblock_inputs(rng, w, h, B, smooth)
+            R.ref_set_recon(y.reshape(-1), cb.reshape(-1), cr.reshape(-1))
+            ry, rcb, rcr = np.zeros_like(y), np.zeros_like(cb), np.zeros_like(cr)
+            R.ref_deblock_picture(vp(bs_v), vp(bs_h), vp(qp), vp(nof) if use_nof else None, boff, toff, vp(ry), vp(rcb), vp(rcr))
+            oy, ocb, ocr = y.copy(), cb.copy(), cr.copy()
+            O.hmo_deblock_picture(P3(oy.ctypes.data, ocb.ctypes.data, ocr.ctypes.data), I3(w, w // 2, w // 2), w, h, B, vp(bs_v), vp(bs_h),
+                                  vp(qp), vp(nof) if use_nof else None, boff, toff)
+            assert np.array_equal(ry, oy), ("luma", B, it, np.argwhere(ry != oy)[:3])
+            assert np.array_equal(rcb, ocb) and np.array_equal(rcr, ocr), ("chroma", B, it)
+            changed += int((oy != y).sum() > 200) + int((ocb != cb).sum() > 50)
+        assert changed >= 6  # the filters fired on luma and chroma

@@ -2774,6 +2774,118 @@ extern "C" int hmx_pic_extend_border(hmx_ctx *c, const hmx_pic *pic, int pic_w, 
   return hmx_pic_extend_border_multi(c, 1, pic, pic_w, pic_h, mx, my);
 }
 
+// ---- deblocking filter, application part (TLibCommon/TComLoopFilter.cpp:571-922) ----
+// One launch per direction over the whole picture (loopFilterPic :153-201 filters every vertical edge of the
+// picture before the first horizontal one).  Work item = one 4x4 luma unit whose left (top) side is an edge of
+// the 8x8 grid with a non-zero strength: the thread filters the unit's four luma lines and, on the chroma grid
+// with strength 2, two lines of Cb and Cr.  Edges are 8 samples apart and a filter reads 4 and writes 3 samples
+// per side, so the work items of one launch touch disjoint samples.
+__constant__ unsigned char kDbkTc[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                         2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
+__constant__ unsigned char kDbkBeta[52] = {0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15,
+                                           16, 17, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
+__constant__ unsigned char kChromaScale[58] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19,
+                                               20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 33, 33, 34, 34, 35, 35,
+                                               36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51};
+struct DbkArgs {
+  PlanesDev rec;
+  const unsigned char *bs; // of this direction
+  const signed char *qp;
+  const unsigned char *no_filter;
+  int uw, uh, dir, B, boff, toff;
+};
+__global__ __launch_bounds__(256) void k_deblock(DbkArgs A) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= A.uw * A.uh) return;
+  const int ux = u % A.uw, uy = u / A.uw, dir = A.dir;
+  const int b = A.bs[u];
+  if (!b || ((dir ? uy : ux) & 1)) return;
+  const int up = dir ? u - A.uw : u - 1;
+  const bool pn = A.no_filter && A.no_filter[up], qn = A.no_filter && A.no_filter[u];
+  const int q_avg = ((int)A.qp[up] + (int)A.qp[u] + 1) >> 1;
+  const int B = A.B, scale = 1 << (B - 8), maxv = (1 << B) - 1;
+  {
+    const int tc = kDbkTc[clip3(0, 53, q_avg + 2 * (b - 1) + (A.toff << 1))] * scale;
+    const int beta = kDbkBeta[clip3(0, 51, q_avg + (A.boff << 1))] * scale;
+    const int side = (beta + (beta >> 1)) >> 3, cut = tc * 10;
+    const int st = A.rec.s[0], across = dir ? st : 1, along = dir ? 1 : st;
+    short *s = A.rec.p[0] + (size_t)(4 * uy) * st + 4 * ux;
+    int m[4][8];
+#pragma unroll
+    for (int l = 0; l < 4; l++)
+#pragma unroll
+      for (int k = 0; k < 8; k++) m[l][k] = s[(ptrdiff_t)l * along + (ptrdiff_t)(k - 4) * across];
+    const int dp0 = abs(m[0][1] - 2 * m[0][2] + m[0][3]), dq0 = abs(m[0][4] - 2 * m[0][5] + m[0][6]);
+    const int dp3 = abs(m[3][1] - 2 * m[3][2] + m[3][3]), dq3 = abs(m[3][4] - 2 * m[3][5] + m[3][6]);
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3, dp = dp0 + dp3, dq = dq0 + dq3, d = d0 + d3;
+    if (d < beta) {
+      const bool fp = dp < side, fq = dq < side;
+      const bool s0 = (abs(m[0][0] - m[0][3]) + abs(m[0][7] - m[0][4]) < (beta >> 3)) && (2 * d0 < (beta >> 2)) &&
+                      (abs(m[0][3] - m[0][4]) < ((tc * 5 + 1) >> 1));
+      const bool s3 = (abs(m[3][0] - m[3][3]) + abs(m[3][7] - m[3][4]) < (beta >> 3)) && (2 * d3 < (beta >> 2)) &&
+                      (abs(m[3][3] - m[3][4]) < ((tc * 5 + 1) >> 1));
+      const bool strong = s0 && s3;
+#pragma unroll
+      for (int l = 0; l < 4; l++) {
+        const int m0 = m[l][0], m1 = m[l][1], m2 = m[l][2], m3 = m[l][3], m4 = m[l][4], m5 = m[l][5], m6 = m[l][6], m7 = m[l][7];
+        int n1 = m1, n2 = m2, n3 = m3, n4 = m4, n5 = m5, n6 = m6;
+        if (strong) {
+          n3 = clip3(m3 - 2 * tc, m3 + 2 * tc, (m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3);
+          n4 = clip3(m4 - 2 * tc, m4 + 2 * tc, (m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3);
+          n2 = clip3(m2 - 2 * tc, m2 + 2 * tc, (m1 + m2 + m3 + m4 + 2) >> 2);
+          n5 = clip3(m5 - 2 * tc, m5 + 2 * tc, (m3 + m4 + m5 + m6 + 2) >> 2);
+          n1 = clip3(m1 - 2 * tc, m1 + 2 * tc, (2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3);
+          n6 = clip3(m6 - 2 * tc, m6 + 2 * tc, (m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3);
+        } else {
+          int delta = (9 * (m4 - m3) - 3 * (m5 - m2) + 8) >> 4;
+          if (abs(delta) < cut) {
+            delta = clip3(-tc, tc, delta);
+            n3 = clip3(0, maxv, m3 + delta);
+            n4 = clip3(0, maxv, m4 - delta);
+            const int tc2 = tc >> 1;
+            if (fp) n2 = clip3(0, maxv, m2 + clip3(-tc2, tc2, ((((m1 + m3 + 1) >> 1) - m2 + delta) >> 1)));
+            if (fq) n5 = clip3(0, maxv, m5 + clip3(-tc2, tc2, ((((m6 + m4 + 1) >> 1) - m5 - delta) >> 1)));
+          }
+        }
+        short *pl = s + (ptrdiff_t)l * along;
+        if (!pn) pl[-across] = (short)n3, pl[-2 * across] = (short)n2, pl[-3 * across] = (short)n1;
+        if (!qn) pl[0] = (short)n4, pl[across] = (short)n5, pl[2 * across] = (short)n6;
+      }
+    }
+  }
+  if (b > 1 && !((dir ? uy : ux) & 3)) { // chroma: its own 8x8 grid, strength 2 only (:709-712, :740)
+    const int qc = kChromaScale[clip3(0, 51, q_avg)];
+    const int tc = kDbkTc[clip3(0, 53, qc + 2 * (b - 1) + (A.toff << 1))] * scale;
+#pragma unroll
+    for (int p = 1; p < 3; p++) {
+      const int st = A.rec.s[p], across = dir ? st : 1, along = dir ? 1 : st;
+      short *c0 = A.rec.p[p] + (size_t)(2 * uy) * st + 2 * ux;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        short *s = c0 + (ptrdiff_t)k * along;
+        const int m2 = s[-2 * across], m3 = s[-across], m4 = s[0], m5 = s[across];
+        const int delta = clip3(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
+        if (!pn) s[-across] = (short)clip3(0, maxv, m3 + delta);
+        if (!qn) s[0] = (short)clip3(0, maxv, m4 - delta);
+      }
+    }
+  }
+}
+extern "C" int hmx_deblock_picture(hmx_ctx *c, const hmx_pic *rec, int pic_w, int pic_h, const uint8_t *d_bs_ver, const uint8_t *d_bs_hor,
+                                   const int8_t *d_qp, const uint8_t *d_no_filter, int beta_offset_div2, int tc_offset_div2) {
+  if (!c || !rec || !d_bs_ver || !d_bs_hor || !d_qp || pic_w <= 0 || pic_h <= 0 || (pic_w & 7) || (pic_h & 7))
+    return fail(c, HMX_ERR_ARG, "hmx_deblock_picture: null argument or picture size not a multiple of 8");
+  DbkArgs A{to_dev(rec), nullptr, d_qp, d_no_filter, pic_w / 4, pic_h / 4, 0, c->cfg.bit_depth, beta_offset_div2, tc_offset_div2};
+  const unsigned blocks = (unsigned)(((size_t)A.uw * A.uh + 255) / 256);
+  for (int dir = 0; dir < 2; dir++) {
+    A.dir = dir;
+    A.bs = dir ? d_bs_hor : d_bs_ver;
+    hipLaunchKernelGGL(k_deblock, dim3(blocks), dim3(256), 0, c->stream, A);
+  }
+  HIPCHK(c, hipGetLastError());
+  return HMX_OK;
+}
+
 // ---- planar 4:2:0 YUV frames (TLibVideoIO/TVideoIOYuv.cpp:226-480) ----
 // A frame travels as the bytes of the file (1 or 2 bytes per sample, Y then Cb then Cr): half or a quarter of
 // the PCIe traffic of int16 planes; widening, bit-depth scaling and the right/bottom padding happen in HBM.
