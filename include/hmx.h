@@ -330,6 +330,20 @@ int hmx_batch_motionCompensation(hmx_ctx *ctx, const hmx_pu *d_pus, int n, const
  * pcm_loop_filter_disable (:609-614).  (The reference's lossless flags are ORed into variables that stay set for
  * the rest of a CU's edge, :616-617; that CU-shaped stickiness is not reproduced.)  Edges on the 8x8 luma grid
  * are filtered, chroma on its own 8x8 grid for strength 2; all vertical edges, then all horizontal ones. */
+/* The boundary strengths of the 8x8-grid edges, xGetBoundaryStrengthSingle (TComLoopFilter.cpp:444-569).  d_units[u]
+ * = what the function reads of a 4x4 partition: intra flag, luma cbf of its transform block and, per reference
+ * list, a picture id (< 0: list unused; equal ids = same picture) and the motion vector.  d_edge_ver / d_edge_hor[u]:
+ * 0 = the unit's left / top side is not a filtered edge (m_aapbEdgeFilter), 1 = filtered edge, 3 = filtered edge
+ * that is also a transform-block or coding-block edge (the value xSetEdgefilterTU / xSetEdgefilterMultiple leave
+ * in m_aapucBS).  Horizontal edges on a CTU boundary read the P side's motion at the compressed position
+ * (g_motionRefer, TComRom.cpp:221-258).  Outputs feed hmx_deblock_picture. */
+typedef struct hmx_dbk_unit {
+  uint8_t intra, cbf;
+  int8_t ref[2];
+  int16_t mv[2][2]; /* [list][x, y], quarter-pel */
+} hmx_dbk_unit;
+int hmx_deblock_strengths(hmx_ctx *ctx, const hmx_dbk_unit *d_units, const uint8_t *d_edge_ver, const uint8_t *d_edge_hor,
+                          int pic_w, int pic_h, int is_b_slice, uint8_t *d_bs_ver, uint8_t *d_bs_hor);
 int hmx_deblock_picture(hmx_ctx *ctx, const hmx_pic *rec, int pic_w, int pic_h, const uint8_t *d_bs_ver,
                         const uint8_t *d_bs_hor, const int8_t *d_qp, const uint8_t *d_no_filter, int beta_offset_div2,
                         int tc_offset_div2);

@@ -1397,3 +1397,42 @@ void hmo_deblock_picture(int16_t *const planes[3], const int strides[3], int pic
       }
   }
 }
+
+static int dbk_mv_far(const int16_t *a, const int16_t *b) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4; }
+static int dbk_strength(const hmo_dbk_unit *P, const hmo_dbk_unit *Pm /* motion of the P side */, const hmo_dbk_unit *Q, int tu_edge,
+                        int is_b) {
+  if (P->intra || Q->intra) return 2;
+  if (tu_edge && (Q->cbf || P->cbf)) return 1;
+  if (!is_b) return (Pm->ref[0] != Q->ref[0]) || dbk_mv_far(Pm->mv[0], Q->mv[0]);
+  /* "no picture" compares equal to "no picture" (NULL == NULL in the reference) */
+  const int p0 = Pm->ref[0] < 0 ? -1 : Pm->ref[0], p1 = Pm->ref[1] < 0 ? -1 : Pm->ref[1];
+  const int q0 = Q->ref[0] < 0 ? -1 : Q->ref[0], q1 = Q->ref[1] < 0 ? -1 : Q->ref[1];
+  if (!((p0 == q0 && p1 == q1) || (p0 == q1 && p1 == q0))) return 1;
+  if (p0 != p1) {
+    if (p0 == q0) return dbk_mv_far(Pm->mv[0], Q->mv[0]) || dbk_mv_far(Pm->mv[1], Q->mv[1]);
+    return dbk_mv_far(Pm->mv[0], Q->mv[1]) || dbk_mv_far(Pm->mv[1], Q->mv[0]);
+  }
+  return (dbk_mv_far(Pm->mv[0], Q->mv[1]) || dbk_mv_far(Pm->mv[1], Q->mv[0])) &&
+         (dbk_mv_far(Pm->mv[0], Q->mv[0]) || dbk_mv_far(Pm->mv[1], Q->mv[1]));
+}
+void hmo_deblock_strengths(const hmo_dbk_unit *units, const uint8_t *edge_ver, const uint8_t *edge_hor, int pic_w, int pic_h,
+                           int ctu, int is_b, uint8_t *bs_ver, uint8_t *bs_hor) {
+  const int uw = pic_w / 4, uh = pic_h / 4;
+  for (int dir = 0; dir < 2; dir++) {
+    const uint8_t *edge = dir ? edge_hor : edge_ver;
+    uint8_t *bs = dir ? bs_hor : bs_ver;
+    for (int uy = 0; uy < uh; uy++)
+      for (int ux = 0; ux < uw; ux++) {
+        const int u = uy * uw + ux;
+        bs[u] = 0;
+        if (!(edge[u] & 1) || ((dir ? uy : ux) & 1) || (dir ? uy : ux) == 0) continue;
+        const int up = dir ? u - uw : u - 1;
+        int um = up;
+        if (dir && (4 * uy) % ctu == 0) { /* the row above belongs to another CTU: compressed motion, [0 0 3 3] per 16 samples */
+          const int g = ux & ~3, k = ux & 3;
+          um = up - ux + g + (k < 2 ? 0 : 3);
+        }
+        bs[u] = (uint8_t)dbk_strength(&units[up], &units[um], &units[u], (edge[u] >> 1) & 1, is_b);
+      }
+  }
+}

@@ -207,6 +207,20 @@ void hmo_mc_frame(const hmo_pu *pus, int n_pu, int B, const int16_t *const *ref_
  *      8x8 grid, strength 2 only).  qp[u] = the unit's luma QP (TComDataCU::getQP); no_filter[u] != 0 marks
  *      IPCM-with-filter-disabled or lossless units (may be NULL).  All vertical edges of the picture, then all
  *      horizontal ones (loopFilterPic :153-201). ---- */
+/* Boundary strengths, xGetBoundaryStrengthSingle (COM/TComLoopFilter.cpp:444-569), for the edges of the 8x8 grid.
+ * units[u]: what the function reads of the partition: intra flag, luma cbf of its transform block, and per
+ * reference list a picture id (< 0: list unused; equal ids = same picture) and the motion vector (quarter-pel).
+ * edge_ver / edge_hor[u]: 0 = the unit's left / top side is not a filtered edge (m_aapbEdgeFilter), 1 = filtered
+ * edge, 3 = filtered edge that is also a transform-block or coding-block edge (the value xSetEdgefilterTU /
+ * xSetEdgefilterMultiple leave in m_aapucBS before the strength is computed).  Horizontal edges on a CTU boundary
+ * read the P side's motion at the compressed position (g_motionRefer, COM/TComRom.cpp:221-258). */
+typedef struct {
+  uint8_t intra, cbf;
+  int8_t ref[2];
+  int16_t mv[2][2]; /* [list][x, y] */
+} hmo_dbk_unit;
+void hmo_deblock_strengths(const hmo_dbk_unit *units, const uint8_t *edge_ver, const uint8_t *edge_hor, int pic_w, int pic_h,
+                           int ctu, int is_b_slice, uint8_t *bs_ver, uint8_t *bs_hor);
 void hmo_deblock_picture(int16_t *const planes[3], const int strides[3], int pic_w, int pic_h, int B, const uint8_t *bs_ver,
                          const uint8_t *bs_hor, const int8_t *qp, const uint8_t *no_filter, int beta_offset_div2,
                          int tc_offset_div2);

@@ -76,6 +76,7 @@ int ref_init(int bit_depth, int pic_w, int pic_h, int sign_hide) {
     initZscanToRaster(5, 1, 0, p); // total depth + 1, as TEncCu::create (ENC/TEncCu.cpp:63,101)
     initRasterToZscan(64, 64, 5);
     initRasterToPelXY(64, 64, 5);
+    initMotionReferIdx(64, 64, 5); // total depth + 1, as TEncCu::create (ENC/TEncCu.cpp:63,106)
     S->tq.init(64, 64, 32, 0, NULL, NULL, NULL, false, true, true, false);
     S->tq.setFlatScalingList();
     S->tq.setUseScalingList(false);
@@ -382,6 +383,62 @@ void ref_deblock_picture(const unsigned char *bs_ver, const unsigned char *bs_ho
     memcpy(cb + j * (w / 2), r->getCbAddr() + j * r->getCStride(), w);
     memcpy(cr + j * (w / 2), r->getCrAddr() + j * r->getCStride(), w);
   }
+}
+
+// xGetBoundaryStrengthSingle for every edge of the 8x8 grid flagged in edge_ver / edge_hor (bit0: filtered edge,
+// bit1: the value left in m_aapucBS by xSetEdgefilterTU / xSetEdgefilterMultiple).  units: 12 bytes per 4x4 unit =
+// {intra, cbf, ref[2] (picture ids, <0 unused), mv[2][2]}; the picture must be whole 64x64 LCUs.
+struct TapDbkUnit {
+  unsigned char intra, cbf;
+  signed char ref[2];
+  short mv[2][2];
+};
+void ref_deblock_strengths(const TapDbkUnit *units, const unsigned char *edge_ver, const unsigned char *edge_hor, int is_b,
+                           unsigned char *bs_ver, unsigned char *bs_hor) {
+  TComPic *pic = S->pic;
+  const int w = S->pic_w, h = S->pic_h, uw = w / 4, lw = w / 64, lh = h / 64;
+  static TComLoopFilter *lf = nullptr;
+  if (!lf) {
+    lf = new TComLoopFilter;
+    lf->create(4);
+  }
+  lf->setCfg(true, 0, 0, 0, true);
+  TComSlice *sl = pic->getSlice(0);
+  sl->setLFCrossSliceBoundaryFlag(true);
+  sl->setSliceType(is_b ? B_SLICE : P_SLICE);
+  for (int l = 0; l < 2; l++)
+    for (int i = 0; i < 16; i++) sl->m_apcRefPicList[l][i] = reinterpret_cast<TComPic *>(static_cast<uintptr_t>(0x10000 + 64 * i));
+  for (int a = 0; a < lw * lh; a++) {
+    TComDataCU *cu = pic->getCU(a);
+    cu->initCU(pic, a);
+    const int lx = (a % lw) * 16, ly = (a / lw) * 16;
+    for (int r = 0; r < 256; r++) {
+      const int z = g_auiRasterToZscan[r];
+      const TapDbkUnit &q = units[(ly + r / 16) * uw + lx + r % 16];
+      cu->m_pePredMode[z] = q.intra ? MODE_INTRA : MODE_INTER;
+      cu->m_puhTrIdx[z] = 0;
+      cu->m_puhCbf[0][z] = q.cbf ? 1 : 0;
+      for (int l = 0; l < 2; l++) {
+        cu->m_acCUMvField[l].m_pcMv[z].set(q.mv[l][0], q.mv[l][1]);
+        cu->m_acCUMvField[l].m_piRefIdx[z] = q.ref[l] < 0 ? -1 : q.ref[l];
+      }
+    }
+  }
+  for (int dir = 0; dir < 2; dir++)
+    for (int a = 0; a < lw * lh; a++) {
+      TComDataCU *cu = pic->getCU(a);
+      const int lx = (a % lw) * 16, ly = (a / lw) * 16;
+      const unsigned char *edge = dir ? edge_hor : edge_ver;
+      unsigned char *bs = dir ? bs_hor : bs_ver;
+      for (int r = 0; r < 256; r++) {
+        const int ux = lx + r % 16, uy = ly + r / 16, u = uy * uw + ux, z = g_auiRasterToZscan[r];
+        bs[u] = 0;
+        if (!(edge[u] & 1) || ((dir ? uy : ux) & 1) || (dir ? uy : ux) == 0) continue;
+        lf->m_aapucBS[dir][z] = (edge[u] >> 1) & 1;
+        lf->xGetBoundaryStrengthSingle(cu, 0, dir, z);
+        bs[u] = lf->m_aapucBS[dir][z];
+      }
+    }
 }
 
 // ---- planar YUV files (TLibVideoIO/TVideoIOYuv.cpp): one frame in, one frame out ----

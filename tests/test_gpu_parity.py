@@ -712,3 +712,27 @@ def test_deblock_picture_vs_oracle(ctx):
         pic.free()
         for x in d:
             x.free()
+
+
+def test_deblock_strengths_vs_oracle(ctx):
+    """Boundary strengths on the device vs the oracle (pinned against xGetBoundaryStrengthSingle), P and B slices,
+    then strengths -> hmx_deblock_picture end to end."""
+    O, B, L = ol.oracle(), ctx.bit_depth, capi.lib()
+    import test_oracle_vs_ref as T
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    w, h = 256, 192
+    uw, uh = w // 4, h // 4
+    for is_b in (0, 1):
+        rng = np.random.default_rng(404 + is_b + B)
+        units, ev, eh = T._dbk_units(rng, uw, uh, is_b)
+        d_u, d_ev, d_eh = ctx.to_device(units), ctx.to_device(ev), ctx.to_device(eh)
+        d_bv, d_bh = ctx.alloc(uw * uh), ctx.alloc(uw * uh)
+        ctx._chk(L.hmx_deblock_strengths(ctx.h, d_u.ptr, d_ev.ptr, d_eh.ptr, w, h, is_b, d_bv.ptr, d_bh.ptr))
+        ctx.sync()
+        ov, oh = np.zeros((uh, uw), np.uint8), np.zeros((uh, uw), np.uint8)
+        O.hmo_deblock_strengths(vp(units), vp(ev), vp(eh), w, h, 64, is_b, vp(ov), vp(oh))
+        assert np.array_equal(d_bv.download(np.uint8).reshape(uh, uw), ov)
+        assert np.array_equal(d_bh.download(np.uint8).reshape(uh, uw), oh)
+        assert (ov == 1).sum() > 100 and (ov == 2).sum() > 100
+        for d in (d_u, d_ev, d_eh, d_bv, d_bh):
+            d.free()

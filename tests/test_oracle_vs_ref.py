@@ -577,3 +577,58 @@ def test_deblock_application():
             assert np.array_equal(rcb, ocb) and np.array_equal(rcr, ocr), ("chroma", B, it)
             changed += int((oy != y).sum() > 200) + int((ocb != cb).sum() > 50)
         assert changed >= 6  # the filters fired on luma and chroma
+
+
+DBK_UNIT = np.dtype([("intra", "u1"), ("cbf", "u1"), ("ref", "i1", 2), ("mv", "<i2", (2, 2))])
+
+
+def _dbk_units(rng, uw, uh, is_b):
+    """Motion in 8x8 granules with many near-equal vectors / shared pictures so that every branch of the
+    strength rule is hit (same pictures swapped between lists, one list unused, same picture in both lists)."""
+    n8 = (uh // 2, uw // 2)
+    units = np.zeros((uh, uw), DBK_UNIT)
+    rep = lambda a: a.repeat(2, 0).repeat(2, 1)
+    units["intra"] = rep((rng.random(n8) < 0.12).astype(np.uint8))
+    units["cbf"] = rep((rng.random(n8) < 0.3).astype(np.uint8))
+    base = rng.integers(-6, 7, n8 + (2,))
+    for l in range(2):
+        r = rng.integers(-1 if is_b else 0, 3, n8).astype(np.int8)
+        if not is_b and l == 1:
+            r[:] = -1
+        units["ref"][:, :, l] = rep(r)
+        mv = (base if rng.random() < 0.7 else 0) + rng.integers(-2, 3, n8 + (2,))
+        units["mv"][:, :, l, 0] = rep(mv[..., 0].astype(np.int16))
+        units["mv"][:, :, l, 1] = rep(mv[..., 1].astype(np.int16))
+    # 4x4-granular motion on the rows above CTU boundaries (8x4 / 4x8 partitions): only then does the compressed-motion
+    # referral [0 0 3 3] of horizontal CTU-boundary edges pick a different vector
+    for row in range(15, uh, 16):
+        units["mv"][row, :, 0, 0] += rng.integers(-5, 6, uw).astype(np.int16)
+        units["ref"][row, :, 0] = rng.integers(0, 2, uw).astype(np.int8)
+    if is_b:  # a unit must use at least one list
+        none = (units["ref"][:, :, 0] < 0) & (units["ref"][:, :, 1] < 0)
+        units["ref"][:, :, 0][none] = 0
+    edge_v = (rng.integers(0, 4, (uh, uw)) | 1).astype(np.uint8) * (rng.random((uh, uw)) < 0.8)
+    edge_h = (rng.integers(0, 4, (uh, uw)) | 1).astype(np.uint8) * (rng.random((uh, uw)) < 0.8)
+    return np.ascontiguousarray(units), np.ascontiguousarray(edge_v.astype(np.uint8)), np.ascontiguousarray(edge_h.astype(np.uint8))
+
+
+def test_deblock_strengths():
+    """xGetBoundaryStrengthSingle over a whole picture (P and B slices) incl. the compressed-motion rule on
+    horizontal CTU boundaries, vs the oracle."""
+    R, O = ol.ref(), ol.oracle()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    w, h = 192, 128
+    R.ref_init(8, w, h, 1)
+    uw, uh = w // 4, h // 4
+    for is_b in (0, 1):
+        rng = np.random.default_rng(2300 + is_b)
+        hist = np.zeros(3, np.int64)
+        for it in range(4):
+            units, ev, eh = _dbk_units(rng, uw, uh, is_b)
+            rv, rh, ov, oh = (np.zeros((uh, uw), np.uint8) for _ in range(4))
+            R.ref_deblock_strengths(vp(units), vp(ev), vp(eh), is_b, vp(rv), vp(rh))
+            O.hmo_deblock_strengths(vp(units), vp(ev), vp(eh), w, h, 64, is_b, vp(ov), vp(oh))
+            assert np.array_equal(rv, ov), ("ver", is_b, it, np.argwhere(rv != ov)[:3])
+            assert np.array_equal(rh, oh), ("hor", is_b, it, np.argwhere(rh != oh)[:3])
+            hist += np.bincount(np.concatenate([ov.reshape(-1), oh.reshape(-1)]), minlength=3)[:3]
+        assert (hist[1:] > 200).all(), hist  # strengths 1 and 2 both occur often

@@ -2871,6 +2871,52 @@ __global__ __launch_bounds__(256) void k_deblock(DbkArgs A) {
     }
   }
 }
+// boundary strengths (xGetBoundaryStrengthSingle :444-569): one thread per 4x4 unit, both directions
+__device__ __forceinline__ bool dbk_mv_far(const short *a, const short *b) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4; }
+__device__ __forceinline__ int dbk_strength(const hmx_dbk_unit &P, const hmx_dbk_unit &Pm, const hmx_dbk_unit &Q, bool tu_edge, bool is_b) {
+  if (P.intra || Q.intra) return 2;
+  if (tu_edge && (Q.cbf || P.cbf)) return 1;
+  if (!is_b) return (Pm.ref[0] != Q.ref[0]) || dbk_mv_far(Pm.mv[0], Q.mv[0]);
+  const int p0 = Pm.ref[0] < 0 ? -1 : Pm.ref[0], p1 = Pm.ref[1] < 0 ? -1 : Pm.ref[1];
+  const int q0 = Q.ref[0] < 0 ? -1 : Q.ref[0], q1 = Q.ref[1] < 0 ? -1 : Q.ref[1];
+  if (!((p0 == q0 && p1 == q1) || (p0 == q1 && p1 == q0))) return 1;
+  if (p0 != p1) {
+    if (p0 == q0) return dbk_mv_far(Pm.mv[0], Q.mv[0]) || dbk_mv_far(Pm.mv[1], Q.mv[1]);
+    return dbk_mv_far(Pm.mv[0], Q.mv[1]) || dbk_mv_far(Pm.mv[1], Q.mv[0]);
+  }
+  return (dbk_mv_far(Pm.mv[0], Q.mv[1]) || dbk_mv_far(Pm.mv[1], Q.mv[0])) && (dbk_mv_far(Pm.mv[0], Q.mv[0]) || dbk_mv_far(Pm.mv[1], Q.mv[1]));
+}
+__global__ __launch_bounds__(256) void k_dbk_strengths(const hmx_dbk_unit *units, const unsigned char *edge_ver, const unsigned char *edge_hor,
+                                                       int uw, int uh, int ctu, int is_b, unsigned char *bs_ver, unsigned char *bs_hor) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= uw * uh) return;
+  const int ux = u % uw, uy = u / uw;
+  const hmx_dbk_unit Q = units[u];
+  int bv = 0, bh = 0;
+  if ((edge_ver[u] & 1) && !(ux & 1) && ux) {
+    const hmx_dbk_unit P = units[u - 1];
+    bv = dbk_strength(P, P, Q, (edge_ver[u] >> 1) & 1, is_b);
+  }
+  if ((edge_hor[u] & 1) && !(uy & 1) && uy) {
+    const int up = u - uw;
+    int um = up;
+    if ((4 * uy) % ctu == 0) um = up - ux + (ux & ~3) + ((ux & 3) < 2 ? 0 : 3); // compressed motion of the CTU row above: [0 0 3 3]
+    bh = dbk_strength(units[up], units[um], Q, (edge_hor[u] >> 1) & 1, is_b);
+  }
+  bs_ver[u] = (unsigned char)bv;
+  bs_hor[u] = (unsigned char)bh;
+}
+extern "C" int hmx_deblock_strengths(hmx_ctx *c, const hmx_dbk_unit *d_units, const uint8_t *d_edge_ver, const uint8_t *d_edge_hor, int pic_w,
+                                     int pic_h, int is_b_slice, uint8_t *d_bs_ver, uint8_t *d_bs_hor) {
+  if (!c || !d_units || !d_edge_ver || !d_edge_hor || !d_bs_ver || !d_bs_hor || pic_w <= 0 || pic_h <= 0 || (pic_w & 7) || (pic_h & 7))
+    return fail(c, HMX_ERR_ARG, "hmx_deblock_strengths: null argument or picture size not a multiple of 8");
+  const int uw = pic_w / 4, uh = pic_h / 4;
+  hipLaunchKernelGGL(k_dbk_strengths, dim3((unsigned)(((size_t)uw * uh + 255) / 256)), dim3(256), 0, c->stream, d_units, d_edge_ver, d_edge_hor,
+                     uw, uh, c->cfg.ctu_size, is_b_slice, d_bs_ver, d_bs_hor);
+  HIPCHK(c, hipGetLastError());
+  return HMX_OK;
+}
+
 extern "C" int hmx_deblock_picture(hmx_ctx *c, const hmx_pic *rec, int pic_w, int pic_h, const uint8_t *d_bs_ver, const uint8_t *d_bs_hor,
                                    const int8_t *d_qp, const uint8_t *d_no_filter, int beta_offset_div2, int tc_offset_div2) {
   if (!c || !rec || !d_bs_ver || !d_bs_hor || !d_qp || pic_w <= 0 || pic_h <= 0 || (pic_w & 7) || (pic_h & 7))
