@@ -348,6 +348,20 @@ int hmx_deblock_picture(hmx_ctx *ctx, const hmx_pic *rec, int pic_w, int pic_h, 
                         const uint8_t *d_bs_hor, const int8_t *d_qp, const uint8_t *d_no_filter, int beta_offset_div2,
                         int tc_offset_div2);
 
+/* Sample adaptive offset, the application part (TLibCommon/TComSampleAdaptiveOffset.cpp:781-1240: SAOProcess,
+ * processSaoUnitAll, processSaoCuOrg), from the deblocked picture `in` to `out` (different
+ * buffers: the reference's line buffers exist to keep the unfiltered neighbours an in-place pass destroys).
+ * d_params (device): [component][CTU in raster order], merge flags already resolved: type -1 = off, 0..3 = edge
+ * offset classes (horizontal, vertical, 135, 45 degrees), 4 = band offset from band `band` of 32; four offsets,
+ * scaled by << (bit depth - min(bit depth, 10)).  n_lcu = CTUs of the picture. */
+typedef struct hmx_sao_lcu {
+  int8_t type;
+  uint8_t band;
+  int8_t offset[4];
+} hmx_sao_lcu;
+int hmx_sao_picture(hmx_ctx *ctx, const hmx_pic *in, const hmx_pic *out, int pic_w, int pic_h, const hmx_sao_lcu *d_params,
+                    int n_lcu);
+
 /* Planar 4:2:0 YUV frames, the format either side of the path (TLibVideoIO/TVideoIOYuv.cpp:226-480, SURVEY.md
  * 8f rank 4).  d_file (device) holds one frame as the file does: 8-bit or 16-bit little-endian samples, Y then
  * Cb then Cr.  unpack = TVideoIOYuv::read: the file's (w_full - pad_x) x (h_full - pad_y) samples are padded to

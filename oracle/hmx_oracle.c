@@ -1436,3 +1436,34 @@ void hmo_deblock_strengths(const hmo_dbk_unit *units, const uint8_t *edge_ver, c
       }
   }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Sample adaptive offset (COM/TComSampleAdaptiveOffset.cpp:781-1240)
+ * ---------------------------------------------------------------------------------------- */
+static int sgn(int v) { return (v > 0) - (v < 0); }
+void hmo_sao_picture(const int16_t *const in[3], int16_t *const out[3], const int strides[3], int pic_w, int pic_h, int B, int ctu,
+                     const hmo_sao_lcu *const params[3]) {
+  static const int eo_table[5] = {1, 2, 0, 3, 4}; /* m_auiEoTable :92-103: edge index -> offset slot, slot 0 = no offset */
+  static const int dx[4] = {1, 0, 1, -1}, dy[4] = {0, 1, 1, 1}; /* b = c + d, a = c - d */
+  const int cw = (pic_w + ctu - 1) / ctu, maxv = (1 << B) - 1, up = B - (B < 10 ? B : 10);
+  for (int p = 0; p < 3; p++) {
+    const int sh = p ? 1 : 0, w = pic_w >> sh, h = pic_h >> sh, cs = ctu >> sh, st = strides[p];
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) {
+        const hmo_sao_lcu *q = &params[p][(y / cs) * cw + x / cs];
+        const int c = in[p][y * st + x];
+        int v = c;
+        if (q->type >= 0 && q->type < 4) {
+          const int ax = x - dx[q->type], ay = y - dy[q->type], bx = x + dx[q->type], by = y + dy[q->type];
+          if (ax >= 0 && ax < w && ay >= 0 && bx >= 0 && bx < w && by < h) {
+            const int slot = eo_table[sgn(c - in[p][ay * st + ax]) + sgn(c - in[p][by * st + bx]) + 2];
+            if (slot) v = clip3(0, maxv, c + (q->offset[slot - 1] << up));
+          }
+        } else if (q->type == 4) {
+          const int k = ((c >> (B - 5)) - q->band) & 31; /* band index relative to the first signalled band */
+          if (k < 4) v = clip3(0, maxv, c + (q->offset[k] << up));
+        }
+        out[p][y * st + x] = (int16_t)v;
+      }
+  }
+}

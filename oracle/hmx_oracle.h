@@ -225,6 +225,20 @@ void hmo_deblock_picture(int16_t *const planes[3], const int strides[3], int pic
                          const uint8_t *bs_hor, const int8_t *qp, const uint8_t *no_filter, int beta_offset_div2,
                          int tc_offset_div2);
 
+/* ---- sample adaptive offset, application (COM/TComSampleAdaptiveOffset.cpp:781-1240: processSaoCuOrg,
+ *      processSaoUnitAll, tables :92-116, :176-215).  Per CTU and component: type -1 = off, 0..3 = edge offset
+ *      classes (horizontal, vertical, 135, 45 degrees), 4 = band offset starting at band `band` (of 32); four
+ *      offsets (scaled by << (B - min(B, 10))).  The reference filters in place with line buffers that keep the
+ *      unfiltered neighbours: the same as filtering from `in` to `out`.  Samples whose class neighbour lies outside
+ *      the picture are copied. ---- */
+typedef struct {
+  int8_t type;
+  uint8_t band;
+  int8_t offset[4];
+} hmo_sao_lcu;
+void hmo_sao_picture(const int16_t *const in[3], int16_t *const out[3], const int strides[3], int pic_w, int pic_h, int B, int ctu,
+                     const hmo_sao_lcu *const params[3]);
+
 /* ---- planar 4:2:0 YUV frames as the reference reads and writes them (VIO/TVideoIOYuv.cpp:226-480):
  *      8-bit or 16-bit little-endian samples, Y then Cb then Cr; on read the active area is padded to the
  *      right and below by replication and the whole padded plane is scaled to the internal bit depth

@@ -17,6 +17,7 @@
 #include "TLibCommon/TComPrediction.h"
 #include "TLibCommon/TComRdCost.h"
 #include "TLibCommon/TComRom.h"
+#include "TLibCommon/TComSampleAdaptiveOffset.h"
 #include "TLibCommon/TComSlice.h"
 #include "TLibCommon/TComTrQuant.h"
 #include "TLibCommon/TComYuv.h"
@@ -439,6 +440,42 @@ void ref_deblock_strengths(const TapDbkUnit *units, const unsigned char *edge_ve
         bs[u] = lf->m_aapucBS[dir][z];
       }
     }
+}
+
+// ---- SAO: SAOProcess on the picture set by ref_set_recon, with per-LCU parameters (6 bytes each: type, band, 4 offsets),
+// params = [Y LCUs][Cb LCUs][Cr LCUs] ----
+void ref_sao_picture(const signed char *params, int n_lcu, short *y, short *cb, short *cr) {
+  TComPic *pic = S->pic;
+  const int w = S->pic_w, h = S->pic_h;
+  TComSampleAdaptiveOffset sao;
+  sao.create(w, h, 64, 64, 4);
+  sao.createPicSaoInfo(pic, 1);
+  sao.setSaoLcuBasedOptimization(true);
+  SAOParam prm;
+  sao.allocSaoParam(&prm);
+  sao.resetSAOParam(&prm);
+  prm.bSaoFlag[0] = prm.bSaoFlag[1] = true;
+  for (int c = 0; c < 3; c++) {
+    prm.oneUnitFlag[c] = false;
+    for (int a = 0; a < n_lcu; a++) {
+      const signed char *q = params + (c * n_lcu + a) * 6;
+      SaoLcuParam &L = prm.saoLcuParam[c][a];
+      L.mergeUpFlag = L.mergeLeftFlag = false;
+      L.typeIdx = q[0];
+      L.subTypeIdx = (unsigned char)q[1];
+      L.length = 4;
+      for (int i = 0; i < 4; i++) L.offset[i] = q[2 + i];
+    }
+  }
+  sao.SAOProcess(pic, &prm);
+  sao.freeSaoParam(&prm);
+  sao.destroy();
+  TComPicYuv *r = pic->getPicYuvRec();
+  for (int j = 0; j < h; j++) memcpy(y + j * w, r->getLumaAddr() + j * r->getStride(), 2 * w);
+  for (int j = 0; j < h / 2; j++) {
+    memcpy(cb + j * (w / 2), r->getCbAddr() + j * r->getCStride(), w);
+    memcpy(cr + j * (w / 2), r->getCrAddr() + j * r->getCStride(), w);
+  }
 }
 
 // ---- planar YUV files (TLibVideoIO/TVideoIOYuv.cpp): one frame in, one frame out ----

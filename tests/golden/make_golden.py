@@ -137,6 +137,28 @@ def deblock(R, B, rng):
     return out
 
 
+def sao(R, B, rng):
+    """SAOProcess of the reference on a 136x72 picture (cut CTUs), random per-CTU parameters."""
+    w, h = 136, 72
+    R.ref_init(B, w, h, 1)
+    mx = (1 << B) - 1
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    n_lcu = 3 * 2
+    dt = np.dtype([("type", "i1"), ("band", "u1"), ("offset", "i1", 4)])
+    y = np.clip(rng.integers(0, mx + 1, (h // 4, w // 4)).repeat(4, 0).repeat(4, 1) // 2 + rng.integers(0, 6, (h, w)), 0, mx).astype(np.int16)
+    cb = rng.integers(0, mx + 1, (h // 2, w // 2)).astype(np.int16)
+    cr = np.clip(rng.integers(0, 40, (h // 2, w // 2)) + mx - 30, 0, mx).astype(np.int16)
+    prm = np.zeros((3, n_lcu), dt)
+    prm["type"] = rng.integers(-1, 5, (3, n_lcu))
+    prm["band"] = rng.integers(0, 32, (3, n_lcu))
+    prm["offset"] = rng.integers(-7, 8, (3, n_lcu, 4))
+    prm = np.ascontiguousarray(prm)
+    R.ref_set_recon(y.reshape(-1), cb.reshape(-1), cr.reshape(-1))
+    ry, rcb, rcr = np.zeros_like(y), np.zeros_like(cb), np.zeros_like(cr)
+    R.ref_sao_picture(vp(prm), n_lcu, vp(ry), vp(rcb), vp(rcr))
+    return {"y": y, "cb": cb, "cr": cr, "prm": prm.view(np.uint8).reshape(3, n_lcu, 6), "oy": ry, "ocb": rcb, "ocr": rcr}
+
+
 def intra(R, B, rng):
     """initAdiPattern on a real picture + all 35 modes, luma and chroma."""
     out = {}
@@ -254,6 +276,10 @@ def main():
         for B in (8, 10):
             R.ref_init(B, 416, 240, 1)
             np.savez_compressed(os.path.join(HERE, f"rdoq_b{B}.npz"), **rdoq(R, B, np.random.default_rng(4048 + B)))
+        return
+    if sys.argv[1:] == ["sao"]:
+        for B in (8, 10):
+            np.savez_compressed(os.path.join(HERE, f"sao_b{B}.npz"), **sao(R, B, np.random.default_rng(7096 + B)))
         return
     if sys.argv[1:] == ["deblock"]:
         for B in (8, 10):

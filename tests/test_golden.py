@@ -94,6 +94,19 @@ def test_oracle_deblock(B):
 
 
 @pytest.mark.parametrize("B", [8, 10])
+def test_oracle_sao(B):
+    g, O = load(f"sao_b{B}.npz"), ol.oracle()
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
+    y, cb, cr = (np.ascontiguousarray(g[k]) for k in ("y", "cb", "cr"))
+    prm = np.ascontiguousarray(g["prm"])
+    h, w = y.shape
+    oy, ocb, ocr = np.zeros_like(y), np.zeros_like(cb), np.zeros_like(cr)
+    O.hmo_sao_picture(P3(y.ctypes.data, cb.ctypes.data, cr.ctypes.data), P3(oy.ctypes.data, ocb.ctypes.data, ocr.ctypes.data),
+                      I3(w, w // 2, w // 2), w, h, B, 64, P3(prm[0].ctypes.data, prm[1].ctypes.data, prm[2].ctypes.data))
+    assert np.array_equal(oy, g["oy"]) and np.array_equal(ocb, g["ocb"]) and np.array_equal(ocr, g["ocr"])
+
+
+@pytest.mark.parametrize("B", [8, 10])
 def test_oracle_intra(B):
     g, O = load(f"intra_b{B}.npz"), ol.oracle()
     w, h = g["pic_y"].shape[1], g["pic_y"].shape[0]
@@ -335,3 +348,23 @@ def test_gpu_deblock(gctx):
         pic.free()
         for x in d:
             x.free()
+
+
+@pytest.mark.gpu
+def test_gpu_sao(gctx):
+    """hmx_sao_picture vs the reference's SAOProcess (golden): all edge classes, band offset, cut CTUs, chroma."""
+    from thevc_amd import capi
+    B, L = gctx.bit_depth, capi.lib()
+    g = load(f"sao_b{B}.npz")
+    y, cb, cr = g["y"], g["cb"], g["cr"]
+    h, w = y.shape
+    src = capi.DevPicture(gctx, w, h).upload([y, cb, cr])
+    dst = capi.DevPicture(gctx, w, h).zero()
+    d_prm = gctx.to_device(np.ascontiguousarray(g["prm"]))
+    a, b = src.as_pic(), dst.as_pic()
+    gctx._chk(L.hmx_sao_picture(gctx.h, C.byref(a), C.byref(b), w, h, d_prm.ptr, g["prm"].shape[1]))
+    gctx.sync()
+    got = dst.download()
+    for x, k in zip(got, ("oy", "ocb", "ocr")):
+        assert np.array_equal(x, g[k]), k
+    src.free(), dst.free(), d_prm.free()

@@ -632,3 +632,43 @@ def test_deblock_strengths():
             assert np.array_equal(rh, oh), ("hor", is_b, it, np.argwhere(rh != oh)[:3])
             hist += np.bincount(np.concatenate([ov.reshape(-1), oh.reshape(-1)]), minlength=3)[:3]
         assert (hist[1:] > 200).all(), hist  # strengths 1 and 2 both occur often
+
+
+SAO_LCU = np.dtype([("type", "i1"), ("band", "u1"), ("offset", "i1", 4)])
+
+
+def _sao_params(rng, n_lcu):
+    p = np.zeros((3, n_lcu), SAO_LCU)
+    p["type"] = rng.integers(-1, 5, (3, n_lcu))
+    p["band"] = rng.integers(0, 32, (3, n_lcu))
+    p["offset"] = rng.integers(-7, 8, (3, n_lcu, 4))
+    return np.ascontiguousarray(p)
+
+
+def test_sao_application():
+    """SAOProcess of the reference (edge offset classes, band offset, off; luma and chroma; a picture that is not a
+    whole number of CTUs) vs the oracle's out-of-place restatement."""
+    R, O = ol.ref(), ol.oracle()
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    for B in (8, 10):
+        for (w, h) in ((192, 128), (200, 136)):
+            R.ref_init(B, w, h, 1)
+            rng = np.random.default_rng(2500 + B + w)
+            mx = (1 << B) - 1
+            n_lcu = -(-w // 64) * -(-h // 64)
+            for it in range(3):
+                # smooth-ish content so that all five edge categories occur
+                y = np.clip(rng.integers(0, mx + 1, (h // 4 + 1, w // 4 + 1)).repeat(4, 0).repeat(4, 1)[:h, :w] // 2 + rng.integers(0, 6, (h, w)), 0, mx).astype(np.int16)
+                cb = rng.integers(0, mx + 1, (h // 2, w // 2)).astype(np.int16)
+                cr = np.clip(rng.integers(0, 40, (h // 2, w // 2)) + mx - 30, 0, mx).astype(np.int16)  # near the clip range
+                prm = _sao_params(rng, n_lcu)
+                R.ref_set_recon(y.reshape(-1), cb.reshape(-1), cr.reshape(-1))
+                ry, rcb, rcr = np.zeros_like(y), np.zeros_like(cb), np.zeros_like(cr)
+                R.ref_sao_picture(vp(prm), n_lcu, vp(ry), vp(rcb), vp(rcr))
+                oy, ocb, ocr = np.zeros_like(y), np.zeros_like(cb), np.zeros_like(cr)
+                O.hmo_sao_picture(P3(y.ctypes.data, cb.ctypes.data, cr.ctypes.data), P3(oy.ctypes.data, ocb.ctypes.data, ocr.ctypes.data),
+                                  I3(w, w // 2, w // 2), w, h, B, 64, P3(prm[0].ctypes.data, prm[1].ctypes.data, prm[2].ctypes.data))
+                assert np.array_equal(ry, oy), ("luma", B, w, it, np.argwhere(ry != oy)[:3])
+                assert np.array_equal(rcb, ocb) and np.array_equal(rcr, ocr), ("chroma", B, w, it)
+                assert (oy != y).sum() > 500

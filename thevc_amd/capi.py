@@ -165,6 +165,7 @@ def lib():
         L.hmx_batch_invtransformNxN_multi.argtypes = [vp, vp, ci, C.POINTER(Levels), C.POINTER(Pic), C.POINTER(Pic),
                                                       C.POINTER(PicParam)]
         L.hmx_pic_extend_border_multi.argtypes = [vp, ci, C.POINTER(Pic), ci, ci, ci, ci]
+        L.hmx_sao_picture.argtypes = [vp, C.POINTER(Pic), C.POINTER(Pic), ci, ci, vp, ci]
         L.hmx_deblock_strengths.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp]
         L.hmx_deblock_picture.argtypes = [vp, C.POINTER(Pic), ci, ci, vp, vp, vp, vp, ci, ci]
         L.hmx_yuv_frame_bytes.argtypes = [ci, ci, ci]

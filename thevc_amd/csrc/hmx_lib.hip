@@ -2932,6 +2932,46 @@ extern "C" int hmx_deblock_picture(hmx_ctx *c, const hmx_pic *rec, int pic_w, in
   return HMX_OK;
 }
 
+// ---- sample adaptive offset, application (TLibCommon/TComSampleAdaptiveOffset.cpp:781-1240) ----
+// The reference filters in place, CTU by CTU, with line buffers that keep the unfiltered neighbours: the same as one
+// pass from `in` to `out`, a thread per sample.
+__global__ __launch_bounds__(256) void k_sao(PlanesDev in, PlanesDev out, int pic_w, int pic_h, int B, int ctu, const hmx_sao_lcu *prm, int n_lcu) {
+  const int p = blockIdx.y, sh = p ? 1 : 0, w = pic_w >> sh, h = pic_h >> sh, cs = ctu >> sh;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w * h) return;
+  const int x = i % w, y = i / w, cw = (pic_w + ctu - 1) / ctu;
+  const hmx_sao_lcu q = prm[(size_t)p * n_lcu + (y / cs) * cw + x / cs];
+  const short *s = in.p[p];
+  const int st = in.s[p], c = s[(size_t)y * st + x], maxv = (1 << B) - 1, up = B - min(B, 10);
+  int v = c;
+  if (q.type >= 0 && q.type < 4) {
+    const int dx = q.type == 1 ? 0 : (q.type == 3 ? -1 : 1), dy = q.type == 0 ? 0 : 1; // b = c + d, a = c - d
+    const int ax = x - dx, ay = y - dy, bx = x + dx, by = y + dy;
+    if (ax >= 0 && ax < w && ay >= 0 && bx >= 0 && bx < w && by < h) {
+      const int a = s[(size_t)ay * st + ax], b = s[(size_t)by * st + bx];
+      const int e = ((c > a) - (c < a)) + ((c > b) - (c < b)) + 2; // 0..4; m_auiEoTable {1, 2, 0, 3, 4} picks the offset
+      const int slot = e == 2 ? 0 : (e < 2 ? e + 1 : e);
+      if (slot) v = clip3(0, maxv, c + ((int)q.offset[slot - 1] << up));
+    }
+  } else if (q.type == 4) {
+    const int k = ((c >> (B - 5)) - q.band) & 31;
+    if (k < 4) v = clip3(0, maxv, c + ((int)q.offset[k] << up));
+  }
+  out.p[p][(size_t)y * out.s[p] + x] = (short)v;
+}
+extern "C" int hmx_sao_picture(hmx_ctx *c, const hmx_pic *in, const hmx_pic *out, int pic_w, int pic_h, const hmx_sao_lcu *d_params, int n_lcu) {
+  const int ctu = c ? c->cfg.ctu_size : 64;
+  if (!c || !in || !out || !d_params || pic_w <= 0 || pic_h <= 0 || (pic_w & 1) || (pic_h & 1) ||
+      n_lcu != ((pic_w + ctu - 1) / ctu) * ((pic_h + ctu - 1) / ctu))
+    return fail(c, HMX_ERR_ARG, "hmx_sao_picture: bad argument (n_lcu must be the CTU count of the picture)");
+  for (int p = 0; p < 3; p++)
+    if (in->plane[p] == out->plane[p]) return fail(c, HMX_ERR_ARG, "hmx_sao_picture: in and out must be different pictures");
+  hipLaunchKernelGGL(k_sao, dim3((unsigned)(((size_t)pic_w * pic_h + 255) / 256), 3), dim3(256), 0, c->stream, to_dev(in), to_dev(out), pic_w, pic_h,
+                     c->cfg.bit_depth, ctu, d_params, n_lcu);
+  HIPCHK(c, hipGetLastError());
+  return HMX_OK;
+}
+
 // ---- planar 4:2:0 YUV frames (TLibVideoIO/TVideoIOYuv.cpp:226-480) ----
 // A frame travels as the bytes of the file (1 or 2 bytes per sample, Y then Cb then Cr): half or a quarter of
 // the PCIe traffic of int16 planes; widening, bit-depth scaling and the right/bottom padding happen in HBM.
