@@ -229,6 +229,8 @@ def main():
     kernel_ms = ctx.elapsed_ms(ev0, ev1)  # HIP events on the stream the kernels run on
     ta, tb, tc = C.c_float(), C.c_float(), C.c_float()
     ctx._chk(L.hmx_last_call_timing(ctx.h, C.byref(ta), C.byref(tb), C.byref(tc)))  # last step: convert / chain / convert
+    sched, groups = C.c_int(), C.c_int()
+    L.hmx_last_call_shape(ctx.h, C.byref(sched), C.byref(groups))  # how the library issued the timed calls
     dt = max_over_ranks(dt, world, "cuda")
 
     verified = None
@@ -243,8 +245,6 @@ def main():
         px_step = w * h_c * F
         nb, nl, nd = C.c_int(), C.c_int(), C.c_int()
         L.hmx_intra_plan_info(plan, C.byref(nb), C.byref(nl), C.byref(nd))
-        sched, groups = C.c_int(), C.c_int()
-        L.hmx_last_call_shape(ctx.h, C.byref(sched), C.byref(groups))  # how the library issued the timed calls
         level_sched = sched.value > 0
         n_levels = nl.value if level_sched else nd.value   # dependent steps of the chain
         n_launch = n_levels * groups.value                 # launches of the dominant kernel per step
@@ -283,6 +283,7 @@ def main():
                          "avg_launch_us": round(tb.value * 1e3 / n_levels, 2),
                          "achieved_per_launch": round(bytes_step / n_launch / (tb.value * 1e-3 / n_levels) / 1e9, 2),
                          "step_ms_events": round(kernel_ms / args.steps, 3),
+                         # conversion in / out as phases of their own (0 when HMX_PIPELINE_CONV=1 overlaps them with the chain)
                          "layout_conversion_ms": [round(ta.value, 3), round(tc.value, 3)]},
         }
         if verified is not None:

@@ -9,3 +9,6 @@ timeout -k 10 600 python bench.py --workload ai1080p8 --steps 2 --warmup 1 --no-
 timeout -k 10 600 python bench.py --workload ai2160p8 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "$P" "ai2160p8 default"
 timeout -k 10 600 python bench.py --workload ra1080p8 --segments 32 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "$P" "ra1080p8 32 segments"
 timeout -k 10 600 python bench.py --workload ra2160p8 --segments 8 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "$P" "ra2160p8 8 segments"
+timeout -k 10 600 python bench.py --workload ldp1080p8 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "$P" "ldp1080p8 default (16 sequences)"
+timeout -k 10 600 python bench.py --workload ra1080p8 --segments 64 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "$P" "ra1080p8 64 segments"
+timeout -k 10 600 python bench.py --workload ra2160p8 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "$P" "ra2160p8 default (16 segments)"
