@@ -1,5 +1,6 @@
 """GPU parity: libhmx (HIP, through the C-ABI) vs the CPU oracle, bit-exact.  Run with -m gpu."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -741,3 +742,48 @@ def test_deblock_strengths_vs_oracle(ctx):
         assert (ov == 1).sum() > 100 and (ov == 2).sum() > 100
         for d in (d_u, d_ev, d_eh, d_bv, d_bh):
             d.free()
+
+
+def test_example_end_to_end(tmp_path):
+    """examples/all_intra_reconstruct.py (file -> unpack -> intra chain -> strengths -> deblock -> SAO -> pack -> file)
+    against the same chain of oracle functions, on a picture whose size is not a multiple of 8."""
+    import argparse
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ex", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples",
+                                                                      "all_intra_reconstruct.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    O = ol.oracle()
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    w, h, B, qp, n_frames = 100, 52, 10, 30, 2
+    rng = np.random.default_rng(12)
+    frames = [np.clip(rng.integers(0, 200, w * h * 3 // 2) + 300, 0, 1023).astype("<u2") for _ in range(n_frames)]
+    inp, outp = str(tmp_path / "in.yuv"), str(tmp_path / "out.yuv")
+    open(inp, "wb").write(b"".join(f.tobytes() for f in frames))
+    args = argparse.Namespace(input=inp, output=outp, width=w, height=h, file_bits=10, bit_depth=B, qp=qp, frames=0, seed=4)
+    n, tus, ev, eh, sao = ex.run(args)
+    assert n == n_frames
+    got = np.frombuffer(open(outp, "rb").read(), np.uint8)
+    pw, ph = 104, 56
+    uw, uh = pw // 4, ph // 4
+    want = b""
+    for f in frames:
+        raw = np.frombuffer(f.tobytes(), np.uint8)
+        pl = [np.zeros((ph, pw), np.int16), np.zeros((ph // 2, pw // 2), np.int16), np.zeros((ph // 2, pw // 2), np.int16)]
+        O.hmo_yuv_unpack(vp(raw), 10, B, pw, ph, pw - w, ph - h, P3(*[p.ctypes.data for p in pl]), I3(pw, pw // 2, pw // 2))
+        rec, _ = ol.o_intra_frame_encode(tus, pw, ph, B, qp, pl)
+        units = np.zeros(uw * uh, np.dtype([("intra", "u1"), ("cbf", "u1"), ("ref", "i1", 2), ("mv", "<i2", (2, 2))]))
+        units["intra"] = 1
+        bv, bh = np.zeros(uw * uh, np.uint8), np.zeros(uw * uh, np.uint8)
+        O.hmo_deblock_strengths(vp(units), vp(ev), vp(eh), pw, ph, 64, 0, vp(bv), vp(bh))
+        qpm = np.full(uw * uh, qp, np.int8)
+        O.hmo_deblock_picture(P3(*[p.ctypes.data for p in rec]), I3(pw, pw // 2, pw // 2), pw, ph, B, vp(bv), vp(bh), vp(qpm), None, 0, 0)
+        so = [np.zeros_like(p) for p in rec]
+        prm = np.ascontiguousarray(sao)
+        O.hmo_sao_picture(P3(*[p.ctypes.data for p in rec]), P3(*[p.ctypes.data for p in so]), I3(pw, pw // 2, pw // 2), pw, ph, B, 64,
+                          P3(prm[0].ctypes.data, prm[1].ctypes.data, prm[2].ctypes.data))
+        packed = np.zeros(w * h * 3, np.uint8)
+        O.hmo_yuv_pack(P3(*[p.ctypes.data for p in so]), I3(pw, pw // 2, pw // 2), pw, ph, pw - w, ph - h, B, 10, vp(packed))
+        want += packed.tobytes()
+    assert got.tobytes() == want
