@@ -3078,29 +3078,68 @@ extern "C" int hmx_deblock_picture(hmx_ctx *c, const hmx_pic *rec, int pic_w, in
 // ---- sample adaptive offset, application (TLibCommon/TComSampleAdaptiveOffset.cpp:781-1240) ----
 // The reference filters in place, CTU by CTU, with line buffers that keep the unfiltered neighbours: the same as one
 // pass from `in` to `out`, a thread per sample.
+// A thread filters 8 consecutive samples of a row (a CTU is a multiple of 8 wide in both planes, so they share their
+// parameters): three 16-byte loads (the row, the rows above and below) and the six samples just outside, one 16-byte store.
+typedef short s8v __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void k_sao(PlanesDev in, PlanesDev out, int pic_w, int pic_h, int B, int ctu, const hmx_sao_lcu *prm, int n_lcu) {
-  const int p = blockIdx.y, sh = p ? 1 : 0, w = pic_w >> sh, h = pic_h >> sh, cs = ctu >> sh;
+  const int p = blockIdx.y, sh = p ? 1 : 0, w = pic_w >> sh, h = pic_h >> sh, cs = ctu >> sh, w8 = (w + 7) >> 3;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= w * h) return;
-  const int x = i % w, y = i / w, cw = (pic_w + ctu - 1) / ctu;
-  const hmx_sao_lcu q = prm[(size_t)p * n_lcu + (y / cs) * cw + x / cs];
+  if (i >= w8 * h) return;
+  const int x0 = (i % w8) << 3, y = i / w8, cw = (pic_w + ctu - 1) / ctu;
+  const hmx_sao_lcu q = prm[(size_t)p * n_lcu + (y / cs) * cw + x0 / cs];
+  // the four offsets in one register, picked by shifts (an indexed copy of the struct would live in scratch)
+  const unsigned offs = (unsigned)(unsigned char)q.offset[0] | (unsigned)(unsigned char)q.offset[1] << 8 | (unsigned)(unsigned char)q.offset[2] << 16 |
+                        (unsigned)(unsigned char)q.offset[3] << 24;
   const short *s = in.p[p];
-  const int st = in.s[p], c = s[(size_t)y * st + x], maxv = (1 << B) - 1, up = B - min(B, 10);
-  int v = c;
-  if (q.type >= 0 && q.type < 4) {
-    const int dx = q.type == 1 ? 0 : (q.type == 3 ? -1 : 1), dy = q.type == 0 ? 0 : 1; // b = c + d, a = c - d
-    const int ax = x - dx, ay = y - dy, bx = x + dx, by = y + dy;
-    if (ax >= 0 && ax < w && ay >= 0 && bx >= 0 && bx < w && by < h) {
-      const int a = s[(size_t)ay * st + ax], b = s[(size_t)by * st + bx];
-      const int e = ((c > a) - (c < a)) + ((c > b) - (c < b)) + 2; // 0..4; m_auiEoTable {1, 2, 0, 3, 4} picks the offset
-      const int slot = e == 2 ? 0 : (e < 2 ? e + 1 : e);
-      if (slot) v = clip3(0, maxv, c + ((int)q.offset[slot - 1] << up));
+  const int st = in.s[p], maxv = (1 << B) - 1, up = B - min(B, 10), n = min(8, w - x0);
+  short *d = out.p[p] + (size_t)y * out.s[p] + x0;
+  // rows y-1, y, y+1 at x0-1 .. x0+8 (clamped addresses; out-of-picture neighbours are excluded by the tests below)
+  int r[3][10];
+  const bool vec = n == 8 && (((uintptr_t)(s + (size_t)y * st + x0) | (uintptr_t)(2 * st)) & 15) == 0;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const int yy = min(max(y + j - 1, 0), h - 1);
+    const short *row = s + (size_t)yy * st;
+    if (vec) {
+      const s8v v = *reinterpret_cast<const s8v *>(row + x0);
+#pragma unroll
+      for (int k = 0; k < 8; k++) r[j][k + 1] = v[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) r[j][k + 1] = row[min(x0 + k, w - 1)];
     }
-  } else if (q.type == 4) {
-    const int k = ((c >> (B - 5)) - q.band) & 31;
-    if (k < 4) v = clip3(0, maxv, c + ((int)q.offset[k] << up));
+    r[j][0] = row[max(x0 - 1, 0)];
+    r[j][9] = row[min(x0 + 8, w - 1)];
   }
-  out.p[p][(size_t)y * out.s[p] + x] = (short)v;
+  int v[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int x = x0 + k, c = r[1][k + 1];
+    int o = c;
+    if (q.type >= 0 && q.type < 4) {
+      const int dx = q.type == 1 ? 0 : (q.type == 3 ? -1 : 1), dy = q.type == 0 ? 0 : 1; // b = c + d, a = c - d
+      if (x - dx >= 0 && x - dx < w && y - dy >= 0 && x + dx >= 0 && x + dx < w && y + dy < h) {
+        // select the neighbours from the register rows (dx, dy are uniform over the thread's samples)
+        const int a = dy ? (dx == 0 ? r[0][k + 1] : (dx > 0 ? r[0][k] : r[0][k + 2])) : r[1][k];
+        const int bb = dy ? (dx == 0 ? r[2][k + 1] : (dx > 0 ? r[2][k + 2] : r[2][k])) : r[1][k + 2];
+        const int e = ((c > a) - (c < a)) + ((c > bb) - (c < bb)) + 2; // 0..4; m_auiEoTable {1, 2, 0, 3, 4} picks the offset
+        const int slot = e == 2 ? 0 : (e < 2 ? e + 1 : e);
+        if (slot) o = clip3(0, maxv, c + ((int)(signed char)(offs >> (8 * (slot - 1))) << up));
+      }
+    } else if (q.type == 4) {
+      const int kk = ((c >> (B - 5)) - q.band) & 31;
+      if (kk < 4) o = clip3(0, maxv, c + ((int)(signed char)(offs >> (8 * kk)) << up));
+    }
+    v[k] = o;
+  }
+  if (n == 8 && (((uintptr_t)d) & 15) == 0) {
+    s8v ov;
+#pragma unroll
+    for (int k = 0; k < 8; k++) ov[k] = (short)v[k];
+    *reinterpret_cast<s8v *>(d) = ov;
+  } else {
+    for (int k = 0; k < n; k++) d[k] = (short)v[k];
+  }
 }
 extern "C" int hmx_sao_picture(hmx_ctx *c, const hmx_pic *in, const hmx_pic *out, int pic_w, int pic_h, const hmx_sao_lcu *d_params, int n_lcu) {
   const int ctu = c ? c->cfg.ctu_size : 64;
@@ -3109,7 +3148,7 @@ extern "C" int hmx_sao_picture(hmx_ctx *c, const hmx_pic *in, const hmx_pic *out
     return fail(c, HMX_ERR_ARG, "hmx_sao_picture: bad argument (n_lcu must be the CTU count of the picture)");
   for (int p = 0; p < 3; p++)
     if (in->plane[p] == out->plane[p]) return fail(c, HMX_ERR_ARG, "hmx_sao_picture: in and out must be different pictures");
-  hipLaunchKernelGGL(k_sao, dim3((unsigned)(((size_t)pic_w * pic_h + 255) / 256), 3), dim3(256), 0, c->stream, to_dev(in), to_dev(out), pic_w, pic_h,
+  hipLaunchKernelGGL(k_sao, dim3((unsigned)(((size_t)((pic_w + 7) / 8) * pic_h + 255) / 256), 3), dim3(256), 0, c->stream, to_dev(in), to_dev(out), pic_w, pic_h,
                      c->cfg.bit_depth, ctu, d_params, n_lcu);
   HIPCHK(c, hipGetLastError());
   return HMX_OK;
@@ -3124,32 +3163,71 @@ __device__ __forceinline__ short yuv_rescale(short v, int shift, int bits) { // 
   const short r = (short)((v + (short)(1 << (-shift - 1))) >> -shift);
   return (short)min(max((int)r, 0), (1 << bits) - 1);
 }
+// 8 consecutive samples of a row per thread (16-byte plane accesses when aligned)
 __global__ __launch_bounds__(256) void k_yuv_unpack(const unsigned char *file, int wide, int shift, int bits, int w_full, int h_full,
                                                     int pad_x, int pad_y, PlanesDev D) {
   const int p = blockIdx.y, c = p ? 1 : 0;
-  const int wf = w_full >> c, hf = h_full >> c, w = wf - (pad_x >> c), h = hf - (pad_y >> c);
+  const int wf = w_full >> c, hf = h_full >> c, w = wf - (pad_x >> c), h = hf - (pad_y >> c), w8 = (wf + 7) >> 3;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= wf * hf) return;
-  const int x = i % wf, y = i / wf, sx = min(x, w - 1), sy = min(y, h - 1); // readPlane :226-275: replicate right, then down
+  if (i >= w8 * hf) return;
+  const int x0 = (i % w8) << 3, y = i / w8, sy = min(y, h - 1), n = min(8, wf - x0); // readPlane :226-275: replicate right, then down
   const size_t luma = (size_t)(w_full - pad_x) * (h_full - pad_y), chroma = (size_t)w * h;
   const size_t plane_off = (p == 0 ? 0 : luma + (p == 2 ? chroma : 0)) * (wide ? 2 : 1);
-  const unsigned char *s = file + plane_off + ((size_t)sy * w + sx) * (wide ? 2 : 1);
-  const short v = wide ? (short)((s[1] << 8) | s[0]) : (short)s[0];
-  D.p[p][(size_t)y * D.s[p] + x] = yuv_rescale(v, shift, bits);
+  const unsigned char *row = file + plane_off + (size_t)sy * w * (wide ? 2 : 1);
+  short v[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int sx = min(x0 + k, w - 1);
+    const short t = wide ? (short)((row[2 * sx + 1] << 8) | row[2 * sx]) : (short)row[sx];
+    v[k] = yuv_rescale(t, shift, bits);
+  }
+  short *d = D.p[p] + (size_t)y * D.s[p] + x0;
+  if (n == 8 && (((uintptr_t)d) & 15) == 0) {
+    s8v ov;
+#pragma unroll
+    for (int k = 0; k < 8; k++) ov[k] = v[k];
+    *reinterpret_cast<s8v *>(d) = ov;
+  } else {
+    for (int k = 0; k < n; k++) d[k] = v[k];
+  }
 }
 __global__ __launch_bounds__(256) void k_yuv_pack(PlanesDev S, int wide, int shift, int bits, int ww, int hh, unsigned char *file) {
-  const int p = blockIdx.y, c = p ? 1 : 0, w = ww >> c, h = hh >> c;
+  const int p = blockIdx.y, c = p ? 1 : 0, w = ww >> c, h = hh >> c, w8 = (w + 7) >> 3;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= w * h) return;
-  const int x = i % w, y = i / w;
+  if (i >= w8 * h) return;
+  const int x0 = (i % w8) << 3, y = i / w8, n = min(8, w - x0);
   const size_t luma = (size_t)ww * hh, chroma = (size_t)w * h;
-  unsigned char *d = file + ((p == 0 ? 0 : luma + (p == 2 ? chroma : 0)) + (size_t)i) * (wide ? 2 : 1);
-  const short v = yuv_rescale(S.p[p][(size_t)y * S.s[p] + x], shift, bits);
+  unsigned char *d = file + ((p == 0 ? 0 : luma + (p == 2 ? chroma : 0)) + (size_t)y * w + x0) * (wide ? 2 : 1);
+  const short *s = S.p[p] + (size_t)y * S.s[p] + x0;
+  short v[8];
+  if (n == 8 && (((uintptr_t)s) & 15) == 0) {
+    const s8v iv = *reinterpret_cast<const s8v *>(s);
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = iv[k];
+  } else {
+    for (int k = 0; k < 8; k++) v[k] = s[min(k, n - 1)];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) v[k] = yuv_rescale(v[k], shift, bits);
   if (wide) {
-    d[0] = (unsigned char)(v & 0xff);
-    d[1] = (unsigned char)((v >> 8) & 0xff);
-  } else
-    d[0] = (unsigned char)v;
+    if (n == 8 && (((uintptr_t)d) & 15) == 0) {
+      s8v ov;
+#pragma unroll
+      for (int k = 0; k < 8; k++) ov[k] = v[k]; // little-endian 16-bit samples are the register layout
+      *reinterpret_cast<s8v *>(d) = ov;
+    } else {
+      for (int k = 0; k < n; k++) d[2 * k] = (unsigned char)(v[k] & 0xff), d[2 * k + 1] = (unsigned char)((v[k] >> 8) & 0xff);
+    }
+  } else {
+    if (n == 8 && (((uintptr_t)d) & 7) == 0) {
+      unsigned long long o = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) o |= (unsigned long long)(unsigned char)v[k] << (8 * k);
+      *reinterpret_cast<unsigned long long *>(d) = o;
+    } else {
+      for (int k = 0; k < n; k++) d[k] = (unsigned char)v[k];
+    }
+  }
 }
 extern "C" size_t hmx_yuv_frame_bytes(int w, int h, int file_bits) { return (size_t)w * h * 3 / 2 * (file_bits > 8 ? 2 : 1); }
 extern "C" int hmx_yuv_unpack(hmx_ctx *c, const void *d_file, int file_bits, const hmx_pic *dst, int w_full, int h_full, int pad_x,
@@ -3157,7 +3235,7 @@ extern "C" int hmx_yuv_unpack(hmx_ctx *c, const void *d_file, int file_bits, con
   if (!c || !d_file || !dst || file_bits < 8 || file_bits > 16 || w_full <= 0 || h_full <= 0 || (w_full & 1) || (h_full & 1) ||
       pad_x < 0 || pad_y < 0 || (pad_x & 1) || (pad_y & 1) || pad_x >= w_full || pad_y >= h_full)
     return fail(c, HMX_ERR_ARG, "hmx_yuv_unpack: bad argument");
-  hipLaunchKernelGGL(k_yuv_unpack, dim3((unsigned)(((size_t)w_full * h_full + 255) / 256), 3), dim3(256), 0, c->stream,
+  hipLaunchKernelGGL(k_yuv_unpack, dim3((unsigned)(((size_t)((w_full + 7) / 8) * h_full + 255) / 256), 3), dim3(256), 0, c->stream,
                      static_cast<const unsigned char *>(d_file), file_bits > 8 ? 1 : 0, c->cfg.bit_depth - file_bits, c->cfg.bit_depth,
                      w_full, h_full, pad_x, pad_y, to_dev(dst));
   HIPCHK(c, hipGetLastError());
@@ -3168,7 +3246,7 @@ extern "C" int hmx_yuv_pack(hmx_ctx *c, const hmx_pic *src, int w, int h, int cr
       crop_bottom >= h || ((w - crop_right) & 1) || ((h - crop_bottom) & 1))
     return fail(c, HMX_ERR_ARG, "hmx_yuv_pack: bad argument");
   const int ww = w - crop_right, hh = h - crop_bottom;
-  hipLaunchKernelGGL(k_yuv_pack, dim3((unsigned)(((size_t)ww * hh + 255) / 256), 3), dim3(256), 0, c->stream, to_dev(src),
+  hipLaunchKernelGGL(k_yuv_pack, dim3((unsigned)(((size_t)((ww + 7) / 8) * hh + 255) / 256), 3), dim3(256), 0, c->stream, to_dev(src),
                      file_bits > 8 ? 1 : 0, file_bits - c->cfg.bit_depth, file_bits, ww, hh, static_cast<unsigned char *>(d_file));
   HIPCHK(c, hipGetLastError());
   return HMX_OK;
