@@ -621,36 +621,49 @@ struct ConvJob { // one plane of one picture
   int stride, w, h;
   TiledPlane T;
 };
-// A 256-thread workgroup moves a 64 x 16 strip: thread = (row, 4-sample group), so a wave reads
-// four whole 128-byte lines of four plane rows, and writes the rows of 16 tiles (8 half-quads).
-// grid = (picture, strip, plane): consecutive workgroups take the same strip of consecutive pictures,
-// which are consecutive lines of the interleaved pool.
+// A 256-thread workgroup moves a 64 x 64 region, a thread one 4x4 tile: four 8-byte accesses on the plane side (16
+// consecutive threads cover a 128-byte line of each row) and the tile's 32 contiguous bytes on the tiled side (the
+// four threads of a quad complete its 128-byte line).  grid = (picture, region, plane): consecutive workgroups take
+// the same region of consecutive pictures, which are consecutive lines of the interleaved pool.
 // Rows [y0, y1) of the luma plane (and the chroma rows below them): a band of CTU rows, so that the conversion of one
-// band overlaps the dependency chain working on the others.
+// band can overlap the dependency chain working on the others.
 template <bool TO_TILED>
 __global__ __launch_bounds__(256) void k_convert_tiled(const ConvJob *jobs, int y0, int y1) {
   const ConvJob J = jobs[blockIdx.x * 3 + blockIdx.z];
   const int stride = J.stride, w = J.w, h = J.h;
   const TiledPlane T = J.T;
   const int c = blockIdx.z ? 1 : 0;
-  const int spr = ((T.ctu_w << T.clog) + 63) >> 6; // strips per row of this plane
+  const int spr = ((T.ctu_w << T.clog) + 63) >> 6; // regions per row of this plane
   const int sx = blockIdx.y % spr, sy = blockIdx.y / spr;
-  const int x = (sx << 6) + ((threadIdx.x & 15) << 2), y = (y0 >> c) + (sy << 4) + (threadIdx.x >> 4);
-  if (x >= w || y >= h || y >= (y1 >> c)) return;
-  short *tp = T.p + tphys(T.qstride, tile_base(T.ctu_w, T.clog, x, y) + ((y & 3) << 2));
+  const int x = (sx << 6) + ((threadIdx.x & 15) << 2), y = (y0 >> c) + (sy << 6) + ((threadIdx.x >> 4) << 2);
+  const int yend = min(h, y1 >> c);
+  if (x >= w || y >= yend) return;
+  short *tp = T.p + tphys(T.qstride, tile_base(T.ctu_w, T.clog, x, y));
   short *pp = J.plane + (size_t)y * stride + x;
-  const bool vec = ((reinterpret_cast<uintptr_t>(pp) & 7) == 0) && x + 4 <= w; // 8-byte accesses when the plane row allows
-  if (TO_TILED) {
-    if (vec)
-      *reinterpret_cast<s4v *>(tp) = *reinterpret_cast<const s4v *>(pp);
-    else
-      for (int k = 0; k < 4 && x + k < w; k++) tp[k] = pp[k];
-  } else {
-    if (vec)
-      *reinterpret_cast<s4v *>(pp) = *reinterpret_cast<const s4v *>(tp);
-    else
-      for (int k = 0; k < 4 && x + k < w; k++) pp[k] = tp[k];
+  const bool vec = (((reinterpret_cast<uintptr_t>(pp) | (uintptr_t)(2 * stride)) & 7) == 0) && x + 4 <= w && y + 4 <= yend;
+  if (vec) { // the common case: whole tile inside the picture, 8-byte aligned plane rows
+    if (TO_TILED) {
+      s4v r[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) r[k] = *reinterpret_cast<const s4v *>(pp + (size_t)k * stride);
+#pragma unroll
+      for (int k = 0; k < 4; k++) *reinterpret_cast<s4v *>(tp + 4 * k) = r[k];
+    } else {
+      s4v r[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) r[k] = *reinterpret_cast<const s4v *>(tp + 4 * k);
+#pragma unroll
+      for (int k = 0; k < 4; k++) *reinterpret_cast<s4v *>(pp + (size_t)k * stride) = r[k];
+    }
+    return;
   }
+  for (int j = 0; j < 4 && y + j < yend; j++)
+    for (int k = 0; k < 4 && x + k < w; k++) {
+      if (TO_TILED)
+        tp[4 * j + k] = pp[(size_t)j * stride + k];
+      else
+        pp[(size_t)j * stride + k] = tp[4 * j + k];
+    }
 }
 
 // Level-synchronous schedule: one launch per picture-wide dependency level.  Every block of a level
@@ -1520,7 +1533,7 @@ static int issue_across_pipelined(hmx_ctx *c, const hmx_intra_plan *p0, int n_pi
   }
   hipEvent_t *ev_in = c->ev_rows.data(), *ev_final = c->ev_rows.data() + ch; // ev_final[g * ch + r]
   hipStream_t conv = c->conv_stream;
-  const unsigned spr = (unsigned)(cw * ctu + 63) / 64, strip_rows = (unsigned)(ctu + 15) / 16;
+  const unsigned spr = (unsigned)(cw * ctu + 63) / 64, strip_rows = (unsigned)(ctu + 63) / 64;
   const dim3 cgrid((unsigned)n_pics, spr * strip_rows, 3);
   // fork: everything starts after what is already on main
   HIPCHK(c, hipEventRecord(c->ev_fork, main));
@@ -1600,8 +1613,8 @@ static int issue_intra_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, 
   // original planes -> tiled working copies (encode), chain, tiled reconstruction -> caller's planes
   const hmx_intra_plan *p0 = plans[0];
   const int cw = (p0->P.pic_w + p0->P.ctu - 1) / p0->P.ctu, ch = (p0->P.pic_h + p0->P.ctu - 1) / p0->P.ctu;
-  // 64 x 16 strips of the padded luma plane (the chroma planes need a quarter of them; the rest exit)
-  const unsigned spr = (unsigned)(cw * p0->P.ctu + 63) / 64, rows = (unsigned)(ch * p0->P.ctu + 15) / 16;
+  // 64 x 64 regions of the padded luma plane (the chroma planes need a quarter of them; the rest exit)
+  const unsigned spr = (unsigned)(cw * p0->P.ctu + 63) / 64, rows = (unsigned)(ch * p0->P.ctu + 63) / 64;
   dim3 cgrid((unsigned)n_pics, spr * rows, 3);
   const bool tm = c->timing;
   if (tm) HIPCHK(c, hipEventRecord(c->tev[0], main));
