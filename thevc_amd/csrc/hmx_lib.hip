@@ -343,6 +343,96 @@ __device__ __forceinline__ int scan4_pos(int scan_idx, int i) { // raster positi
   return scan_idx == 1 ? hor : (scan_idx == 2 ? ver : dg[i]);
 }
 
+// The transform half of a 4x4 block held by ONE lane (used by the lane-per-block chain and by the inter list kernel).
+// lane4_forward: residual (row-major) -> packed words (level | neg << 16 | deltaU << 17) after sign-bit hiding.
+__device__ __forceinline__ void lane4_forward(const int *resid, bool use_dst, bool ts, bool luma, int scan_idx, const PicDev &P, int *w) {
+  const int B = P.bit_depth, tshift = 15 - B - 2;
+  int coef[16];
+  if (ts) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) coef[k] = resid[k] << tshift; // tshift >= 1 for B <= 12
+  } else {
+    int t1[16];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { // tmp[k][r] = pass1(row r)[k]
+      int yk[4];
+      fwd_pass<4>(resid + 4 * r, yk, 1 + (B - 8), use_dst);
+#pragma unroll
+      for (int k = 0; k < 4; k++) t1[4 * k + r] = yk[k];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { // coeff[k][r] = pass2(row r of tmp)[k]
+      int yk[4];
+      fwd_pass<4>(t1 + 4 * r, yk, 8, use_dst);
+#pragma unroll
+      for (int k = 0; k < 4; k++) coef[4 * k + r] = yk[k];
+    }
+  }
+  const QuantDev &qd = P.qd[luma ? 0 : 1];
+  const int qbits = 14 + qd.per_qbits + tshift;
+  int sum = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    int al;
+    w[k] = quant_one<false>(coef[k], qd.q, qbits, qd.rnd_factor, al);
+    sum += al;
+  }
+  if (P.sign_hide && sum >= 2) { // one coefficient group = the whole block; it is "the last group"
+    // the scan differs per lane, but there are only three of them: scan entry k of each is a
+    // compile-time register, so the reorder is two selects per entry
+    constexpr int dg[16] = {0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15};
+    const bool hor = scan_idx == 1, ver = scan_idx == 2;
+    int ws[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int d = w[dg[k]], hv = w[k], vv = w[((k & 3) << 2) | (k >> 2)];
+      ws[k] = hor ? hv : (ver ? vv : d);
+    }
+    int nw;
+    const int bi = sbh_decide(ws, true, nw);
+    if (bi >= 0) {
+      const int bd = (int)((0xfbe7ad369c258140ull >> (4 * bi)) & 15); // dg[bi], one nibble per entry
+      const int bp = hor ? bi : (ver ? (((bi & 3) << 2) | (bi >> 2)) : bd);
+#pragma unroll
+      for (int q = 0; q < 16; q++) w[q] = (q == bp) ? nw : w[q];
+    }
+  }
+}
+// lane4_inverse: levels (row-major) -> residual
+__device__ __forceinline__ void lane4_inverse(const int *lv, bool use_dst, bool ts, bool luma, const PicDev &P, int *out) {
+  const int B = P.bit_depth, tshift = 15 - B - 2;
+  const QuantDev &qd = P.qd[luma ? 0 : 1];
+  int c[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) c[k] = dequant_one(lv[k], qd.iq_scale, 6 - tshift);
+  if (ts) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[k] = wrap16((c[k] + (1 << (tshift - 1))) >> tshift);
+    return;
+  }
+  int t1[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) c[k] = wrap16(c[k]);
+#pragma unroll
+  for (int j = 0; j < 4; j++) { // tmp[j][n] = sum_k M[k][n] * c[k][j]
+    int col[4], yn[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) col[k] = c[4 * k + j];
+    inv_pass<4>(col, yn, 7, use_dst);
+#pragma unroll
+    for (int nn = 0; nn < 4; nn++) t1[4 * j + nn] = yn[nn];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) { // block[j][n] = sum_k M[k][n] * tmp[k][j]
+    int col[4], yn[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) col[k] = t1[4 * k + j];
+    inv_pass<4>(col, yn, 12 - (B - 8), use_dst);
+#pragma unroll
+    for (int nn = 0; nn < 4; nn++) out[4 * j + nn] = yn[nn];
+  }
+}
+
 template <bool ENC, bool ONCE = false, typename SRC>
 __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, const PicDev &P, int count) {
   Lane4Lds &LS = *reinterpret_cast<Lane4Lds *>(smem);
@@ -437,62 +527,14 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
     const int lrow = zlev ? 4 : V.lev_stride;
     int w[16];
     if (ENC) {
-      int coef[16];
 #pragma unroll
       for (int k = 0; k < 16; k++) v[k] = wrap16(v[k] - pred[k]);
-      if (ts) {
+      lane4_forward(v, luma, ts, luma, coef_scan_idx(4, luma, true, mode), P, w);
 #pragma unroll
-        for (int k = 0; k < 16; k++) coef[k] = v[k] << tshift; // tshift >= 1 for B <= 12
-      } else {
-        int t1[16];
-#pragma unroll
-        for (int r = 0; r < 4; r++) { // tmp[k][r] = pass1(row r)[k]
-          int yk[4];
-          fwd_pass<4>(v + 4 * r, yk, 1 + (B - 8), luma);
-#pragma unroll
-          for (int k = 0; k < 4; k++) t1[4 * k + r] = yk[k];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) { // coeff[k][r] = pass2(row r of tmp)[k]
-          int yk[4];
-          fwd_pass<4>(t1 + 4 * r, yk, 8, luma);
-#pragma unroll
-          for (int k = 0; k < 4; k++) coef[4 * k + r] = yk[k];
-        }
-      }
-      const QuantDev &qd = P.qd[luma ? 0 : 1];
-      const int qbits = 14 + qd.per_qbits + tshift;
-      int sum = 0;
-#pragma unroll
-      for (int k = 0; k < 16; k++) {
-        int al;
-        w[k] = quant_one<false>(coef[k], qd.q, qbits, qd.rnd_factor, al);
-        sum += al;
-      }
-      if (P.sign_hide && sum >= 2) { // one coefficient group = the whole block; it is "the last group"
-        const int scan_idx = coef_scan_idx(4, luma, true, mode);
-        // the scan differs per lane, but there are only three of them: scan entry k of each is a
-        // compile-time register, so the reorder is two selects per entry
-        constexpr int dg[16] = {0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15};
-        const bool hor = scan_idx == 1, ver = scan_idx == 2;
-        int ws[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-          const int d = w[dg[k]], hv = w[k], vv = w[((k & 3) << 2) | (k >> 2)];
-          ws[k] = hor ? hv : (ver ? vv : d);
-        }
-        int nw;
-        const int bi = sbh_decide(ws, true, nw);
-        if (bi >= 0) {
-          const int bd = (int)((0xfbe7ad369c258140ull >> (4 * bi)) & 15); // dg[bi], one nibble per entry
-          const int bp = hor ? bi : (ver ? (((bi & 3) << 2) | (bi >> 2)) : bd);
-#pragma unroll
-          for (int q = 0; q < 16; q++) w[q] = (q == bp) ? nw : w[q];
-        }
-      }
+      for (int k = 0; k < 16; k++) w[k] = level_of(w[k]);
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        i4v o = {level_of(w[4 * r]), level_of(w[4 * r + 1]), level_of(w[4 * r + 2]), level_of(w[4 * r + 3])};
+        i4v o = {w[4 * r], w[4 * r + 1], w[4 * r + 2], w[4 * r + 3]};
         *reinterpret_cast<i4v *>(lev_ptr + l0 + (unsigned)r * (unsigned)lrow) = o;
       }
     } else {
@@ -502,37 +544,8 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
         w[4 * r] = o[0], w[4 * r + 1] = o[1], w[4 * r + 2] = o[2], w[4 * r + 3] = o[3];
       }
     }
-    // ---- inverse
-    const QuantDev &qd = P.qd[luma ? 0 : 1];
-    int c[16], out[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) c[k] = dequant_one(ENC ? level_of(w[k]) : w[k], qd.iq_scale, 6 - tshift);
-    if (ts) {
-#pragma unroll
-      for (int k = 0; k < 16; k++) out[k] = wrap16((c[k] + (1 << (tshift - 1))) >> tshift);
-    } else {
-      int t1[16];
-#pragma unroll
-      for (int k = 0; k < 16; k++) c[k] = wrap16(c[k]);
-#pragma unroll
-      for (int j = 0; j < 4; j++) { // tmp[j][n] = sum_k M[k][n] * c[k][j]
-        int col[4], yn[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) col[k] = c[4 * k + j];
-        inv_pass<4>(col, yn, 7, luma);
-#pragma unroll
-        for (int nn = 0; nn < 4; nn++) t1[4 * j + nn] = yn[nn];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) { // block[j][n] = sum_k M[k][n] * tmp[k][j]
-        int col[4], yn[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) col[k] = t1[4 * k + j];
-        inv_pass<4>(col, yn, 12 - (B - 8), luma);
-#pragma unroll
-        for (int nn = 0; nn < 4; nn++) out[4 * j + nn] = yn[nn];
-      }
-    }
+    int out[16];
+    lane4_inverse(w, luma, ts, luma, P, out);
     i4v r0, r1;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -770,6 +783,47 @@ __global__ __launch_bounds__(64, 4) void k_intra_wave(FrameArgs A) {
     default: wave_chain_32<ENC>(smem, src, A.P, sg.count); break;
     }
   }
+}
+
+// The inter block chain for 4x4 blocks, ONE LANE PER BLOCK (k_list spends four lanes on a 4x4 block and runs its
+// sign-bit hiding in one of them): residual org - pred, T, Q + sign hiding, levels out, IQ, IT, Clip(pred + resi) out.
+// grid.y = picture of a multi-picture call (ListArgs::pics).
+__global__ __launch_bounds__(256) void k_inter4(ListArgs A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A.n) return;
+  const DTu d = A.tus[i];
+  const hmx_tu t = d.t;
+  const int pl = t.plane, x = t.x, y = t.y;
+  const ListPic &Q = A.pics[blockIdx.y];
+  const bool luma = pl == 0, inter = t.flags & HMX_TU_INTER, ts = t.flags & HMX_TU_TRANSFORM_SKIP;
+  const bool use_dst = luma && !inter;
+  const short *org = Q.a.p[pl] + (size_t)y * Q.a.s[pl] + x, *prd = Q.b.p[pl] + (size_t)y * Q.b.s[pl] + x;
+  int pred[16], v[16], w[16];
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      pred[4 * r + k] = prd[(size_t)r * Q.b.s[pl] + k];
+      v[4 * r + k] = wrap16(org[(size_t)r * Q.a.s[pl] + k] - pred[4 * r + k]);
+    }
+  lane4_forward(v, use_dst, ts, luma, coef_scan_idx(4, luma, !inter, t.mode), A.P, w);
+  int sum = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) w[k] = level_of(w[k]);
+  int *lev = Q.lev.p[pl] + (size_t)y * Q.lev.s[pl] + x;
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) lev[(size_t)r * Q.lev.s[pl] + k] = w[4 * r + k];
+  (void)sum;
+  int out[16];
+  lane4_inverse(w, use_dst, ts, luma, A.P, out);
+  const int mx = (1 << A.P.bit_depth) - 1;
+  short *rec = Q.rec.p[pl] + (size_t)y * Q.rec.s[pl] + x;
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) rec[(size_t)r * Q.rec.s[pl] + k] = (short)clip3(0, mx, pred[4 * r + k] + out[4 * r + k]);
 }
 
 // =============================================================================================
@@ -1139,6 +1193,11 @@ static int run_list(hmx_ctx *c, int op, const hmx_tu_list *l, ListArgs A) {
     if (!l->cnt[s]) continue;
     A.tus = l->d + l->off[s];
     A.n = l->cnt[s];
+    if (op == OP_TRANSFORM_RECON && s == 0 && A.pics && !A.abs_sum) { // 4x4 blocks: one lane per block
+      hipLaunchKernelGGL(k_inter4, dim3((unsigned)((A.n + 255) / 256), (unsigned)A.n_pics), dim3(256), 0, c->stream, A);
+      HIPCHK(c, hipGetLastError());
+      continue;
+    }
     int r = launch_op(c, op, s + 2, A);
     if (r) return r;
   }
