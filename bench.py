@@ -41,12 +41,13 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def algorithmic_bytes(tus, n_pics):
+def algorithmic_bytes(tus, n_pics, decode=False):
     """Bytes the all-intra chain must move per step: per sample 2 (original) +
     4 (level written) + 2 (reconstruction written), plus the 4N+1 reference samples (2 B) each block
-    gathers from the reconstruction."""
+    gathers from the reconstruction.  Decoder direction: 4 (level read) + 2 (reconstruction written)
+    + the reference samples."""
     n = (1 << tus["log2n"].astype(np.int64))
-    return int(((n * n) * 8 + (4 * n + 1) * 2).sum()) * n_pics
+    return int(((n * n) * (6 if decode else 8) + (4 * n + 1) * 2).sum()) * n_pics
 
 
 def cpu_baseline(tus, w, h, B, qp, seconds_target=12.0):
@@ -159,6 +160,9 @@ def main():
     ap.add_argument("--segments", type=int, default=16,
                     help="random-access workloads: intra-period segments (32 pictures each) per GPU; the I pictures of all "
                          "segments share one whole-picture call, so few segments are dominated by its 4844 dependent launches")
+    ap.add_argument("--decode", action="store_true",
+                    help="time the decoder direction of the chain (levels -> reconstruction, DEC/TDecCu.cpp:469-687) instead of the "
+                         "encoder direction; the levels come from one untimed encode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check picture 0 against the oracle after the run")
     args = ap.parse_args()
@@ -207,6 +211,12 @@ def main():
     lev_arr = (capi.Levels * F)(*[d.as_pic() for d in d_lev])
 
     def step():
+        if args.decode:
+            ctx._chk(L.hmx_frame_intra_decode(ctx.h, plan, F, rec_arr, lev_arr))
+        else:
+            ctx._chk(L.hmx_frame_intra_encode(ctx.h, plan, F, org_arr, rec_arr, lev_arr))
+
+    if args.decode:  # produce the levels the decoder direction consumes
         ctx._chk(L.hmx_frame_intra_encode(ctx.h, plan, F, org_arr, rec_arr, lev_arr))
 
     def fence():
@@ -248,16 +258,16 @@ def main():
         level_sched = sched.value > 0
         n_levels = nl.value if level_sched else nd.value   # dependent steps of the chain
         n_launch = n_levels * groups.value                 # launches of the dominant kernel per step
-        kernel = ["k_intra_wave<true>", "k_intra_level<true>", "k_intra_level_across<true>"][sched.value]
+        kernel = ["k_intra_wave<%s>", "k_intra_level<%s>", "k_intra_level_across<%s>"][sched.value] % ("false" if args.decode else "true")
         traffic = None
         tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tj) and args.workload == "ai2160p10" and args.tiling == "mix" and level_sched:
+        if os.path.exists(tj) and args.workload == "ai2160p10" and args.tiling == "mix" and level_sched and not args.decode:
             t = json.load(open(tj))
             if t.get("frames") == F:
                 # PMC bytes per launch (profiles/r01_traffic.json): gfx950 FETCH_SIZE counts 64 B per
                 # 128-B request (MI355X_MICROARCH.md, HBM), hence the factor 2 on the read side
                 traffic = round((2 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024 / t["launches"])
-        bytes_step = algorithmic_bytes(tus, F)
+        bytes_step = algorithmic_bytes(tus, F, args.decode)
         # the dominant kernel alone: HIP events around the chain launches of the last step (the two
         # layout-conversion launches are timed separately); algorithmic bytes / that time
         ach = bytes_step / (tb.value * 1e-3) / 1e9
@@ -269,7 +279,9 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {cfg_name}; all-intra chain (intra refs+pred, T, flat Q+SBH, IQ, IT, recon), "
+            "config": {"workload": f"{args.workload}: {cfg_name}; all-intra chain " +
+                                   ("DECODER direction (intra refs+pred, IQ, IT, recon from levels), " if args.decode else
+                                    "(intra refs+pred, T, flat Q+SBH, IQ, IT, recon), ") +
                                    f"{F} pictures {w}x{h_c} per GPU per step, QP {qp}, TU tiling '{args.tiling}' "
                                    f"({len(tus)} blocks/picture), frames sharded over ranks, no collective",
                        "pictures_per_gpu": F, "width": w, "height": h_c, "bit_depth": B, "qp": qp, "tiling": str(args.tiling)},

@@ -787,3 +787,29 @@ def test_example_end_to_end(tmp_path):
         O.hmo_yuv_pack(P3(*[p.ctypes.data for p in so]), I3(pw, pw // 2, pw // 2), pw, ph, pw - w, ph - h, B, 10, vp(packed))
         want += packed.tobytes()
     assert got.tobytes() == want
+
+
+def test_cell_map_growth_keeps_rdoq_workspace(ctx):
+    """Regression: growing the motion-compensation cell map once released the RDOQ workspace of the same context.
+    RDOQ, then a mapped MC call on a picture larger than any before it (the map is re-allocated), then RDOQ again."""
+    L, B = capi.lib(), ctx.bit_depth
+    test_rdoq_batch_vs_oracle(ctx)
+    w, h, m = 640, 384, 80
+    d_ref = capi.DevPicture(ctx, w, h, m, m).upload(workload.make_planes(3, w, h, B))
+    ctx._chk(L.hmx_pic_extend_border(ctx.h, C.byref(d_ref.as_pic()), w, h, m, m))
+    pus = workload.make_pus(4, w, h, n_refs=1)
+    d_pus = ctx.to_device(pus)
+    d_a, d_b = capi.DevPicture(ctx, w, h).zero(), capi.DevPicture(ctx, w, h).zero()
+    ref_arr = (capi.Pic * 1)(d_ref.as_pic())
+    ctx._chk(L.hmx_batch_motionCompensation(ctx.h, d_pus.ptr, len(pus), ref_arr, 1, C.byref(d_a.as_pic())))  # wave per PU
+    pic_b = d_b.as_pic()
+    job = (capi.McJob * 1)()
+    job[0].d_pus, job[0].n_pus, job[0].refs, job[0].n_refs = d_pus.ptr, len(pus), ref_arr, 1
+    job[0].dst, job[0].pic_w, job[0].pic_h = C.pointer(pic_b), w, h
+    ctx._chk(L.hmx_batch_motionCompensation_multi(ctx.h, 1, job))  # cell map
+    ctx.sync()
+    for a, b in zip(d_a.download(), d_b.download()):
+        assert np.array_equal(a, b)
+    test_rdoq_batch_vs_oracle(ctx)
+    for d in (d_ref, d_a, d_b):
+        d.free()

@@ -62,7 +62,14 @@ template <int N, int OP>
 __global__ __launch_bounds__(256) void k_list(ListArgs A) {
   __shared__ __attribute__((aligned(16))) char smem[HMX_SMEM_BYTES];
   constexpr int SL = Slots<N>::v;
-  const int tid = threadIdx.x, slot = tid / N, gl = tid % N;
+  // Lane -> (block, row).  Row-fastest keeps a block on consecutive lanes.  The fused inter chain on 8x8 blocks
+  // interleaves the 8 blocks of a wave instead (block-fastest, rows 8 lanes apart): the list is in raster order,
+  // so the lanes of a quad then touch the same row of adjacent blocks -- one cache line instead of four.  The L1
+  // looks up one line per cycle and this kernel is bound by exactly that (TA busy 94 %, profiles/).
+  constexpr bool BF = OP == OP_TRANSFORM_RECON && N == 8;
+  constexpr int BPW = 64 / N, LS = BF ? BPW : 1;
+  const int tid = threadIdx.x;
+  const int slot = BF ? (tid >> 6) * BPW + (tid & 63) % BPW : tid / N, gl = BF ? (tid & 63) / BPW : tid % N;
   const bool lane_on = slot < SL;
   TuLds<N> &L = reinterpret_cast<TuLds<N> *>(smem)[lane_on ? slot : 0];
   const int i = blockIdx.x * SL + slot;
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
         for (int k = 0; k < N; k++) row[k] = wrap16(row[k] - pr[k]);
       }
     }
-    int sum = fwd_tq_block<N>(L, gl, active, row, ts, use_dst, luma, scan_idx, OP != OP_XT, A.P);
+    int sum = fwd_tq_block<N, LS>(L, gl, active, row, ts, use_dst, luma, scan_idx, OP != OP_XT, A.P);
     if (active) {
       load_row32<N>(&L.tile[gl][0], row);
       if (OP != OP_XT) {
@@ -1125,6 +1132,14 @@ extern "C" int hmx_tu_list_create(hmx_ctx *c, const hmx_tu *tus, int n, hmx_tu_l
     for (int i = 0; i < n; i++)
       if (tus[i].log2n == s) v.push_back(DTu{tus[i], (uint32_t)i});
     l->cnt[s - 2] = (int)v.size() - l->off[s - 2];
+    // The blocks of a list call are independent, so the order inside a size class is ours: raster order per plane
+    // puts horizontally adjacent blocks on adjacent lanes, whose row accesses then share cache lines (coding order
+    // only ever pairs them).  Results that are per block (abs sums, costs) go by DTu::idx, the caller's index.
+    std::stable_sort(v.begin() + l->off[s - 2], v.end(), [](const DTu &a, const DTu &b) {
+      if (a.t.plane != b.t.plane) return a.t.plane < b.t.plane;
+      if (a.t.y != b.t.y) return a.t.y < b.t.y;
+      return a.t.x < b.t.x;
+    });
   }
   if ((int)v.size() != n) {
     delete l;
@@ -2734,139 +2749,182 @@ struct McArgs {
   int B;
 };
 
-// One interpolated sample from NTAP values already in registers (v[NTAP/2 - 1] is the co-located one):
-// the arithmetic of interp_sample.
+// ---- the prediction of one cell, on packed 16-bit pairs ----
+// A cell is 4x4 luma samples (2x2 chroma) of one PU.  Its reference window is read row by row with
+// DWORD-ALIGNED wide loads (x4 + x2 / x3 per row: tools/loadshape_probe.hip measures 41 cycles per wave-row
+// against 105 for the same loads at a 2-byte-aligned address and 194 for twelve 16-bit loads), the samples stay
+// packed two per register as they lie in memory, and both filter stages run on v_dot2_i32_i16 (two taps per
+// instruction, full rate).  With p = 1 when the window starts on the odd half of a dword, output c of a
+// row starts at sample p + c of the loaded registers d[]:
+//   p + c even:  pairs d[(p+c)/2 + j] with tap pairs (t0,t1)(t2,t3)...                 NTAP/2 products
+//   p + c odd:   pairs d[(p+c-1)/2 + j] with the taps moved up by one, (0,t0)(t1,t2)...(t7,0)   NTAP/2+1
+// Both cases are written as NTAP/2+1 products on d[c/2 + j] with a tap set chosen by (fraction, p) -- T0 for
+// even c, T1 for odd c, one of them padded with a zero pair -- so no lane ever re-aligns samples and the
+// lanes of a wave (different PUs, fractions and parities) run the same instructions.  Every cell takes the
+// two-stage route (horizontal into the 14-bit intermediate, then vertical), a zero fraction being the filter
+// {0,..,64,..,0}: with the reference's offsets and shifts that is bit-identical to its one-stage and copy
+// cases (xPredInterLumaBlk :554-601 -- for a first-and-last stage (sum + 32) >> 6 ==
+// ((sum >> (6-head)) + (1 << (head-1))) >> head because 8192 << (6-head) is a multiple of the first shift).
 template <int NTAP>
-__device__ __forceinline__ int interp_core(const int *v, const int *taps, int frac, bool first, bool last, int B) {
-  const int head = 14 - B, maxv = (1 << B) - 1;
-  if (frac == 0) {
-    const int x = v[NTAP / 2 - 1];
-    if (first == last) return x;
-    if (first) return wrap16(wrap16(x << head) - 8192);
-    const int off = wrap16(8192 + (head ? (1 << (head - 1)) : 0));
-    return clip3(0, maxv, wrap16((x + off) >> head));
+__device__ __forceinline__ int tap_pair(int frac, int k) { // the pair (t[k], t[k+1]); taps outside 0..NTAP-1 are 0
+  auto tap = [&](int t) { return (t < 0 || t >= NTAP) ? 0 : (NTAP == 8 ? luma_tap(frac, t) : chroma_tap(frac, t)); };
+  return (tap(k) & 0xffff) | (tap(k + 1) << 16);
+}
+// table[frac][p][set][j]: set 0 = T0 (even c), set 1 = T1 (odd c); rows padded to 12 / 8 registers
+constexpr int kLumaRow = 12, kChromaRow = 8;
+constexpr int kTapTable = 4 * 2 * kLumaRow + 8 * 2 * kChromaRow;
+template <int NTAP>
+__device__ __forceinline__ int tap_table_entry(int frac, int p, int i) {
+  constexpr int NO = NTAP / 2 + 1;
+  if (i >= 2 * NO) return 0;
+  const int set = i / NO, j = i % NO;
+  // p + c even (set == p): even pairs from register 0 when c is even, from register 1 when c is odd
+  if (set == p) return set == 0 ? tap_pair<NTAP>(frac, 2 * j) : tap_pair<NTAP>(frac, 2 * j - 2);
+  return tap_pair<NTAP>(frac, 2 * j - 1);
+}
+__device__ __forceinline__ void fill_tap_table(int *lds, int tid, int nthreads) {
+  for (int i = tid; i < kTapTable; i += nthreads) {
+    if (i < 8 * kLumaRow) lds[i] = tap_table_entry<8>(i / (2 * kLumaRow), (i / kLumaRow) & 1, i % kLumaRow);
+    else {
+      const int k = i - 8 * kLumaRow;
+      lds[i] = tap_table_entry<4>(k / (2 * kChromaRow), (k / kChromaRow) & 1, k % kChromaRow);
+    }
   }
-  int shift = 6, offset;
-  if (last) {
-    shift += first ? 0 : head;
-    offset = (1 << (shift - 1)) + (first ? 0 : 8192 << 6);
-  } else {
-    shift -= first ? head : 0;
-    offset = first ? -(8192 << shift) : 0;
-  }
-  int sum = 0;
-#pragma unroll
-  for (int t = 0; t < NTAP; t++) sum += v[t] * taps[t];
-  const int r = wrap16((sum + offset) >> shift);
-  return last ? clip3(0, maxv, r) : r;
+  __syncthreads();
+}
+typedef short s2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot2(int pair, int taps, int acc) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(s2v, pair), __builtin_bit_cast(s2v, taps), acc, false);
 }
 
-// Prediction of one list for a W x W cell (4x4 luma, 2x2 chroma) whose first sample is `ref` in the
-// reference plane: xPredInterLumaBlk / ChromaBlk (:554-642) restricted to the cell.  The reference's
-// two-stage filtering is position-wise (every output is the vertical filter of horizontally filtered
-// rows), so cutting a PU into cells gives the same samples.
+// Prediction of one list for a W x W cell whose first sample is `ref` in the reference plane:
+// xPredInterLumaBlk / ChromaBlk (:554-642) restricted to the cell.  The reference's two-stage
+// filtering is position-wise (every output is the vertical filter of horizontally filtered rows), so
+// cutting a PU into cells gives the same samples.
 template <int NTAP, int W>
-__device__ __forceinline__ void mc_cell(const short *ref, int rs, int mvx, int mvy, bool bi, int B, int *out) {
+__device__ __forceinline__ void mc_cell(const int *lds_taps, const short *ref, int rs, int mvx, int mvy, bool bi, int B, int *out) {
   constexpr int SH = NTAP == 8 ? 2 : 3, MASK = (1 << SH) - 1, HALF = NTAP / 2, R = W + NTAP - 1;
-  ref += (mvx >> SH) + (ptrdiff_t)(mvy >> SH) * rs;
-  const int xf = mvx & MASK, yf = mvy & MASK;
-  int tx[NTAP], ty[NTAP];
+  constexpr int ND = (R + 2) / 2;               // registers per window row: 12 / 6 samples, R + 1 of them used
+  constexpr int NE = NTAP / 2, NO = NTAP / 2 + 1, NP = (R + 1) / 2, ROW = NTAP == 8 ? kLumaRow : kChromaRow;
+  typedef __attribute__((address_space(1))) const short gpel; // the table pointer is generic to the compiler: no FLAT loads
+  typedef __attribute__((address_space(1))) const int gword;
+  const gpel *win = (const gpel *)ref + (mvx >> SH) - (HALF - 1) + (ptrdiff_t)((mvy >> SH) - (HALF - 1)) * rs;
+  const int p = (int)(((uintptr_t)win >> 1) & 1); // window starts on the odd half of a dword: start one sample earlier
+  win -= p; // (with an odd stride every other row is still 2-byte aligned: the same samples, merely slower loads)
+  const int *base = lds_taps + (NTAP == 8 ? 0 : 8 * kLumaRow);
+  const int *tx = base + ((mvx & MASK) * 2 + p) * ROW, *ty = base + (mvy & MASK) * 2 * ROW;
+  int t0[NO], t1[NO], ey[NE], oy[NO];
 #pragma unroll
-  for (int t = 0; t < NTAP; t++) {
-    tx[t] = NTAP == 8 ? luma_tap(xf, t) : chroma_tap(xf, t);
-    ty[t] = NTAP == 8 ? luma_tap(yf, t) : chroma_tap(yf, t);
+  for (int j = 0; j < NO; j++) t0[j] = tx[j], t1[j] = tx[NO + j], oy[j] = ty[NO + j];
+#pragma unroll
+  for (int j = 0; j < NE; j++) ey[j] = ty[j];
+  const int head = 14 - B, maxv = (1 << B) - 1;
+  // stage 1, first and not last (:206-221): shift 6 - head, offset -(8192 << shift); narrowed to 16 bits
+  const int sh1 = 6 - head, off1 = -(8192 << sh1);
+  int P[NP][W]; // the intermediate, rows 2k and 2k+1 packed per column
+  int lo[W];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    int d[ND];
+    __builtin_memcpy(d, (gword *)(win + (ptrdiff_t)r * rs), ND * 4);
+#pragma unroll
+    for (int c = 0; c < W; c++) {
+      int s = off1;
+#pragma unroll
+      for (int j = 0; j < NO; j++) s = dot2(d[c / 2 + j], c % 2 ? t1[j] : t0[j], s);
+      s >>= sh1;
+      if (r % 2 == 0) lo[c] = s;
+      else P[r / 2][c] = (int)__builtin_amdgcn_perm((unsigned)s, (unsigned)lo[c], 0x05040100u);
+    }
   }
-  if (yf == 0) { // horizontal only (or plain copy)
+  if (R % 2)
+#pragma unroll
+    for (int c = 0; c < W; c++) P[NP - 1][c] = lo[c] & 0xffff;
+  // stage 2, not first: last -> shift 6 + head, offset (1 << (shift-1)) + (8192 << 6), clipped; else shift 6
+  const bool last = !bi;
+  const int sh2 = last ? 6 + head : 6, off2 = last ? (1 << (5 + head)) + (8192 << 6) : 0;
+#pragma unroll
+  for (int c = 0; c < W; c++)
 #pragma unroll
     for (int r = 0; r < W; r++) {
-      int row[R];
+      int s = off2;
+      if (r % 2 == 0) {
 #pragma unroll
-      for (int k = 0; k < R; k++) row[k] = ref[(ptrdiff_t)r * rs + k - (HALF - 1)];
+        for (int j = 0; j < NE; j++) s = dot2(P[r / 2 + j][c], ey[j], s);
+      } else {
 #pragma unroll
-      for (int c = 0; c < W; c++) out[r * W + c] = interp_core<NTAP>(row + c, tx, xf, true, !bi, B);
+        for (int j = 0; j < NO; j++) s = dot2(P[r / 2 + j][c], oy[j], s);
+      }
+      const int v = wrap16(s >> sh2);
+      out[r * W + c] = last ? clip3(0, maxv, v) : v;
     }
-  } else if (xf == 0) { // vertical only
-#pragma unroll
-    for (int c = 0; c < W; c++) {
-      int col[R];
-#pragma unroll
-      for (int k = 0; k < R; k++) col[k] = ref[(ptrdiff_t)(k - (HALF - 1)) * rs + c];
-#pragma unroll
-      for (int r = 0; r < W; r++) out[r * W + c] = interp_core<NTAP>(col + r, ty, yf, true, !bi, B);
-    }
-  } else { // horizontal into 14-bit intermediates for W + NTAP - 1 rows, then vertical
-    int tmp[R][W];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      int row[R];
-#pragma unroll
-      for (int k = 0; k < R; k++) row[k] = ref[(ptrdiff_t)(r - (HALF - 1)) * rs + k - (HALF - 1)];
-#pragma unroll
-      for (int c = 0; c < W; c++) tmp[r][c] = interp_core<NTAP>(row + c, tx, xf, true, false, B);
-    }
-#pragma unroll
-    for (int c = 0; c < W; c++) {
-      int col[R];
-#pragma unroll
-      for (int k = 0; k < R; k++) col[k] = tmp[k][c];
-#pragma unroll
-      for (int r = 0; r < W; r++) out[r * W + c] = interp_core<NTAP>(col + r, ty, yf, false, !bi, B);
-    }
-  }
 }
 
 // prediction of one plane's cell from both lists (+ addAvg) into dst
 template <int NTAP, int W>
-__device__ __forceinline__ void mc_cell_plane(const McArgs &A, const McJob &J, const hmx_pu &u, int pl, int x, int y) {
+__device__ __forceinline__ void mc_cell_plane(const int *lds_taps, const McArgs &A, const McJob &J, const hmx_pu &u, int pl, int x, int y) {
   const bool bi = u.ref0 != 255 && u.ref1 != 255;
   int p0[W * W], p1[W * W];
-  const int sc = NTAP == 8 ? 1 : 1; // chroma MVs are the luma MVs in eighth-pel units (4:2:0)
-  (void)sc;
   if (u.ref0 != 255) {
     const PlanesDev &R = A.refs[J.ref_off + u.ref0];
-    mc_cell<NTAP, W>(R.p[pl] + (ptrdiff_t)y * R.s[pl] + x, R.s[pl], u.mv0x, u.mv0y, bi, A.B, p0);
+    mc_cell<NTAP, W>(lds_taps, R.p[pl] + (ptrdiff_t)y * R.s[pl] + x, R.s[pl], u.mv0x, u.mv0y, bi, A.B, p0);
   }
   if (u.ref1 != 255) {
     const PlanesDev &R = A.refs[J.ref_off + u.ref1];
-    mc_cell<NTAP, W>(R.p[pl] + (ptrdiff_t)y * R.s[pl] + x, R.s[pl], u.mv1x, u.mv1y, bi, A.B, bi ? p1 : p0);
+    mc_cell<NTAP, W>(lds_taps, R.p[pl] + (ptrdiff_t)y * R.s[pl] + x, R.s[pl], u.mv1x, u.mv1y, bi, A.B, bi ? p1 : p0);
   }
-  short *d = J.dst.p[pl] + (size_t)y * J.dst.s[pl] + x;
+  typedef __attribute__((address_space(1))) short gpel;
+  gpel *d = (gpel *)J.dst.p[pl] + (size_t)y * J.dst.s[pl] + x;
 #pragma unroll
-  for (int r = 0; r < W; r++)
+  for (int r = 0; r < W; r++) {
+    short row[W];
 #pragma unroll
-    for (int c = 0; c < W; c++) d[(size_t)r * J.dst.s[pl] + c] = (short)(bi ? add_avg(p0[r * W + c], p1[r * W + c], A.B) : p0[r * W + c]);
+    for (int c = 0; c < W; c++) row[c] = (short)(bi ? add_avg(p0[r * W + c], p1[r * W + c], A.B) : p0[r * W + c]);
+    __builtin_memcpy(d + (size_t)r * J.dst.s[pl], row, W * 2); // one 8-byte (4-byte) store per row, 2-byte aligned
+  }
 }
 
 // Two ways to hand cells to lanes.  With the picture size known (hmx_mc_job::pic_w/pic_h) a scatter pass
 // writes each PU's index into a cell map and the prediction kernel runs one lane per cell of the PICTURE:
 // every wave is full whatever the PU sizes.  Without it, one wave per PU, its lanes looping over the
-// PU's cells (an 8x4 PU keeps 2 of 64 lanes busy).  A cell reads its (W+7)^2 / (W+3)^2 reference samples
-// straight from the margin-extended reference planes (the caches absorb the overlap between neighbouring
-// cells); nothing is staged, nothing synchronises.
-__global__ __launch_bounds__(64) void k_mc_map(McArgs A) {
+// PU's cells (an 8x4 PU keeps 2 of 64 lanes busy).  A cell reads its (W+7) / (W+3) window rows straight
+// from the margin-extended reference planes (the caches absorb the overlap between neighbouring
+// cells); nothing is staged, nothing synchronises after the tap table is in LDS.
+__global__ __launch_bounds__(256) void k_mc_map(McArgs A) { // 16 threads per PU, one per row of its cells (PUs are <= 64 high)
   const McJob J = A.jobs[blockIdx.y];
-  if ((int)blockIdx.x >= J.n) return;
-  const hmx_pu u = J.pus[blockIdx.x];
+  const int pi = blockIdx.x * 16 + (threadIdx.x >> 4), r = threadIdx.x & 15;
+  if (pi >= J.n) return;
+  const hmx_pu u = J.pus[pi];
   if (u.ref0 == 255 && u.ref1 == 255) return;
-  const int cw = u.w >> 2, cells = cw * (u.h >> 2);
-  for (int i = threadIdx.x; i < cells; i += 64) {
-    const int cx = (u.x >> 2) + i % cw, cy = (u.y >> 2) + i / cw;
-    if (cx < J.cw && cy < J.ch) J.map[(size_t)cy * J.cw + cx] = (int)blockIdx.x;
+  const int cw = u.w >> 2, rows = u.h >> 2;
+  for (int rr = r; rr < rows; rr += 16) { // one pass for every legal PU
+    const int cy = (u.y >> 2) + rr;
+    if (cy >= J.ch) break;
+    for (int i = 0; i < cw; i++)
+      if ((u.x >> 2) + i < J.cw) J.map[(size_t)cy * J.cw + (u.x >> 2) + i] = pi;
   }
 }
 __global__ __launch_bounds__(256) void k_mc_cells(McArgs A) {
+  __shared__ int taps[kTapTable];
+  fill_tap_table(taps, threadIdx.x, 256);
   const McJob J = A.jobs[blockIdx.y];
-  const int cell = blockIdx.x * 256 + threadIdx.x;
-  if (cell >= J.cw * J.ch) return;
-  const int pi = J.map[cell];
+  // a workgroup is a 64x64 luma tile (16x16 cells), a wave one 32x32 quadrant, a lane one cell of its 8x8: the
+  // window rows of the cells of one PU fall into the same cache lines of the same load instruction, and the
+  // rows a cell shares with the cell below it are fetched by the same wave
+  const int tiles_x = (J.cw + 15) >> 4, tile = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cx = (tile % tiles_x) * 16 + (wave & 1) * 8 + (lane & 7), cy = (tile / tiles_x) * 16 + (wave >> 1) * 8 + (lane >> 3);
+  if (cx >= J.cw || cy >= J.ch) return;
+  const int pi = J.map[cy * J.cw + cx];
   if (pi < 0) return;
   const hmx_pu u = J.pus[pi];
-  const int x = (cell % J.cw) << 2, y = (cell / J.cw) << 2;
-  mc_cell_plane<8, 4>(A, J, u, 0, x, y);
-  mc_cell_plane<4, 2>(A, J, u, 1, x >> 1, y >> 1);
-  mc_cell_plane<4, 2>(A, J, u, 2, x >> 1, y >> 1);
+  const int x = cx << 2, y = cy << 2;
+  mc_cell_plane<8, 4>(taps, A, J, u, 0, x, y);
+  mc_cell_plane<4, 2>(taps, A, J, u, 1, x >> 1, y >> 1);
+  mc_cell_plane<4, 2>(taps, A, J, u, 2, x >> 1, y >> 1);
 }
 __global__ __launch_bounds__(64) void k_mc(McArgs A) {
+  __shared__ int taps[kTapTable];
+  fill_tap_table(taps, threadIdx.x, 64);
   const McJob J = A.jobs[blockIdx.y];
   if ((int)blockIdx.x >= J.n) return; // jobs of one call may differ in length
   const hmx_pu u = J.pus[blockIdx.x];
@@ -2874,9 +2932,9 @@ __global__ __launch_bounds__(64) void k_mc(McArgs A) {
   const int cw = u.w >> 2, cells = cw * (u.h >> 2);
   for (int i = threadIdx.x; i < cells; i += 64) {
     const int x = u.x + ((i % cw) << 2), y = u.y + ((i / cw) << 2);
-    mc_cell_plane<8, 4>(A, J, u, 0, x, y);
-    mc_cell_plane<4, 2>(A, J, u, 1, x >> 1, y >> 1);
-    mc_cell_plane<4, 2>(A, J, u, 2, x >> 1, y >> 1);
+    mc_cell_plane<8, 4>(taps, A, J, u, 0, x, y);
+    mc_cell_plane<4, 2>(taps, A, J, u, 1, x >> 1, y >> 1);
+    mc_cell_plane<4, 2>(taps, A, J, u, 2, x >> 1, y >> 1);
   }
 }
 
@@ -2885,7 +2943,7 @@ extern "C" int hmx_batch_motionCompensation_multi(hmx_ctx *c, int n_jobs, const 
   std::vector<McJob> hj(n_jobs);
   std::vector<PlanesDev> hr;
   int max_n = 0;
-  size_t map_cells = 0, max_cells = 0;
+  size_t map_cells = 0, max_cells = 0, max_tiles = 0;
   bool mapped = true;
   for (int i = 0; i < n_jobs; i++) {
     const hmx_mc_job &j = jobs[i];
@@ -2898,16 +2956,13 @@ extern "C" int hmx_batch_motionCompensation_multi(hmx_ctx *c, int n_jobs, const 
     mapped = mapped && cells > 0;
     map_cells += cells;
     max_cells = std::max(max_cells, cells);
+    max_tiles = std::max(max_tiles, (size_t)((hj[i].cw + 15) / 16) * ((hj[i].ch + 15) / 16));
   }
   if (!max_n) return HMX_OK;
   if (mapped) { // cell maps of all jobs, back to back, in a grow-only scratch buffer
     if (map_cells > c->mcmap_cap) {
       HIPCHK(c, hipStreamSynchronize(c->stream));
       hipFree(c->d_mcmap);
-  hipFree(c->rdoq_wd);
-  hipFree(c->rdoq_wi);
-  hipFree(c->rdoq_blocks);
-  hipFree(c->rdoq_est);
       c->d_mcmap = nullptr;
       c->mcmap_cap = 0;
       if (hipMalloc((void **)&c->d_mcmap, map_cells * sizeof(int)) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc cell map");
@@ -2932,8 +2987,8 @@ extern "C" int hmx_batch_motionCompensation_multi(hmx_ctx *c, int n_jobs, const 
   A.refs = reinterpret_cast<const PlanesDev *>(d + jb);
   A.B = c->cfg.bit_depth;
   if (mapped) {
-    hipLaunchKernelGGL(k_mc_map, dim3((unsigned)max_n, (unsigned)n_jobs), dim3(64), 0, c->stream, A);
-    hipLaunchKernelGGL(k_mc_cells, dim3((unsigned)((max_cells + 255) / 256), (unsigned)n_jobs), dim3(256), 0, c->stream, A);
+    hipLaunchKernelGGL(k_mc_map, dim3((unsigned)((max_n + 15) / 16), (unsigned)n_jobs), dim3(256), 0, c->stream, A);
+    hipLaunchKernelGGL(k_mc_cells, dim3((unsigned)max_tiles, (unsigned)n_jobs), dim3(256), 0, c->stream, A);
   } else {
     hipLaunchKernelGGL(k_mc, dim3((unsigned)max_n, (unsigned)n_jobs), dim3(64), 0, c->stream, A);
   }
