@@ -57,6 +57,13 @@ struct ListArgs {
   PicDev P;
 };
 
+template <typename T>
+__device__ __forceinline__ T pick3(const T (&a)[3], int i) { // a[i] without a run-time index (see k_list)
+  T r = a[0];
+  r = i == 1 ? a[1] : r;
+  return i == 2 ? a[2] : r;
+}
+
 // One kernel per (operation, block size): every block of the launch has size N.
 template <int N, int OP>
 __global__ __launch_bounds__(256) void k_list(ListArgs A) {
@@ -79,10 +86,14 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
   const int pl = t.plane, x = t.x, y = t.y;
   // blockIdx.y = picture of a multi-picture call (planes from the table); single calls carry theirs inline
   const ListPic *Q = A.pics ? A.pics + blockIdx.y : nullptr;
-  short *a_p = Q ? Q->a.p[pl] : A.a.p[pl], *b_p = Q ? Q->b.p[pl] : A.b.p[pl];
-  const int a_s = Q ? Q->a.s[pl] : A.a.s[pl], b_s = Q ? Q->b.s[pl] : A.b.s[pl];
-  int *lev_p = Q ? Q->lev.p[pl] : A.lev.p[pl], *lev2_p = A.lev2.p[pl];
-  const int lev_s = Q ? Q->lev.s[pl] : A.lev.s[pl], lev2_s = A.lev2.s[pl];
+  // (members of the by-value argument struct are picked with constant indices: a run-time index into it makes
+  // the compiler copy all of ListArgs to scratch memory, 22 stores per wave before the first useful load)
+  // The picture table entry is uniform over the launch's x dimension: its fields come in by scalar loads and the
+  // lane's plane selects among them, instead of one vector load per field and lane.
+  short *a_p = Q ? pick3(Q->a.p, pl) : pick3(A.a.p, pl), *b_p = Q ? pick3(Q->b.p, pl) : pick3(A.b.p, pl);
+  const int a_s = Q ? pick3(Q->a.s, pl) : pick3(A.a.s, pl), b_s = Q ? pick3(Q->b.s, pl) : pick3(A.b.s, pl);
+  int *lev_p = Q ? pick3(Q->lev.p, pl) : pick3(A.lev.p, pl), *lev2_p = pick3(A.lev2.p, pl);
+  const int lev_s = Q ? pick3(Q->lev.s, pl) : pick3(A.lev.s, pl), lev2_s = pick3(A.lev2.s, pl);
   uint32_t *abs_sum = A.abs_sum ? A.abs_sum + (size_t)blockIdx.y * A.abs_stride : nullptr;
   const bool luma = pl == 0, inter = t.flags & HMX_TU_INTER, ts = t.flags & HMX_TU_TRANSFORM_SKIP;
   const bool use_dst = luma && !inter; // uiMode != REG_DCT, only consulted for N == 4
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
         const int mx = (1 << A.P.bit_depth) - 1;
 #pragma unroll
         for (int k = 0; k < N; k++) row[k] = clip3(0, mx, pr[k] + row[k]);
-        store_row16<N>(Q->rec.p[pl] + (size_t)(y + gl) * Q->rec.s[pl] + x, row);
+        store_row16<N>(pick3(Q->rec.p, pl) + (size_t)(y + gl) * pick3(Q->rec.s, pl) + x, row);
       }
     }
   } else if constexpr (OP == OP_XQUANT) {
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
   } else if constexpr (OP == OP_XDEQUANT) {
     constexpr int LG = Log2<N>::v;
     const int tshift = 15 - A.P.bit_depth - LG, dshift = 6 - tshift, dadd = 1 << (dshift - 1);
-    const QuantDev &qd = A.P.qd[luma ? 0 : 1];
+    const QuantDev &qd = luma ? A.P.qd[0] : A.P.qd[1];
     if (active) {
       load_row32<N>(lev_p + (size_t)(y + gl) * lev_s + x, row);
 #pragma unroll
@@ -172,11 +183,11 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
     intra_refs<N, N>(L, gl, active, [&](int dx, int dy) { return (int)rec0[(ptrdiff_t)dy * rst + dx]; }, luma, avail, A.P);
     if (active) {
       int org_row[N];
-      if (A.cost) load_row16<N>(A.org.p[pl] + (size_t)(y + gl) * A.org.s[pl] + x, org_row);
+      if (A.cost) load_row16<N>(pick3(A.org.p, pl) + (size_t)(y + gl) * pick3(A.org.s, pl) + x, org_row);
       const int nm = A.n_modes <= 0 ? 1 : A.n_modes;
       for (int m = 0; m < nm; m++) {
         intra_pred_block<N>(L, gl, A.n_modes <= 0 ? (int)t.mode : (int)A.modes[m], luma, A.P, row);
-        if (b_p) store_row16<N>(b_p + (A.n_modes <= 0 ? 0 : m * A.mode_elems[pl]) + (size_t)(y + gl) * b_s + x, row);
+        if (b_p) store_row16<N>(b_p + (A.n_modes <= 0 ? 0 : m * pick3(A.mode_elems, pl)) + (size_t)(y + gl) * b_s + x, row);
         if (A.cost) { // the prediction never leaves the registers: estIntraPredQT's calcHAD(org, pred) fused in
 #pragma unroll
           for (int k = 0; k < N; k++) row[k] = org_row[k] - row[k];
@@ -804,33 +815,41 @@ __global__ __launch_bounds__(256) void k_inter4(ListArgs A) {
   const ListPic &Q = A.pics[blockIdx.y];
   const bool luma = pl == 0, inter = t.flags & HMX_TU_INTER, ts = t.flags & HMX_TU_TRANSFORM_SKIP;
   const bool use_dst = luma && !inter;
-  const short *org = Q.a.p[pl] + (size_t)y * Q.a.s[pl] + x, *prd = Q.b.p[pl] + (size_t)y * Q.b.s[pl] + x;
+  // table fields by scalar loads + per-lane plane select; rows as single 8 / 16-byte accesses (dword-aligned planes)
+  typedef __attribute__((address_space(1))) const short gpel;
+  typedef __attribute__((address_space(1))) short gpel_w;
+  typedef __attribute__((address_space(1))) int gint_w;
+  const int a_s = pick3(Q.a.s, pl), b_s = pick3(Q.b.s, pl), l_s = pick3(Q.lev.s, pl), r_s = pick3(Q.rec.s, pl);
+  gpel *org = (gpel *)pick3(Q.a.p, pl) + (size_t)y * a_s + x, *prd = (gpel *)pick3(Q.b.p, pl) + (size_t)y * b_s + x;
   int pred[16], v[16], w[16];
 #pragma unroll
-  for (int r = 0; r < 4; r++)
+  for (int r = 0; r < 4; r++) {
+    short o4[4], p4[4];
+    __builtin_memcpy(o4, org + (size_t)r * a_s, 8);
+    __builtin_memcpy(p4, prd + (size_t)r * b_s, 8);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      pred[4 * r + k] = prd[(size_t)r * Q.b.s[pl] + k];
-      v[4 * r + k] = wrap16(org[(size_t)r * Q.a.s[pl] + k] - pred[4 * r + k]);
+      pred[4 * r + k] = p4[k];
+      v[4 * r + k] = wrap16(o4[k] - p4[k]);
     }
+  }
   lane4_forward(v, use_dst, ts, luma, coef_scan_idx(4, luma, !inter, t.mode), A.P, w);
-  int sum = 0;
 #pragma unroll
   for (int k = 0; k < 16; k++) w[k] = level_of(w[k]);
-  int *lev = Q.lev.p[pl] + (size_t)y * Q.lev.s[pl] + x;
+  gint_w *lev = (gint_w *)pick3(Q.lev.p, pl) + (size_t)y * l_s + x;
 #pragma unroll
-  for (int r = 0; r < 4; r++)
-#pragma unroll
-    for (int k = 0; k < 4; k++) lev[(size_t)r * Q.lev.s[pl] + k] = w[4 * r + k];
-  (void)sum;
+  for (int r = 0; r < 4; r++) __builtin_memcpy(lev + (size_t)r * l_s, w + 4 * r, 16);
   int out[16];
   lane4_inverse(w, use_dst, ts, luma, A.P, out);
   const int mx = (1 << A.P.bit_depth) - 1;
-  short *rec = Q.rec.p[pl] + (size_t)y * Q.rec.s[pl] + x;
+  gpel_w *rec = (gpel_w *)pick3(Q.rec.p, pl) + (size_t)y * r_s + x;
 #pragma unroll
-  for (int r = 0; r < 4; r++)
+  for (int r = 0; r < 4; r++) {
+    short r4[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) rec[(size_t)r * Q.rec.s[pl] + k] = (short)clip3(0, mx, pred[4 * r + k] + out[4 * r + k]);
+    for (int k = 0; k < 4; k++) r4[k] = (short)clip3(0, mx, pred[4 * r + k] + out[4 * r + k]);
+    __builtin_memcpy(rec + (size_t)r * r_s, r4, 8);
+  }
 }
 
 // =============================================================================================
