@@ -156,6 +156,24 @@ struct PicDev { // parameters shared by the block kernels
   QuantDev qd[2];   // [0] luma, [1] chroma
 };
 
+// P.qd[luma ? 0 : 1] by value.  The parameters live in the kernel-argument segment; a select between two
+// references makes the compiler select the ADDRESS and fetch every field with a per-lane load from that
+// segment.  Here both sets arrive as scalars (v_readfirstlane pins them) and the lane selects values.
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T *wave_uniform(T *p) {
+  const unsigned long long u = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32));
+  return (T *)((unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+__device__ __forceinline__ QuantDev pick_qd(const PicDev &P, bool luma) {
+  const int a0 = wave_uniform(P.qd[0].q), a1 = wave_uniform(P.qd[0].per_qbits), a2 = wave_uniform(P.qd[0].iq_scale),
+            a3 = wave_uniform(P.qd[0].rnd_factor);
+  const int b0 = wave_uniform(P.qd[1].q), b1 = wave_uniform(P.qd[1].per_qbits), b2 = wave_uniform(P.qd[1].iq_scale),
+            b3 = wave_uniform(P.qd[1].rnd_factor);
+  return QuantDev{luma ? a0 : b0, luma ? a1 : b1, luma ? a2 : b2, luma ? a3 : b3};
+}
+
 // Scan tables g_auiSigLastScan (TComRom.cpp:564-698 with REMOVAL_8x2_2x8_CG): coefficient groups
 // of 4x4, groups ordered like the samples inside a group.  Index 0 = diagonal (also used for the
 // reference's "zigzag" index, TComTrQuant.cpp:1135), 1 = horizontal, 2 = vertical.  Entry = raster

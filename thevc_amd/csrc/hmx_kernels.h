@@ -139,7 +139,7 @@ __device__ __forceinline__ int quant_sbh_block(TuLds<N> &L, int gl, bool active,
                                                bool luma, int scan_idx, const PicDev &P) {
   constexpr int LG = Log2<N>::v;
   const int tshift = 15 - P.bit_depth - LG;
-  const QuantDev &qd = P.qd[luma ? 0 : 1];
+  const QuantDev qd = pick_qd(P, luma);
   const int qbits = 14 + qd.per_qbits + tshift;
   int sum = 0;
   if (active) { // idle lanes may alias another block's scratch: never let them write
@@ -256,7 +256,7 @@ __device__ __forceinline__ void inv_tq_block(TuLds<N> &L, int gl, bool active, b
                                              bool do_dequant, const PicDev &P, int *out) {
   constexpr int LG = Log2<N>::v;
   const int B = P.bit_depth, tshift = 15 - B - LG;
-  const QuantDev &qd = P.qd[luma ? 0 : 1];
+  const QuantDev qd = pick_qd(P, luma);
   const int dshift = 6 - tshift;
   int c[N], t[N];
 #pragma unroll

@@ -20,6 +20,14 @@ struct DTu { // device descriptor of the list kernels: hmx_tu + index in the cal
   hmx_tu t;
   uint32_t idx;
 };
+__device__ __forceinline__ DTu load_dtu(const DTu *p) { // one 12-byte load instead of one per field read
+  typedef __attribute__((address_space(1))) const int gint;
+  int w[3];
+  __builtin_memcpy(w, (gint *)p, 12);
+  DTu d;
+  __builtin_memcpy(&d, w, 12);
+  return d;
+}
 
 // list kernels: 256-thread workgroups = four autonomous waves; blocks per workgroup
 template <int N>
@@ -63,6 +71,15 @@ __device__ __forceinline__ T pick3(const T (&a)[3], int i) { // a[i] without a r
   r = i == 1 ? a[1] : r;
   return i == 2 ? a[2] : r;
 }
+// The same for a table entry that is uniform over the wave: the three values are pinned as wave-uniform (scalar
+// loads), or the compiler turns the select of loads back into one per-lane load from a selected address.
+template <typename T>
+__device__ __forceinline__ T uniform3(const T (&a)[3], int i) {
+  const T v0 = wave_uniform(a[0]), v1 = wave_uniform(a[1]), v2 = wave_uniform(a[2]);
+  T r = v0;
+  r = i == 1 ? v1 : r;
+  return i == 2 ? v2 : r;
+}
 
 // One kernel per (operation, block size): every block of the launch has size N.
 template <int N, int OP>
@@ -81,7 +98,7 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
   TuLds<N> &L = reinterpret_cast<TuLds<N> *>(smem)[lane_on ? slot : 0];
   const int i = blockIdx.x * SL + slot;
   const bool active = lane_on && i < A.n;
-  DTu d = A.tus[active ? i : 0];
+  const DTu d = load_dtu(A.tus + (active ? i : 0));
   const hmx_tu t = d.t;
   const int pl = t.plane, x = t.x, y = t.y;
   // blockIdx.y = picture of a multi-picture call (planes from the table); single calls carry theirs inline
@@ -90,10 +107,10 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
   // the compiler copy all of ListArgs to scratch memory, 22 stores per wave before the first useful load)
   // The picture table entry is uniform over the launch's x dimension: its fields come in by scalar loads and the
   // lane's plane selects among them, instead of one vector load per field and lane.
-  short *a_p = Q ? pick3(Q->a.p, pl) : pick3(A.a.p, pl), *b_p = Q ? pick3(Q->b.p, pl) : pick3(A.b.p, pl);
-  const int a_s = Q ? pick3(Q->a.s, pl) : pick3(A.a.s, pl), b_s = Q ? pick3(Q->b.s, pl) : pick3(A.b.s, pl);
-  int *lev_p = Q ? pick3(Q->lev.p, pl) : pick3(A.lev.p, pl), *lev2_p = pick3(A.lev2.p, pl);
-  const int lev_s = Q ? pick3(Q->lev.s, pl) : pick3(A.lev.s, pl), lev2_s = pick3(A.lev2.s, pl);
+  short *a_p = Q ? uniform3(Q->a.p, pl) : pick3(A.a.p, pl), *b_p = Q ? uniform3(Q->b.p, pl) : pick3(A.b.p, pl);
+  const int a_s = Q ? uniform3(Q->a.s, pl) : pick3(A.a.s, pl), b_s = Q ? uniform3(Q->b.s, pl) : pick3(A.b.s, pl);
+  int *lev_p = Q ? uniform3(Q->lev.p, pl) : pick3(A.lev.p, pl), *lev2_p = pick3(A.lev2.p, pl);
+  const int lev_s = Q ? uniform3(Q->lev.s, pl) : pick3(A.lev.s, pl), lev2_s = pick3(A.lev2.s, pl);
   uint32_t *abs_sum = A.abs_sum ? A.abs_sum + (size_t)blockIdx.y * A.abs_stride : nullptr;
   const bool luma = pl == 0, inter = t.flags & HMX_TU_INTER, ts = t.flags & HMX_TU_TRANSFORM_SKIP;
   const bool use_dst = luma && !inter; // uiMode != REG_DCT, only consulted for N == 4
@@ -126,7 +143,7 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
         const int mx = (1 << A.P.bit_depth) - 1;
 #pragma unroll
         for (int k = 0; k < N; k++) row[k] = clip3(0, mx, pr[k] + row[k]);
-        store_row16<N>(pick3(Q->rec.p, pl) + (size_t)(y + gl) * pick3(Q->rec.s, pl) + x, row);
+        store_row16<N>(uniform3(Q->rec.p, pl) + (size_t)(y + gl) * uniform3(Q->rec.s, pl) + x, row);
       }
     }
   } else if constexpr (OP == OP_XQUANT) {
@@ -165,7 +182,7 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
   } else if constexpr (OP == OP_XDEQUANT) {
     constexpr int LG = Log2<N>::v;
     const int tshift = 15 - A.P.bit_depth - LG, dshift = 6 - tshift, dadd = 1 << (dshift - 1);
-    const QuantDev &qd = luma ? A.P.qd[0] : A.P.qd[1];
+    const QuantDev qd = pick_qd(A.P, luma);
     if (active) {
       load_row32<N>(lev_p + (size_t)(y + gl) * lev_s + x, row);
 #pragma unroll
@@ -386,7 +403,7 @@ __device__ __forceinline__ void lane4_forward(const int *resid, bool use_dst, bo
       for (int k = 0; k < 4; k++) coef[4 * k + r] = yk[k];
     }
   }
-  const QuantDev &qd = P.qd[luma ? 0 : 1];
+  const QuantDev qd = pick_qd(P, luma);
   const int qbits = 14 + qd.per_qbits + tshift;
   int sum = 0;
 #pragma unroll
@@ -419,7 +436,7 @@ __device__ __forceinline__ void lane4_forward(const int *resid, bool use_dst, bo
 // lane4_inverse: levels (row-major) -> residual
 __device__ __forceinline__ void lane4_inverse(const int *lv, bool use_dst, bool ts, bool luma, const PicDev &P, int *out) {
   const int B = P.bit_depth, tshift = 15 - B - 2;
-  const QuantDev &qd = P.qd[luma ? 0 : 1];
+  const QuantDev qd = pick_qd(P, luma);
   int c[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) c[k] = dequant_one(lv[k], qd.iq_scale, 6 - tshift);
@@ -628,7 +645,7 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const 
       for (int g = 0; g < 16; g++) v[g] = lev0[__umul24((unsigned)mrow(g, h), (unsigned)lstep)];
     }
     const int tshift = 15 - P.bit_depth - LG;
-    const QuantDev &qd = P.qd[luma ? 0 : 1];
+    const QuantDev qd = pick_qd(P, luma);
     int out[16];
 #pragma unroll
     for (int g = 0; g < 16; g++) v[g] = wrap16(dequant_one(v[g], qd.iq_scale, 6 - tshift));
@@ -809,7 +826,7 @@ __global__ __launch_bounds__(64, 4) void k_intra_wave(FrameArgs A) {
 __global__ __launch_bounds__(256) void k_inter4(ListArgs A) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= A.n) return;
-  const DTu d = A.tus[i];
+  const DTu d = load_dtu(A.tus + i);
   const hmx_tu t = d.t;
   const int pl = t.plane, x = t.x, y = t.y;
   const ListPic &Q = A.pics[blockIdx.y];
@@ -819,8 +836,8 @@ __global__ __launch_bounds__(256) void k_inter4(ListArgs A) {
   typedef __attribute__((address_space(1))) const short gpel;
   typedef __attribute__((address_space(1))) short gpel_w;
   typedef __attribute__((address_space(1))) int gint_w;
-  const int a_s = pick3(Q.a.s, pl), b_s = pick3(Q.b.s, pl), l_s = pick3(Q.lev.s, pl), r_s = pick3(Q.rec.s, pl);
-  gpel *org = (gpel *)pick3(Q.a.p, pl) + (size_t)y * a_s + x, *prd = (gpel *)pick3(Q.b.p, pl) + (size_t)y * b_s + x;
+  const int a_s = uniform3(Q.a.s, pl), b_s = uniform3(Q.b.s, pl), l_s = uniform3(Q.lev.s, pl), r_s = uniform3(Q.rec.s, pl);
+  gpel *org = (gpel *)uniform3(Q.a.p, pl) + (size_t)y * a_s + x, *prd = (gpel *)uniform3(Q.b.p, pl) + (size_t)y * b_s + x;
   int pred[16], v[16], w[16];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -836,13 +853,13 @@ __global__ __launch_bounds__(256) void k_inter4(ListArgs A) {
   lane4_forward(v, use_dst, ts, luma, coef_scan_idx(4, luma, !inter, t.mode), A.P, w);
 #pragma unroll
   for (int k = 0; k < 16; k++) w[k] = level_of(w[k]);
-  gint_w *lev = (gint_w *)pick3(Q.lev.p, pl) + (size_t)y * l_s + x;
+  gint_w *lev = (gint_w *)uniform3(Q.lev.p, pl) + (size_t)y * l_s + x;
 #pragma unroll
   for (int r = 0; r < 4; r++) __builtin_memcpy(lev + (size_t)r * l_s, w + 4 * r, 16);
   int out[16];
   lane4_inverse(w, use_dst, ts, luma, A.P, out);
   const int mx = (1 << A.P.bit_depth) - 1;
-  gpel_w *rec = (gpel_w *)pick3(Q.rec.p, pl) + (size_t)y * r_s + x;
+  gpel_w *rec = (gpel_w *)uniform3(Q.rec.p, pl) + (size_t)y * r_s + x;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     short r4[4];
