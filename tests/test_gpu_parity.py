@@ -813,3 +813,24 @@ def test_cell_map_growth_keeps_rdoq_workspace(ctx):
     test_rdoq_batch_vs_oracle(ctx)
     for d in (d_ref, d_a, d_b):
         d.free()
+
+
+@pytest.mark.parametrize("w,h,m", [(64, 48, 80), (72, 40, 16), (64, 48, 12), (36, 20, 6)])
+def test_extend_border_shapes(ctx, w, h, m):
+    """extendPicBorder (TComPicYuv.cpp:248-286) through both kernels: four samples per thread (widths and margins that
+    are multiples of 8 luma samples) and the one-sample fallback."""
+    O, B, L = ol.oracle(), ctx.bit_depth, capi.lib()
+    planes = workload.make_planes(5, w, h, B)
+    d = capi.DevPicture(ctx, w, h, m, m).upload(planes)
+    ctx._chk(L.hmx_pic_extend_border(ctx.h, C.byref(d.as_pic()), w, h, m, m))
+    ctx.sync()
+    full = d.download(with_margins=True)
+    for p in range(3):
+        pw, ph, pmx, pmy = d.dims[p]
+        st = pw + 2 * pmx
+        e = np.zeros((ph + 2 * pmy, st), np.int16)
+        e[pmy:pmy + ph, pmx:pmx + pw] = planes[p]
+        flat = e.reshape(-1)
+        O.hmo_extendPicBorder(ol.ptr(flat, pmy * st + pmx), st, pw, ph, pmx, pmy)
+        assert np.array_equal(full[p], e), ("border", p)
+    d.free()

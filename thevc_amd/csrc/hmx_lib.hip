@@ -74,12 +74,13 @@ __device__ __forceinline__ T pick3(const T (&a)[3], int i) { // a[i] without a r
 // The same for a table entry that is uniform over the wave: the three values are pinned as wave-uniform (scalar
 // loads), or the compiler turns the select of loads back into one per-lane load from a selected address.
 template <typename T>
-__device__ __forceinline__ T uniform3(const T (&a)[3], int i) {
-  const T v0 = wave_uniform(a[0]), v1 = wave_uniform(a[1]), v2 = wave_uniform(a[2]);
+__device__ __forceinline__ T uniform3v(T a0, T a1, T a2, int i) {
+  const T v0 = wave_uniform(a0), v1 = wave_uniform(a1), v2 = wave_uniform(a2);
   T r = v0;
   r = i == 1 ? v1 : r;
   return i == 2 ? v2 : r;
 }
+#define uniform3(arr, i) uniform3v((arr)[0], (arr)[1], (arr)[2], (i))
 
 // One kernel per (operation, block size): every block of the launch has size N.
 template <int N, int OP>
@@ -3042,7 +3043,7 @@ extern "C" int hmx_batch_motionCompensation(hmx_ctx *c, const hmx_pu *d_pus, int
 
 // ---- extendPicBorder (TComPicYuv.cpp:248-286): every margin sample is the nearest picture sample, so
 // one launch covers all margins of all planes of all pictures (no left/right-then-up/down ordering) ----
-__global__ __launch_bounds__(256) void k_border(const PlanesDev *pics, int pic_w, int pic_h, int mx, int my) {
+__global__ __launch_bounds__(256) void k_border1(const PlanesDev *pics, int pic_w, int pic_h, int mx, int my) {
   const int pl = blockIdx.y % 3;
   const PlanesDev &D = pics[blockIdx.y / 3];
   const int sh = pl ? 1 : 0, w = pic_w >> sh, h = pic_h >> sh, bx = mx >> sh, by = my >> sh;
@@ -3063,6 +3064,38 @@ __global__ __launch_bounds__(256) void k_border(const PlanesDev *pics, int pic_w
   const int s = D.s[pl];
   p[(ptrdiff_t)y * s + x] = p[(ptrdiff_t)min(max(y, 0), h - 1) * s + min(max(x, 0), w - 1)];
 }
+// The same with four samples per thread (one 8-byte store): for plane widths and margins that are multiples of
+// four samples a group never straddles the picture edge, so it is either a copy of four picture samples
+// (above / below the picture) or one edge sample four times.
+__global__ __launch_bounds__(256) void k_border(const PlanesDev *pics, int pic_w, int pic_h, int mx, int my) {
+  typedef __attribute__((address_space(1))) short gpel;
+  const int pl = blockIdx.y % 3;
+  const PlanesDev &D = pics[blockIdx.y / 3];
+  const int sh = pl ? 1 : 0, w = pic_w >> sh, h = pic_h >> sh, bx = mx >> sh, by = my >> sh;
+  const int gw = (w + 2 * bx) >> 2, gb = bx >> 2, band = gw * by, side = h * gb;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int x, y;
+  if (i < band) { // above
+    y = -1 - i / gw, x = ((i % gw) << 2) - bx;
+  } else if ((i -= band) < band) { // below
+    y = h + i / gw, x = ((i % gw) << 2) - bx;
+  } else if ((i -= band) < side) { // left
+    y = i / gb, x = ((i % gb) << 2) - bx;
+  } else if ((i -= side) < side) { // right
+    y = i / gb, x = w + ((i % gb) << 2);
+  } else
+    return;
+  gpel *p = (gpel *)wave_uniform(D.p[pl]);
+  const int s = wave_uniform(D.s[pl]);
+  gpel *src = p + (ptrdiff_t)min(max(y, 0), h - 1) * s;
+  short v[4];
+  if (x >= 0 && x < w) {
+    __builtin_memcpy(v, src + x, 8);
+  } else {
+    v[0] = v[1] = v[2] = v[3] = src[x < 0 ? 0 : w - 1];
+  }
+  __builtin_memcpy(p + (ptrdiff_t)y * s + x, v, 8);
+}
 extern "C" int hmx_pic_extend_border_multi(hmx_ctx *c, int n_pics, const hmx_pic *pics, int pic_w, int pic_h, int mx, int my) {
   if (!c || !pics || n_pics <= 0 || n_pics > 21845 || mx < 0 || my < 0) return fail(c, HMX_ERR_ARG, "hmx_pic_extend_border_multi: bad argument");
   if (!mx && !my) return HMX_OK;
@@ -3071,7 +3104,10 @@ extern "C" int hmx_pic_extend_border_multi(hmx_ctx *c, int n_pics, const hmx_pic
   const PlanesDev *d = static_cast<const PlanesDev *>(arena_push(c, t.data(), sizeof(PlanesDev) * n_pics));
   if (!d) return fail(c, HMX_ERR_NOMEM, "argument arena");
   const long long total = 2LL * (pic_w + 2 * mx) * my + 2LL * pic_h * mx; // luma margin samples (chroma has fewer)
-  hipLaunchKernelGGL(k_border, dim3((unsigned)((total + 255) / 256), (unsigned)n_pics * 3), dim3(256), 0, c->stream, d, pic_w, pic_h, mx, my);
+  if (pic_w % 8 == 0 && mx % 8 == 0) // chroma width and margin are then multiples of four as well
+    hipLaunchKernelGGL(k_border, dim3((unsigned)((total / 4 + 255) / 256), (unsigned)n_pics * 3), dim3(256), 0, c->stream, d, pic_w, pic_h, mx, my);
+  else
+    hipLaunchKernelGGL(k_border1, dim3((unsigned)((total + 255) / 256), (unsigned)n_pics * 3), dim3(256), 0, c->stream, d, pic_w, pic_h, mx, my);
   HIPCHK(c, hipGetLastError());
   return HMX_OK;
 }
