@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhmx.so")
+LIB_PATH = os.environ.get("HMX_LIB_PATH", os.path.join(HERE, "libhmx.so"))  # the override is for A/B runs of a variant build
 
 REG_DCT = 65535
 TEXT_LUMA, TEXT_CHROMA, TEXT_CHROMA_U, TEXT_CHROMA_V = 0, 1, 2, 3

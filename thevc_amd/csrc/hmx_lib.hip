@@ -267,6 +267,13 @@ struct PlaneView {
   int *lev;
   int lev_stride;   // > 0: plane geometry; 0: the reference's Z-order coefficient layout
 };
+// 4x4 blocks per wave in the level schedules: 16 = four lanes per block (one row each, through LDS like the 8x8 and
+// 16x16 blocks), 64 = one lane per block (wave_chain_4_lane).  Measured at 1024 pictures of the 2160p mix: four lanes
+// +3 % encoder direction, +16 % decoder direction (more, shorter waves); the one-lane form stays for A/B builds.
+#ifndef HMX_SLOTS4
+#define HMX_SLOTS4 16
+#endif
+constexpr int kSlots4 = HMX_SLOTS4;
 // Two ways a wave finds its work.  "Own": every item of the wave is another block of ONE picture
 // (descriptor i of a list).  "Across": every item is the SAME block of another picture -- pictures that
 // follow one plan (same decisions) run in SIMD across pictures: the descriptor, its mode, position and
@@ -740,15 +747,17 @@ __global__ __launch_bounds__(64, 4) void k_intra_level(LevelArgs A) {
 #pragma unroll
   for (int s = 0; s < 4; s++) {
     const int per = s == 3 ? 1 : (16 >> (2 * s)) * 1; // blocks per wave: 16, 8(=64/8), 4, 1
-    const int slots = s == 0 ? 64 : s == 1 ? 8 : s == 2 ? 4 : 1;
+    const int slots = s == 0 ? kSlots4 : s == 1 ? 8 : s == 2 ? 4 : 1;
     (void)per;
     const int chunks = (int)(row.count[s] + slots - 1) / slots;
     if (c < chunks) {
       const FTu *tus = ltus + row.start[s] + (size_t)c * slots;
       const int n = min(slots, (int)row.count[s] - c * slots);
       const OwnPicture src{W, tus};
-      if (s == 0) wave_chain_4_lane<ENC, true>(smem, src, A.P, n);
-      else if (s == 1) wave_chain_valu<8, ENC, true>(smem, src, A.P, n);
+      if (s == 0) {
+        if constexpr (kSlots4 == 64) wave_chain_4_lane<ENC, true>(smem, src, A.P, n);
+        else wave_chain_valu<4, ENC, true>(smem, src, A.P, n);
+      } else if (s == 1) wave_chain_valu<8, ENC, true>(smem, src, A.P, n);
       else if (s == 2) wave_chain_valu<16, ENC, true>(smem, src, A.P, n);
       else wave_chain_32<ENC, true>(smem, src, A.P, n);
       return;
@@ -779,15 +788,17 @@ __global__ __launch_bounds__(64, 4) void k_intra_level_across(AcrossArgs A) {
   uint32_t c = blockIdx.x;
 #pragma unroll
   for (int s = 0; s < 4; s++) {
-    const int slots = s == 0 ? 64 : s == 1 ? 8 : s == 2 ? 4 : 1;
+    const int slots = s == 0 ? kSlots4 : s == 1 ? 8 : s == 2 ? 4 : 1;
     const uint32_t waves = A.row.count[s] * A.cpb[s];
     if (c < waves) {
       const uint32_t blk = c / A.cpb[s], chunk = c - blk * A.cpb[s];
       const int pic0 = (int)chunk * slots, n = min(slots, A.n_pics - pic0);
       const AcrossPictures src{A.pics, A.ltus + A.row.start[s] + blk, pic0, A.n_pics, A.pool_org, A.pool_rec,
                                A.plane_off[1], A.plane_off[2] - A.plane_off[1], A.ctu_w, A.clog};
-      if (s == 0) wave_chain_4_lane<ENC, true>(smem, src, A.P, n);
-      else if (s == 1) wave_chain_valu<8, ENC, true>(smem, src, A.P, n);
+      if (s == 0) {
+        if constexpr (kSlots4 == 64) wave_chain_4_lane<ENC, true>(smem, src, A.P, n);
+        else wave_chain_valu<4, ENC, true>(smem, src, A.P, n);
+      } else if (s == 1) wave_chain_valu<8, ENC, true>(smem, src, A.P, n);
       else if (s == 2) wave_chain_valu<16, ENC, true>(smem, src, A.P, n);
       else wave_chain_32<ENC, true>(smem, src, A.P, n);
       return;
@@ -1485,7 +1496,7 @@ extern "C" int hmx_intra_plan_create(hmx_ctx *c, const hmx_tu *tus, int n_tu, co
       for (int sidx = 0; sidx < 4; sidx++) {
         ltab[l].start[sidx] = off;
         off += ltab[l].count[sidx];
-        const uint32_t slots = sidx == 0 ? 64 : sidx == 1 ? 8 : sidx == 2 ? 4 : 1;
+        const uint32_t slots = sidx == 0 ? kSlots4 : sidx == 1 ? 8 : sidx == 2 ? 4 : 1;
         chunks += (ltab[l].count[sidx] + slots - 1) / slots;
       }
       level_chunks[l] = chunks;
@@ -1687,7 +1698,7 @@ static int issue_across_pipelined(hmx_ctx *c, const hmx_intra_plan *p0, int n_pi
       AA.pool_rec = c->pool_rec + (size_t)first[g] * c->tiled_pic_elems;
       uint64_t waves = 0;
       for (int s2 = 0; s2 < 4; s2++) {
-        const int slots = s2 == 0 ? 64 : s2 == 1 ? 8 : s2 == 2 ? 4 : 1;
+        const int slots = s2 == 0 ? kSlots4 : s2 == 1 ? 8 : s2 == 2 ? 4 : 1;
         AA.cpb[s2] = (uint32_t)((np + slots - 1) / slots);
         waves += (uint64_t)AA.row.count[s2] * AA.cpb[s2];
       }
@@ -1792,7 +1803,7 @@ static int issue_chain_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, 
           AA.pool_rec = c->pool_rec + (size_t)first[g] * c->tiled_pic_elems;
           uint64_t waves = 0;
           for (int s2 = 0; s2 < 4; s2++) {
-            const int slots = s2 == 0 ? 64 : s2 == 1 ? 8 : s2 == 2 ? 4 : 1;
+            const int slots = s2 == 0 ? kSlots4 : s2 == 1 ? 8 : s2 == 2 ? 4 : 1;
             AA.cpb[s2] = (uint32_t)((np + slots - 1) / slots);
             waves += (uint64_t)AA.row.count[s2] * AA.cpb[s2];
           }
