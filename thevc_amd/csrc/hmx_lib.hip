@@ -832,6 +832,64 @@ __global__ __launch_bounds__(64, 4) void k_intra_wave(FrameArgs A) {
   }
 }
 
+// The inter block chain for 32x32 blocks on the matrix cores, ONE WAVE PER BLOCK (k_list<32> spends 32 lanes on a
+// block and multiplies on the VALU): the data layout and the MFMA passes of wave_chain_32 with the prediction read
+// from its plane.  grid = (blocks, pictures of a multi-picture call).
+__global__ __launch_bounds__(64) void k_inter32(ListArgs A) {
+  __shared__ __attribute__((aligned(16))) char smem[sizeof(TuLds<32>)];
+  TuLds<32> &L = *reinterpret_cast<TuLds<32> *>(smem);
+  typedef __attribute__((address_space(1))) const short gpel;
+  typedef __attribute__((address_space(1))) short gpel_w;
+  typedef __attribute__((address_space(1))) int gint_w;
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const DTu d = load_dtu(A.tus + blockIdx.x);
+  const hmx_tu t = d.t;
+  const int pl = wave_uniform((int)t.plane), x = wave_uniform((int)t.x), y = wave_uniform((int)t.y);
+  const ListPic &Q = A.pics[blockIdx.y];
+  const bool luma = pl == 0;
+  const int a_s = uniform3(Q.a.s, pl), b_s = uniform3(Q.b.s, pl), l_s = uniform3(Q.lev.s, pl), r_s = uniform3(Q.rec.s, pl);
+  // this lane: row r, the four 4-sample pieces at columns 8q + 4h (mrow), as the MFMA passes want them
+  gpel *org = (gpel *)uniform3(Q.a.p, pl) + (size_t)(y + r) * a_s + x + 4 * h;
+  gpel *prd = (gpel *)uniform3(Q.b.p, pl) + (size_t)(y + r) * b_s + x + 4 * h;
+  int v[16], coef[16];
+  unsigned pred2[8]; // the prediction waits packed for the reconstruction
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    short o4[4], p4[4];
+    __builtin_memcpy(o4, org + 8 * q, 8);
+    __builtin_memcpy(p4, prd + 8 * q, 8);
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[4 * q + k] = wrap16(o4[k] - p4[k]);
+    pred2[2 * q] = (unsigned)(unsigned short)p4[0] | ((unsigned)(unsigned short)p4[1] << 16);
+    pred2[2 * q + 1] = (unsigned)(unsigned short)p4[2] | ((unsigned)(unsigned short)p4[3] << 16);
+  }
+  fwd32_mfma(v, r, h, A.P.bit_depth, coef);
+  const int sum = quant_sbh_block<32, 64, 16, false>(
+      L, lane, true, coef, [&](int k) { return mrow(k, h); }, [&](int) { return r; }, luma, 0, A.P);
+  gint_w *lev = (gint_w *)uniform3(Q.lev.p, pl) + (size_t)y * l_s + x + r;
+#pragma unroll
+  for (int g = 0; g < 16; g++) {
+    v[g] = level_of(L.tile[mrow(g, h)][r]);
+    lev[(size_t)mrow(g, h) * l_s] = v[g]; // 32 lanes = one 128-byte row of levels
+  }
+  if (lane == 0 && A.abs_sum) A.abs_sum[(size_t)blockIdx.y * A.abs_stride + d.idx] = (uint32_t)sum;
+  const int tshift = 15 - A.P.bit_depth - 5;
+  const QuantDev qd = pick_qd(A.P, luma);
+  int out[16];
+#pragma unroll
+  for (int g = 0; g < 16; g++) v[g] = wrap16(dequant_one(v[g], qd.iq_scale, 6 - tshift));
+  inv32_mfma(v, r, h, A.P.bit_depth, out);
+  const int mx = (1 << A.P.bit_depth) - 1;
+  gpel_w *rec = (gpel_w *)uniform3(Q.rec.p, pl) + (size_t)(y + r) * r_s + x + 4 * h;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int p0 = pred2[2 * q] & 0xffff, p1 = pred2[2 * q] >> 16, p2 = pred2[2 * q + 1] & 0xffff, p3 = pred2[2 * q + 1] >> 16;
+    short r4[4] = {(short)clip3(0, mx, p0 + out[4 * q]), (short)clip3(0, mx, p1 + out[4 * q + 1]),
+                   (short)clip3(0, mx, p2 + out[4 * q + 2]), (short)clip3(0, mx, p3 + out[4 * q + 3])};
+    __builtin_memcpy(rec + 8 * q, r4, 8);
+  }
+}
+
 // The inter block chain for 4x4 blocks, ONE LANE PER BLOCK (k_list spends four lanes on a 4x4 block and runs its
 // sign-bit hiding in one of them): residual org - pred, T, Q + sign hiding, levels out, IQ, IT, Clip(pred + resi) out.
 // grid.y = picture of a multi-picture call (ListArgs::pics).
@@ -1258,6 +1316,11 @@ static int run_list(hmx_ctx *c, int op, const hmx_tu_list *l, ListArgs A) {
     A.n = l->cnt[s];
     if (op == OP_TRANSFORM_RECON && s == 0 && A.pics && !A.abs_sum) { // 4x4 blocks: one lane per block
       hipLaunchKernelGGL(k_inter4, dim3((unsigned)((A.n + 255) / 256), (unsigned)A.n_pics), dim3(256), 0, c->stream, A);
+      HIPCHK(c, hipGetLastError());
+      continue;
+    }
+    if (op == OP_TRANSFORM_RECON && s == 3 && A.pics) { // 32x32 blocks: one wave per block on the matrix cores
+      hipLaunchKernelGGL(k_inter32, dim3((unsigned)A.n, (unsigned)A.n_pics), dim3(64), 0, c->stream, A);
       HIPCHK(c, hipGetLastError());
       continue;
     }
@@ -1915,10 +1978,11 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
   if (const char *e = getenv("HMX_INTRA_SCHEDULE")) use_level = e[0] == 'l' ? true : (e[0] == 'w' ? false : use_level);
   bool across = use_level && plan_stride == 0;
   if (const char *e = getenv("HMX_INTRA_ACROSS")) across = across && e[0] != '0';
-  // Picture groups on separate streams: the launches of two groups overlap, which hides part of the
-  // per-level latency floor once each group still fills its waves (measured: +4 % at 512 pictures, +10 % at
-  // 1024, +13 % at 1400 with two groups; four or more are slower, and so is any split of the per-picture kernel)
-  int groups = across && n_pics >= 384 ? 2 : 1;
+  // Picture groups on separate streams: the launches of the groups overlap, which hides part of the per-level
+  // latency floor once each group still fills its waves.  Measured at 1024 pictures (four lanes per 4x4 block):
+  // 64.8 / 73.6 / 76.1 / 51.8 Gpx/s with 1 / 2 / 3 / 4 groups -- the fourth side stream shares a hardware queue
+  // (the runtime maps streams onto four) and serialises; 256 pictures: 32.6 / 32.9 with 1 / 2.
+  int groups = !across ? 1 : n_pics >= 960 ? 3 : n_pics >= 384 ? 2 : 1;
   if (use_level)
     if (const char *e = getenv("HMX_INTRA_STREAMS")) groups = std::min(std::max(atoi(e), 1), std::min(n_pics, (int)hmx_ctx::kMaxSide));
   c->across_call = across;
