@@ -238,7 +238,9 @@ def main():
     dt = time.perf_counter() - t0
     kernel_ms = ctx.elapsed_ms(ev0, ev1)  # HIP events on the stream the kernels run on
     ta, tb, tc = C.c_float(), C.c_float(), C.c_float()
-    ctx._chk(L.hmx_last_call_timing(ctx.h, C.byref(ta), C.byref(tb), C.byref(tc)))  # last step: convert / chain / convert
+    if L.hmx_last_call_timing(ctx.h, C.byref(ta), C.byref(tb), C.byref(tc)):  # last step: convert / chain / convert
+        # graph replay (HMX_GRAPH=1) records no inner events: the whole step stands in for the chain
+        ta.value, tb.value, tc.value = 0.0, kernel_ms / args.steps, 0.0
     sched, groups = C.c_int(), C.c_int()
     L.hmx_last_call_shape(ctx.h, C.byref(sched), C.byref(groups))  # how the library issued the timed calls
     dt = max_over_ranks(dt, world, "cuda")

@@ -834,3 +834,45 @@ def test_extend_border_shapes(ctx, w, h, m):
         O.hmo_extendPicBorder(ol.ptr(flat, pmy * st + pmx), st, pw, ph, pmx, pmy)
         assert np.array_equal(full[p], e), ("border", p)
     d.free()
+
+
+def test_inter_path_on_unaligned_planes(ctx):
+    """The inter kernels read window and block rows with multi-dword accesses: motion compensation, the fused residual
+    chain (lane per 4x4 block, list kernels, one wave per 32x32 block) and the border extension on planes with an ODD
+    stride that start on an odd sample (2-byte-aligned addresses) must give what they give on aligned planes (which
+    the other tests pin to the oracle)."""
+    L, B = capi.lib(), ctx.bit_depth
+    w, h, m = 192, 128, 80
+    pus = workload.make_pus(21, w, h, n_refs=2, bi_frac=0.5)
+    d_pus = ctx.to_device(pus)
+    tus = workload.make_tus(22, w, h, "mix", ts_prob=0.0)
+    tus["flags"] = capi.TU_INTER
+    tl = ctx.tu_list(tus)
+    pp = capi.PicParam(w, h, 30, 1, capi.B_SLICE, 1)
+    planes = [workload.make_planes(60 + i, w, h, B, "texture") for i in range(3)]
+    got = []
+    for pad, skew in ((0, 0), (1, 1)):
+        refs = [capi.DevPicture(ctx, w, h, m, m, pad=pad, skew=skew).upload(planes[i]) for i in range(2)]
+        for r in refs:
+            ctx._chk(L.hmx_pic_extend_border(ctx.h, C.byref(r.as_pic()), w, h, m, m))
+        org = capi.DevPicture(ctx, w, h, pad=pad, skew=skew).upload(planes[2])
+        pred = capi.DevPicture(ctx, w, h, pad=pad, skew=skew).zero()
+        rec = capi.DevPicture(ctx, w, h, m, m, pad=pad, skew=skew).zero()
+        lev = capi.DevPicture(ctx, w, h, dtype=np.int32, pad=pad).zero()
+        ref_arr = (capi.Pic * 2)(*[r.as_pic() for r in refs])
+        a_pred, a_rec, a_org, a_lev = (capi.Pic * 1)(pred.as_pic()), (capi.Pic * 1)(rec.as_pic()), (capi.Pic * 1)(org.as_pic()), (capi.Levels * 1)(lev.as_pic())
+        job = (capi.McJob * 1)()
+        job[0].d_pus, job[0].n_pus, job[0].refs, job[0].n_refs = d_pus.ptr, len(pus), ref_arr, 2
+        job[0].dst, job[0].pic_w, job[0].pic_h = C.pointer(a_pred[0]), w, h
+        ctx._chk(L.hmx_batch_motionCompensation_multi(ctx.h, 1, job))
+        ctx._chk(L.hmx_batch_residual_transform_recon_multi(ctx.h, tl, 1, a_org, a_pred, a_lev, a_rec, None, C.byref(pp)))
+        ctx._chk(L.hmx_pic_extend_border(ctx.h, C.byref(rec.as_pic()), w, h, m, m))
+        ctx.sync()
+        got.append((refs[0].download(True), pred.download(), lev.download(), rec.download(True)))
+        for d in refs + [org, pred, rec, lev]:
+            d.free()
+    names = ("reference with border", "prediction", "levels", "reconstruction with border")
+    for k, name in enumerate(names):
+        for p in range(3):
+            assert np.array_equal(got[0][k][p], got[1][k][p]), (name, p)
+    assert any(np.count_nonzero(a) for a in got[0][2])

@@ -397,17 +397,20 @@ class DevPicture:
     """Three Pel planes in HBM with the reference's margin layout (TComPicYuv.cpp:82-94):
     luma margin mx,my; chroma half of it.  Also usable without margins (mx = my = 0)."""
 
-    def __init__(self, ctx, w, h, mx=0, my=0, dtype=np.int16):
+    def __init__(self, ctx, w, h, mx=0, my=0, dtype=np.int16, pad=0, skew=0):
+        """pad: extra samples per row (an odd stride with pad=1); skew: samples the planes start after their
+        allocation (skew=1: plane addresses that are not dword-aligned) -- for tests of the alignment paths."""
         self.ctx, self.w, self.h, self.mx, self.my = ctx, w, h, mx, my
+        self.pad, self.skew = pad, skew
         self.dtype = np.dtype(dtype)
         self.dims = [(w, h, mx, my), (w // 2, h // 2, mx // 2, my // 2), (w // 2, h // 2, mx // 2, my // 2)]
-        self.strides = [pw + 2 * pmx for (pw, ph, pmx, pmy) in self.dims]
-        self.elems = [(pw + 2 * pmx) * (ph + 2 * pmy) for (pw, ph, pmx, pmy) in self.dims]
+        self.strides = [pw + 2 * pmx + pad for (pw, ph, pmx, pmy) in self.dims]
+        self.elems = [(pw + 2 * pmx + pad) * (ph + 2 * pmy) + skew for (pw, ph, pmx, pmy) in self.dims]
         self.bufs = [ctx.alloc(e * self.dtype.itemsize) for e in self.elems]
 
     def origin_ptr(self, p):
         pw, ph, pmx, pmy = self.dims[p]
-        return self.bufs[p].ptr + (pmy * self.strides[p] + pmx) * self.dtype.itemsize
+        return self.bufs[p].ptr + (self.skew + pmy * self.strides[p] + pmx) * self.dtype.itemsize
 
     def as_pic(self):
         s = Pic() if self.dtype == np.int16 else Levels()
@@ -420,17 +423,19 @@ class DevPicture:
         """planes: three 2-D arrays (h x w) without margins"""
         for p in range(3):
             pw, ph, pmx, pmy = self.dims[p]
-            full = np.zeros((ph + 2 * pmy, pw + 2 * pmx), self.dtype)
+            flat = np.zeros(self.elems[p], self.dtype)
+            full = flat[self.skew:].reshape(ph + 2 * pmy, self.strides[p])
             full[pmy:pmy + ph, pmx:pmx + pw] = np.asarray(planes[p]).reshape(ph, pw)
-            self.bufs[p].upload(full)
+            self.bufs[p].upload(flat)
         return self
 
     def download(self, with_margins=False):
         out = []
         for p in range(3):
             pw, ph, pmx, pmy = self.dims[p]
-            full = self.bufs[p].download(self.dtype).reshape(ph + 2 * pmy, pw + 2 * pmx)
-            out.append(full if with_margins else full[pmy:pmy + ph, pmx:pmx + pw].copy())
+            flat = self.bufs[p].download(self.dtype)
+            full = flat[self.skew:].reshape(ph + 2 * pmy, self.strides[p])[:, :pw + 2 * pmx]
+            out.append(full.copy() if with_margins else full[pmy:pmy + ph, pmx:pmx + pw].copy())
         return out
 
     def zero(self):

@@ -120,11 +120,8 @@ __device__ __forceinline__ void wave_global_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// sum over the `width` lanes of a group: consecutive lanes, or (LS > 1) lanes LS apart -- the layout in which the
-// blocks of a wave are interleaved lane by lane (k_list, block-fastest)
-template <int LS = 1>
-__device__ __forceinline__ int group_sum(int v, int width) {
-  for (int off = width >> 1; off > 0; off >>= 1) v += LS == 1 ? __shfl_xor(v, off, width) : __shfl_xor(v, off * LS, 64);
+__device__ __forceinline__ int group_sum(int v, int width) { // sum over `width` consecutive lanes
+  for (int off = width >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, width);
   return v;
 }
 
@@ -134,7 +131,7 @@ __device__ __forceinline__ int group_sum(int v, int width) {
 // Leaves packed words (level in the low half) in L.tile[row][col]; returns uiAbsSum (before sign-bit
 // hiding, :1256).  WIDE: see quant_one.
 // ---------------------------------------------------------------------------------------------
-template <int N, int NL, int NCOEF, bool WIDE, int LS = 1, typename RowFn, typename ColFn>
+template <int N, int NL, int NCOEF, bool WIDE, typename RowFn, typename ColFn>
 __device__ __forceinline__ int quant_sbh_block(TuLds<N> &L, int gl, bool active, const int *coef, RowFn row_of, ColFn col_of,
                                                bool luma, int scan_idx, const PicDev &P) {
   constexpr int LG = Log2<N>::v;
@@ -152,7 +149,7 @@ __device__ __forceinline__ int quant_sbh_block(TuLds<N> &L, int gl, bool active,
       L.tile[row_of(k)][col_of(k)] = word;
     }
   }
-  sum = group_sum<LS>(active ? sum : 0, NL);
+  sum = group_sum(active ? sum : 0, NL);
   wave_sync();
   constexpr int NG = (N / 4) * (N / 4), PER = (NG + NL - 1) / NL;
   const bool hide = P.sign_hide && sum >= 2; // uniform over the block's lanes
@@ -201,7 +198,7 @@ __device__ __forceinline__ int quant_sbh_block(TuLds<N> &L, int gl, bool active,
 // transformNxN core: residual row -> final levels in L.tile.  ts = transform skip (:1622),
 // use_dst = 4x4 luma intra.  do_quant = false leaves the Int coefficients (xT / xTransformSkip).
 // ---------------------------------------------------------------------------------------------
-template <int N, int LS = 1>
+template <int N>
 __device__ __forceinline__ int fwd_tq_block(TuLds<N> &L, int gl, bool active, const int *x, bool ts, bool use_dst,
                                             bool luma, int scan_idx, bool do_quant, const PicDev &P) {
   // everything quantised here went through a forward pass (int16) or transform skip (|x| << shift
@@ -239,7 +236,7 @@ __device__ __forceinline__ int fwd_tq_block(TuLds<N> &L, int gl, bool active, co
     wave_sync();
     return 0;
   }
-  return quant_sbh_block<N, N, N, false, LS>(
+  return quant_sbh_block<N, N, N, false>(
       L, gl, active, coef, [&](int k) { return ts ? gl : k; }, [&](int k) { return ts ? k : gl; }, luma, scan_idx, P);
 }
 

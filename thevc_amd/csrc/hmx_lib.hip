@@ -87,14 +87,7 @@ template <int N, int OP>
 __global__ __launch_bounds__(256) void k_list(ListArgs A) {
   __shared__ __attribute__((aligned(16))) char smem[HMX_SMEM_BYTES];
   constexpr int SL = Slots<N>::v;
-  // Lane -> (block, row).  Row-fastest keeps a block on consecutive lanes.  The fused inter chain on 8x8 blocks
-  // interleaves the 8 blocks of a wave instead (block-fastest, rows 8 lanes apart): the list is in raster order,
-  // so the lanes of a quad then touch the same row of adjacent blocks -- one cache line instead of four.  The L1
-  // looks up one line per cycle and this kernel is bound by exactly that (TA busy 94 %, profiles/).
-  constexpr bool BF = OP == OP_TRANSFORM_RECON && N == 8;
-  constexpr int BPW = 64 / N, LS = BF ? BPW : 1;
-  const int tid = threadIdx.x;
-  const int slot = BF ? (tid >> 6) * BPW + (tid & 63) % BPW : tid / N, gl = BF ? (tid & 63) / BPW : tid % N;
+  const int tid = threadIdx.x, slot = tid / N, gl = tid % N;
   const bool lane_on = slot < SL;
   TuLds<N> &L = reinterpret_cast<TuLds<N> *>(smem)[lane_on ? slot : 0];
   const int i = blockIdx.x * SL + slot;
@@ -128,7 +121,7 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
         for (int k = 0; k < N; k++) row[k] = wrap16(row[k] - pr[k]);
       }
     }
-    int sum = fwd_tq_block<N, LS>(L, gl, active, row, ts, use_dst, luma, scan_idx, OP != OP_XT, A.P);
+    int sum = fwd_tq_block<N>(L, gl, active, row, ts, use_dst, luma, scan_idx, OP != OP_XT, A.P);
     if (active) {
       load_row32<N>(&L.tile[gl][0], row);
       if (OP != OP_XT) {
@@ -267,13 +260,14 @@ struct PlaneView {
   int *lev;
   int lev_stride;   // > 0: plane geometry; 0: the reference's Z-order coefficient layout
 };
-// 4x4 blocks per wave in the level schedules: 16 = four lanes per block (one row each, through LDS like the 8x8 and
+// 4x4 blocks per wave in the across-pictures level schedule: 16 = four lanes per block (one row each, through LDS like the 8x8 and
 // 16x16 blocks), 64 = one lane per block (wave_chain_4_lane).  Measured at 1024 pictures of the 2160p mix: four lanes
 // +3 % encoder direction, +16 % decoder direction (more, shorter waves); the one-lane form stays for A/B builds.
 #ifndef HMX_SLOTS4
 #define HMX_SLOTS4 16
 #endif
-constexpr int kSlots4 = HMX_SLOTS4;
+constexpr int kSlots4 = HMX_SLOTS4; // across pictures
+constexpr int kSlots4Own = 64;       // per-picture level kernel: one lane per block (four lanes: 51.5 vs 54.5 Gpx/s at 1024 pictures)
 // Two ways a wave finds its work.  "Own": every item of the wave is another block of ONE picture
 // (descriptor i of a list).  "Across": every item is the SAME block of another picture -- pictures that
 // follow one plan (same decisions) run in SIMD across pictures: the descriptor, its mode, position and
@@ -747,7 +741,7 @@ __global__ __launch_bounds__(64, 4) void k_intra_level(LevelArgs A) {
 #pragma unroll
   for (int s = 0; s < 4; s++) {
     const int per = s == 3 ? 1 : (16 >> (2 * s)) * 1; // blocks per wave: 16, 8(=64/8), 4, 1
-    const int slots = s == 0 ? kSlots4 : s == 1 ? 8 : s == 2 ? 4 : 1;
+    const int slots = s == 0 ? kSlots4Own : s == 1 ? 8 : s == 2 ? 4 : 1;
     (void)per;
     const int chunks = (int)(row.count[s] + slots - 1) / slots;
     if (c < chunks) {
@@ -755,7 +749,7 @@ __global__ __launch_bounds__(64, 4) void k_intra_level(LevelArgs A) {
       const int n = min(slots, (int)row.count[s] - c * slots);
       const OwnPicture src{W, tus};
       if (s == 0) {
-        if constexpr (kSlots4 == 64) wave_chain_4_lane<ENC, true>(smem, src, A.P, n);
+        if constexpr (kSlots4Own == 64) wave_chain_4_lane<ENC, true>(smem, src, A.P, n);
         else wave_chain_valu<4, ENC, true>(smem, src, A.P, n);
       } else if (s == 1) wave_chain_valu<8, ENC, true>(smem, src, A.P, n);
       else if (s == 2) wave_chain_valu<16, ENC, true>(smem, src, A.P, n);
@@ -1559,7 +1553,7 @@ extern "C" int hmx_intra_plan_create(hmx_ctx *c, const hmx_tu *tus, int n_tu, co
       for (int sidx = 0; sidx < 4; sidx++) {
         ltab[l].start[sidx] = off;
         off += ltab[l].count[sidx];
-        const uint32_t slots = sidx == 0 ? kSlots4 : sidx == 1 ? 8 : sidx == 2 ? 4 : 1;
+        const uint32_t slots = sidx == 0 ? kSlots4Own : sidx == 1 ? 8 : sidx == 2 ? 4 : 1;
         chunks += (ltab[l].count[sidx] + slots - 1) / slots;
       }
       level_chunks[l] = chunks;
