@@ -1974,8 +1974,8 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
   if (const char *e = getenv("HMX_INTRA_ACROSS")) across = across && e[0] != '0';
   // Picture groups on separate streams: the launches of the groups overlap, which hides part of the per-level
   // latency floor once each group still fills its waves.  Measured at 1024 pictures (four lanes per 4x4 block):
-  // 64.8 / 73.6 / 76.1 / 51.8 Gpx/s with 1 / 2 / 3 / 4 groups -- the fourth side stream shares a hardware queue
-  // (the runtime maps streams onto four) and serialises; 256 pictures: 32.6 / 32.9 with 1 / 2.
+  // 64.8 / 73.6 / 76.1 / 51.8 Gpx/s with 1 / 2 / 3 / 4 groups (four collapse whether one host thread or one per group
+  // issues the launches; likely the runtime's four hardware queues); 256 pictures: 32.6 / 32.9 with 1 / 2.
   int groups = !across ? 1 : n_pics >= 960 ? 3 : n_pics >= 384 ? 2 : 1;
   if (use_level)
     if (const char *e = getenv("HMX_INTRA_STREAMS")) groups = std::min(std::max(atoi(e), 1), std::min(n_pics, (int)hmx_ctx::kMaxSide));
