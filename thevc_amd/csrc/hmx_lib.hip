@@ -2903,14 +2903,14 @@ __device__ __forceinline__ int dot2(int pair, int taps, int acc) {
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(s2v, pair), __builtin_bit_cast(s2v, taps), acc, false);
 }
 
-// Prediction of one list for a W x W cell whose first sample is `ref` in the reference plane:
+// Prediction of one list for a W x H cell whose first sample is `ref` in the reference plane:
 // xPredInterLumaBlk / ChromaBlk (:554-642) restricted to the cell.  The reference's two-stage
 // filtering is position-wise (every output is the vertical filter of horizontally filtered rows), so
-// cutting a PU into cells gives the same samples.
-template <int NTAP, int W>
-__device__ __forceinline__ void mc_cell(const int *lds_taps, const short *ref, int rs, int mvx, int mvy, bool bi, int B, int *out) {
-  constexpr int SH = NTAP == 8 ? 2 : 3, MASK = (1 << SH) - 1, HALF = NTAP / 2, R = W + NTAP - 1;
-  constexpr int ND = (R + 2) / 2;               // registers per window row: 12 / 6 samples, R + 1 of them used
+// cutting a PU into cells gives the same samples.  Rows go to emit(r, v[W]) as they are finished.
+template <int NTAP, int W, int H, typename Emit>
+__device__ __forceinline__ void mc_cell(const int *lds_taps, const short *ref, int rs, int mvx, int mvy, bool bi, int B, Emit emit) {
+  constexpr int SH = NTAP == 8 ? 2 : 3, MASK = (1 << SH) - 1, HALF = NTAP / 2, R = H + NTAP - 1;
+  constexpr int ND = (W + NTAP + 1) / 2;        // registers per window row: 12 / 6 samples, W + NTAP of them used
   constexpr int NE = NTAP / 2, NO = NTAP / 2 + 1, NP = (R + 1) / 2, ROW = NTAP == 8 ? kLumaRow : kChromaRow;
   typedef __attribute__((address_space(1))) const short gpel; // the table pointer is generic to the compiler: no FLAT loads
   typedef __attribute__((address_space(1))) const int gword;
@@ -2950,9 +2950,10 @@ __device__ __forceinline__ void mc_cell(const int *lds_taps, const short *ref, i
   const bool last = !bi;
   const int sh2 = last ? 6 + head : 6, off2 = last ? (1 << (5 + head)) + (8192 << 6) : 0;
 #pragma unroll
-  for (int c = 0; c < W; c++)
+  for (int r = 0; r < H; r++) {
+    int v[W];
 #pragma unroll
-    for (int r = 0; r < W; r++) {
+    for (int c = 0; c < W; c++) {
       int s = off2;
       if (r % 2 == 0) {
 #pragma unroll
@@ -2961,32 +2962,47 @@ __device__ __forceinline__ void mc_cell(const int *lds_taps, const short *ref, i
 #pragma unroll
         for (int j = 0; j < NO; j++) s = dot2(P[r / 2 + j][c], oy[j], s);
       }
-      const int v = wrap16(s >> sh2);
-      out[r * W + c] = last ? clip3(0, maxv, v) : v;
+      const int w16 = wrap16(s >> sh2);
+      v[c] = last ? clip3(0, maxv, w16) : w16;
     }
+    emit(r, v);
+  }
 }
 
-// prediction of one plane's cell from both lists (+ addAvg) into dst
-template <int NTAP, int W>
+// Prediction of one plane's W x H cell from both lists (+ addAvg) into dst.  Pass one runs for every lane: the
+// only list of a uni-predicted PU (final samples, stored) or list 0 of a bi-predicted one (14-bit samples, kept
+// packed two per register); pass two runs list 1 for the bi-predicted lanes and stores addAvg rows.
+template <int NTAP, int W, int H>
 __device__ __forceinline__ void mc_cell_plane(const int *lds_taps, const McArgs &A, const McJob &J, const hmx_pu &u, int pl, int x, int y) {
-  const bool bi = u.ref0 != 255 && u.ref1 != 255;
-  int p0[W * W], p1[W * W];
-  if (u.ref0 != 255) {
-    const PlanesDev &R = A.refs[J.ref_off + u.ref0];
-    mc_cell<NTAP, W>(lds_taps, R.p[pl] + (ptrdiff_t)y * R.s[pl] + x, R.s[pl], u.mv0x, u.mv0y, bi, A.B, p0);
-  }
-  if (u.ref1 != 255) {
-    const PlanesDev &R = A.refs[J.ref_off + u.ref1];
-    mc_cell<NTAP, W>(lds_taps, R.p[pl] + (ptrdiff_t)y * R.s[pl] + x, R.s[pl], u.mv1x, u.mv1y, bi, A.B, bi ? p1 : p0);
-  }
   typedef __attribute__((address_space(1))) short gpel;
+  const bool bi = u.ref0 != 255 && u.ref1 != 255, first1 = u.ref0 == 255;
   gpel *d = (gpel *)J.dst.p[pl] + (size_t)y * J.dst.s[pl] + x;
+  const int ds = J.dst.s[pl];
+  unsigned keep[H * W / 2];
+  {
+    const PlanesDev &R = A.refs[J.ref_off + (first1 ? u.ref1 : u.ref0)];
+    mc_cell<NTAP, W, H>(lds_taps, R.p[pl] + (ptrdiff_t)y * R.s[pl] + x, R.s[pl], first1 ? u.mv1x : u.mv0x, first1 ? u.mv1y : u.mv0y,
+                        bi, A.B, [&](int r, const int *v) {
+                          short row[W];
 #pragma unroll
-  for (int r = 0; r < W; r++) {
-    short row[W];
+                          for (int c = 0; c < W; c++) row[c] = (short)v[c];
 #pragma unroll
-    for (int c = 0; c < W; c++) row[c] = (short)(bi ? add_avg(p0[r * W + c], p1[r * W + c], A.B) : p0[r * W + c]);
-    __builtin_memcpy(d + (size_t)r * J.dst.s[pl], row, W * 2); // one 8-byte (4-byte) store per row, 2-byte aligned
+                          for (int c = 0; c < W; c += 2) keep[(r * W + c) / 2] = (unsigned)(unsigned short)row[c] | ((unsigned)(unsigned short)row[c + 1] << 16);
+                          if (!bi) __builtin_memcpy(d + (size_t)r * ds, row, W * 2); // one 8-byte (4-byte) store per row
+                        });
+  }
+  if (bi) {
+    const PlanesDev &R = A.refs[J.ref_off + u.ref1];
+    mc_cell<NTAP, W, H>(lds_taps, R.p[pl] + (ptrdiff_t)y * R.s[pl] + x, R.s[pl], u.mv1x, u.mv1y, true, A.B, [&](int r, const int *v) {
+      short row[W];
+#pragma unroll
+      for (int c = 0; c < W; c += 2) {
+        const unsigned k = keep[(r * W + c) / 2];
+        row[c] = (short)add_avg((int)(short)(k & 0xffff), v[c], A.B);
+        row[c + 1] = (short)add_avg((int)(short)(k >> 16), v[c + 1], A.B);
+      }
+      __builtin_memcpy(d + (size_t)r * ds, row, W * 2);
+    });
   }
 }
 
@@ -3014,19 +3030,32 @@ __global__ __launch_bounds__(256) void k_mc_cells(McArgs A) {
   __shared__ int taps[kTapTable];
   fill_tap_table(taps, threadIdx.x, 256);
   const McJob J = A.jobs[blockIdx.y];
-  // a workgroup is a 64x64 luma tile (16x16 cells), a wave one 32x32 quadrant, a lane one cell of its 8x8: the
-  // window rows of the cells of one PU fall into the same cache lines of the same load instruction, and the
-  // rows a cell shares with the cell below it are fetched by the same wave
+  // A lane owns two vertically adjacent cells (4 x 8 luma samples); a wave 8 x 8 such pairs = 32 x 64 samples, a
+  // workgroup 64 x 128: the window rows of the cells of one PU fall into the same cache lines of the same load
+  // instruction, and rows shared by vertical neighbours are fetched by the same wave.  When both cells belong to
+  // ONE PU (every PU at least 8 high does that) they are predicted as one 4 x 8 cell -- 15 window rows instead of
+  // 2 x 11, one horizontal pass over them; otherwise each cell on its own.
   const int tiles_x = (J.cw + 15) >> 4, tile = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int cx = (tile % tiles_x) * 16 + (wave & 1) * 8 + (lane & 7), cy = (tile / tiles_x) * 16 + (wave >> 1) * 8 + (lane >> 3);
+  const int cx = (tile % tiles_x) * 16 + (wave & 1) * 8 + (lane & 7), cy = (tile / tiles_x) * 32 + (wave >> 1) * 16 + (lane >> 3) * 2;
   if (cx >= J.cw || cy >= J.ch) return;
-  const int pi = J.map[cy * J.cw + cx];
-  if (pi < 0) return;
-  const hmx_pu u = J.pus[pi];
+  const int pi0 = J.map[cy * J.cw + cx], pi1 = cy + 1 < J.ch ? J.map[(cy + 1) * J.cw + cx] : -1;
   const int x = cx << 2, y = cy << 2;
-  mc_cell_plane<8, 4>(taps, A, J, u, 0, x, y);
-  mc_cell_plane<4, 2>(taps, A, J, u, 1, x >> 1, y >> 1);
-  mc_cell_plane<4, 2>(taps, A, J, u, 2, x >> 1, y >> 1);
+  if (pi0 >= 0 && pi0 == pi1) {
+    const hmx_pu u = J.pus[pi0];
+    mc_cell_plane<8, 4, 8>(taps, A, J, u, 0, x, y);
+    mc_cell_plane<4, 2, 4>(taps, A, J, u, 1, x >> 1, y >> 1);
+    mc_cell_plane<4, 2, 4>(taps, A, J, u, 2, x >> 1, y >> 1);
+  } else {
+#pragma unroll 1
+    for (int k = 0; k < 2; k++) {
+      const int pi = k ? pi1 : pi0;
+      if (pi < 0) continue;
+      const hmx_pu u = J.pus[pi];
+      mc_cell_plane<8, 4, 4>(taps, A, J, u, 0, x, y + 4 * k);
+      mc_cell_plane<4, 2, 2>(taps, A, J, u, 1, x >> 1, (y >> 1) + 2 * k);
+      mc_cell_plane<4, 2, 2>(taps, A, J, u, 2, x >> 1, (y >> 1) + 2 * k);
+    }
+  }
 }
 __global__ __launch_bounds__(64) void k_mc(McArgs A) {
   __shared__ int taps[kTapTable];
@@ -3038,9 +3067,9 @@ __global__ __launch_bounds__(64) void k_mc(McArgs A) {
   const int cw = u.w >> 2, cells = cw * (u.h >> 2);
   for (int i = threadIdx.x; i < cells; i += 64) {
     const int x = u.x + ((i % cw) << 2), y = u.y + ((i / cw) << 2);
-    mc_cell_plane<8, 4>(taps, A, J, u, 0, x, y);
-    mc_cell_plane<4, 2>(taps, A, J, u, 1, x >> 1, y >> 1);
-    mc_cell_plane<4, 2>(taps, A, J, u, 2, x >> 1, y >> 1);
+    mc_cell_plane<8, 4, 4>(taps, A, J, u, 0, x, y);
+    mc_cell_plane<4, 2, 2>(taps, A, J, u, 1, x >> 1, y >> 1);
+    mc_cell_plane<4, 2, 2>(taps, A, J, u, 2, x >> 1, y >> 1);
   }
 }
 
@@ -3062,7 +3091,7 @@ extern "C" int hmx_batch_motionCompensation_multi(hmx_ctx *c, int n_jobs, const 
     mapped = mapped && cells > 0;
     map_cells += cells;
     max_cells = std::max(max_cells, cells);
-    max_tiles = std::max(max_tiles, (size_t)((hj[i].cw + 15) / 16) * ((hj[i].ch + 15) / 16));
+    max_tiles = std::max(max_tiles, (size_t)((hj[i].cw + 15) / 16) * ((hj[i].ch + 31) / 32)); // 64 x 128 luma samples
   }
   if (!max_n) return HMX_OK;
   if (mapped) { // cell maps of all jobs, back to back, in a grow-only scratch buffer
