@@ -2929,18 +2929,35 @@ __device__ __forceinline__ void mc_cell(const int *lds_taps, const short *ref, i
   const int sh1 = 6 - head, off1 = -(8192 << sh1);
   int P[NP][W]; // the intermediate, rows 2k and 2k+1 packed per column
   int lo[W];
+  // The rows are fetched four at a time, one chunk ahead of the arithmetic: a wave spends its life waiting for
+  // window rows (25 us per wave against 2 us of VALU issue when every row was loaded where it is used), so the
+  // loads of the next chunk are in flight while this one is filtered.
+  constexpr int CH = 4, NCH = (R + CH - 1) / CH;
+  int buf[2][CH][ND];
+  auto fetch = [&](int k, int (&dst)[CH][ND]) {
 #pragma unroll
-  for (int r = 0; r < R; r++) {
-    int d[ND];
-    __builtin_memcpy(d, (gword *)(win + (ptrdiff_t)r * rs), ND * 4);
+    for (int i = 0; i < CH; i++)
+      if (k * CH + i < R) __builtin_memcpy(dst[i], (gword *)(win + (ptrdiff_t)(k * CH + i) * rs), ND * 4);
+  };
+  fetch(0, buf[0]);
 #pragma unroll
-    for (int c = 0; c < W; c++) {
-      int s = off1;
+  for (int k = 0; k < NCH; k++) {
+    if (k + 1 < NCH) fetch(k + 1, buf[(k + 1) & 1]);
 #pragma unroll
-      for (int j = 0; j < NO; j++) s = dot2(d[c / 2 + j], c % 2 ? t1[j] : t0[j], s);
-      s >>= sh1;
-      if (r % 2 == 0) lo[c] = s;
-      else P[r / 2][c] = (int)__builtin_amdgcn_perm((unsigned)s, (unsigned)lo[c], 0x05040100u);
+    for (int i = 0; i < CH; i++) {
+      const int r = k * CH + i;
+      if (r < R) {
+        const int *d = buf[k & 1][i];
+#pragma unroll
+        for (int c = 0; c < W; c++) {
+          int s = off1;
+#pragma unroll
+          for (int j = 0; j < NO; j++) s = dot2(d[c / 2 + j], c % 2 ? t1[j] : t0[j], s);
+          s >>= sh1;
+          if (r % 2 == 0) lo[c] = s;
+          else P[r / 2][c] = (int)__builtin_amdgcn_perm((unsigned)s, (unsigned)lo[c], 0x05040100u);
+        }
+      }
     }
   }
   if (R % 2)
