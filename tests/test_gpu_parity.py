@@ -276,18 +276,18 @@ def test_frame_intra_parameter_corners(B, qp, ctu, sign_hide, cqo):
         ctx.close()
 
 
-@pytest.mark.parametrize("across", ["1", "pipelined", "pipelined3", "0"])
+@pytest.mark.parametrize("across", ["1", "groups3", "pipelined", "pipelined3", "0"])
 @pytest.mark.parametrize("pic,n_pics", [((64, 64), 70), ((136, 72), 9), ((200, 264), 5)])
 def test_frame_intra_many_pictures_one_plan(ctx, pic, n_pics, across, monkeypatch):
-    """Pictures that follow one plan run in SIMD across pictures (one wave = one block of 64/N pictures):
-    more pictures than a wave has slots (70 > 64), a ragged last chunk (9 = 8 + 1 for 8x8 blocks), and the
+    """Pictures that follow one plan run in SIMD across pictures (one wave = one block of 16/8/4/1 pictures):
+    more pictures than a wave has slots (70 > 64), ragged last chunks (9 = 8 + 1 for 8x8 blocks, 70 = 4 x 16 + 6), and the
     per-picture level kernel (HMX_INTRA_ACROSS=0) must all give the oracle's bits."""
     monkeypatch.setenv("HMX_INTRA_SCHEDULE", "level")
     # "pipelined": the layout conversions run CTU row by CTU row on their own stream, overlapped with the chain
     # (the default from 256 pictures up); "pipelined3": the same with three picture groups on three streams
     monkeypatch.setenv("HMX_INTRA_ACROSS", "0" if across == "0" else "1")
     monkeypatch.setenv("HMX_PIPELINE_CONV", "1" if across.startswith("pipelined") else "0")
-    if across == "pipelined3":
+    if across in ("pipelined3", "groups3"):  # "groups3": what a call of 960 pictures or more does by default
         monkeypatch.setenv("HMX_INTRA_STREAMS", "3")
     B = ctx.bit_depth
     w, h = pic
