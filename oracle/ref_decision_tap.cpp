@@ -1,0 +1,190 @@
+// TEST INFRASTRUCTURE (see oracle/README in hmx_oracle.h's header): a tap on the compiled REFERENCE DECODER.
+//
+//   hm_decision_tap <bitstream.bin> <out.hmxd>
+//
+// drives the reference's decoder library (TDecTop, built by oracle/build_ref_apps.sh from the sources where they
+// lie under /root/reference) over an Annex-B stream and writes, for every decoded picture, what SURVEY.md 8f rank 4
+// calls the per-CTU decision list: the transform blocks of the picture in decoding order (position, size, plane,
+// resolved intra mode, transform-skip flag), the parsed levels in the reference's own per-CTU coefficient layout,
+// and the reference's reconstruction of that picture.  tests/golden/make_stream_golden.py turns the file into a
+// fixture; the parity tests then reconstruct the picture from the decisions (oracle on the CPU, libhmx on the
+// GPU) and compare with what the reference decoder itself produced.  Intra pictures only this round.
+//
+// File layout (little endian, int32 unless noted):
+//   magic "HMXD", version 1, n_pictures (patched at the end)
+//   per picture: poc, width, height, bit_depth, slice_qp, ctu, n_tu,
+//                n_tu x { u16 x, u16 y, u8 log2n, u8 plane, u8 mode, u8 flags }      (= hmx_tu, include/hmx.h)
+//                3 planes x levels  (CTUs in raster order, ctu*ctu ints each (chroma: /4), TComDataCU::m_pcTrCoeff*)
+//                3 planes x reconstruction (int16, w x h, no margins)
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <vector>
+
+#include "TLibCommon/TComPic.h"
+#include "TLibCommon/TComRom.h"
+#include "TLibDecoder/AnnexBread.h"
+#include "TLibDecoder/NALread.h"
+#include "TLibDecoder/TDecTop.h"
+
+// The decoder library reports a picture-digest mismatch through a flag its application owns (decmain.cpp).
+bool g_md5_mismatch = false;
+
+namespace {
+
+struct Tu {
+  uint16_t x, y;
+  uint8_t log2n, plane, mode, flags;
+};
+const uint8_t kTransformSkip = 1; // HMX_TU_TRANSFORM_SKIP
+
+void put32(FILE *f, int32_t v) { fwrite(&v, 4, 1, f); }
+
+// Transform blocks of the coding unit that starts at partition `part` of CTU `cu`, in the order
+// TDecCu::xIntraRecQT visits them (DEC/TDecCu.cpp:663-687): luma block, then Cb and Cr of the same node; a
+// 4x4 luma node carries no chroma except the first of its four siblings, which carries the parent's 4x4 chroma.
+void walk(TComDataCU *cu, unsigned part, unsigned depth, unsigned cu_part, int ctu_x, int ctu_y, int ctu, std::vector<Tu> &out) {
+  const unsigned n_part = cu->getPic()->getNumPartInCU();
+  const unsigned leaf_depth = cu->getDepth(cu_part) + cu->getTransformIdx(part);
+  const unsigned span = n_part >> (2 * depth); // partitions covered by a node at this depth
+  if (depth < leaf_depth) {
+    for (unsigned q = 0; q < 4; q++) walk(cu, part + q * (span >> 2), depth + 1, cu_part, ctu_x, ctu_y, ctu, out);
+    return;
+  }
+  const int size = ctu >> depth, log2n = g_aucConvertToBit[size] + 2;
+  const unsigned raster = g_auiZscanToRaster[part];
+  const int per_row = ctu / 4; // 4x4 units per CTU row (minimum partition is 4x4 at depth 4)
+  const int x = ctu_x + (int)(raster % per_row) * 4, y = ctu_y + (int)(raster / per_row) * 4;
+  const int luma_mode = cu->getLumaIntraDir(part);
+  Tu t;
+  t.x = (uint16_t)x, t.y = (uint16_t)y, t.log2n = (uint8_t)log2n, t.plane = 0, t.mode = (uint8_t)luma_mode;
+  t.flags = cu->getTransformSkip(part, TEXT_LUMA) ? kTransformSkip : 0;
+  out.push_back(t);
+  // chroma of this node
+  unsigned cpart = part;
+  int clog = log2n - 1;
+  if (log2n == 2) {
+    const unsigned parent_span = span << 2;
+    if (part % parent_span) return; // not the first of the four 4x4 siblings
+    clog = 2;
+  }
+  int cmode = cu->getChromaIntraDir(cu_part);
+  if (cmode == DM_CHROMA_IDX) cmode = cu->getLumaIntraDir(cu_part); // derived from the CU's first luma mode (:576-580)
+  for (int pl = 1; pl <= 2; pl++) {
+    Tu c;
+    c.x = (uint16_t)(x >> 1), c.y = (uint16_t)(y >> 1), c.log2n = (uint8_t)clog, c.plane = (uint8_t)pl, c.mode = (uint8_t)cmode;
+    c.flags = cu->getTransformSkip(cpart, pl == 1 ? TEXT_CHROMA_U : TEXT_CHROMA_V) ? kTransformSkip : 0;
+    out.push_back(c);
+  }
+}
+
+int dump_picture(FILE *f, TComPic *pic) {
+  TComPicYuv *rec = pic->getPicYuvRec();
+  const int w = rec->getWidth(), h = rec->getHeight(), ctu = (int)g_uiMaxCUWidth;
+  const int B = (int)(g_uiBitDepth + g_uiBitIncrement);
+  const unsigned n_ctu = pic->getNumCUsInFrame(), per_row = pic->getFrameWidthInCU(), n_part = pic->getNumPartInCU();
+  std::vector<Tu> tus;
+  for (unsigned a = 0; a < n_ctu; a++) {
+    TComDataCU *cu = pic->getCU(a);
+    const int cx = (int)(a % per_row) * ctu, cy = (int)(a / per_row) * ctu;
+    for (unsigned part = 0; part < n_part;) {
+      const unsigned depth = cu->getDepth(part), span = n_part >> (2 * depth);
+      const unsigned raster = g_auiZscanToRaster[part];
+      const int x = cx + (int)(raster % (ctu / 4)) * 4, y = cy + (int)(raster / (ctu / 4)) * 4;
+      if (x < w && y < h) { // coding units outside the picture are not coded
+        if (cu->getPredictionMode(part) != MODE_INTRA) {
+          fprintf(stderr, "hm_decision_tap: picture %d holds a non-intra coding unit (inter pictures: next round)\n", pic->getPOC());
+          return 1;
+        }
+        if (cu->getIPCMFlag(part) || cu->isLosslessCoded(part)) {
+          fprintf(stderr, "hm_decision_tap: PCM / lossless coding units are outside the path\n");
+          return 1;
+        }
+        walk(cu, part, depth, part, cx, cy, ctu, tus);
+      }
+      part += span;
+    }
+  }
+  put32(f, pic->getPOC()), put32(f, w), put32(f, h), put32(f, B), put32(f, pic->getSlice(0)->getSliceQp()), put32(f, ctu);
+  put32(f, (int32_t)tus.size());
+  fwrite(tus.data(), sizeof(Tu), tus.size(), f);
+  for (int pl = 0; pl < 3; pl++) {
+    const size_t per_ctu = (size_t)ctu * ctu >> (pl ? 2 : 0);
+    for (unsigned a = 0; a < n_ctu; a++) {
+      TComDataCU *cu = pic->getCU(a);
+      const TCoeff *c = pl == 0 ? cu->getCoeffY() : pl == 1 ? cu->getCoeffCb() : cu->getCoeffCr();
+      fwrite(c, sizeof(TCoeff), per_ctu, f);
+    }
+  }
+  for (int pl = 0; pl < 3; pl++) {
+    const Pel *p = pl == 0 ? rec->getLumaAddr() : pl == 1 ? rec->getCbAddr() : rec->getCrAddr();
+    const int s = pl ? rec->getCStride() : rec->getStride(), pw = w >> (pl ? 1 : 0), ph = h >> (pl ? 1 : 0);
+    for (int r = 0; r < ph; r++) fwrite(p + (size_t)r * s, sizeof(Pel), pw, f);
+  }
+  return 0;
+}
+
+} // namespace
+
+int main(int argc, char **argv) {
+  if (argc != 3) {
+    fprintf(stderr, "usage: %s <bitstream> <out.hmxd>\n", argv[0]);
+    return 2;
+  }
+  std::ifstream in(argv[1], std::ifstream::in | std::ifstream::binary);
+  if (!in) {
+    fprintf(stderr, "hm_decision_tap: cannot open %s\n", argv[1]);
+    return 2;
+  }
+  // all NAL units first: the decoder wants the first slice of a new picture a second time once it has closed
+  // the previous picture (TDecTop::decode returns true and has consumed nothing), which is an index step here
+  std::vector<std::vector<uint8_t> > units;
+  {
+    InputByteStream bs(in);
+    while (!!in) {
+      std::vector<uint8_t> u;
+      AnnexBStats stats = AnnexBStats();
+      byteStreamNALUnit(bs, u, stats);
+      if (!u.empty()) units.push_back(u);
+    }
+  }
+  FILE *f = fopen(argv[2], "wb");
+  if (!f) return 2;
+  fwrite("HMXD", 1, 4, f);
+  put32(f, 1), put32(f, 0);
+  TDecTop dec;
+  dec.create();
+  dec.init();
+  dec.setPictureDigestEnabled(true);
+  int skip = 0, last_display = -1, n_pics = 0, rc = 0;
+  auto close_picture = [&]() {
+    UInt poc = 0;
+    TComList<TComPic *> *list = NULL;
+    dec.executeDeblockAndAlf(poc, list, skip, last_display);
+    if (!list) return;
+    for (TComList<TComPic *>::iterator it = list->begin(); it != list->end(); ++it)
+      if ((*it)->getPOC() == (Int)poc && (*it)->getReconMark()) {
+        rc |= dump_picture(f, *it);
+        n_pics++;
+        break;
+      }
+  };
+  for (size_t i = 0; i < units.size() && !rc;) {
+    std::vector<uint8_t> bytes = units[i]; // read() rewrites its buffer
+    InputNALUnit nalu;
+    read(nalu, bytes);
+    if (dec.decode(nalu, skip, last_display))
+      close_picture(); // the unit at i opens the next picture: feed it again
+    else
+      i++;
+  }
+  if (!rc) close_picture();
+  fseek(f, 8, SEEK_SET);
+  put32(f, n_pics);
+  fclose(f);
+  dec.deletePicBuffer();
+  dec.destroy();
+  fprintf(stderr, "hm_decision_tap: %d picture(s)%s\n", n_pics, g_md5_mismatch ? ", PICTURE DIGEST MISMATCH" : "");
+  return rc || g_md5_mismatch;
+}

@@ -1,0 +1,113 @@
+"""Fixtures from REAL reference streams: a synthetic clip is encoded by the reference's own
+encoder (oracle/_ref/TAppEncoder, built by oracle/build_ref_apps.sh), the stream is decoded by the reference's decoder
+library under oracle/ref_decision_tap.cpp, and every picture's decision list (transform blocks, levels) is stored
+with the reference decoder's reconstruction.  Needs /root/reference (not on the GPU box); the .npz travels.
+
+  python tests/golden/make_stream_golden.py            # writes tests/golden/stream_*.npz
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REFBIN = os.path.join(ROOT, "oracle", "_ref")
+TU_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2n", "u1"), ("plane", "u1"), ("mode", "u1"), ("flags", "u1")])
+
+
+def synthetic_clip(seed, w, h, n, B):
+    """Pictures with flat areas, ramps, sharp rectangles, fine noise and text-like 1-sample detail, so that the
+    encoder's search picks every block size, many directions and transform skip."""
+    rng = np.random.default_rng(seed)
+    mx = (1 << B) - 1
+    out = []
+    for i in range(n):
+        planes = []
+        for (pw, ph) in ((w, h), (w // 2, h // 2), (w // 2, h // 2)):
+            yy, xx = np.mgrid[0:ph, 0:pw]
+            p = 0.5 * mx * (1 + 0.5 * np.sin(xx / 19.0 + seed + i) * np.cos(yy / 13.0))
+            p[:, : pw // 3] = 0.3 * mx + 0.4 * mx * xx[:, : pw // 3] / pw                   # ramp
+            for _ in range(12):                                                             # sharp rectangles
+                x0, y0 = int(rng.integers(0, pw - 8)), int(rng.integers(0, ph - 8))
+                p[y0:y0 + int(rng.integers(3, 24)), x0:x0 + int(rng.integers(3, 40))] = rng.integers(0, mx + 1)
+            noisy = (xx // 16 + yy // 16) % 3 == 0
+            p = np.where(noisy, p + rng.normal(0, 0.08 * mx, (ph, pw)), p + rng.normal(0, 0.004 * mx, (ph, pw)))
+            p[ph // 2: ph // 2 + 12, ::2] = mx * (rng.random((12, (pw + 1) // 2)) < 0.5)   # 1-sample detail
+            planes.append(np.clip(np.rint(p), 0, mx).astype(np.uint16))
+        out.append(planes)
+    return out
+
+
+def parse_hmxd(path):
+    b = open(path, "rb").read()
+    assert b[:4] == b"HMXD"
+    ver, n = np.frombuffer(b, "<i4", 2, 4)
+    assert ver == 1
+    off, pics = 12, []
+    for _ in range(n):
+        poc, w, h, B, qp, ctu, n_tu = (int(v) for v in np.frombuffer(b, "<i4", 7, off))
+        off += 28
+        tus = np.frombuffer(b, TU_DTYPE, n_tu, off).copy()
+        off += 8 * n_tu
+        n_ctu = -(-w // ctu) * -(-h // ctu)
+        lev = []
+        for p in range(3):
+            e = n_ctu * ctu * ctu >> (2 if p else 0)
+            lev.append(np.frombuffer(b, "<i4", e, off).copy())
+            off += 4 * e
+        rec = []
+        for p in range(3):
+            pw, ph = w >> (1 if p else 0), h >> (1 if p else 0)
+            rec.append(np.frombuffer(b, "<i2", pw * ph, off).reshape(ph, pw).copy())
+            off += 2 * pw * ph
+        pics.append(dict(poc=poc, w=w, h=h, B=B, qp=qp, ctu=ctu, tus=tus, lev=lev, rec=rec))
+    assert off == len(b)
+    return pics
+
+
+def make(name, seed, w, h, n, B, qp, cfg, extra=()):
+    enc, tap = os.path.join(REFBIN, "TAppEncoder"), os.path.join(REFBIN, "hm_decision_tap")
+    if not (os.path.exists(enc) and os.path.exists(tap)):
+        subprocess.check_call(["bash", os.path.join(ROOT, "oracle", "build_ref_apps.sh")])
+    with tempfile.TemporaryDirectory() as d:
+        yuv, bit, out = (os.path.join(d, f) for f in ("in.yuv", "str.bin", "out.hmxd"))
+        with open(yuv, "wb") as f:
+            for planes in synthetic_clip(seed, w, h, n, B):
+                for p in planes:
+                    f.write(p.astype(np.uint8 if B == 8 else "<u2").tobytes())
+        cmd = [enc, "-c", os.path.join("/root/reference/cfg", cfg), "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "30",
+               "-f", str(n), "-q", str(qp), "-b", bit, "--SEIpictureDigest=1", f"--InputBitDepth={B}",
+               f"--InternalBitDepth={B}"] + list(extra)
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+        subprocess.run([tap, bit, out], check=True, stdout=subprocess.DEVNULL)
+        pics = parse_hmxd(out)
+        nbytes = os.path.getsize(bit)
+    arrays = {"n": np.int32(len(pics)), "stream_bytes": np.int32(nbytes), "command": np.array(" ".join(cmd[3:]))}
+    for i, p in enumerate(pics):
+        arrays[f"hdr{i}"] = np.array([p["poc"], p["w"], p["h"], p["B"], p["qp"], p["ctu"]], np.int32)
+        arrays[f"tus{i}"] = p["tus"]
+        for k in range(3):
+            arrays[f"lev{i}_{k}"] = p["lev"][k]
+            arrays[f"rec{i}_{k}"] = p["rec"][k]
+    path = os.path.join(HERE, f"stream_{name}.npz")
+    np.savez_compressed(path, **arrays)
+    sizes = np.bincount(np.concatenate([p["tus"]["log2n"][p["tus"]["plane"] == 0] for p in pics]), minlength=6)[2:]
+    ts = sum(int((p["tus"]["flags"] & 1).sum()) for p in pics)
+    print(f"{path}: {len(pics)} picture(s), {nbytes} stream bytes, luma blocks 4/8/16/32 = {sizes.tolist()}, transform-skip blocks {ts}, "
+          f"{os.path.getsize(path)} bytes")
+
+
+# loop filters off (the slice-level disable is only signalled with the control-present flag)
+PURE = ["--DeblockingFilterControlPresent=1", "--LoopFilterDisable=1", "--SAO=0"]
+
+if __name__ == "__main__":
+    # pure reconstruction: loop filters off, so the decoder's output IS prediction + residual of the block path
+    make("intra_main_q27", 11, 192, 128, 2, 8, 27, "encoder_intra_main.cfg", PURE)
+    make("intra_he10_q32", 12, 128, 128, 1, 10, 32, "encoder_intra_he10.cfg", PURE)
+    # deblocking as the configuration ships it (all-intra: every filtered edge has strength 2), SAO off: the decoder's
+    # output is the block path followed by the deblocking filter
+    make("intra_main_q34_dbk", 13, 192, 128, 1, 8, 34, "encoder_intra_main.cfg", ["--SAO=0"])
