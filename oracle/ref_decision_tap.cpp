@@ -11,10 +11,13 @@
 // GPU) and compare with what the reference decoder itself produced.  Intra pictures only this round.
 //
 // File layout (little endian, int32 unless noted):
-//   magic "HMXD", version 1, n_pictures (patched at the end)
+//   magic "HMXD", version 2, n_pictures (patched at the end)
 //   per picture: poc, width, height, bit_depth, slice_qp, ctu, n_tu,
 //                n_tu x { u16 x, u16 y, u8 log2n, u8 plane, u8 mode, u8 flags }      (= hmx_tu, include/hmx.h)
 //                3 planes x levels  (CTUs in raster order, ctu*ctu ints each (chroma: /4), TComDataCU::m_pcTrCoeff*)
+//                3 components x n_ctu x { i8 type, u8 band, i8 offset[4] }  SAO as the decoder parsed it, merges
+//                                         resolved (= hmx_sao_lcu; type -1 everywhere when SAO is off for the component)
+//                deblocking: int32 disabled (slice flag), beta_offset_div2, tc_offset_div2
 //                3 planes x reconstruction (int16, w x h, no margins)
 #include <cstdint>
 #include <cstdio>
@@ -117,6 +120,24 @@ int dump_picture(FILE *f, TComPic *pic) {
       fwrite(c, sizeof(TCoeff), per_ctu, f);
     }
   }
+  // SAO parameters of the picture (TDecGop::filterPicture :243-262 hands exactly these to SAOProcess)
+  TComSlice *slice = pic->getSlice(0);
+  SAOParam *sp = pic->getPicSym()->getSaoParam();
+  const bool sao_on = slice->getSPS()->getUseSAO() && slice->getSaoEnabledFlag() && sp;
+  for (int c = 0; c < 3; c++) {
+    const bool on = sao_on && (c == 0 ? slice->getSaoEnabledFlag() : slice->getSaoEnabledFlagChroma());
+    for (unsigned a = 0; a < n_ctu; a++) {
+      int8_t q[6] = {-1, 0, 0, 0, 0, 0};
+      if (on) {
+        const SaoLcuParam &L = sp->saoLcuParam[c][a];
+        q[0] = (int8_t)L.typeIdx, q[1] = (int8_t)(uint8_t)L.subTypeIdx;
+        for (int i = 0; i < 4; i++) q[2 + i] = (int8_t)L.offset[i];
+      }
+      fwrite(q, 1, 6, f);
+    }
+  }
+  put32(f, slice->getLoopFilterDisable() ? 1 : 0), put32(f, slice->getLoopFilterBetaOffset()),
+      put32(f, slice->getLoopFilterTcOffset());
   for (int pl = 0; pl < 3; pl++) {
     const Pel *p = pl == 0 ? rec->getLumaAddr() : pl == 1 ? rec->getCbAddr() : rec->getCrAddr();
     const int s = pl ? rec->getCStride() : rec->getStride(), pw = w >> (pl ? 1 : 0), ph = h >> (pl ? 1 : 0);
@@ -152,7 +173,7 @@ int main(int argc, char **argv) {
   FILE *f = fopen(argv[2], "wb");
   if (!f) return 2;
   fwrite("HMXD", 1, 4, f);
-  put32(f, 1), put32(f, 0);
+  put32(f, 2), put32(f, 0);
   TDecTop dec;
   dec.create();
   dec.init();

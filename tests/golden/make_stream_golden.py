@@ -17,9 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REFBIN = os.path.join(ROOT, "oracle", "_ref")
 TU_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2n", "u1"), ("plane", "u1"), ("mode", "u1"), ("flags", "u1")])
+SAO_DTYPE = np.dtype([("type", "i1"), ("band", "u1"), ("offset", "i1", 4)])
 
 
-def synthetic_clip(seed, w, h, n, B):
+def synthetic_clip(seed, w, h, n, B, smooth=False):
     """Pictures with flat areas, ramps, sharp rectangles, fine noise and text-like 1-sample detail, so that the
     encoder's search picks every block size, many directions and transform skip."""
     rng = np.random.default_rng(seed)
@@ -31,10 +32,10 @@ def synthetic_clip(seed, w, h, n, B):
             yy, xx = np.mgrid[0:ph, 0:pw]
             p = 0.5 * mx * (1 + 0.5 * np.sin(xx / 19.0 + seed + i) * np.cos(yy / 13.0))
             p[:, : pw // 3] = 0.3 * mx + 0.4 * mx * xx[:, : pw // 3] / pw                   # ramp
-            for _ in range(12):                                                             # sharp rectangles
+            for _ in range(3 if smooth else 12):                                            # sharp rectangles
                 x0, y0 = int(rng.integers(0, pw - 8)), int(rng.integers(0, ph - 8))
                 p[y0:y0 + int(rng.integers(3, 24)), x0:x0 + int(rng.integers(3, 40))] = rng.integers(0, mx + 1)
-            noisy = (xx // 16 + yy // 16) % 3 == 0
+            noisy = ((xx // 16 + yy // 16) % 3 == 0) & ((not smooth) | (xx > 0.7 * pw))
             p = np.where(noisy, p + rng.normal(0, 0.08 * mx, (ph, pw)), p + rng.normal(0, 0.004 * mx, (ph, pw)))
             p[ph // 2: ph // 2 + 12, ::2] = mx * (rng.random((12, (pw + 1) // 2)) < 0.5)   # 1-sample detail
             planes.append(np.clip(np.rint(p), 0, mx).astype(np.uint16))
@@ -46,7 +47,7 @@ def parse_hmxd(path):
     b = open(path, "rb").read()
     assert b[:4] == b"HMXD"
     ver, n = np.frombuffer(b, "<i4", 2, 4)
-    assert ver == 1
+    assert ver == 2
     off, pics = 12, []
     for _ in range(n):
         poc, w, h, B, qp, ctu, n_tu = (int(v) for v in np.frombuffer(b, "<i4", 7, off))
@@ -59,24 +60,28 @@ def parse_hmxd(path):
             e = n_ctu * ctu * ctu >> (2 if p else 0)
             lev.append(np.frombuffer(b, "<i4", e, off).copy())
             off += 4 * e
+        sao = np.frombuffer(b, SAO_DTYPE, 3 * n_ctu, off).reshape(3, n_ctu).copy()
+        off += 6 * 3 * n_ctu
+        dbk = np.frombuffer(b, "<i4", 3, off).copy()  # disabled, beta_offset_div2, tc_offset_div2
+        off += 12
         rec = []
         for p in range(3):
             pw, ph = w >> (1 if p else 0), h >> (1 if p else 0)
             rec.append(np.frombuffer(b, "<i2", pw * ph, off).reshape(ph, pw).copy())
             off += 2 * pw * ph
-        pics.append(dict(poc=poc, w=w, h=h, B=B, qp=qp, ctu=ctu, tus=tus, lev=lev, rec=rec))
+        pics.append(dict(poc=poc, w=w, h=h, B=B, qp=qp, ctu=ctu, tus=tus, lev=lev, rec=rec, sao=sao, dbk=dbk))
     assert off == len(b)
     return pics
 
 
-def make(name, seed, w, h, n, B, qp, cfg, extra=()):
+def make(name, seed, w, h, n, B, qp, cfg, extra=(), smooth=False):
     enc, tap = os.path.join(REFBIN, "TAppEncoder"), os.path.join(REFBIN, "hm_decision_tap")
     if not (os.path.exists(enc) and os.path.exists(tap)):
         subprocess.check_call(["bash", os.path.join(ROOT, "oracle", "build_ref_apps.sh")])
     with tempfile.TemporaryDirectory() as d:
         yuv, bit, out = (os.path.join(d, f) for f in ("in.yuv", "str.bin", "out.hmxd"))
         with open(yuv, "wb") as f:
-            for planes in synthetic_clip(seed, w, h, n, B):
+            for planes in synthetic_clip(seed, w, h, n, B, smooth):
                 for p in planes:
                     f.write(p.astype(np.uint8 if B == 8 else "<u2").tobytes())
         cmd = [enc, "-c", os.path.join("/root/reference/cfg", cfg), "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "30",
@@ -90,6 +95,8 @@ def make(name, seed, w, h, n, B, qp, cfg, extra=()):
     for i, p in enumerate(pics):
         arrays[f"hdr{i}"] = np.array([p["poc"], p["w"], p["h"], p["B"], p["qp"], p["ctu"]], np.int32)
         arrays[f"tus{i}"] = p["tus"]
+        arrays[f"sao{i}"] = p["sao"]
+        arrays[f"dbk{i}"] = p["dbk"]
         for k in range(3):
             arrays[f"lev{i}_{k}"] = p["lev"][k]
             arrays[f"rec{i}_{k}"] = p["rec"][k]
@@ -97,7 +104,8 @@ def make(name, seed, w, h, n, B, qp, cfg, extra=()):
     np.savez_compressed(path, **arrays)
     sizes = np.bincount(np.concatenate([p["tus"]["log2n"][p["tus"]["plane"] == 0] for p in pics]), minlength=6)[2:]
     ts = sum(int((p["tus"]["flags"] & 1).sum()) for p in pics)
-    print(f"{path}: {len(pics)} picture(s), {nbytes} stream bytes, luma blocks 4/8/16/32 = {sizes.tolist()}, transform-skip blocks {ts}, "
+    sao_on = sum(int((p["sao"]["type"] >= 0).sum()) for p in pics)
+    print(f"{path}: {len(pics)} picture(s), {nbytes} stream bytes, luma blocks 4/8/16/32 = {sizes.tolist()}, transform-skip blocks {ts}, SAO CTU-components on {sao_on}, "
           f"{os.path.getsize(path)} bytes")
 
 
@@ -111,3 +119,8 @@ if __name__ == "__main__":
     # deblocking as the configuration ships it (all-intra: every filtered edge has strength 2), SAO off: the decoder's
     # output is the block path followed by the deblocking filter
     make("intra_main_q34_dbk", 13, 192, 128, 1, 8, 34, "encoder_intra_main.cfg", ["--SAO=0"])
+    # 416x240: 6.5 x 3.75 CTUs (coding units cut by the picture boundary), smoother content for 32x32 blocks, deblocked
+    make("intra_main_q37_416x240_dbk", 14, 416, 240, 1, 8, 37, "encoder_intra_main.cfg", ["--SAO=0"], smooth=True)
+    # the shipped configurations as they are: deblocking and SAO on (the decoder's output = block path, deblocking, SAO)
+    make("intra_main_q32_full", 15, 256, 192, 2, 8, 32, "encoder_intra_main.cfg")
+    make("intra_he10_q30_416x240_full", 16, 416, 240, 1, 10, 30, "encoder_intra_he10.cfg")

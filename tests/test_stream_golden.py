@@ -33,7 +33,7 @@ def pictures(path):
     for i in range(int(d["n"])):
         poc, w, h, B, qp, ctu = (int(v) for v in d[f"hdr{i}"])
         yield dict(poc=poc, w=w, h=h, B=B, qp=qp, ctu=ctu, tus=d[f"tus{i}"], lev=[d[f"lev{i}_{k}"] for k in range(3)],
-                   rec=[d[f"rec{i}_{k}"] for k in range(3)])
+                   rec=[d[f"rec{i}_{k}"] for k in range(3)], sao=np.ascontiguousarray(d[f"sao{i}"]), dbk=[int(v) for v in d[f"dbk{i}"]])
 
 
 def deblock_maps(p):
@@ -53,12 +53,20 @@ def deblock_maps(p):
     return bsv, bsh, np.full((uh, uw), p["qp"], np.int8)
 
 
-def is_deblocked(path):
-    return "_dbk" in os.path.basename(path)
+def is_deblocked(p):
+    return not p["dbk"][0]
+
+
+def has_sao(p):
+    return bool((p["sao"]["type"] >= 0).any())
 
 
 def test_fixtures_present():
-    assert len(FIXTURES) >= 3 and any(is_deblocked(f) for f in FIXTURES)
+    assert len(FIXTURES) >= 6
+    allp = [p for f in FIXTURES for p in pictures(f)]
+    assert any(is_deblocked(p) for p in allp) and any(not is_deblocked(p) for p in allp)
+    sao_types = set(int(t) for p in allp for t in p["sao"]["type"].reshape(-1))
+    assert {-1, 4} <= sao_types and sao_types & {0, 1, 2, 3}, sao_types  # off, band offset, edge offsets
     for f in FIXTURES:
         pics = list(pictures(f))
         assert pics and all(len(p["tus"]) > 100 for p in pics)
@@ -84,10 +92,16 @@ def test_oracle_reconstructs_reference_streams(path):
         st = I3(w, w // 2, w // 2)
         O.hmo_intra_frame_decode(C.byref(cfg), tus.ctypes.data, len(tus), P3(*[a.ctypes.data for a in rec]), st,
                                  P3(*[a.ctypes.data for a in lev]))
-        if is_deblocked(path):
+        if is_deblocked(p):
             bsv, bsh, qpm = deblock_maps(p)
             vp = lambda a: a.ctypes.data_as(C.c_void_p)
-            O.hmo_deblock_picture(P3(*[a.ctypes.data for a in rec]), st, w, h, p["B"], vp(bsv), vp(bsh), vp(qpm), None, 0, 0)
+            O.hmo_deblock_picture(P3(*[a.ctypes.data for a in rec]), st, w, h, p["B"], vp(bsv), vp(bsh), vp(qpm), None, p["dbk"][1], p["dbk"][2])
+        if has_sao(p):
+            out = [np.zeros_like(a) for a in rec]
+            prm = p["sao"]
+            O.hmo_sao_picture(P3(*[a.ctypes.data for a in rec]), P3(*[a.ctypes.data for a in out]), st, w, h, p["B"], p["ctu"],
+                              P3(prm[0].ctypes.data, prm[1].ctypes.data, prm[2].ctypes.data))
+            rec = out
         for k in range(3):
             bad = np.argwhere(rec[k] != p["rec"][k])
             assert not len(bad), (os.path.basename(path), p["poc"], "plane", k, "first mismatch (y, x)", bad[0].tolist(), len(bad))
@@ -112,12 +126,18 @@ def test_gpu_reconstructs_reference_streams(path):
             d_rec = capi.DevPicture(ctx, w, h).zero()
             rec_arr, lev_arr = (capi.Pic * 1)(d_rec.as_pic()), (capi.Levels * 1)(d_lev.as_pic())
             ctx._chk(L.hmx_frame_intra_decode(ctx.h, plan, 1, rec_arr, lev_arr))
-            if is_deblocked(path):
+            if is_deblocked(p):
                 bsv, bsh, qpm = deblock_maps(p)
                 d_bv, d_bh, d_qp = ctx.to_device(bsv), ctx.to_device(bsh), ctx.to_device(qpm)
-                ctx._chk(L.hmx_deblock_picture(ctx.h, C.byref(rec_arr[0]), w, h, d_bv.ptr, d_bh.ptr, d_qp.ptr, None, 0, 0))
+                ctx._chk(L.hmx_deblock_picture(ctx.h, C.byref(rec_arr[0]), w, h, d_bv.ptr, d_bh.ptr, d_qp.ptr, None, p["dbk"][1], p["dbk"][2]))
+            d_out = d_rec
+            if has_sao(p):
+                d_out = capi.DevPicture(ctx, w, h).zero()
+                d_prm = ctx.to_device(p["sao"])
+                a, b = d_rec.as_pic(), d_out.as_pic()
+                ctx._chk(L.hmx_sao_picture(ctx.h, C.byref(a), C.byref(b), w, h, d_prm.ptr, p["sao"].shape[1]))
             ctx.sync()
-            got = d_rec.download()
+            got = d_out.download()
             for k in range(3):
                 bad = np.argwhere(got[k] != p["rec"][k])
                 assert not len(bad), (os.path.basename(path), p["poc"], "plane", k, "first mismatch (y, x)", bad[0].tolist(), len(bad))
