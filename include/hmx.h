@@ -307,6 +307,14 @@ int hmx_frame_intra_decode(hmx_ctx *ctx, const hmx_intra_plan *plan, int n_pics,
  * real stream); all plans of one call share picture size, QP and slice settings. */
 int hmx_frame_intra_encode_multi(hmx_ctx *ctx, const hmx_intra_plan *const *plans, int n_pics, const hmx_pic *org,
                                  const hmx_pic *rec, const hmx_levels *lev);
+/* The same for the intra blocks of an INTER picture: the plan lists only the intra-coded blocks, and they are
+ * reconstructed ONTO what `rec` already holds -- the inter-coded blocks (motion compensation + residual) of the same
+ * picture, which the decoder has reconstructed before any later coding unit predicts from them
+ * (DEC/TDecCu.cpp:384-446 xDecompressCU: xReconInter / xReconIntraQT per coding unit; an intra block only ever reads
+ * samples of coding units that precede it, so "all inter blocks first, then the intra blocks in dependency order"
+ * gives the same picture).  The reconstruction planes are brought into the working pool first. */
+int hmx_frame_intra_decode_onto(hmx_ctx *ctx, const hmx_intra_plan *plan, int n_pics, const hmx_pic *rec,
+                                const hmx_levels *lev);
 int hmx_frame_intra_decode_multi(hmx_ctx *ctx, const hmx_intra_plan *const *plans, int n_pics, const hmx_pic *rec,
                                  const hmx_levels *lev);
 

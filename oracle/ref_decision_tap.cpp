@@ -8,12 +8,17 @@
 // resolved intra mode, transform-skip flag), the parsed levels in the reference's own per-CTU coefficient layout,
 // and the reference's reconstruction of that picture.  tests/golden/make_stream_golden.py turns the file into a
 // fixture; the parity tests then reconstruct the picture from the decisions (oracle on the CPU, libhmx on the
-// GPU) and compare with what the reference decoder itself produced.  Intra pictures only this round.
+// GPU) and compare with what the reference decoder itself produced.
 //
 // File layout (little endian, int32 unless noted):
-//   magic "HMXD", version 2, n_pictures (patched at the end)
-//   per picture: poc, width, height, bit_depth, slice_qp, ctu, n_tu,
-//                n_tu x { u16 x, u16 y, u8 log2n, u8 plane, u8 mode, u8 flags }      (= hmx_tu, include/hmx.h)
+//   magic "HMXD", version 3, n_pictures (patched at the end)
+//   per picture: poc, width, height, bit_depth, slice_qp, ctu, slice_type (0 B, 1 P, 2 I), n_tu, n_pu,
+//                n_tu x { u16 x, u16 y, u8 log2n, u8 plane, u8 mode, u8 flags }      (= hmx_tu, include/hmx.h;
+//                         flags bit 0 transform skip, bit 1 block of an inter coding unit)
+//                n_pu x { u16 x, u16 y, u16 cu_x, u16 cu_y, u8 w, u8 h, i16 poc0, i16 poc1, i16 mv0x, mv0y, mv1x, mv1y }   prediction units
+//                         of the inter coding units, merge / skip resolved; pocN = POC of the reference picture
+//                         of list N, -32768 = list unused; vectors as decoded (TComDataCU::clipMv, which motion
+//                         compensation applies relative to the coding unit's origin cu_x, cu_y, is left to the reader)
 //                3 planes x levels  (CTUs in raster order, ctu*ctu ints each (chroma: /4), TComDataCU::m_pcTrCoeff*)
 //                3 components x n_ctu x { i8 type, u8 band, i8 offset[4] }  SAO as the decoder parsed it, merges
 //                                         resolved (= hmx_sao_lcu; type -1 everywhere when SAO is off for the component)
@@ -29,7 +34,9 @@
 #include "TLibCommon/TComRom.h"
 #include "TLibDecoder/AnnexBread.h"
 #include "TLibDecoder/NALread.h"
+#define private public /* TDecTop::m_pcPic: the picture under decoding, before TDecGop::filterPicture compresses its motion */
 #include "TLibDecoder/TDecTop.h"
+#undef private
 
 // The decoder library reports a picture-digest mismatch through a flag its application owns (decmain.cpp).
 bool g_md5_mismatch = false;
@@ -40,29 +47,34 @@ struct Tu {
   uint16_t x, y;
   uint8_t log2n, plane, mode, flags;
 };
-const uint8_t kTransformSkip = 1; // HMX_TU_TRANSFORM_SKIP
+const uint8_t kTransformSkip = 1, kInter = 2; // HMX_TU_TRANSFORM_SKIP, HMX_TU_INTER
+struct Pu {
+  uint16_t x, y, cu_x, cu_y;
+  uint8_t w, h;
+  int16_t poc0, poc1, mv0x, mv0y, mv1x, mv1y;
+};
 
 void put32(FILE *f, int32_t v) { fwrite(&v, 4, 1, f); }
 
 // Transform blocks of the coding unit that starts at partition `part` of CTU `cu`, in the order
 // TDecCu::xIntraRecQT visits them (DEC/TDecCu.cpp:663-687): luma block, then Cb and Cr of the same node; a
 // 4x4 luma node carries no chroma except the first of its four siblings, which carries the parent's 4x4 chroma.
-void walk(TComDataCU *cu, unsigned part, unsigned depth, unsigned cu_part, int ctu_x, int ctu_y, int ctu, std::vector<Tu> &out) {
+void walk(TComDataCU *cu, unsigned part, unsigned depth, unsigned cu_part, int ctu_x, int ctu_y, int ctu, bool inter, std::vector<Tu> &out) {
   const unsigned n_part = cu->getPic()->getNumPartInCU();
   const unsigned leaf_depth = cu->getDepth(cu_part) + cu->getTransformIdx(part);
   const unsigned span = n_part >> (2 * depth); // partitions covered by a node at this depth
   if (depth < leaf_depth) {
-    for (unsigned q = 0; q < 4; q++) walk(cu, part + q * (span >> 2), depth + 1, cu_part, ctu_x, ctu_y, ctu, out);
+    for (unsigned q = 0; q < 4; q++) walk(cu, part + q * (span >> 2), depth + 1, cu_part, ctu_x, ctu_y, ctu, inter, out);
     return;
   }
   const int size = ctu >> depth, log2n = g_aucConvertToBit[size] + 2;
   const unsigned raster = g_auiZscanToRaster[part];
   const int per_row = ctu / 4; // 4x4 units per CTU row (minimum partition is 4x4 at depth 4)
   const int x = ctu_x + (int)(raster % per_row) * 4, y = ctu_y + (int)(raster / per_row) * 4;
-  const int luma_mode = cu->getLumaIntraDir(part);
+  const int luma_mode = inter ? 0 : cu->getLumaIntraDir(part);
   Tu t;
   t.x = (uint16_t)x, t.y = (uint16_t)y, t.log2n = (uint8_t)log2n, t.plane = 0, t.mode = (uint8_t)luma_mode;
-  t.flags = cu->getTransformSkip(part, TEXT_LUMA) ? kTransformSkip : 0;
+  t.flags = (cu->getTransformSkip(part, TEXT_LUMA) ? kTransformSkip : 0) | (inter ? kInter : 0);
   out.push_back(t);
   // chroma of this node
   unsigned cpart = part;
@@ -72,22 +84,60 @@ void walk(TComDataCU *cu, unsigned part, unsigned depth, unsigned cu_part, int c
     if (part % parent_span) return; // not the first of the four 4x4 siblings
     clog = 2;
   }
-  int cmode = cu->getChromaIntraDir(cu_part);
-  if (cmode == DM_CHROMA_IDX) cmode = cu->getLumaIntraDir(cu_part); // derived from the CU's first luma mode (:576-580)
+  int cmode = inter ? 0 : cu->getChromaIntraDir(cu_part);
+  if (!inter && cmode == DM_CHROMA_IDX) cmode = cu->getLumaIntraDir(cu_part); // derived from the CU's first luma mode (:576-580)
   for (int pl = 1; pl <= 2; pl++) {
     Tu c;
     c.x = (uint16_t)(x >> 1), c.y = (uint16_t)(y >> 1), c.log2n = (uint8_t)clog, c.plane = (uint8_t)pl, c.mode = (uint8_t)cmode;
-    c.flags = cu->getTransformSkip(cpart, pl == 1 ? TEXT_CHROMA_U : TEXT_CHROMA_V) ? kTransformSkip : 0;
+    c.flags = (cu->getTransformSkip(cpart, pl == 1 ? TEXT_CHROMA_U : TEXT_CHROMA_V) ? kTransformSkip : 0) | (inter ? kInter : 0);
     out.push_back(c);
   }
 }
 
-int dump_picture(FILE *f, TComPic *pic) {
+// Prediction units of the inter coding unit of `size` samples at (x, y) whose first partition is `part`
+// (TComDataCU::getPartIndexAndSize, COM/TComDataCU.cpp:3180-3250: the eight partition shapes).
+void units_of(TComDataCU *cu, unsigned part, int x, int y, int size, int ctu_x, int ctu_y, int ctu, std::vector<Pu> &out) {
+  const int q = size / 4, h2 = size / 2;
+  int n = 1, rx[4] = {0, 0, 0, 0}, ry[4] = {0, 0, 0, 0}, rw[4] = {size, 0, 0, 0}, rh[4] = {size, 0, 0, 0};
+  switch (cu->getPartitionSize(part)) {
+  case SIZE_2Nx2N: break;
+  case SIZE_2NxN: n = 2, rh[0] = rh[1] = h2, rw[1] = size, ry[1] = h2; break;
+  case SIZE_Nx2N: n = 2, rw[0] = rw[1] = h2, rh[1] = size, rx[1] = h2; break;
+  case SIZE_NxN:
+    n = 4;
+    for (int i = 0; i < 4; i++) rw[i] = rh[i] = h2, rx[i] = (i & 1) * h2, ry[i] = (i >> 1) * h2;
+    break;
+  case SIZE_2NxnU: n = 2, rh[0] = q, rw[1] = size, rh[1] = size - q, ry[1] = q; break;
+  case SIZE_2NxnD: n = 2, rh[0] = size - q, rw[1] = size, rh[1] = q, ry[1] = size - q; break;
+  case SIZE_nLx2N: n = 2, rw[0] = q, rh[1] = size, rw[1] = size - q, rx[1] = q; break;
+  case SIZE_nRx2N: n = 2, rw[0] = size - q, rh[1] = size, rw[1] = q, rx[1] = size - q; break;
+  default: break;
+  }
+  TComSlice *slice = cu->getSlice();
+  for (int i = 0; i < n; i++) {
+    const int px = x + rx[i], py = y + ry[i];
+    const unsigned idx = g_auiRasterToZscan[((py - ctu_y) / 4) * (ctu / 4) + (px - ctu_x) / 4]; // the unit's first partition
+    Pu u;
+    u.x = (uint16_t)px, u.y = (uint16_t)py, u.cu_x = (uint16_t)x, u.cu_y = (uint16_t)y, u.w = (uint8_t)rw[i], u.h = (uint8_t)rh[i];
+    int16_t *poc[2] = {&u.poc0, &u.poc1}, *mvx[2] = {&u.mv0x, &u.mv1x}, *mvy[2] = {&u.mv0y, &u.mv1y};
+    for (int l = 0; l < 2; l++) {
+      TComCUMvField *mf = cu->getCUMvField(l ? REF_PIC_LIST_1 : REF_PIC_LIST_0);
+      const int ri = mf->getRefIdx((Int)idx);
+      *poc[l] = ri < 0 ? (int16_t)-32768 : (int16_t)slice->getRefPOC(l ? REF_PIC_LIST_1 : REF_PIC_LIST_0, ri);
+      *mvx[l] = ri < 0 ? 0 : (int16_t)mf->getMv((Int)idx).getHor();
+      *mvy[l] = ri < 0 ? 0 : (int16_t)mf->getMv((Int)idx).getVer();
+    }
+    out.push_back(u);
+  }
+}
+
+// The decisions of a picture whose slices have all been decoded; called BEFORE the loop filters run, because
+// TDecGop::filterPicture ends with TComPic::compressMotion (:289), which overwrites the motion of every 16x16 area
+// with that of its first unit.
+int collect(TComPic *pic, std::vector<Tu> &tus, std::vector<Pu> &pus) {
   TComPicYuv *rec = pic->getPicYuvRec();
   const int w = rec->getWidth(), h = rec->getHeight(), ctu = (int)g_uiMaxCUWidth;
-  const int B = (int)(g_uiBitDepth + g_uiBitIncrement);
   const unsigned n_ctu = pic->getNumCUsInFrame(), per_row = pic->getFrameWidthInCU(), n_part = pic->getNumPartInCU();
-  std::vector<Tu> tus;
   for (unsigned a = 0; a < n_ctu; a++) {
     TComDataCU *cu = pic->getCU(a);
     const int cx = (int)(a % per_row) * ctu, cy = (int)(a / per_row) * ctu;
@@ -96,22 +146,30 @@ int dump_picture(FILE *f, TComPic *pic) {
       const unsigned raster = g_auiZscanToRaster[part];
       const int x = cx + (int)(raster % (ctu / 4)) * 4, y = cy + (int)(raster / (ctu / 4)) * 4;
       if (x < w && y < h) { // coding units outside the picture are not coded
-        if (cu->getPredictionMode(part) != MODE_INTRA) {
-          fprintf(stderr, "hm_decision_tap: picture %d holds a non-intra coding unit (inter pictures: next round)\n", pic->getPOC());
-          return 1;
-        }
         if (cu->getIPCMFlag(part) || cu->isLosslessCoded(part)) {
           fprintf(stderr, "hm_decision_tap: PCM / lossless coding units are outside the path\n");
           return 1;
         }
-        walk(cu, part, depth, part, cx, cy, ctu, tus);
+        const bool inter = cu->getPredictionMode(part) != MODE_INTRA;
+        if (inter) units_of(cu, part, x, y, ctu >> depth, cx, cy, ctu, pus);
+        // an inter coding unit without residual has no transform blocks (its reconstruction is its prediction)
+        if (!inter || cu->getQtRootCbf(part)) walk(cu, part, depth, part, cx, cy, ctu, inter, tus);
       }
       part += span;
     }
   }
+  return 0;
+}
+
+int dump_picture(FILE *f, TComPic *pic, const std::vector<Tu> &tus, const std::vector<Pu> &pus) {
+  TComPicYuv *rec = pic->getPicYuvRec();
+  const int w = rec->getWidth(), h = rec->getHeight(), ctu = (int)g_uiMaxCUWidth;
+  const int B = (int)(g_uiBitDepth + g_uiBitIncrement);
+  const unsigned n_ctu = pic->getNumCUsInFrame();
   put32(f, pic->getPOC()), put32(f, w), put32(f, h), put32(f, B), put32(f, pic->getSlice(0)->getSliceQp()), put32(f, ctu);
-  put32(f, (int32_t)tus.size());
+  put32(f, (int32_t)pic->getSlice(0)->getSliceType()), put32(f, (int32_t)tus.size()), put32(f, (int32_t)pus.size());
   fwrite(tus.data(), sizeof(Tu), tus.size(), f);
+  fwrite(pus.data(), sizeof(Pu), pus.size(), f);
   for (int pl = 0; pl < 3; pl++) {
     const size_t per_ctu = (size_t)ctu * ctu >> (pl ? 2 : 0);
     for (unsigned a = 0; a < n_ctu; a++) {
@@ -173,23 +231,24 @@ int main(int argc, char **argv) {
   FILE *f = fopen(argv[2], "wb");
   if (!f) return 2;
   fwrite("HMXD", 1, 4, f);
-  put32(f, 2), put32(f, 0);
+  put32(f, 3), put32(f, 0);
   TDecTop dec;
   dec.create();
   dec.init();
   dec.setPictureDigestEnabled(true);
   int skip = 0, last_display = -1, n_pics = 0, rc = 0;
   auto close_picture = [&]() {
+    TComPic *cur = dec.m_pcPic;
+    if (!cur) return;
+    std::vector<Tu> tus;
+    std::vector<Pu> pus;
+    rc |= collect(cur, tus, pus);
     UInt poc = 0;
     TComList<TComPic *> *list = NULL;
-    dec.executeDeblockAndAlf(poc, list, skip, last_display);
-    if (!list) return;
-    for (TComList<TComPic *>::iterator it = list->begin(); it != list->end(); ++it)
-      if ((*it)->getPOC() == (Int)poc && (*it)->getReconMark()) {
-        rc |= dump_picture(f, *it);
-        n_pics++;
-        break;
-      }
+    dec.executeDeblockAndAlf(poc, list, skip, last_display); // loop filters; the picture's samples are final after this
+    if (!list || rc) return;
+    rc |= dump_picture(f, cur, tus, pus);
+    n_pics++;
   };
   for (size_t i = 0; i < units.size() && !rc;) {
     std::vector<uint8_t> bytes = units[i]; // read() rewrites its buffer

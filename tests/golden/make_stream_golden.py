@@ -18,14 +18,35 @@ sys.path.insert(0, ROOT)
 REFBIN = os.path.join(ROOT, "oracle", "_ref")
 TU_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2n", "u1"), ("plane", "u1"), ("mode", "u1"), ("flags", "u1")])
 SAO_DTYPE = np.dtype([("type", "i1"), ("band", "u1"), ("offset", "i1", 4)])
+PU_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("cu_x", "<u2"), ("cu_y", "<u2"), ("w", "u1"), ("h", "u1"), ("poc0", "<i2"), ("poc1", "<i2"),
+                     ("mv0x", "<i2"), ("mv0y", "<i2"), ("mv1x", "<i2"), ("mv1y", "<i2")])
 
 
-def synthetic_clip(seed, w, h, n, B, smooth=False):
+def synthetic_clip(seed, w, h, n, B, smooth=False, motion=False):
     """Pictures with flat areas, ramps, sharp rectangles, fine noise and text-like 1-sample detail, so that the
     encoder's search picks every block size, many directions and transform skip."""
     rng = np.random.default_rng(seed)
     mx = (1 << B) - 1
     out = []
+    if motion:
+        # one larger canvas seen through a window that pans 4 x 2 luma samples per picture, an object that moves
+        # against the pan, fresh noise every picture and a new rectangle in every picture (uncovered content: the
+        # encoder codes it intra inside inter pictures)
+        canvas = synthetic_clip(seed + 1000, w + 64, h + 64, 1, B)[0]
+        for i in range(n):
+            planes = []
+            for k, c in enumerate(canvas):
+                s = 1 if k else 0
+                ox, oy = (8 + 4 * i) >> s, (8 + 2 * i) >> s
+                p = c[oy:oy + (h >> s), ox:ox + (w >> s)].astype(np.float64)
+                bx, by = (100 - 6 * i) >> s, (40 + 4 * i) >> s
+                p[by:by + (24 >> s), bx:bx + (32 >> s)] = (0.8 if k == 0 else 0.3) * mx
+                nx, ny = int(rng.integers(0, (w >> s) - 24)), int(rng.integers(0, (h >> s) - 24))
+                p[ny:ny + (20 >> s), nx:nx + (20 >> s)] = rng.integers(0, mx + 1, ((20 >> s), (20 >> s)))
+                p += rng.normal(0, 0.004 * mx, p.shape)
+                planes.append(np.clip(np.rint(p), 0, mx).astype(np.uint16))
+            out.append(planes)
+        return out
     for i in range(n):
         planes = []
         for (pw, ph) in ((w, h), (w // 2, h // 2), (w // 2, h // 2)):
@@ -47,13 +68,15 @@ def parse_hmxd(path):
     b = open(path, "rb").read()
     assert b[:4] == b"HMXD"
     ver, n = np.frombuffer(b, "<i4", 2, 4)
-    assert ver == 2
+    assert ver == 3
     off, pics = 12, []
     for _ in range(n):
-        poc, w, h, B, qp, ctu, n_tu = (int(v) for v in np.frombuffer(b, "<i4", 7, off))
-        off += 28
+        poc, w, h, B, qp, ctu, slice_type, n_tu, n_pu = (int(v) for v in np.frombuffer(b, "<i4", 9, off))
+        off += 36
         tus = np.frombuffer(b, TU_DTYPE, n_tu, off).copy()
         off += 8 * n_tu
+        pus = np.frombuffer(b, PU_DTYPE, n_pu, off).copy()
+        off += PU_DTYPE.itemsize * n_pu
         n_ctu = -(-w // ctu) * -(-h // ctu)
         lev = []
         for p in range(3):
@@ -69,19 +92,19 @@ def parse_hmxd(path):
             pw, ph = w >> (1 if p else 0), h >> (1 if p else 0)
             rec.append(np.frombuffer(b, "<i2", pw * ph, off).reshape(ph, pw).copy())
             off += 2 * pw * ph
-        pics.append(dict(poc=poc, w=w, h=h, B=B, qp=qp, ctu=ctu, tus=tus, lev=lev, rec=rec, sao=sao, dbk=dbk))
+        pics.append(dict(poc=poc, w=w, h=h, B=B, qp=qp, ctu=ctu, tus=tus, pus=pus, slice_type=slice_type, lev=lev, rec=rec, sao=sao, dbk=dbk))
     assert off == len(b)
     return pics
 
 
-def make(name, seed, w, h, n, B, qp, cfg, extra=(), smooth=False):
+def make(name, seed, w, h, n, B, qp, cfg, extra=(), smooth=False, motion=False):
     enc, tap = os.path.join(REFBIN, "TAppEncoder"), os.path.join(REFBIN, "hm_decision_tap")
     if not (os.path.exists(enc) and os.path.exists(tap)):
         subprocess.check_call(["bash", os.path.join(ROOT, "oracle", "build_ref_apps.sh")])
     with tempfile.TemporaryDirectory() as d:
         yuv, bit, out = (os.path.join(d, f) for f in ("in.yuv", "str.bin", "out.hmxd"))
         with open(yuv, "wb") as f:
-            for planes in synthetic_clip(seed, w, h, n, B, smooth):
+            for planes in synthetic_clip(seed, w, h, n, B, smooth, motion):
                 for p in planes:
                     f.write(p.astype(np.uint8 if B == 8 else "<u2").tobytes())
         cmd = [enc, "-c", os.path.join("/root/reference/cfg", cfg), "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "30",
@@ -93,7 +116,8 @@ def make(name, seed, w, h, n, B, qp, cfg, extra=(), smooth=False):
         nbytes = os.path.getsize(bit)
     arrays = {"n": np.int32(len(pics)), "stream_bytes": np.int32(nbytes), "command": np.array(" ".join(cmd[3:]))}
     for i, p in enumerate(pics):
-        arrays[f"hdr{i}"] = np.array([p["poc"], p["w"], p["h"], p["B"], p["qp"], p["ctu"]], np.int32)
+        arrays[f"hdr{i}"] = np.array([p["poc"], p["w"], p["h"], p["B"], p["qp"], p["ctu"], p["slice_type"]], np.int32)
+        arrays[f"pus{i}"] = p["pus"]
         arrays[f"tus{i}"] = p["tus"]
         arrays[f"sao{i}"] = p["sao"]
         arrays[f"dbk{i}"] = p["dbk"]
@@ -105,7 +129,10 @@ def make(name, seed, w, h, n, B, qp, cfg, extra=(), smooth=False):
     sizes = np.bincount(np.concatenate([p["tus"]["log2n"][p["tus"]["plane"] == 0] for p in pics]), minlength=6)[2:]
     ts = sum(int((p["tus"]["flags"] & 1).sum()) for p in pics)
     sao_on = sum(int((p["sao"]["type"] >= 0).sum()) for p in pics)
-    print(f"{path}: {len(pics)} picture(s), {nbytes} stream bytes, luma blocks 4/8/16/32 = {sizes.tolist()}, transform-skip blocks {ts}, SAO CTU-components on {sao_on}, "
+    n_pu = sum(len(p["pus"]) for p in pics)
+    n_bi = sum(int(((p["pus"]["poc0"] > -32768) & (p["pus"]["poc1"] > -32768)).sum()) for p in pics)
+    intra_in_inter = sum(int(((p["tus"]["flags"] & 2) == 0).sum()) for p in pics if p["slice_type"] != 2)
+    print(f"{path}: {len(pics)} picture(s), {nbytes} stream bytes, luma blocks 4/8/16/32 = {sizes.tolist()}, transform-skip blocks {ts}, SAO CTU-components on {sao_on}, PUs {n_pu} ({n_bi} bi), intra blocks in inter pictures {intra_in_inter}, "
           f"{os.path.getsize(path)} bytes")
 
 
@@ -124,3 +151,7 @@ if __name__ == "__main__":
     # the shipped configurations as they are: deblocking and SAO on (the decoder's output = block path, deblocking, SAO)
     make("intra_main_q32_full", 15, 256, 192, 2, 8, 32, "encoder_intra_main.cfg")
     make("intra_he10_q30_416x240_full", 16, 416, 240, 1, 10, 30, "encoder_intra_he10.cfg")
+    # inter pictures (low delay P, random access), loop filters off: motion compensation + inter residual + the intra
+    # blocks the encoder chose inside inter pictures
+    make("lowdelay_P_main_q30", 17, 192, 128, 4, 8, 30, "encoder_lowdelay_P_main.cfg", PURE, motion=True)
+    make("randomaccess_main_q32", 18, 192, 128, 9, 8, 32, "encoder_randomaccess_main.cfg", PURE, motion=True)

@@ -965,6 +965,7 @@ struct hmx_ctx {
   std::vector<GraphEntry> graphs;
   uint64_t graph_clock = 0;
   int last_schedule = 0, last_groups = 1; // of the last whole-picture call (hmx_last_call_shape)
+  bool onto_call = false;                 // this call reconstructs onto what the reconstruction planes already hold
   bool pipeline_conv = false;  // this call converts CTU row by CTU row, overlapped with the chain
   bool across_call = false;    // the call being issued uses the across-pictures schedule (interleaved pool)
   int level_mode_min_pics = 1; // measured: the level schedule is at least as fast as the wave schedule at every batch size
@@ -1808,6 +1809,8 @@ static int issue_intra_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, 
     return HMX_OK;
   }
   if (enc) hipLaunchKernelGGL(k_convert_tiled<true>, cgrid, dim3(256), 0, main, d_jobs, 0, 1 << 30);
+  if (c->onto_call) // the pool starts from the caller's reconstruction (the inter-coded parts of the picture)
+    hipLaunchKernelGGL(k_convert_tiled<true>, cgrid, dim3(256), 0, main, d_jobs + (size_t)n_pics * 3, 0, 1 << 30);
   if (tm) HIPCHK(c, hipEventRecord(c->tev[1], main));
   int r = issue_chain_launches(c, plans, plan_stride, n_pics, d_work, enc, use_level, groups, main);
   if (r) return r;
@@ -1985,7 +1988,7 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
   // conversions' traffic and queue behind their waves, so the per-launch figures of bench.py would no longer be the
   // kernel's own.  HMX_PIPELINE_CONV=1 turns it on.
   c->pipeline_conv = false;
-  if (const char *e = getenv("HMX_PIPELINE_CONV")) c->pipeline_conv = across && e[0] != '0' && !getenv("HMX_GRAPH");
+  if (const char *e = getenv("HMX_PIPELINE_CONV")) c->pipeline_conv = across && e[0] != '0' && !getenv("HMX_GRAPH") && !c->onto_call;
   c->last_schedule = !use_level ? 0 : (across ? 2 : 1);
   c->last_groups = groups;
   std::vector<PicWork> hw(n_pics);
@@ -2119,6 +2122,15 @@ extern "C" int hmx_frame_intra_encode(hmx_ctx *c, const hmx_intra_plan *pl, int 
 extern "C" int hmx_frame_intra_decode(hmx_ctx *c, const hmx_intra_plan *pl, int n_pics, const hmx_pic *rec,
                                       const hmx_levels *lev) {
   return frame_intra(c, &pl, 0, n_pics, nullptr, rec, lev, false);
+}
+extern "C" int hmx_frame_intra_decode_onto(hmx_ctx *c, const hmx_intra_plan *pl, int n_pics, const hmx_pic *rec,
+                                           const hmx_levels *lev) {
+  if (!c) return HMX_ERR_ARG;
+  if (getenv("HMX_GRAPH")) return fail(c, HMX_ERR_ARG, "hmx_frame_intra_decode_onto: not available with HMX_GRAPH");
+  c->onto_call = true;
+  const int r = frame_intra(c, &pl, 0, n_pics, nullptr, rec, lev, false);
+  c->onto_call = false;
+  return r;
 }
 extern "C" int hmx_frame_intra_encode_multi(hmx_ctx *c, const hmx_intra_plan *const *plans, int n_pics, const hmx_pic *org,
                                             const hmx_pic *rec, const hmx_levels *lev) {
