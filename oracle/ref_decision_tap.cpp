@@ -11,14 +11,17 @@
 // GPU) and compare with what the reference decoder itself produced.
 //
 // File layout (little endian, int32 unless noted):
-//   magic "HMXD", version 3, n_pictures (patched at the end)
-//   per picture: poc, width, height, bit_depth, slice_qp, ctu, slice_type (0 B, 1 P, 2 I), n_tu, n_pu,
+//   magic "HMXD", version 4, n_pictures (patched at the end)
+//   per picture: poc, width, height, bit_depth, slice_qp, ctu, slice_type (0 B, 1 P, 2 I), n_tu, n_pu, n_cu,
 //                n_tu x { u16 x, u16 y, u8 log2n, u8 plane, u8 mode, u8 flags }      (= hmx_tu, include/hmx.h;
-//                         flags bit 0 transform skip, bit 1 block of an inter coding unit)
+//                         flags bit 0 transform skip, bit 1 block of an inter coding unit, bit 7 (luma blocks) coded
+//                         block flag: what the deblocking filter's boundary strength asks of a transform block)
 //                n_pu x { u16 x, u16 y, u16 cu_x, u16 cu_y, u8 w, u8 h, i16 poc0, i16 poc1, i16 mv0x, mv0y, mv1x, mv1y }   prediction units
 //                         of the inter coding units, merge / skip resolved; pocN = POC of the reference picture
 //                         of list N, -32768 = list unused; vectors as decoded (TComDataCU::clipMv, which motion
 //                         compensation applies relative to the coding unit's origin cu_x, cu_y, is left to the reader)
+//                n_cu x { u16 x, u16 y, u8 log2size, u8 intra, u8 skipped, u8 0 }   coding units (their edges are
+//                         deblocking edges also where a unit has no transform block)
 //                3 planes x levels  (CTUs in raster order, ctu*ctu ints each (chroma: /4), TComDataCU::m_pcTrCoeff*)
 //                3 components x n_ctu x { i8 type, u8 band, i8 offset[4] }  SAO as the decoder parsed it, merges
 //                                         resolved (= hmx_sao_lcu; type -1 everywhere when SAO is off for the component)
@@ -47,7 +50,11 @@ struct Tu {
   uint16_t x, y;
   uint8_t log2n, plane, mode, flags;
 };
-const uint8_t kTransformSkip = 1, kInter = 2; // HMX_TU_TRANSFORM_SKIP, HMX_TU_INTER
+const uint8_t kTransformSkip = 1, kInter = 2, kCbf = 0x80; // HMX_TU_TRANSFORM_SKIP, HMX_TU_INTER; tap-only: luma cbf
+struct Cu {
+  uint16_t x, y;
+  uint8_t log2size, intra, skipped, pad;
+};
 struct Pu {
   uint16_t x, y, cu_x, cu_y;
   uint8_t w, h;
@@ -74,7 +81,8 @@ void walk(TComDataCU *cu, unsigned part, unsigned depth, unsigned cu_part, int c
   const int luma_mode = inter ? 0 : cu->getLumaIntraDir(part);
   Tu t;
   t.x = (uint16_t)x, t.y = (uint16_t)y, t.log2n = (uint8_t)log2n, t.plane = 0, t.mode = (uint8_t)luma_mode;
-  t.flags = (cu->getTransformSkip(part, TEXT_LUMA) ? kTransformSkip : 0) | (inter ? kInter : 0);
+  t.flags = (cu->getTransformSkip(part, TEXT_LUMA) ? kTransformSkip : 0) | (inter ? kInter : 0) |
+            (cu->getCbf(part, TEXT_LUMA, leaf_depth - cu->getDepth(cu_part)) ? kCbf : 0);
   out.push_back(t);
   // chroma of this node
   unsigned cpart = part;
@@ -134,7 +142,7 @@ void units_of(TComDataCU *cu, unsigned part, int x, int y, int size, int ctu_x, 
 // The decisions of a picture whose slices have all been decoded; called BEFORE the loop filters run, because
 // TDecGop::filterPicture ends with TComPic::compressMotion (:289), which overwrites the motion of every 16x16 area
 // with that of its first unit.
-int collect(TComPic *pic, std::vector<Tu> &tus, std::vector<Pu> &pus) {
+int collect(TComPic *pic, std::vector<Tu> &tus, std::vector<Pu> &pus, std::vector<Cu> &cus) {
   TComPicYuv *rec = pic->getPicYuvRec();
   const int w = rec->getWidth(), h = rec->getHeight(), ctu = (int)g_uiMaxCUWidth;
   const unsigned n_ctu = pic->getNumCUsInFrame(), per_row = pic->getFrameWidthInCU(), n_part = pic->getNumPartInCU();
@@ -151,6 +159,8 @@ int collect(TComPic *pic, std::vector<Tu> &tus, std::vector<Pu> &pus) {
           return 1;
         }
         const bool inter = cu->getPredictionMode(part) != MODE_INTRA;
+        Cu cc = {(uint16_t)x, (uint16_t)y, (uint8_t)(g_aucConvertToBit[ctu >> depth] + 2), (uint8_t)!inter, (uint8_t)cu->getSkipFlag(part), 0};
+        cus.push_back(cc);
         if (inter) units_of(cu, part, x, y, ctu >> depth, cx, cy, ctu, pus);
         // an inter coding unit without residual has no transform blocks (its reconstruction is its prediction)
         if (!inter || cu->getQtRootCbf(part)) walk(cu, part, depth, part, cx, cy, ctu, inter, tus);
@@ -161,15 +171,17 @@ int collect(TComPic *pic, std::vector<Tu> &tus, std::vector<Pu> &pus) {
   return 0;
 }
 
-int dump_picture(FILE *f, TComPic *pic, const std::vector<Tu> &tus, const std::vector<Pu> &pus) {
+int dump_picture(FILE *f, TComPic *pic, const std::vector<Tu> &tus, const std::vector<Pu> &pus, const std::vector<Cu> &cus) {
   TComPicYuv *rec = pic->getPicYuvRec();
   const int w = rec->getWidth(), h = rec->getHeight(), ctu = (int)g_uiMaxCUWidth;
   const int B = (int)(g_uiBitDepth + g_uiBitIncrement);
   const unsigned n_ctu = pic->getNumCUsInFrame();
   put32(f, pic->getPOC()), put32(f, w), put32(f, h), put32(f, B), put32(f, pic->getSlice(0)->getSliceQp()), put32(f, ctu);
   put32(f, (int32_t)pic->getSlice(0)->getSliceType()), put32(f, (int32_t)tus.size()), put32(f, (int32_t)pus.size());
+  put32(f, (int32_t)cus.size());
   fwrite(tus.data(), sizeof(Tu), tus.size(), f);
   fwrite(pus.data(), sizeof(Pu), pus.size(), f);
+  fwrite(cus.data(), sizeof(Cu), cus.size(), f);
   for (int pl = 0; pl < 3; pl++) {
     const size_t per_ctu = (size_t)ctu * ctu >> (pl ? 2 : 0);
     for (unsigned a = 0; a < n_ctu; a++) {
@@ -231,7 +243,7 @@ int main(int argc, char **argv) {
   FILE *f = fopen(argv[2], "wb");
   if (!f) return 2;
   fwrite("HMXD", 1, 4, f);
-  put32(f, 3), put32(f, 0);
+  put32(f, 4), put32(f, 0);
   TDecTop dec;
   dec.create();
   dec.init();
@@ -242,12 +254,13 @@ int main(int argc, char **argv) {
     if (!cur) return;
     std::vector<Tu> tus;
     std::vector<Pu> pus;
-    rc |= collect(cur, tus, pus);
+    std::vector<Cu> cus;
+    rc |= collect(cur, tus, pus, cus);
     UInt poc = 0;
     TComList<TComPic *> *list = NULL;
     dec.executeDeblockAndAlf(poc, list, skip, last_display); // loop filters; the picture's samples are final after this
     if (!list || rc) return;
-    rc |= dump_picture(f, cur, tus, pus);
+    rc |= dump_picture(f, cur, tus, pus, cus);
     n_pics++;
   };
   for (size_t i = 0; i < units.size() && !rc;) {

@@ -18,6 +18,7 @@ sys.path.insert(0, ROOT)
 REFBIN = os.path.join(ROOT, "oracle", "_ref")
 TU_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2n", "u1"), ("plane", "u1"), ("mode", "u1"), ("flags", "u1")])
 SAO_DTYPE = np.dtype([("type", "i1"), ("band", "u1"), ("offset", "i1", 4)])
+CU_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2size", "u1"), ("intra", "u1"), ("skipped", "u1"), ("pad", "u1")])
 PU_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("cu_x", "<u2"), ("cu_y", "<u2"), ("w", "u1"), ("h", "u1"), ("poc0", "<i2"), ("poc1", "<i2"),
                      ("mv0x", "<i2"), ("mv0y", "<i2"), ("mv1x", "<i2"), ("mv1y", "<i2")])
 
@@ -68,15 +69,17 @@ def parse_hmxd(path):
     b = open(path, "rb").read()
     assert b[:4] == b"HMXD"
     ver, n = np.frombuffer(b, "<i4", 2, 4)
-    assert ver == 3
+    assert ver == 4
     off, pics = 12, []
     for _ in range(n):
-        poc, w, h, B, qp, ctu, slice_type, n_tu, n_pu = (int(v) for v in np.frombuffer(b, "<i4", 9, off))
-        off += 36
+        poc, w, h, B, qp, ctu, slice_type, n_tu, n_pu, n_cu = (int(v) for v in np.frombuffer(b, "<i4", 10, off))
+        off += 40
         tus = np.frombuffer(b, TU_DTYPE, n_tu, off).copy()
         off += 8 * n_tu
         pus = np.frombuffer(b, PU_DTYPE, n_pu, off).copy()
         off += PU_DTYPE.itemsize * n_pu
+        cus = np.frombuffer(b, CU_DTYPE, n_cu, off).copy()
+        off += 8 * n_cu
         n_ctu = -(-w // ctu) * -(-h // ctu)
         lev = []
         for p in range(3):
@@ -92,7 +95,7 @@ def parse_hmxd(path):
             pw, ph = w >> (1 if p else 0), h >> (1 if p else 0)
             rec.append(np.frombuffer(b, "<i2", pw * ph, off).reshape(ph, pw).copy())
             off += 2 * pw * ph
-        pics.append(dict(poc=poc, w=w, h=h, B=B, qp=qp, ctu=ctu, tus=tus, pus=pus, slice_type=slice_type, lev=lev, rec=rec, sao=sao, dbk=dbk))
+        pics.append(dict(poc=poc, w=w, h=h, B=B, qp=qp, ctu=ctu, tus=tus, pus=pus, cus=cus, slice_type=slice_type, lev=lev, rec=rec, sao=sao, dbk=dbk))
     assert off == len(b)
     return pics
 
@@ -118,6 +121,7 @@ def make(name, seed, w, h, n, B, qp, cfg, extra=(), smooth=False, motion=False):
     for i, p in enumerate(pics):
         arrays[f"hdr{i}"] = np.array([p["poc"], p["w"], p["h"], p["B"], p["qp"], p["ctu"], p["slice_type"]], np.int32)
         arrays[f"pus{i}"] = p["pus"]
+        arrays[f"cus{i}"] = p["cus"]
         arrays[f"tus{i}"] = p["tus"]
         arrays[f"sao{i}"] = p["sao"]
         arrays[f"dbk{i}"] = p["dbk"]
@@ -155,3 +159,6 @@ if __name__ == "__main__":
     # blocks the encoder chose inside inter pictures
     make("lowdelay_P_main_q30", 17, 192, 128, 4, 8, 30, "encoder_lowdelay_P_main.cfg", PURE, motion=True)
     make("randomaccess_main_q32", 18, 192, 128, 9, 8, 32, "encoder_randomaccess_main.cfg", PURE, motion=True)
+    # the same two structures with the loop filters of the shipped configurations (boundary strengths from motion)
+    make("lowdelay_P_main_q32_full", 19, 192, 128, 4, 8, 32, "encoder_lowdelay_P_main.cfg", motion=True)
+    make("randomaccess_main_q34_full", 20, 256, 192, 9, 8, 34, "encoder_randomaccess_main.cfg", motion=True)

@@ -32,7 +32,7 @@ def pictures(path):
     d = np.load(path)
     for i in range(int(d["n"])):
         poc, w, h, B, qp, ctu, slice_type = (int(v) for v in d[f"hdr{i}"])
-        yield dict(poc=poc, w=w, h=h, B=B, qp=qp, ctu=ctu, slice_type=slice_type, pus=d[f"pus{i}"], tus=d[f"tus{i}"], lev=[d[f"lev{i}_{k}"] for k in range(3)],
+        yield dict(poc=poc, w=w, h=h, B=B, qp=qp, ctu=ctu, slice_type=slice_type, pus=d[f"pus{i}"], cus=d[f"cus{i}"], tus=d[f"tus{i}"], lev=[d[f"lev{i}_{k}"] for k in range(3)],
                    rec=[d[f"rec{i}_{k}"] for k in range(3)], sao=np.ascontiguousarray(d[f"sao{i}"]), dbk=[int(v) for v in d[f"dbk{i}"]])
 
 
@@ -51,6 +51,45 @@ def deblock_maps(p):
         if y and y % 2 == 0:
             bsh[y, x:x + n] = 2
     return bsv, bsh, np.full((uh, uw), p["qp"], np.int8)
+
+
+DBK_UNIT = np.dtype([("intra", "u1"), ("cbf", "u1"), ("ref", "i1", 2), ("mv", "<i2", (2, 2))])
+
+
+def strength_inputs(p):
+    """What xGetBoundaryStrengthSingle reads, per 4x4 unit, and the edge maps (hmx_deblock_strengths): intra flag from the
+    coding units, luma coded-block flag from the transform blocks, reference picture (its POC; -1 = list unused) and
+    vector from the prediction units; edges: coding-unit and transform-block sides = 3, prediction-unit sides inside
+    a coding unit = 1 (xSetEdgefilterTU / xSetEdgefilterPU, COM/TComLoopFilter.cpp:264-330)."""
+    uw, uh = p["w"] // 4, p["h"] // 4
+    units = np.zeros((uh, uw), DBK_UNIT)
+    units["ref"][:] = -1
+    ev, eh = np.zeros((uh, uw), np.uint8), np.zeros((uh, uw), np.uint8)
+
+    def sides(x, y, wd, ht, v):
+        if x:
+            ev[y:y + ht, x] |= v
+        if y:
+            eh[y, x:x + wd] |= v
+
+    for c in p["cus"]:
+        n, x, y = (1 << int(c["log2size"])) // 4, int(c["x"]) // 4, int(c["y"]) // 4
+        units["intra"][y:y + n, x:x + n] = c["intra"]
+        sides(x, y, n, n, 3)
+    for t in p["tus"]:
+        if t["plane"] == 0:
+            n, x, y = (1 << int(t["log2n"])) // 4, int(t["x"]) // 4, int(t["y"]) // 4
+            units["cbf"][y:y + n, x:x + n] = 1 if int(t["flags"]) & 0x80 else 0
+            sides(x, y, n, n, 3)
+    for u in p["pus"]:
+        x, y, wd, ht = int(u["x"]) // 4, int(u["y"]) // 4, int(u["w"]) // 4, int(u["h"]) // 4
+        for l in (0, 1):
+            if u[f"poc{l}"] > -32768:
+                units["ref"][y:y + ht, x:x + wd, l] = int(u[f"poc{l}"])
+                units["mv"][y:y + ht, x:x + wd, l, 0] = int(u[f"mv{l}x"])
+                units["mv"][y:y + ht, x:x + wd, l, 1] = int(u[f"mv{l}y"])
+        sides(x, y, wd, ht, 1)
+    return np.ascontiguousarray(units), ev, eh
 
 
 def is_deblocked(p):
@@ -133,9 +172,11 @@ def oracle_decode_sequence(pics):
             O.hmo_intra_frame_decode(C.byref(cfg), intra_tus.ctypes.data, len(intra_tus), P3(*[a.ctypes.data for a in rec]), st,
                                      P3(*[a.ctypes.data for a in lev]))
         if is_deblocked(p):
-            assert not len(p["pus"]), "deblocking of inter pictures: boundary strengths from motion are not derived here"
-            bsv, bsh, qpm = deblock_maps(p)
             vp = lambda a: a.ctypes.data_as(C.c_void_p)
+            bsv, bsh, qpm = deblock_maps(p)
+            if len(p["pus"]):  # boundary strengths from motion, coded-block flags and intra flags (:444-569)
+                units, ev, eh = strength_inputs(p)
+                O.hmo_deblock_strengths(vp(units), vp(ev), vp(eh), w, h, p["ctu"], int(p["slice_type"] == 0), vp(bsv), vp(bsh))
             O.hmo_deblock_picture(P3(*[a.ctypes.data for a in rec]), st, w, h, B, vp(bsv), vp(bsh), vp(qpm), None, p["dbk"][1], p["dbk"][2])
         if has_sao(p):
             flt = [np.zeros_like(a) for a in rec]
@@ -158,7 +199,7 @@ def oracle_decode_sequence(pics):
 
 
 def test_fixtures_present():
-    assert len(FIXTURES) >= 8
+    assert len(FIXTURES) >= 10
     allp = [p for f in FIXTURES for p in pictures(f)]
     assert any(is_deblocked(p) for p in allp) and any(not is_deblocked(p) for p in allp)
     sao_types = set(int(t) for p in allp for t in p["sao"]["type"].reshape(-1))
@@ -234,9 +275,12 @@ def test_gpu_reconstructs_reference_streams(path):
                 L.hmx_intra_plan_destroy(ctx.h, plan)
                 d_lev.free()
             if is_deblocked(p):
-                assert not len(p["pus"])
                 bsv, bsh, qpm = deblock_maps(p)
                 d_bv, d_bh, d_qp = ctx.to_device(bsv), ctx.to_device(bsh), ctx.to_device(qpm)
+                if len(p["pus"]):
+                    units, ev, eh = strength_inputs(p)
+                    d_u, d_ev, d_eh = ctx.to_device(units), ctx.to_device(ev), ctx.to_device(eh)
+                    ctx._chk(L.hmx_deblock_strengths(ctx.h, d_u.ptr, d_ev.ptr, d_eh.ptr, w, h, int(p["slice_type"] == 0), d_bv.ptr, d_bh.ptr))
                 ctx._chk(L.hmx_deblock_picture(ctx.h, C.byref(rec_arr[0]), w, h, d_bv.ptr, d_bh.ptr, d_qp.ptr, None, p["dbk"][1], p["dbk"][2]))
             d_out = d_rec
             if has_sao(p):
