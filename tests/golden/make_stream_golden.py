@@ -144,6 +144,10 @@ def make(name, seed, w, h, n, B, qp, cfg, extra=(), smooth=False, motion=False):
 PURE = ["--DeblockingFilterControlPresent=1", "--LoopFilterDisable=1", "--SAO=0"]
 
 if __name__ == "__main__":
+    only = sys.argv[1:]
+    if only:
+        _make = make
+        make = lambda name, *a, **k: _make(name, *a, **k) if name in only else None  # noqa: E731
     # pure reconstruction: loop filters off, so the decoder's output IS prediction + residual of the block path
     make("intra_main_q27", 11, 192, 128, 2, 8, 27, "encoder_intra_main.cfg", PURE)
     make("intra_he10_q32", 12, 128, 128, 1, 10, 32, "encoder_intra_he10.cfg", PURE)
@@ -162,3 +166,5 @@ if __name__ == "__main__":
     # the same two structures with the loop filters of the shipped configurations (boundary strengths from motion)
     make("lowdelay_P_main_q32_full", 19, 192, 128, 4, 8, 32, "encoder_lowdelay_P_main.cfg", motion=True)
     make("randomaccess_main_q34_full", 20, 256, 192, 9, 8, 34, "encoder_randomaccess_main.cfg", motion=True)
+    # 10-bit low-delay B, 416x240 (coding units cut by the picture boundary, vectors that leave the picture), filters on
+    make("lowdelay_he10_q33_416x240_full", 21, 416, 240, 3, 10, 33, "encoder_lowdelay_he10.cfg", motion=True)

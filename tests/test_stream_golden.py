@@ -199,7 +199,7 @@ def oracle_decode_sequence(pics):
 
 
 def test_fixtures_present():
-    assert len(FIXTURES) >= 10
+    assert len(FIXTURES) >= 11
     allp = [p for f in FIXTURES for p in pictures(f)]
     assert any(is_deblocked(p) for p in allp) and any(not is_deblocked(p) for p in allp)
     sao_types = set(int(t) for p in allp for t in p["sao"]["type"].reshape(-1))
