@@ -100,14 +100,15 @@ def parse_hmxd(path):
     return pics
 
 
-def make(name, seed, w, h, n, B, qp, cfg, extra=(), smooth=False, motion=False):
+def make(name, seed, w, h, n, B, qp, cfg, extra=(), smooth=False, motion=False, keep_org=False):
     enc, tap = os.path.join(REFBIN, "TAppEncoder"), os.path.join(REFBIN, "hm_decision_tap")
     if not (os.path.exists(enc) and os.path.exists(tap)):
         subprocess.check_call(["bash", os.path.join(ROOT, "oracle", "build_ref_apps.sh")])
     with tempfile.TemporaryDirectory() as d:
         yuv, bit, out = (os.path.join(d, f) for f in ("in.yuv", "str.bin", "out.hmxd"))
+        clip = synthetic_clip(seed, w, h, n, B, smooth, motion)
         with open(yuv, "wb") as f:
-            for planes in synthetic_clip(seed, w, h, n, B, smooth, motion):
+            for planes in clip:
                 for p in planes:
                     f.write(p.astype(np.uint8 if B == 8 else "<u2").tobytes())
         cmd = [enc, "-c", os.path.join("/root/reference/cfg", cfg), "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "30",
@@ -122,6 +123,9 @@ def make(name, seed, w, h, n, B, qp, cfg, extra=(), smooth=False, motion=False):
         arrays[f"hdr{i}"] = np.array([p["poc"], p["w"], p["h"], p["B"], p["qp"], p["ctu"], p["slice_type"]], np.int32)
         arrays[f"pus{i}"] = p["pus"]
         arrays[f"cus{i}"] = p["cus"]
+        if keep_org:  # the encoder's input picture (all-intra: coding order = input order)
+            for k in range(3):
+                arrays[f"org{i}_{k}"] = clip[p["poc"]][k].astype(np.int16)
         arrays[f"tus{i}"] = p["tus"]
         arrays[f"sao{i}"] = p["sao"]
         arrays[f"dbk{i}"] = p["dbk"]
@@ -159,6 +163,10 @@ if __name__ == "__main__":
     # the shipped configurations as they are: deblocking and SAO on (the decoder's output = block path, deblocking, SAO)
     make("intra_main_q32_full", 15, 256, 192, 2, 8, 32, "encoder_intra_main.cfg")
     make("intra_he10_q30_416x240_full", 16, 416, 240, 1, 10, 30, "encoder_intra_he10.cfg")
+    # encoder direction: with the flat quantiser (RDOQ off; sign-bit hiding stays on) the levels in the stream are a
+    # function of the decisions and the input picture alone, so the encoder-side chain can be held against them
+    make("intra_main_q29_rdoq0", 22, 192, 128, 2, 8, 29, "encoder_intra_main.cfg", PURE + ["--RDOQ=0"], keep_org=True)
+    make("intra_he10_q35_rdoq0", 23, 128, 128, 1, 10, 35, "encoder_intra_he10.cfg", PURE + ["--RDOQ=0"], keep_org=True)
     # inter pictures (low delay P, random access), loop filters off: motion compensation + inter residual + the intra
     # blocks the encoder chose inside inter pictures
     make("lowdelay_P_main_q30", 17, 192, 128, 4, 8, 30, "encoder_lowdelay_P_main.cfg", PURE, motion=True)

@@ -33,7 +33,7 @@ def pictures(path):
     for i in range(int(d["n"])):
         poc, w, h, B, qp, ctu, slice_type = (int(v) for v in d[f"hdr{i}"])
         yield dict(poc=poc, w=w, h=h, B=B, qp=qp, ctu=ctu, slice_type=slice_type, pus=d[f"pus{i}"], cus=d[f"cus{i}"], tus=d[f"tus{i}"], lev=[d[f"lev{i}_{k}"] for k in range(3)],
-                   rec=[d[f"rec{i}_{k}"] for k in range(3)], sao=np.ascontiguousarray(d[f"sao{i}"]), dbk=[int(v) for v in d[f"dbk{i}"]])
+                   rec=[d[f"rec{i}_{k}"] for k in range(3)], org=[d[f"org{i}_{k}"] for k in range(3)] if f"org{i}_0" in d else None, sao=np.ascontiguousarray(d[f"sao{i}"]), dbk=[int(v) for v in d[f"dbk{i}"]])
 
 
 def deblock_maps(p):
@@ -199,7 +199,7 @@ def oracle_decode_sequence(pics):
 
 
 def test_fixtures_present():
-    assert len(FIXTURES) >= 11
+    assert len(FIXTURES) >= 13 and len(ENC_FIXTURES) >= 2
     allp = [p for f in FIXTURES for p in pictures(f)]
     assert any(is_deblocked(p) for p in allp) and any(not is_deblocked(p) for p in allp)
     sao_types = set(int(t) for p in allp for t in p["sao"]["type"].reshape(-1))
@@ -221,6 +221,50 @@ def test_oracle_reconstructs_reference_streams(path):
         for k in range(3):
             bad = np.argwhere(rec[k] != p["rec"][k])
             assert not len(bad), (os.path.basename(path), "poc", p["poc"], "plane", k, "first mismatch (y, x)", bad[0].tolist(), len(bad))
+
+
+ENC_FIXTURES = [f for f in FIXTURES if "rdoq0" in f]
+
+
+@pytest.mark.parametrize("path", ENC_FIXTURES, ids=[os.path.basename(f)[:-4] for f in ENC_FIXTURES])
+def test_oracle_encodes_like_the_reference_encoder(path):
+    """ENCODER direction (ENC/TEncSearch.cpp:1006-1390 with the flat quantiser + sign-bit hiding): the reference
+    encoder's decisions and its input picture must give the levels it wrote into the stream and its reconstruction."""
+    for p in pictures(path):
+        assert p["org"] is not None and p["slice_type"] == 2
+        rec, lev = ol.o_intra_frame_encode(np.ascontiguousarray(p["tus"], ol.TU_DTYPE), p["w"], p["h"], p["B"], p["qp"], p["org"])
+        want = levels_to_planes(p)
+        for k in range(3):
+            assert np.array_equal(lev[k], want[k]), (os.path.basename(path), p["poc"], "levels", k, int((lev[k] != want[k]).sum()))
+            assert np.array_equal(rec[k], p["rec"][k]), (os.path.basename(path), p["poc"], "reconstruction", k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ENC_FIXTURES, ids=[os.path.basename(f)[:-4] for f in ENC_FIXTURES])
+def test_gpu_encodes_like_the_reference_encoder(path):
+    """hmx_frame_intra_encode on the reference encoder's decisions and input: its stream's levels, its reconstruction."""
+    from thevc_amd import capi
+    L = capi.lib()
+    pics = list(pictures(path))
+    ctx = capi.Context(bit_depth=pics[0]["B"], ctu_size=pics[0]["ctu"])
+    try:
+        for p in pics:
+            w, h = p["w"], p["h"]
+            plan = ctx.intra_plan(p["tus"], capi.PicParam(w, h, p["qp"], 0, capi.I_SLICE, 1))
+            d_org = capi.DevPicture(ctx, w, h).upload(p["org"])
+            d_rec = capi.DevPicture(ctx, w, h).zero()
+            d_lev = capi.DevLevelsZ(ctx, w, h, p["ctu"]).zero()
+            ctx._chk(L.hmx_frame_intra_encode(ctx.h, plan, 1, (capi.Pic * 1)(d_org.as_pic()), (capi.Pic * 1)(d_rec.as_pic()),
+                                              (capi.Levels * 1)(d_lev.as_pic())))
+            ctx.sync()
+            got = d_rec.download()
+            for k in range(3):
+                assert np.array_equal(d_lev.bufs[k].download(np.int32), p["lev"][k]), (os.path.basename(path), p["poc"], "levels", k)
+                assert np.array_equal(got[k], p["rec"][k]), (os.path.basename(path), p["poc"], "reconstruction", k)
+            L.hmx_intra_plan_destroy(ctx.h, plan)
+            d_org.free(), d_rec.free(), d_lev.free()
+    finally:
+        ctx.close()
 
 
 @pytest.mark.gpu
