@@ -167,6 +167,9 @@ if __name__ == "__main__":
     # function of the decisions and the input picture alone, so the encoder-side chain can be held against them
     make("intra_main_q29_rdoq0", 22, 192, 128, 2, 8, 29, "encoder_intra_main.cfg", PURE + ["--RDOQ=0"], keep_org=True)
     make("intra_he10_q35_rdoq0", 23, 128, 128, 1, 10, 35, "encoder_intra_he10.cfg", PURE + ["--RDOQ=0"], keep_org=True)
+    # the same for inter residuals (rounding offset of inter slices): wherever the encoder kept a transform block's
+    # residual, its levels are the flat quantiser's of (input - prediction)
+    make("lowdelay_P_main_q28_rdoq0", 24, 192, 128, 3, 8, 28, "encoder_lowdelay_P_main.cfg", PURE + ["--RDOQ=0"], motion=True, keep_org=True)
     # inter pictures (low delay P, random access), loop filters off: motion compensation + inter residual + the intra
     # blocks the encoder chose inside inter pictures
     make("lowdelay_P_main_q30", 17, 192, 128, 4, 8, 30, "encoder_lowdelay_P_main.cfg", PURE, motion=True)

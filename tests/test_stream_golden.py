@@ -141,7 +141,7 @@ def split_blocks(p):
     return np.ascontiguousarray(p["tus"][~inter], ol.TU_DTYPE), np.ascontiguousarray(p["tus"][inter], ol.TU_DTYPE)
 
 
-def oracle_decode_sequence(pics):
+def oracle_decode_sequence(pics, hook=None):
     """Every picture of a stream, in decoding order, from its decisions; references are this function's own outputs."""
     O = ol.oracle()
     P3, I3 = C.c_void_p * 3, C.c_int * 3
@@ -161,6 +161,8 @@ def oracle_decode_sequence(pics):
                     pm, pw = (m, w) if k == 0 else (m // 2, w // 2)
                     ptrs[i * 3 + k] = ext[poc][k].ctypes.data + 2 * (pm * (pw + 2 * pm) + pm)
             O.hmo_mc_frame(pus.ctypes.data, len(pus), B, ptrs, I3(w + 2 * m, w // 2 + m, w // 2 + m), P3(*[a.ctypes.data for a in rec]), st)
+            if hook:
+                hook(p, [a.copy() for a in rec], lev, inter_tus)
             mx = (1 << B) - 1
             for t in inter_tus:  # residual of the inter coding units onto their prediction (invRecurTransformNxN + addClip)
                 n, k, x, y = 1 << int(t["log2n"]), int(t["plane"]), int(t["x"]), int(t["y"])
@@ -199,7 +201,7 @@ def oracle_decode_sequence(pics):
 
 
 def test_fixtures_present():
-    assert len(FIXTURES) >= 13 and len(ENC_FIXTURES) >= 2
+    assert len(FIXTURES) >= 14 and len(ENC_FIXTURES) >= 3
     allp = [p for f in FIXTURES for p in pictures(f)]
     assert any(is_deblocked(p) for p in allp) and any(not is_deblocked(p) for p in allp)
     sao_types = set(int(t) for p in allp for t in p["sao"]["type"].reshape(-1))
@@ -228,15 +230,42 @@ ENC_FIXTURES = [f for f in FIXTURES if "rdoq0" in f]
 
 @pytest.mark.parametrize("path", ENC_FIXTURES, ids=[os.path.basename(f)[:-4] for f in ENC_FIXTURES])
 def test_oracle_encodes_like_the_reference_encoder(path):
-    """ENCODER direction (ENC/TEncSearch.cpp:1006-1390 with the flat quantiser + sign-bit hiding): the reference
-    encoder's decisions and its input picture must give the levels it wrote into the stream and its reconstruction."""
-    for p in pictures(path):
-        assert p["org"] is not None and p["slice_type"] == 2
+    """ENCODER direction with the flat quantiser + sign-bit hiding.  Intra pictures (ENC/TEncSearch.cpp:1006-1390): the
+    reference encoder's decisions and its input picture must give the levels it wrote into the stream and its
+    reconstruction.  Inter pictures (:4526-4990): wherever the encoder kept a transform block's residual (its rate-
+    distortion check may zero a block, which is a decision), the stream's levels must be the quantised transform of
+    input - prediction."""
+    O = ol.oracle()
+    pics = list(pictures(path))
+    checked = [0, 0]
+
+    def inter_residuals(p, pred, lev, inter_tus):
+        B = p["B"]
+        for t in inter_tus:
+            n, k, x, y = 1 << int(t["log2n"]), int(t["plane"]), int(t["x"]), int(t["y"])
+            want = lev[k][y:y + n, x:x + n]
+            checked[1] += 1
+            if not want.any():
+                continue
+            q = O.hmo_setQPforQuant(p["qp"], int(k != 0), 6 * (B - 8), 0)
+            cfg = ol.quant_cfg(q.per, q.rem, intra_slice=0, sign_hide=1, scan_idx=0)
+            resi = (p["org"][k][y:y + n, x:x + n].astype(np.int32) - pred[k][y:y + n, x:x + n]).astype(np.int16)
+            got, _ = ol.o_transformNxN(resi, n, B, 65535, int(t["flags"]) & 1, cfg)
+            assert np.array_equal(np.asarray(got).reshape(n, n), want), (os.path.basename(path), p["poc"], "inter levels", k, x, y, n)
+            checked[0] += 1
+
+    for p in pics:
+        assert p["org"] is not None
+        if p["slice_type"] != 2:
+            continue
         rec, lev = ol.o_intra_frame_encode(np.ascontiguousarray(p["tus"], ol.TU_DTYPE), p["w"], p["h"], p["B"], p["qp"], p["org"])
         want = levels_to_planes(p)
         for k in range(3):
             assert np.array_equal(lev[k], want[k]), (os.path.basename(path), p["poc"], "levels", k, int((lev[k] != want[k]).sum()))
             assert np.array_equal(rec[k], p["rec"][k]), (os.path.basename(path), p["poc"], "reconstruction", k)
+    if any(p["slice_type"] != 2 for p in pics):
+        oracle_decode_sequence(pics, inter_residuals)
+        assert checked[0] > 150, checked
 
 
 @pytest.mark.gpu
@@ -248,8 +277,39 @@ def test_gpu_encodes_like_the_reference_encoder(path):
     pics = list(pictures(path))
     ctx = capi.Context(bit_depth=pics[0]["B"], ctu_size=pics[0]["ctu"])
     try:
+        refs = {}
         for p in pics:
             w, h = p["w"], p["h"]
+            if p["slice_type"] != 2:  # inter picture: residual chain of the kept blocks on libhmx's own prediction
+                m = MARGIN
+                intra_tus, inter_tus = split_blocks(p)
+                pocs = reference_pocs(p)
+                pus = prediction_units(p, {poc: i for i, poc in enumerate(pocs)})
+                d_pus = ctx.to_device(pus)
+                ref_arr = (capi.Pic * len(pocs))(*[refs[poc].as_pic() for poc in pocs])
+                d_pred, d_org = capi.DevPicture(ctx, w, h).zero(), capi.DevPicture(ctx, w, h).upload(p["org"])
+                d_rec = capi.DevPicture(ctx, w, h, m, m).upload(p["rec"])  # the reference decoder's picture as next reference
+                d_tmp, d_lp = capi.DevPicture(ctx, w, h).zero(), capi.DevPicture(ctx, w, h, dtype=np.int32).zero()
+                pred_arr = (capi.Pic * 1)(d_pred.as_pic())
+                job = (capi.McJob * 1)()
+                job[0].d_pus, job[0].n_pus, job[0].refs, job[0].n_refs = d_pus.ptr, len(pus), ref_arr, len(pocs)
+                job[0].dst, job[0].pic_w, job[0].pic_h = C.pointer(pred_arr[0]), w, h
+                ctx._chk(L.hmx_batch_motionCompensation_multi(ctx.h, 1, job))
+                tl = ctx.tu_list(inter_tus)
+                pp = capi.PicParam(w, h, p["qp"], 0, capi.P_SLICE if p["slice_type"] == 1 else capi.B_SLICE, 1)
+                ctx._chk(L.hmx_batch_residual_transform_recon_multi(ctx.h, tl, 1, (capi.Pic * 1)(d_org.as_pic()), pred_arr,
+                                                                    (capi.Levels * 1)(d_lp.as_pic()), (capi.Pic * 1)(d_tmp.as_pic()), None, C.byref(pp)))
+                ctx._chk(L.hmx_pic_extend_border(ctx.h, C.byref(d_rec.as_pic()), w, h, m, m))
+                ctx.sync()
+                got, want, kept = d_lp.download(), levels_to_planes(p), 0
+                for t in inter_tus:
+                    n, k, x, y = 1 << int(t["log2n"]), int(t["plane"]), int(t["x"]), int(t["y"])
+                    if want[k][y:y + n, x:x + n].any():
+                        assert np.array_equal(got[k][y:y + n, x:x + n], want[k][y:y + n, x:x + n]), (p["poc"], "inter levels", k, x, y, n)
+                        kept += 1
+                assert kept > 50, kept
+                refs[p["poc"]] = d_rec
+                continue
             plan = ctx.intra_plan(p["tus"], capi.PicParam(w, h, p["qp"], 0, capi.I_SLICE, 1))
             d_org = capi.DevPicture(ctx, w, h).upload(p["org"])
             d_rec = capi.DevPicture(ctx, w, h).zero()
@@ -262,6 +322,9 @@ def test_gpu_encodes_like_the_reference_encoder(path):
                 assert np.array_equal(d_lev.bufs[k].download(np.int32), p["lev"][k]), (os.path.basename(path), p["poc"], "levels", k)
                 assert np.array_equal(got[k], p["rec"][k]), (os.path.basename(path), p["poc"], "reconstruction", k)
             L.hmx_intra_plan_destroy(ctx.h, plan)
+            d_ref = capi.DevPicture(ctx, w, h, MARGIN, MARGIN).upload(got)  # reference picture for the stream's inter pictures
+            ctx._chk(L.hmx_pic_extend_border(ctx.h, C.byref(d_ref.as_pic()), w, h, MARGIN, MARGIN))
+            refs[p["poc"]] = d_ref
             d_org.free(), d_rec.free(), d_lev.free()
     finally:
         ctx.close()
