@@ -474,7 +474,7 @@ template <bool ENC, bool ONCE = false, typename SRC>
 __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, const PicDev &P, int count) {
   Lane4Lds &LS = *reinterpret_cast<Lane4Lds *>(smem);
   const int lane = threadIdx.x;
-  const int B = P.bit_depth, mx = (1 << B) - 1, tshift = 15 - B - 2;
+  const int B = P.bit_depth, mx = (1 << B) - 1;
   for (int base = 0; ONCE ? base < 1 : base < count; base += 64) {
     const int i = base + lane;
     const bool active = i < count;
