@@ -876,3 +876,57 @@ def test_inter_path_on_unaligned_planes(ctx):
         for p in range(3):
             assert np.array_equal(got[0][k][p], got[1][k][p]), (name, p)
     assert any(np.count_nonzero(a) for a in got[0][2])
+
+
+@pytest.mark.parametrize("n_pics,schedule", [(1, "wave"), (5, "level"), (70, "level")])
+def test_frame_intra_decode_onto(ctx, n_pics, schedule, monkeypatch):
+    """hmx_frame_intra_decode_onto: the plan lists only SOME blocks (those of an inter picture's intra coding units);
+    they are reconstructed onto what the pictures already hold, and everything else stays.  Both schedules, the
+    across-pictures pool included (70 pictures), vs the oracle decoding the same blocks onto the same pictures."""
+    monkeypatch.setenv("HMX_INTRA_SCHEDULE", schedule)
+    O, B, L = ol.oracle(), ctx.bit_depth, capi.lib()
+    w, h, qp = 136, 72, 29
+    tus_all = workload.make_tus(31, w, h, "mix")
+    sh = (tus_all["plane"] != 0).astype(np.int64)
+    region = ((tus_all["x"].astype(np.int64) << sh) // 16) * 7 + ((tus_all["y"].astype(np.int64) << sh) // 16) * 3
+    tus = np.ascontiguousarray(tus_all[region % 3 != 0])  # two thirds of the 16x16 regions are "intra", the rest stays
+    assert 0 < len(tus) < len(tus_all)
+    rng = np.random.default_rng(5 + n_pics)
+    held = [workload.make_planes(400 + i, w, h, B, "texture") for i in range(n_pics)]  # "inter reconstruction"
+    orgs = [workload.make_planes(500 + i, w, h, B, "noise" if i % 2 else "texture") for i in range(n_pics)]
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
+    st = I3(w, w // 2, w // 2)
+    cfg = ol.frame_cfg(w, h, B, qp)
+    plan = ctx.intra_plan(tus, capi.PicParam(w, h, qp, 0, capi.I_SLICE, 1))
+    d_rec, d_lev, want = [], [], []
+    for i in range(n_pics):
+        # levels that make sense for these blocks: encode the blocks against an original, onto the held picture
+        rec = [np.ascontiguousarray(a, np.int16).copy() for a in held[i]]
+        lev = [np.zeros(a.shape, np.int32) for a in rec]
+        t = np.ascontiguousarray(tus, ol.TU_DTYPE)
+        oo = [np.ascontiguousarray(a, np.int16) for a in orgs[i]]
+        O.hmo_intra_frame_encode(C.byref(cfg), t.ctypes.data, len(t), P3(*[a.ctypes.data for a in oo]), st,
+                                 P3(*[a.ctypes.data for a in rec]), st, P3(*[a.ctypes.data for a in lev]))
+        rec2 = [np.ascontiguousarray(a, np.int16).copy() for a in held[i]]
+        O.hmo_intra_frame_decode(C.byref(cfg), t.ctypes.data, len(t), P3(*[a.ctypes.data for a in rec2]), st, P3(*[a.ctypes.data for a in lev]))
+        assert all(np.array_equal(a, b) for a, b in zip(rec, rec2))
+        want.append(rec2)
+        d_rec.append(capi.DevPicture(ctx, w, h).upload(held[i]))
+        d_lev.append(capi.DevPicture(ctx, w, h, dtype=np.int32).upload(lev))
+    A = lambda lst, T: (T * n_pics)(*[x.as_pic() for x in lst])
+    ctx._chk(L.hmx_frame_intra_decode_onto(ctx.h, plan, n_pics, A(d_rec, capi.Pic), A(d_lev, capi.Levels)))
+    ctx.sync()
+    untouched = np.ones((h, w), bool)
+    for t in tus:
+        if t["plane"] == 0:
+            n = 1 << int(t["log2n"])
+            untouched[int(t["y"]):int(t["y"]) + n, int(t["x"]):int(t["x"]) + n] = False
+    assert untouched.any()
+    for i in range(n_pics):
+        got = d_rec[i].download()
+        for p in range(3):
+            assert np.array_equal(got[p], want[i][p]), ("onto", i, p)
+        assert np.array_equal(got[0][untouched], np.asarray(held[i][0])[untouched])
+    L.hmx_intra_plan_destroy(ctx.h, plan)
+    for d in d_rec + d_lev:
+        d.free()
