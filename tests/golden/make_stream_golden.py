@@ -112,13 +112,13 @@ def make(name, seed, w, h, n, B, qp, cfg, extra=(), smooth=False, motion=False, 
                 for p in planes:
                     f.write(p.astype(np.uint8 if B == 8 else "<u2").tobytes())
         cmd = [enc, "-c", os.path.join("/root/reference/cfg", cfg), "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "30",
-               "-f", str(n), "-q", str(qp), "-b", bit, "--SEIpictureDigest=1", f"--InputBitDepth={B}",
+               "-f", str(n), "-q", str(qp), "-b", bit, "-o", os.path.join(d, "rec.yuv"), "--SEIpictureDigest=1", f"--InputBitDepth={B}",
                f"--InternalBitDepth={B}"] + list(extra)
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
         subprocess.run([tap, bit, out], check=True, stdout=subprocess.DEVNULL)
         pics = parse_hmxd(out)
         nbytes = os.path.getsize(bit)
-    arrays = {"n": np.int32(len(pics)), "stream_bytes": np.int32(nbytes), "command": np.array(" ".join(cmd[3:]))}
+    arrays = {"n": np.int32(len(pics)), "stream_bytes": np.int32(nbytes), "command": np.array(" ".join(c for c in cmd[1:] if not c.startswith(d)))}  # without the temporary paths
     for i, p in enumerate(pics):
         arrays[f"hdr{i}"] = np.array([p["poc"], p["w"], p["h"], p["B"], p["qp"], p["ctu"], p["slice_type"]], np.int32)
         arrays[f"pus{i}"] = p["pus"]
