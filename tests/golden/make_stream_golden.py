@@ -100,7 +100,7 @@ def parse_hmxd(path):
     return pics
 
 
-def make(name, seed, w, h, n, B, qp, cfg, extra=(), smooth=False, motion=False, keep_org=False):
+def make(name, seed, w, h, n, B, qp, cfg, extra=(), smooth=False, motion=False, keep_org=False, out_dir=HERE):
     enc, tap = os.path.join(REFBIN, "TAppEncoder"), os.path.join(REFBIN, "hm_decision_tap")
     if not (os.path.exists(enc) and os.path.exists(tap)):
         subprocess.check_call(["bash", os.path.join(ROOT, "oracle", "build_ref_apps.sh")])
@@ -132,7 +132,7 @@ def make(name, seed, w, h, n, B, qp, cfg, extra=(), smooth=False, motion=False, 
         for k in range(3):
             arrays[f"lev{i}_{k}"] = p["lev"][k]
             arrays[f"rec{i}_{k}"] = p["rec"][k]
-    path = os.path.join(HERE, f"stream_{name}.npz")
+    path = os.path.join(out_dir, f"stream_{name}.npz")
     np.savez_compressed(path, **arrays)
     sizes = np.bincount(np.concatenate([p["tus"]["log2n"][p["tus"]["plane"] == 0] for p in pics]), minlength=6)[2:]
     ts = sum(int((p["tus"]["flags"] & 1).sum()) for p in pics)

@@ -90,6 +90,20 @@ def test_fixtures_present():
         assert any((p["tus"]["flags"] & 1).any() for p in pics), "no transform-skip block in the stream"
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/source/Lib/TLibDecoder"), reason="needs the reference sources (not on the GPU box)")
+def test_fixture_comes_from_the_reference(tmp_path):
+    """Provenance: re-make one fixture with the reference encoder + decoder tap and compare it with the committed file."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_stream_golden", os.path.join(HERE, "golden", "make_stream_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.make("lowdelay_P_main_q30", 17, 192, 128, 4, 8, 30, "encoder_lowdelay_P_main.cfg", mod.PURE, motion=True, out_dir=str(tmp_path))
+    new, old = np.load(tmp_path / "stream_lowdelay_P_main_q30.npz"), np.load(os.path.join(HERE, "golden", "stream_lowdelay_P_main_q30.npz"))
+    assert sorted(new.files) == sorted(old.files)
+    for k in new.files:
+        assert np.array_equal(new[k], old[k]), k
+
+
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(f)[:-4] for f in FIXTURES])
 def test_oracle_reconstructs_reference_streams(path):
     """CPU restatement (decoder direction: DEC/TDecCu.cpp:384-687, motion compensation, loop filters) vs the reference
