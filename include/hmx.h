@@ -315,6 +315,11 @@ int hmx_frame_intra_encode_multi(hmx_ctx *ctx, const hmx_intra_plan *const *plan
  * gives the same picture).  The reconstruction planes are brought into the working pool first. */
 int hmx_frame_intra_decode_onto(hmx_ctx *ctx, const hmx_intra_plan *plan, int n_pics, const hmx_pic *rec,
                                 const hmx_levels *lev);
+/* Encoder side of the same (ENC/TEncSearch.cpp:1006-1390 for the intra coding units the encoder chose inside an inter
+ * picture): prediction from what `rec` holds, residual against `org`, T, flat Q + sign hiding -> levels, IQ, IT,
+ * reconstruction of the plan's blocks onto `rec`. */
+int hmx_frame_intra_encode_onto(hmx_ctx *ctx, const hmx_intra_plan *plan, int n_pics, const hmx_pic *org, const hmx_pic *rec,
+                                const hmx_levels *lev);
 int hmx_frame_intra_decode_multi(hmx_ctx *ctx, const hmx_intra_plan *const *plans, int n_pics, const hmx_pic *rec,
                                  const hmx_levels *lev);
 

@@ -1191,7 +1191,7 @@ static void tu_quant_cfg(const hmo_frame_cfg *cfg, const hmo_tu *t, hmo_qp *qp, 
   qc->per = qp->per;
   qc->rem = qp->rem;
   qc->per_qbits = qp->per;
-  qc->intra_slice = 1;
+  qc->intra_slice = !cfg->inter_slice;
   qc->sign_hide = cfg->sign_hide;
   qc->scan_idx = hmo_coef_scan_idx(N, !chroma, 1, t->mode);
 }

@@ -173,6 +173,7 @@ typedef struct {
   int qp;           /* slice/CU luma QP */
   int chroma_qp_offset;
   int sign_hide;
+  int inter_slice;  /* != 0: the blocks belong to a P/B slice (quantiser rounding 85 instead of 171, :1142) */
 } hmo_frame_cfg;
 
 /* Encoder-side all-intra reconstruction of one picture from decisions (HOT LOOP B of

@@ -64,7 +64,7 @@ def make_est_bits(rng):
 
 class FrameCfg(C.Structure):
     _fields_ = [("pic_w", ci), ("pic_h", ci), ("ctu", ci), ("B", ci), ("qp", ci),
-                ("chroma_qp_offset", ci), ("sign_hide", ci)]
+                ("chroma_qp_offset", ci), ("sign_hide", ci), ("inter_slice", ci)]
 
 
 TU_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2n", "u1"), ("plane", "u1"),
@@ -228,8 +228,8 @@ def o_intra_pred(rec_plane, stride, x, y, N, mode, B, pic_w, pic_h, chroma, ctu=
     return pred
 
 
-def frame_cfg(w, h, B, qp, sign_hide=1, chroma_qp_offset=0, ctu=64):
-    return FrameCfg(w, h, ctu, B, qp, chroma_qp_offset, sign_hide)
+def frame_cfg(w, h, B, qp, sign_hide=1, chroma_qp_offset=0, ctu=64, inter_slice=0):
+    return FrameCfg(w, h, ctu, B, qp, chroma_qp_offset, sign_hide, inter_slice)
 
 
 def o_intra_frame_encode(tus, w, h, B, qp, org, sign_hide=1):

@@ -927,6 +927,17 @@ def test_frame_intra_decode_onto(ctx, n_pics, schedule, monkeypatch):
         for p in range(3):
             assert np.array_equal(got[p], want[i][p]), ("onto", i, p)
         assert np.array_equal(got[0][untouched], np.asarray(held[i][0])[untouched])
+    # encoder side: the same blocks from the originals onto the held pictures -> the oracle's levels and pictures
+    d_org = [capi.DevPicture(ctx, w, h).upload(o) for o in orgs]
+    d_rec2 = [capi.DevPicture(ctx, w, h).upload(held[i]) for i in range(n_pics)]
+    d_lev2 = [capi.DevPicture(ctx, w, h, dtype=np.int32).zero() for _ in range(n_pics)]
+    ctx._chk(L.hmx_frame_intra_encode_onto(ctx.h, plan, n_pics, A(d_org, capi.Pic), A(d_rec2, capi.Pic), A(d_lev2, capi.Levels)))
+    ctx.sync()
+    for i in range(n_pics):
+        got, lv, lv_want = d_rec2[i].download(), d_lev2[i].download(), d_lev[i].download()
+        for p in range(3):
+            assert np.array_equal(got[p], want[i][p]), ("encode onto", i, p)
+            assert np.array_equal(lv[p], lv_want[p]), ("encode onto levels", i, p)
     L.hmx_intra_plan_destroy(ctx.h, plan)
-    for d in d_rec + d_lev:
+    for d in d_rec + d_lev + d_org + d_rec2 + d_lev2:
         d.free()

@@ -156,6 +156,28 @@ def test_oracle_encodes_like_the_reference_encoder(path):
     if any(p["slice_type"] != 2 for p in pics):
         oracle_decode_sequence(pics, inter_residuals)
         assert checked[0] > 150, checked
+        n_intra = 0
+        for p in pics:  # the intra coding units the encoder chose inside inter pictures: encoded onto the picture
+            intra_tus, _ = split_blocks(p)
+            if p["slice_type"] == 2 or not len(intra_tus):
+                continue
+            w, h = p["w"], p["h"]
+            P3, I3 = C.c_void_p * 3, C.c_int * 3
+            st = I3(w, w // 2, w // 2)
+            rec = [np.ascontiguousarray(a, np.int16).copy() for a in p["rec"]]  # holds the inter reconstruction
+            lev = [np.zeros(a.shape, np.int32) for a in rec]
+            org = [np.ascontiguousarray(a, np.int16) for a in p["org"]]
+            cfg = ol.frame_cfg(w, h, p["B"], p["qp"], 1, 0, p["ctu"], inter_slice=1)  # rounding of a P/B slice
+            O.hmo_intra_frame_encode(C.byref(cfg), intra_tus.ctypes.data, len(intra_tus), P3(*[a.ctypes.data for a in org]), st,
+                                     P3(*[a.ctypes.data for a in rec]), st, P3(*[a.ctypes.data for a in lev]))
+            want = levels_to_planes(p)
+            for t in intra_tus:
+                n, k, x, y = 1 << int(t["log2n"]), int(t["plane"]), int(t["x"]), int(t["y"])
+                assert np.array_equal(lev[k][y:y + n, x:x + n], want[k][y:y + n, x:x + n]), (p["poc"], "intra-in-inter levels", k, x, y, n)
+                n_intra += 1
+            for k in range(3):
+                assert np.array_equal(rec[k], p["rec"][k]), (p["poc"], "intra-in-inter reconstruction", k)
+        assert n_intra > 100, n_intra
 
 
 @pytest.mark.gpu
@@ -198,6 +220,22 @@ def test_gpu_encodes_like_the_reference_encoder(path):
                         assert np.array_equal(got[k][y:y + n, x:x + n], want[k][y:y + n, x:x + n]), (p["poc"], "inter levels", k, x, y, n)
                         kept += 1
                 assert kept > 50, kept
+                if len(intra_tus):  # the intra coding units of this inter picture, encoder side, onto the picture
+                    plan = ctx.intra_plan(intra_tus, capi.PicParam(w, h, p["qp"], 0, capi.P_SLICE, 1))  # rounding of a P slice
+                    d_held = capi.DevPicture(ctx, w, h).upload(p["rec"])
+                    d_lz = capi.DevLevelsZ(ctx, w, h, p["ctu"]).zero()
+                    ctx._chk(L.hmx_frame_intra_encode_onto(ctx.h, plan, 1, (capi.Pic * 1)(d_org.as_pic()), (capi.Pic * 1)(d_held.as_pic()),
+                                                           (capi.Levels * 1)(d_lz.as_pic())))
+                    ctx.sync()
+                    held = d_held.download()
+                    raw = [d_lz.bufs[k].download(np.int32) for k in range(3)]
+                    for k in range(3):
+                        assert np.array_equal(held[k], p["rec"][k]), (p["poc"], "intra-in-inter reconstruction", k)
+                    for t in intra_tus:
+                        n, k, x, y = 1 << int(t["log2n"]), int(t["plane"]), int(t["x"]), int(t["y"])
+                        o = z_offset(k, x, y, w, p["ctu"])
+                        assert np.array_equal(raw[k][o:o + n * n], p["lev"][k][o:o + n * n]), (p["poc"], "intra-in-inter levels", k, x, y, n)
+                    L.hmx_intra_plan_destroy(ctx.h, plan)
                 refs[p["poc"]] = d_rec
                 continue
             plan = ctx.intra_plan(p["tus"], capi.PicParam(w, h, p["qp"], 0, capi.I_SLICE, 1))

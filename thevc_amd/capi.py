@@ -153,6 +153,7 @@ def lib():
         L.hmx_frame_intra_encode_multi.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(Levels)]
         L.hmx_frame_intra_decode_multi.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Levels)]
         L.hmx_frame_intra_decode_onto.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Levels)]
+        L.hmx_frame_intra_encode_onto.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(Levels)]
         L.hmx_batch_motionCompensation.argtypes = [vp, vp, ci, C.POINTER(Pic), ci, C.POINTER(Pic)]
         L.hmx_pic_extend_border.argtypes = [vp, C.POINTER(Pic), ci, ci, ci, ci]
         L.hmx_batch_motionCompensation_multi.argtypes = [vp, ci, C.POINTER(McJob)]

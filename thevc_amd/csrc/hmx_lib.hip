@@ -2132,6 +2132,15 @@ extern "C" int hmx_frame_intra_decode_onto(hmx_ctx *c, const hmx_intra_plan *pl,
   c->onto_call = false;
   return r;
 }
+extern "C" int hmx_frame_intra_encode_onto(hmx_ctx *c, const hmx_intra_plan *pl, int n_pics, const hmx_pic *org, const hmx_pic *rec,
+                                           const hmx_levels *lev) {
+  if (!c) return HMX_ERR_ARG;
+  if (getenv("HMX_GRAPH")) return fail(c, HMX_ERR_ARG, "hmx_frame_intra_encode_onto: not available with HMX_GRAPH");
+  c->onto_call = true;
+  const int r = frame_intra(c, &pl, 0, n_pics, org, rec, lev, true);
+  c->onto_call = false;
+  return r;
+}
 extern "C" int hmx_frame_intra_encode_multi(hmx_ctx *c, const hmx_intra_plan *const *plans, int n_pics, const hmx_pic *org,
                                             const hmx_pic *rec, const hmx_levels *lev) {
   return frame_intra(c, plans, 1, n_pics, org, rec, lev, true);
