@@ -270,3 +270,36 @@ def test_gpu_reconstructs_reference_streams(path):
         for k in range(3):
             bad = np.argwhere(got[k] != p["rec"][k])
             assert not len(bad), (os.path.basename(path), "poc", p["poc"], "plane", k, "first mismatch (y, x)", bad[0].tolist(), len(bad))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_pics", [70, 400])
+def test_gpu_real_decisions_across_pictures(n_pics, monkeypatch):
+    """The across-pictures level schedule (one wave = one block of 16/8/4/1 pictures; two picture groups on two streams
+    from 384 pictures) on the block structure of a real stream: n_pics copies of one picture's decisions and levels
+    must all come out as the reference decoder's picture."""
+    from thevc_amd import capi
+    L = capi.lib()
+    path = os.path.join(HERE, "golden", "stream_intra_main_q37_416x240_dbk.npz")
+    p = next(iter(pictures(path)))
+    monkeypatch.setenv("HMX_INTRA_SCHEDULE", "level")
+    ctx = capi.Context(bit_depth=p["B"], ctu_size=p["ctu"])
+    try:
+        w, h = p["w"], p["h"]
+        plan = ctx.intra_plan(p["tus"], capi.PicParam(w, h, p["qp"], 0, capi.I_SLICE, 1))
+        d_lev = capi.DevLevelsZ(ctx, w, h, p["ctu"])
+        for k in range(3):
+            d_lev.bufs[k].upload(np.ascontiguousarray(p["lev"][k], np.int32))
+        d_rec = [capi.DevPicture(ctx, w, h).zero() for _ in range(n_pics)]
+        rec_arr = (capi.Pic * n_pics)(*[d.as_pic() for d in d_rec])
+        lev_arr = (capi.Levels * n_pics)(*[d_lev.as_pic() for _ in range(n_pics)])  # every picture reads the same levels
+        ctx._chk(L.hmx_frame_intra_decode(ctx.h, plan, n_pics, rec_arr, lev_arr))
+        ctx.sync()
+        want = list(oracle_decode_sequence([dict(p, dbk=[1, 0, 0])]))[0]  # before the loop filter
+        for i in sorted({0, 1, 15, 16, n_pics // 2, n_pics - 1}):
+            got = d_rec[i].download()
+            for k in range(3):
+                assert np.array_equal(got[k], want[k]), (i, k)
+        L.hmx_intra_plan_destroy(ctx.h, plan)
+    finally:
+        ctx.close()
