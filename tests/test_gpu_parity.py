@@ -287,7 +287,7 @@ def test_frame_intra_many_pictures_one_plan(ctx, pic, n_pics, across, monkeypatc
     # (the default from 256 pictures up); "pipelined3": the same with three picture groups on three streams
     monkeypatch.setenv("HMX_INTRA_ACROSS", "0" if across == "0" else "1")
     monkeypatch.setenv("HMX_PIPELINE_CONV", "1" if across.startswith("pipelined") else "0")
-    if across in ("pipelined3", "groups3"):  # "groups3": what a call of 960 pictures or more does by default
+    if across in ("pipelined3", "groups3"):  # "groups3": what a call of 640 pictures or more does by default
         monkeypatch.setenv("HMX_INTRA_STREAMS", "3")
     B = ctx.bit_depth
     w, h = pic

@@ -1979,7 +1979,8 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
   // latency floor once each group still fills its waves.  Measured at 1024 pictures (four lanes per 4x4 block):
   // 64.8 / 73.6 / 76.1 / 51.8 Gpx/s with 1 / 2 / 3 / 4 groups (four collapse whether one host thread or one per group
   // issues the launches; likely the runtime's four hardware queues); 256 pictures: 32.6 / 32.9 with 1 / 2.
-  int groups = !across ? 1 : n_pics >= 960 ? 3 : n_pics >= 384 ? 2 : 1;
+  // 640 pictures: 60.2 / 61.5 with 2 / 3 groups, 768: 65.7 / 66.0, 512: 53.7 / 53.8
+  int groups = !across ? 1 : n_pics >= 640 ? 3 : n_pics >= 384 ? 2 : 1;
   if (use_level)
     if (const char *e = getenv("HMX_INTRA_STREAMS")) groups = std::min(std::max(atoi(e), 1), std::min(n_pics, (int)hmx_ctx::kMaxSide));
   c->across_call = across;
