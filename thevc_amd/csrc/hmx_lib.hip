@@ -739,7 +739,7 @@ __global__ __launch_bounds__(64, 4) void k_intra_level(LevelArgs A) {
   const FTu *ltus = A.shared ? A.ltus : W.ltus;
   int c = blockIdx.x;
 #pragma unroll
-  for (int s = 0; s < 4; s++) {
+  for (int s = 3; s >= 0; s--) { // largest blocks first (see k_intra_level_across)
     const int per = s == 3 ? 1 : (16 >> (2 * s)) * 1; // blocks per wave: 16, 8(=64/8), 4, 1
     const int slots = s == 0 ? kSlots4Own : s == 1 ? 8 : s == 2 ? 4 : 1;
     (void)per;
@@ -781,7 +781,9 @@ __global__ __launch_bounds__(64, 4) void k_intra_level_across(AcrossArgs A) {
   __shared__ __attribute__((aligned(16))) char smem[HMX_WAVE_SMEM];
   uint32_t c = blockIdx.x;
 #pragma unroll
-  for (int s = 0; s < 4; s++) {
+  // The size classes of a level in descending block size: waves are dispatched in workgroup order, the 32x32 waves
+  // run longest, and a level lasts until its last wave ends (4x4 first: 84.4 Gpx/s, 32x32 first: 87.4, 1536 pictures).
+  for (int s = 3; s >= 0; s--) {
     const int slots = s == 0 ? kSlots4 : s == 1 ? 8 : s == 2 ? 4 : 1;
     const uint32_t waves = A.row.count[s] * A.cpb[s];
     if (c < waves) {
