@@ -50,26 +50,30 @@ def algorithmic_bytes(tus, n_pics, decode=False):
     return int(((n * n) * (6 if decode else 8) + (4 * n + 1) * 2).sum()) * n_pics
 
 
-def cpu_baseline(tus, w, h, B, qp, seconds_target=12.0):
-    """Time the CPU path on one picture of the same workload (one thread)."""
+def cpu_baseline(tus, w, h, B, qp, org, gpu_result=None, seconds_target=12.0):
+    """Time the CPU path on one picture of the same workload (one thread): the batch's first picture, so that what the
+    CPU computes doubles as a check of what the GPU wrote for it (gpu_result = (reconstruction planes, level planes))."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
-    from thevc_amd import workload
 
-    org = workload.make_planes(100, w, h, B, "texture")
     kind = "reference" if ol.have_ref() else "port"
     fn = ol.r_intra_frame_encode if kind == "reference" else ol.o_intra_frame_encode
     t0 = time.perf_counter()
-    n = 0
+    n, same = 0, None
     while True:
-        fn(tus, w, h, B, qp, org)
+        rec, lev = fn(tus, w, h, B, qp, org)
+        if n == 0 and gpu_result is not None:
+            same = all(np.array_equal(gpu_result[0][p], rec[p]) and np.array_equal(gpu_result[1][p], lev[p]) for p in range(3))
         n += 1
         dt = time.perf_counter() - t0
         if dt >= seconds_target or n >= 256:
             break
-    return {"value": round(n * w * h / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": kind,
-            "sample": f"{n} picture(s) {w}x{h} of the same block structure, single thread, "
-                      + ("HM's own functions from oracle/_ref" if kind == "reference" else "CPU oracle (oracle/hmx_oracle.c)")}
+    out = {"value": round(n * w * h / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": kind,
+           "sample": f"{n} picture(s) {w}x{h} of the same block structure, single thread, "
+                     + ("HM's own functions from oracle/_ref" if kind == "reference" else "CPU oracle (oracle/hmx_oracle.c)")}
+    if same is not None:
+        out["gpu_picture_0_identical"] = bool(same)  # levels and reconstruction of the batch's first picture
+    return out
 
 
 def rank_picture_seeds(rank, n_pics, n_distinct=4):
@@ -315,7 +319,8 @@ def main():
         if verified is not None:
             out["verified_bit_exact_vs_oracle"] = bool(verified)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(tus, w, h_c, B, qp)
+            gpu0 = None if args.decode else (d_rec[0].download(), d_lev[0].to_planes(tus))
+            out["cpu_baseline"] = cpu_baseline(tus, w, h_c, B, qp, src[0], gpu0)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
