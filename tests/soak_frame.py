@@ -1,5 +1,5 @@
 """Soak test of the whole-picture chain against the oracle: random picture sizes (multiples of 8, cut CTUs), bit depths,
-QPs, CTU sizes, picture counts, both level kernels.  python tools/fuzz_frame.py [iterations] [seed]"""
+QPs, CTU sizes, picture counts, both level kernels.  python tests/soak_frame.py [iterations] [seed]"""
 import ctypes as C
 import os
 import sys
