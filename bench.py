@@ -175,7 +175,7 @@ def main():
     ap.add_argument("--workload", default="ai2160p10", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=None,
                     help="pictures per GPU per step (150 MB of HBM each at 2160p: planes, levels and the working pool); "
-                         "default 1536 at 2160p (230 GB of the 288 GB) and 4096 at 1080p, reduced to what the free HBM holds")
+                         "default 1792 at 2160p (272 GB of the 309 GB) and 4096 at 1080p, reduced to what the free HBM holds")
     ap.add_argument("--tiling", default="mix", help="mix | 4 | 8 | 16 | 32 (uniform transform size)")
     ap.add_argument("--segments", type=int, default=16,
                     help="random-access workloads: intra-period segments (32 pictures each) per GPU; the I pictures of all "
@@ -218,7 +218,7 @@ def main():
 
     # Batch size: the chain is latency-bound per dependency level, so throughput comes from pictures in flight;
     # the default fills most of the HBM (18.2 bytes per luma sample: planes 6 + levels 6 + tiled working pool 6.2).
-    F = args.frames if args.frames else (1536 if w >= 3840 else 4096)
+    F = args.frames if args.frames else (1792 if w >= 3840 else 4096)
     free_b, _total_b = torch.cuda.mem_get_info()
     per_pic = int(18.3 * w * h_c)
     if not args.frames and F * per_pic > 0.92 * free_b:

@@ -2,7 +2,7 @@
 # Round profiles of the default bench: kernel-trace stats, the bench line under the profiler, the plain
 # bench line, and the PMC traffic passes.  Copies the summaries to gpurun_out/final/ (then into profiles/).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-TAG=${1:-r01}; F=${2:-1536}
+TAG=${1:-r01}; F=${2:-1792}
 mkdir -p gpurun_out/final
 rm -rf gpurun_out/fp_stats
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fp_stats -- python3 bench.py --frames $F --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/final/${TAG}_bench_under_rocprof.json 2> gpurun_out/fp_stats.err || exit 1
