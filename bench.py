@@ -4,21 +4,27 @@
 Metric (BASELINE.json): Mpixels/sec through transform + pred (+MC), all-intra, bit-exact vs HM.
 One "step" = one pass of the all-intra chain (refs <- recon, intra prediction, residual, T, Q, IQ,
 IT, reconstruction) over a batch of synthetic pictures that is resident in HBM before the timed
-region starts.  Weak scaling: every rank (one process per GPU) owns its own batch of pictures
-(IntraPeriod 1 => pictures are independent, no data-path collective).
+region starts.  Every picture follows its own decisions: by default 64 distinct block structures
+(seeded quadtrees + modes, picture i follows plan i mod 64, so the 64 pictures of a packing group are
+all different) and 64 distinct source pictures.  Weak scaling: every rank (one process per GPU) owns
+its own batch (IntraPeriod 1 => pictures are independent, no data-path collective).
 
     python bench.py --gpus N --steps K --warmup W [--workload ai2160p10|ai2160p8|ai1080p8] [--frames F]
     python bench.py --workload ra2160p8|ra1080p8|ldp1080p8 [--segments S]     (secondary workloads)
 
-Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (k_intra_level_across) against the
-HBM peak with ALGORITHMIC bytes; `cpu_baseline` times the reference's own CPU
-functions (oracle/_ref, kind "reference") or, if that library is absent, the CPU oracle (kind "port")
-on a bounded sample of the same workload, rank 0 at N=1 only.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a child
+`python -m torch.distributed.run`, before this process touches the GPU).  Prints ONE JSON line on rank 0.
+`roofline` prices the dominant kernel (k_intra_packed, one persistent launch per step) against the HBM
+peak with ALGORITHMIC bytes; `cpu_baseline` times the reference's own CPU functions
+(oracle/_ref, kind "reference") or, if that library is absent, the CPU oracle (kind "port") on a bounded
+sample of the same workload, rank 0 at N=1 only: one core in-process (which doubles as a bit-exactness
+check of what the GPU wrote), then all host cores as independent worker processes.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -39,59 +45,105 @@ WORKLOADS = {
     "ldp1080p8": (1920, 1080, 8, 32, "configs[2] Low-delay-P main 1920x1080 8-bit, 64 pictures per sequence"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+METRIC = "Mpixels/sec transform+pred+MC, 2160p all-intra, 1/2/4/8 MI355X; bit-exact vs HM"
 
 
-def algorithmic_bytes(tus, n_pics, decode=False):
-    """Bytes the all-intra chain must move per step: per sample 2 (original) +
+def algorithmic_bytes(tus, decode=False):
+    """Bytes the all-intra chain must move for ONE picture: per sample 2 (original) +
     4 (level written) + 2 (reconstruction written), plus the 4N+1 reference samples (2 B) each block
     gathers from the reconstruction.  Decoder direction: 4 (level read) + 2 (reconstruction written)
     + the reference samples."""
     n = (1 << tus["log2n"].astype(np.int64))
-    return int(((n * n) * (6 if decode else 8) + (4 * n + 1) * 2).sum()) * n_pics
+    return int(((n * n) * (6 if decode else 8) + (4 * n + 1) * 2).sum())
 
 
-def cpu_baseline(tus, w, h, B, qp, checks, seconds_target=12.0):
-    """Time the CPU path on one picture of the same workload (one thread): the batch's first picture, so that what the
-    CPU computes doubles as a check of what the GPU wrote.  checks = [(picture index, original planes, (GPU
-    reconstruction planes, GPU level planes))]; the first entry is timed, further ones (--verify: a picture of every
-    picture group) are computed once."""
+def _cpu_fn():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
-
     kind = "reference" if ol.have_ref() else "port"
-    fn = ol.r_intra_frame_encode if kind == "reference" else ol.o_intra_frame_encode
+    return kind, (ol.r_intra_frame_encode if kind == "reference" else ol.o_intra_frame_encode)
+
+
+def cpu_worker(argv):
+    """`bench.py --cpu-worker W H B QP TILING PLAN_SEED PIC_SEED SECONDS`: one host core codes one synthetic picture of the
+    workload over and over for SECONDS and prints the pictures it finished and the time it took (a worker process of
+    the all-cores leg of cpu_baseline; no GPU, no torch)."""
+    from thevc_amd import workload
+    w, h, B, qp = (int(v) for v in argv[:4])
+    tiling = argv[4] if argv[4] == "mix" else int(argv[4])
+    plan_seed, pic_seed, seconds = int(argv[5]), int(argv[6]), float(argv[7])
+    _kind, fn = _cpu_fn()
+    tus = workload.make_tus(plan_seed, w, h, tiling)
+    org = workload.make_planes(pic_seed, w, h, B, "texture")
+    fn(tus, w, h, B, qp, org)  # warm
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        fn(tus, w, h, B, qp, org)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    print(json.dumps({"pictures": n, "seconds": dt}), flush=True)
+
+
+def cpu_baseline(w, h, B, qp, tiling, checks, seconds_target=10.0, all_cores=True):
+    """checks = [(picture index, decisions (tus), plan seed, picture seed, original planes, (GPU reconstruction planes,
+    GPU level planes))].  Leg 1: ONE core, in this process, codes the first entry over and over for seconds_target (what
+    the CPU computes doubles as a check of what the GPU wrote; further entries -- --verify: a picture of every packing
+    group -- are computed once).  Leg 2: every host core this process may run on, one worker process per core, each
+    coding its own picture of the workload for the same time: the node's CPU throughput on independent pictures."""
+    kind, fn = _cpu_fn()
 
     def identical(result, gpu):
         return all(np.array_equal(gpu[0][p], result[0][p]) and np.array_equal(gpu[1][p], result[1][p]) for p in range(3))
 
-    org = checks[0][1]
+    _i, tus, _ps, _is, org, gpu = checks[0]
     t0 = time.perf_counter()
     n, same = 0, None
     while True:
         rec, lev = fn(tus, w, h, B, qp, org)
         if n == 0:
-            same = identical((rec, lev), checks[0][2])
+            same = identical((rec, lev), gpu)
         n += 1
         dt = time.perf_counter() - t0
         if dt >= seconds_target or n >= 256:
             break
-    out = {"value": round(n * w * h / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": kind,
-           "sample": f"{n} picture(s) {w}x{h} of the same block structure, single thread, "
-                     + ("HM's own functions from oracle/_ref" if kind == "reference" else "CPU oracle (oracle/hmx_oracle.c)")}
+    one = n * w * h / dt / 1e6
+    src = "HM's own functions from oracle/_ref" if kind == "reference" else "CPU oracle (oracle/hmx_oracle.c)"
+    out = {"value": round(one, 3), "unit": "Mpixels/s", "cores": 1, "kind": kind,
+           "sample": f"{n} picture(s) {w}x{h} of the workload's block structure, single thread, {src}"}
     out["gpu_picture_0_identical"] = bool(same)  # levels and reconstruction of the batch's first picture
     if len(checks) > 1:
-        cache = {}
-        for (i, o, gpu) in checks[1:]:
-            key = tuple(a.tobytes()[:64] for a in o)
-            if key not in cache:
-                cache[key] = fn(tus, w, h, B, qp, o)
-            same = same and identical(cache[key], gpu)
+        for (_i, tus_i, _ps, _is, o, g) in checks[1:]:
+            same = same and identical(fn(tus_i, w, h, B, qp, o), g)
         out["gpu_pictures_checked"] = [c[0] for c in checks]
         out["gpu_pictures_identical"] = bool(same)
+    if all_cores and seconds_target > 0:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        procs = []
+        for k in range(cores):
+            cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(w), str(h), str(B), str(qp), str(tiling),
+                   str(checks[0][2]), str(checks[0][3] + k), str(seconds_target)]
+            procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True))
+        rate, done = 0.0, 0
+        for pr in procs:
+            so, _ = pr.communicate()
+            try:
+                r = json.loads(so.strip().splitlines()[-1])
+                rate += r["pictures"] * w * h / r["seconds"] / 1e6
+                done += r["pictures"]
+            except (ValueError, IndexError, KeyError):
+                pass
+        # the contract's fields describe the node: all cores; the single-thread figure stays beside them
+        out.update({"value": round(rate, 3), "cores": cores, "one_core_value": round(one, 3),
+                    "sample": f"{done} pictures {w}x{h} of the workload's block structure in {seconds_target:.0f} s on {cores} "
+                              f"worker processes (one per host core, independent pictures: HM is single-threaded), {src}; "
+                              f"one core alone: {one:.1f} Mpixels/s"})
     return out
 
 
-def rank_picture_seeds(rank, n_pics, n_distinct=4):
+def rank_picture_seeds(rank, n_pics, n_distinct=64):
     """Sharding rule of the all-intra path: pictures are independent, rank r owns its
     own batch; picture i of rank r is synthetic picture seed 1000*r + (i mod n_distinct)."""
     return [1000 * rank + (i % min(n_pics, n_distinct)) for i in range(n_pics)]
@@ -113,79 +165,109 @@ def whole_job_value(pixels_per_rank_step, steps, world, seconds):
     return pixels_per_rank_step * steps * world / seconds / 1e6
 
 
-def bench_random_access(args, torch, dist, rank, local_rank, world):
+def launch_ranks(n):
+    """Start the N ranks of a multi-GPU run: a CHILD process running torch.distributed.run (this process has not
+    touched the GPU and never will; nothing is exec'ed over a process that has).  Returns the child's exit code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def run_random_access(args, torch, dist, rank, local_rank, world, workload_name, segments, steps, warmup):
     """configs[3]: one step = every rank codes its intra-period segments (I pictures through the intra
     chain, B/P pictures through MC + residual transform + reconstruction); boundary I pictures travel
-    between ranks by RCCL send/recv.  Weak scaling: --segments segments PER RANK."""
+    between ranks by RCCL send/recv.  Weak scaling: `segments` segments PER RANK.  Returns the result object."""
     from thevc_amd import capi
     from thevc_amd import ra_pipeline as ra
-    w, h, B, qp, cfg_name = WORKLOADS[args.workload]
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = capi.Context(bit_depth=B, device=local_rank, stream=stream)
-    n_seg = args.segments * world
-    ldp = args.workload.startswith("ldp")
-    wl = ra.RAWorkload(w, h, B, qp, n_segments=n_seg, seed=7, n_distinct=4, structure="ldp" if ldp else "ra",
-                       intra_period=64 if ldp else 32)
-    pipe = ra.RAPipeline(ctx, torch, wl, rank, world, dist if world > 1 else None)
-    n_pics = pipe.load_originals()
+    w, h, B, qp, cfg_name = WORKLOADS[workload_name]
+    # ONE stream for the library's kernels, torch's uploads and the RCCL exchange: the exchange sends reconstructions
+    # the intra chain has just written and motion compensation reads what it received
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx = capi.Context(bit_depth=B, device=local_rank, stream=stream.cuda_stream)
+        n_seg = segments * world
+        ldp = workload_name.startswith("ldp")
+        wl = ra.RAWorkload(w, h, B, qp, n_segments=n_seg, seed=7, n_distinct=4, structure="ldp" if ldp else "ra",
+                           intra_period=64 if ldp else 32)
+        pipe = ra.RAPipeline(ctx, torch, wl, rank, world, dist if world > 1 else None, stream=stream)
+        n_pics = pipe.load_originals()
 
-    def fence():
+        def fence():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(warmup):
+            pipe.run()
+        fence()
+        t0 = time.perf_counter()
+        px = 0
+        for _ in range(steps):
+            px += pipe.run()
+        fence()
+        dt = max_over_ranks(time.perf_counter() - t0, world, "cuda")
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        pipe.run()
-    fence()
-    t0 = time.perf_counter()
-    px = 0
-    for _ in range(args.steps):
-        px += pipe.run()
-    fence()
-    dt = max_over_ranks(time.perf_counter() - t0, world, "cuda")
-    if world > 1:
-        t = torch.tensor([px], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t)
-        px = float(t.item())
-    if rank == 0:
-        print(json.dumps({
-            "metric": "Mpixels/sec transform+pred+MC, 2160p all-intra, 1/2/4/8 MI355X; bit-exact vs HM",
-            "value": round(px / dt / 1e6, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32", "data": "synthetic",
-            "config": {"workload": (f"{args.workload}: {cfg_name}; {args.segments} independent sequence(s) per GPU, I picture through the "
-                                    f"intra chain, P pictures (each references the previous one) MC + residual T/Q + IQ/IT + recon; "
-                                    f"no exchange between sequences" if ldp else
-                                    f"{args.workload}: {cfg_name}; {args.segments} segment(s) of 32 pictures per GPU, I pictures through "
-                                    f"the intra chain, B/P pictures MC (50% bi-pred) + residual T/Q + IQ/IT + recon, boundary I pictures "
-                                    f"exchanged by RCCL send/recv"), "segments_per_gpu": args.segments, "pictures_per_gpu": n_pics,
-                       "width": w, "height": h, "bit_depth": B, "qp": qp},
-            "roofline": None, "note": "secondary workload (SURVEY.md 8e); the roofline line is reported for the all-intra default"}), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+            t = torch.tensor([px], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t)
+            px = float(t.item())
+        exch = pipe.exchange_stats()
+        ctx.sync()
+    out = {
+        "metric": METRIC,
+        "value": round(px / dt / 1e6, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32", "data": "synthetic",
+        "config": {"workload": (f"{workload_name}: {cfg_name}; {segments} independent sequence(s) per GPU, I picture through the "
+                                f"intra chain, P pictures (each references the previous one) MC + residual T/Q + IQ/IT + recon; "
+                                f"no exchange between sequences" if ldp else
+                                f"{workload_name}: {cfg_name}; {segments} segment(s) of 32 pictures per GPU, I pictures through "
+                                f"the intra chain, B/P pictures MC (50% bi-pred) + residual T/Q + IQ/IT + recon, boundary I pictures "
+                                f"exchanged by RCCL send/recv"), "segments_per_gpu": segments, "pictures_per_gpu": n_pics,
+                   "width": w, "height": h, "bit_depth": B, "qp": qp},
+        "exchange": exch,
+    }
+    pipe.free()
     ctx.close()
+    return out
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        return cpu_worker(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="ai2160p10", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=None,
-                    help="pictures per GPU per step (150 MB of HBM each at 2160p: planes, levels and the working pool); "
-                         "default 1792 at 2160p (272 GB of the 309 GB) and 4096 at 1080p, reduced to what the free HBM holds")
+                    help="pictures per GPU per step (157 MB of HBM each at 2160p: planes, levels, the working pool and the packed "
+                         "schedule's tables); default 1728 at 2160p (27 groups of 64) and 4096 at 1080p, reduced to what the free HBM holds")
+    ap.add_argument("--plans", type=int, default=64,
+                    help="distinct decision structures (block quadtrees + modes) in the batch; picture i follows plan i mod PLANS. "
+                         "1 = every picture shares one structure (the best case of round 1's headline)")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic source pictures, cycled over the batch")
     ap.add_argument("--tiling", default="mix", help="mix | 4 | 8 | 16 | 32 (uniform transform size)")
     ap.add_argument("--segments", type=int, default=16,
                     help="random-access workloads: intra-period segments (32 pictures each) per GPU; the I pictures of all "
-                         "segments share one whole-picture call, so few segments are dominated by its 4844 dependent launches")
+                         "segments share one whole-picture call")
     ap.add_argument("--decode", action="store_true",
                     help="time the decoder direction of the chain (levels -> reconstruction, DEC/TDecCu.cpp:469-687) instead of the "
                          "encoder direction; the levels come from one untimed encode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify", action="store_true", help="the cpu_baseline leg also checks a picture of every picture group")
+    ap.add_argument("--one-core-only", action="store_true", help="cpu_baseline: skip the all-cores leg")
+    ap.add_argument("--no-ra", action="store_true", help="N > 1: skip the random-access leg (ra2160p8 with the RCCL exchange) after the all-intra line")
+    ap.add_argument("--ra-segments", type=int, default=4, help="segments per GPU of the random-access leg of a multi-GPU run")
+    ap.add_argument("--verify", action="store_true", help="the cpu_baseline leg also checks a picture of every packing group")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))  # before anything touches the GPU
 
     import torch
     import torch.distributed as dist
@@ -205,25 +287,37 @@ def main():
     from thevc_amd import capi, workload
 
     if args.workload.startswith(("ra", "ldp")):
-        return bench_random_access(args, torch, dist, rank, local_rank, world)
+        out = run_random_access(args, torch, dist, rank, local_rank, world, args.workload, args.segments, args.steps, args.warmup)
+        out["roofline"] = None
+        out["note"] = "secondary workload (SURVEY.md 8e); the roofline line is reported for the all-intra default"
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     w, h, B, qp, cfg_name = WORKLOADS[args.workload]
     h_c = h - (h % 8)  # pictures are coded in multiples of the minimum CU (8): 1080 -> 1072 + cropped row
     tiling = args.tiling if args.tiling == "mix" else int(args.tiling)
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = capi.Context(bit_depth=B, device=local_rank, stream=stream)
+    stream = torch.cuda.Stream()  # the library's kernels, its events and torch's fences share this stream
+    torch.cuda.set_stream(stream)
+    ctx = capi.Context(bit_depth=B, device=local_rank, stream=stream.cuda_stream)
     L = capi.lib()
-    tus = workload.make_tus(1, w, h_c, tiling)
+    n_plans = max(1, args.plans)
+    plan_seeds = [1 + j for j in range(n_plans)]
+    tus_list = [workload.make_tus(sd, w, h_c, tiling) for sd in plan_seeds]
     pp = capi.PicParam(w, h_c, qp, 0, capi.I_SLICE, 1)
-    plan = ctx.intra_plan(tus, pp)
+    plans = [ctx.intra_plan(t, pp) for t in tus_list]
 
-    # Batch size: the chain is latency-bound per dependency level, so throughput comes from pictures in flight;
-    # the default fills most of the HBM (18.2 bytes per luma sample: planes 6 + levels 6 + tiled working pool 6.2).
-    F = args.frames if args.frames else (1792 if w >= 3840 else 4096)
+    # Batch size: throughput comes from pictures in flight; the default fills most of the HBM (planes 6 + levels 6 +
+    # tiled working pool 6.2 bytes per luma sample, plus 16 B per block of the packed schedule's item table).
+    F = args.frames if args.frames else (1728 if w >= 3840 else 4096)
     free_b, _total_b = torch.cuda.mem_get_info()
-    per_pic = int(18.3 * w * h_c)
+    per_pic = int(18.3 * w * h_c) + 18 * max(len(t) for t in tus_list)
     if not args.frames and F * per_pic > 0.92 * free_b:
-        F = max(8, int(0.92 * free_b / per_pic))
-    seeds = rank_picture_seeds(rank, F)  # distinct synthetic pictures, cycled over the batch
+        F = max(8, int(0.92 * free_b / per_pic) // 64 * 64 or 8)
+    n_plans = min(n_plans, F)
+    seeds = rank_picture_seeds(rank, F, max(1, args.distinct))  # distinct synthetic pictures, cycled over the batch
     cache = {}
     for sd in seeds:
         if sd not in cache:
@@ -235,15 +329,24 @@ def main():
     org_arr = (capi.Pic * F)(*[d.as_pic() for d in d_org])
     rec_arr = (capi.Pic * F)(*[d.as_pic() for d in d_rec])
     lev_arr = (capi.Levels * F)(*[d.as_pic() for d in d_lev])
+    plan_arr = (C.c_void_p * F)(*[plans[i % n_plans].value for i in range(F)])
+
+    def encode():
+        if n_plans == 1:
+            ctx._chk(L.hmx_frame_intra_encode(ctx.h, plans[0], F, org_arr, rec_arr, lev_arr))
+        else:
+            ctx._chk(L.hmx_frame_intra_encode_multi(ctx.h, plan_arr, F, org_arr, rec_arr, lev_arr))
 
     def step():
-        if args.decode:
-            ctx._chk(L.hmx_frame_intra_decode(ctx.h, plan, F, rec_arr, lev_arr))
+        if not args.decode:
+            return encode()
+        if n_plans == 1:
+            ctx._chk(L.hmx_frame_intra_decode(ctx.h, plans[0], F, rec_arr, lev_arr))
         else:
-            ctx._chk(L.hmx_frame_intra_encode(ctx.h, plan, F, org_arr, rec_arr, lev_arr))
+            ctx._chk(L.hmx_frame_intra_decode_multi(ctx.h, plan_arr, F, rec_arr, lev_arr))
 
     if args.decode:  # produce the levels the decoder direction consumes
-        ctx._chk(L.hmx_frame_intra_encode(ctx.h, plan, F, org_arr, rec_arr, lev_arr))
+        encode()
 
     def fence():
         if world > 1:
@@ -262,75 +365,98 @@ def main():
     ctx.record(ev1)
     fence()
     dt = time.perf_counter() - t0
+    ctx.sync()  # also reads the packed schedule's abort word: a timed-out dependency wait fails loudly here
     kernel_ms = ctx.elapsed_ms(ev0, ev1)  # HIP events on the stream the kernels run on
     ta, tb, tc = C.c_float(), C.c_float(), C.c_float()
     if L.hmx_last_call_timing(ctx.h, C.byref(ta), C.byref(tb), C.byref(tc)):  # last step: convert / chain / convert
-        # graph replay (HMX_GRAPH=1) records no inner events: the whole step stands in for the chain
         ta.value, tb.value, tc.value = 0.0, kernel_ms / args.steps, 0.0
     sched, groups = C.c_int(), C.c_int()
     L.hmx_last_call_shape(ctx.h, C.byref(sched), C.byref(groups))  # how the library issued the timed calls
     dt = max_over_ranks(dt, world, "cuda")
 
+    out = None
     if rank == 0:
         px_step = w * h_c * F
-        nb, nl, nd = C.c_int(), C.c_int(), C.c_int()
-        L.hmx_intra_plan_info(plan, C.byref(nb), C.byref(nl), C.byref(nd))
-        level_sched = sched.value > 0
-        n_levels = nl.value if level_sched else nd.value   # dependent steps of the chain
-        n_launch = n_levels * groups.value                 # launches of the dominant kernel per step
-        kernel = ["k_intra_wave<%s>", "k_intra_level<%s>", "k_intra_level_across<%s>"][sched.value] % ("false" if args.decode else "true")
+        levels = []
+        for p in plans[:n_plans]:
+            nb, nl, nd = C.c_int(), C.c_int(), C.c_int()
+            L.hmx_intra_plan_info(p, C.byref(nb), C.byref(nl), C.byref(nd))
+            levels.append(nl.value if sched.value > 0 else nd.value)
+        n_levels = max(levels)                                       # dependent steps of the chain
+        n_launch = 1 if sched.value == 3 else n_levels * groups.value  # launches of the dominant kernel per step
+        kernel = ["k_intra_wave<%s>", "k_intra_level<%s>", "k_intra_level_across<%s>", "k_intra_packed<%s>"][sched.value] % (
+            "false" if args.decode else "true")
+        per_plan_bytes = [algorithmic_bytes(t, args.decode) for t in tus_list[:n_plans]]
+        bytes_step = sum(per_plan_bytes[i % n_plans] for i in range(F))
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tj) and args.workload == "ai2160p10" and args.tiling == "mix" and level_sched and not args.decode:
+        tj = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        if os.path.exists(tj) and args.workload == "ai2160p10" and args.tiling == "mix" and not args.decode:
             t = json.load(open(tj))
-            if t.get("frames") == F:
-                # PMC bytes per launch (profiles/r01_traffic.json): gfx950 FETCH_SIZE counts 64 B per
-                # 128-B request (MI355X_MICROARCH.md, HBM), hence the factor 2 on the read side
+            if t.get("frames") == F and t.get("plans") == n_plans and t.get("kernel", "").startswith(kernel.split("<")[0]):
+                # PMC bytes per launch (tools/pmc.sh): gfx950 FETCH_SIZE counts 64 B per 128-B request
+                # (MI355X_MICROARCH.md, HBM), hence the factor 2 on the read side
                 traffic = round((2 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024 / t["launches"])
-        bytes_step = algorithmic_bytes(tus, F, args.decode)
-        # the dominant kernel alone: HIP events around the chain launches of the last step (the two
-        # layout-conversion launches are timed separately); algorithmic bytes / that time
+        step_ms = dt / args.steps * 1e3
+        # the dominant kernel: HIP events around its launch(es) in the last step (the two layout-conversion launches are
+        # timed separately); algorithmic bytes / that time.  `frac_step` prices the same bytes against the WHOLE step the
+        # driver clocks (conversions included).
         ach = bytes_step / (tb.value * 1e-3) / 1e9
+        ach_step = bytes_step / (step_ms * 1e-3) / 1e9
         out = {
-            "metric": "Mpixels/sec transform+pred+MC, 2160p all-intra, 1/2/4/8 MI355X; bit-exact vs HM",
+            "metric": METRIC,
             "value": round(whole_job_value(px_step, args.steps, world, dt), 2),
             "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "ms_per_step": round(step_ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {cfg_name}; all-intra chain " +
                                    ("DECODER direction (intra refs+pred, IQ, IT, recon from levels), " if args.decode else
                                     "(intra refs+pred, T, flat Q+SBH, IQ, IT, recon), ") +
-                                   f"{F} pictures {w}x{h_c} per GPU per step, QP {qp}, TU tiling '{args.tiling}' "
-                                   f"({len(tus)} blocks/picture), frames sharded over ranks, no collective",
-                       "pictures_per_gpu": F, "width": w, "height": h_c, "bit_depth": B, "qp": qp, "tiling": str(args.tiling)},
+                                   f"{F} pictures {w}x{h_c} per GPU per step, QP {qp}, TU tiling '{args.tiling}', "
+                                   f"{n_plans} distinct decision structures (picture i follows plan i mod {n_plans}: "
+                                   f"{min(len(t) for t in tus_list[:n_plans])}-{max(len(t) for t in tus_list[:n_plans])} blocks, "
+                                   f"{min(levels)}-{max(levels)} dependency levels per picture), "
+                                   f"{len(cache)} distinct source pictures, frames sharded over ranks, no collective",
+                       "pictures_per_gpu": F, "width": w, "height": h_c, "bit_depth": B, "qp": qp, "tiling": str(args.tiling),
+                       "distinct_plans": n_plans, "distinct_pictures": len(cache), "shared_decisions": n_plans == 1},
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         # `achieved` is the device-level rate of the chain: the library runs `concurrent_launches`
-                         # picture groups on separate streams, so that many launches of the kernel share the GPU
-                         # at any time and each lasts about chain time / dependency levels
                          "kernel": kernel, "launches_per_step": n_launch, "concurrent_launches": groups.value,
                          "algorithmic_bytes_per_launch": round(bytes_step / n_launch),
-                         "avg_launch_us": round(tb.value * 1e3 / n_levels, 2),
-                         "achieved_per_launch": round(bytes_step / n_launch / (tb.value * 1e-3 / n_levels) / 1e9, 2),
+                         "avg_launch_us": round(tb.value * 1e3 / n_launch, 2),
+                         "achieved_step": round(ach_step, 2), "frac_step": round(ach_step / HBM_PEAK_GBS, 5),
                          "step_ms_events": round(kernel_ms / args.steps, 3),
-                         # conversion in / out as phases of their own (0 when HMX_PIPELINE_CONV=1 overlaps them with the chain)
+                         # conversion in / out as phases of their own
                          "layout_conversion_ms": [round(ta.value, 3), round(tc.value, 3)]},
         }
         if world == 1 and (args.verify or not args.no_cpu_baseline):
-            # --verify: one picture of every picture group (the groups are separate interleave domains of the pool)
-            idx = sorted({0, F // 3, (2 * F) // 3, F // 2, F - 1}) if args.verify else [0]
-            checks = [(i, src[i], (d_rec[i].download(), d_lev[i].to_planes(tus))) for i in idx]
-            out["cpu_baseline"] = cpu_baseline(tus, w, h_c, B, qp, checks, 0.0 if args.no_cpu_baseline else 12.0)
+            # --verify: one picture of every few packing groups, first and last included
+            idx = sorted({0, F - 1} | set(range(0, F, max(64, F // 6 // 64 * 64 or 64)))) if args.verify else [0]
+            checks = [(i, tus_list[i % n_plans], plan_seeds[i % n_plans], seeds[i], src[i],
+                       (d_rec[i].download(), d_lev[i].to_planes(tus_list[i % n_plans]))) for i in idx]
+            out["cpu_baseline"] = cpu_baseline(w, h_c, B, qp, args.tiling, checks, 0.0 if args.no_cpu_baseline else 10.0,
+                                               all_cores=not args.one_core_only)
             if args.verify:
                 cb = out["cpu_baseline"]
                 out["verified_bit_exact_vs_oracle"] = cb.get("gpu_pictures_identical", cb["gpu_picture_0_identical"])
+    # free the batch before the optional random-access leg
+    for d in d_org + d_rec + d_lev:
+        d.free()
+    for p in plans:
+        L.hmx_intra_plan_destroy(ctx.h, p)
+    ctx.close()
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    if world > 1 and not args.no_ra:
+        # north_star's second claim: frame-sharded random access with the reference-picture exchange over RCCL/xGMI
+        ra = run_random_access(args, torch, dist, rank, local_rank, world, "ra2160p8", args.ra_segments, max(1, min(args.steps, 3)), 1)
+        if rank == 0:
+            out["random_access"] = {k: ra[k] for k in ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "config", "exchange")}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
 
 
 if __name__ == "__main__":

@@ -57,6 +57,12 @@ int hmx_create(const hmx_config *cfg, hmx_ctx **out);
 void hmx_destroy(hmx_ctx *ctx);
 const char *hmx_last_error(const hmx_ctx *ctx);
 int hmx_sync(hmx_ctx *ctx);
+/* Tuning knobs (the reference has none: these select between schedules of the SAME arithmetic for A/B runs and
+ * cross-checks).  Each is read once from the environment variable of the same name in hmx_create; hmx_set_option
+ * changes one afterwards, value NULL restores the default.  HMX_INTRA_SCHEDULE = packed (default) | level | wave,
+ * HMX_INTRA_ACROSS, HMX_INTRA_STREAMS, HMX_PIPELINE_CONV, HMX_GRAPH (level schedules), HMX_PACK_SLOTS4 = 16 | 64,
+ * HMX_PACK_K, HMX_PACK_WAVES (packed schedule). */
+int hmx_set_option(hmx_ctx *ctx, const char *name, const char *value);
 /* device memory + timing plumbing so that callers need no HIP headers */
 int hmx_malloc(hmx_ctx *ctx, size_t bytes, void **dptr);
 int hmx_free(hmx_ctx *ctx, void *dptr);

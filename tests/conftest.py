@@ -18,3 +18,20 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "ref" in it.keywords and not have_ref():
             it.add_marker(skip_ref)
+
+
+@pytest.fixture
+def hmx_opts():
+    """Set tuning knobs of a libhmx context for one test (hmx_set_option) and restore the defaults afterwards:
+    hmx_opts(ctx, HMX_INTRA_SCHEDULE="level").  The environment is only read when a context is created."""
+    applied = []
+
+    def set_(ctx, **kw):
+        for k, v in kw.items():
+            ctx.set_option(k, v)
+            applied.append((ctx, k))
+
+    yield set_
+    for ctx, k in applied:
+        if ctx.h:
+            ctx.set_option(k, None)

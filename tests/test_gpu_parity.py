@@ -186,14 +186,14 @@ def _oracle_frame(tus, w, h, B, qp, org, sign_hide=1, decode_levels=None):
     return rec, lev
 
 
-@pytest.mark.parametrize("schedule", ["wave", "level"])
+@pytest.mark.parametrize("schedule", ["wave", "level", "packed"])
 @pytest.mark.parametrize("pic,tiling", [((192, 128), "mix"), ((416, 240), "mix"), ((128, 64), 4), ((128, 64), 8),
                                         ((128, 128), 16), ((128, 128), 32), ((200, 136), "mix")])
-def test_frame_intra_encode_decode(ctx, pic, tiling, schedule, monkeypatch):
+def test_frame_intra_encode_decode(ctx, pic, tiling, schedule, hmx_opts):
     """Whole-picture all-intra chain (refs <- recon, pred, T, Q, IQ, IT, recon) incl. pictures whose
     right/bottom edge cuts the last CTU; 3 pictures per call share one plan.  Both dependency
     schedules of the library (CTU-diagonal waves / picture-wide levels) must give the same bits."""
-    monkeypatch.setenv("HMX_INTRA_SCHEDULE", schedule)
+    hmx_opts(ctx, HMX_INTRA_SCHEDULE=schedule)
     B = ctx.bit_depth
     w, h = pic
     tus = workload.make_tus(7, w, h, tiling)
@@ -278,17 +278,17 @@ def test_frame_intra_parameter_corners(B, qp, ctu, sign_hide, cqo):
 
 @pytest.mark.parametrize("across", ["1", "groups3", "pipelined", "pipelined3", "0"])
 @pytest.mark.parametrize("pic,n_pics", [((64, 64), 70), ((136, 72), 9), ((200, 264), 5)])
-def test_frame_intra_many_pictures_one_plan(ctx, pic, n_pics, across, monkeypatch):
+def test_frame_intra_many_pictures_one_plan(ctx, pic, n_pics, across, hmx_opts):
     """Pictures that follow one plan run in SIMD across pictures (one wave = one block of 16/8/4/1 pictures):
     more pictures than a wave has slots (70 > 64), ragged last chunks (9 = 8 + 1 for 8x8 blocks, 70 = 4 x 16 + 6), and the
     per-picture level kernel (HMX_INTRA_ACROSS=0) must all give the oracle's bits."""
-    monkeypatch.setenv("HMX_INTRA_SCHEDULE", "level")
+    hmx_opts(ctx, HMX_INTRA_SCHEDULE="level")
     # "pipelined": the layout conversions run CTU row by CTU row on their own stream, overlapped with the chain
     # (the default from 256 pictures up); "pipelined3": the same with three picture groups on three streams
-    monkeypatch.setenv("HMX_INTRA_ACROSS", "0" if across == "0" else "1")
-    monkeypatch.setenv("HMX_PIPELINE_CONV", "1" if across.startswith("pipelined") else "0")
+    hmx_opts(ctx, HMX_INTRA_ACROSS="0" if across == "0" else "1")
+    hmx_opts(ctx, HMX_PIPELINE_CONV="1" if across.startswith("pipelined") else "0")
     if across in ("pipelined3", "groups3"):  # "groups3": what a call of 640 pictures or more does by default
-        monkeypatch.setenv("HMX_INTRA_STREAMS", "3")
+        hmx_opts(ctx, HMX_INTRA_STREAMS="3")
     B = ctx.bit_depth
     w, h = pic
     tus = workload.make_tus(21, w, h, "mix")
@@ -502,10 +502,10 @@ def test_batch_motion_compensation(ctx):
                 assert np.array_equal(got2[p], dst[p]), ("mc multi", bi_frac, q, p)
 
 
-@pytest.mark.parametrize("schedule", ["wave", "level"])
-def test_frame_intra_multi_plan(ctx, schedule, monkeypatch):
+@pytest.mark.parametrize("schedule", ["wave", "level", "packed"])
+def test_frame_intra_multi_plan(ctx, schedule, hmx_opts):
     """Every picture with its own block structure and modes (hmx_frame_intra_encode_multi)."""
-    monkeypatch.setenv("HMX_INTRA_SCHEDULE", schedule)
+    hmx_opts(ctx, HMX_INTRA_SCHEDULE=schedule)
     B, L = ctx.bit_depth, capi.lib()
     w, h, n = 256, 192, 4
     pp = capi.PicParam(w, h, 27, 0, capi.I_SLICE, 1)
@@ -534,11 +534,62 @@ def test_frame_intra_multi_plan(ctx, schedule, monkeypatch):
         L.hmx_intra_plan_destroy(ctx.h, p)
 
 
-@pytest.mark.parametrize("schedule", ["wave", "level"])
+@pytest.mark.parametrize("knobs", [{}, {"HMX_PACK_SLOTS4": "64"}, {"HMX_PACK_SLOTS4": "16", "HMX_PACK_K": "3"},
+                                   {"HMX_PACK_WAVES": "3", "HMX_PACK_K": "2"}, {"HMX_PACK_WAVES": "4096", "HMX_PACK_SLOTS4": "64"}])
+@pytest.mark.parametrize("pic,n", [((136, 72), 70), ((256, 192), 9), ((64, 64), 130)])
+def test_frame_intra_packed_own_plans(ctx, pic, n, knobs, hmx_opts):
+    """The packed schedule (one persistent launch, k_intra_packed): n pictures, EVERY ONE with its own block structure
+    and modes, packed into waves across pictures -- more pictures than a group holds (70 and 130 > 64: a full group
+    plus a ragged one), plans with different numbers of dependency levels (uniform 4x4 / 16x16 / 32x32 tilings next to
+    mixed ones), both 4x4 wave shapes, several wave-items per ticket, three persistent waves only (every wave-item
+    then waits behind tickets drawn much earlier) and far more waves than work.  Bit-exact vs the oracle, encoder and
+    decoder direction, both level layouts."""
+    hmx_opts(ctx, HMX_INTRA_SCHEDULE="packed", **knobs)
+    B, L = ctx.bit_depth, capi.lib()
+    w, h = pic
+    qp = 30
+    pp = capi.PicParam(w, h, qp, 0, capi.I_SLICE, 1)
+    tilings = ["mix", "mix", "mix", 4, "mix", 16, "mix", 32, 8]
+    tus = [workload.make_tus(500 + i, w, h, tilings[i % len(tilings)]) for i in range(n)]
+    plans = [ctx.intra_plan(t, pp) for t in tus]
+    orgs = [workload.make_planes(700 + i, w, h, B, "texture" if i % 3 else "noise") for i in range(n)]
+    d_org = [capi.DevPicture(ctx, w, h).upload(o) for o in orgs]
+    d_rec = [capi.DevPicture(ctx, w, h).zero() for _ in range(n)]
+    d_lev = [capi.DevLevelsZ(ctx, w, h) if i % 2 else capi.DevPicture(ctx, w, h, dtype=np.int32).zero() for i in range(n)]
+    A = lambda lst, T: (T * n)(*[x.as_pic() for x in lst])
+    parr = (C.c_void_p * n)(*[p.value for p in plans])
+    for rep in range(2):  # the second call re-uses the schedule tables of the first (same pictures, same plans)
+        ctx._chk(L.hmx_frame_intra_encode_multi(ctx.h, parr, n, A(d_org, capi.Pic), A(d_rec, capi.Pic), A(d_lev, capi.Levels)))
+    ctx.sync()
+    sched, groups = C.c_int(), C.c_int()
+    L.hmx_last_call_shape(ctx.h, C.byref(sched), C.byref(groups))
+    assert sched.value == 3
+    recs = []
+    for i in range(n):
+        rr, lr = ol.o_intra_frame_encode(tus[i], w, h, B, qp, orgs[i])
+        rec = d_rec[i].download()
+        recs.append(rec)
+        lev = d_lev[i].to_planes(tus[i]) if i % 2 else d_lev[i].download()
+        for p in range(3):
+            assert np.array_equal(rec[p], rr[p]), ("recon", i, p)
+            assert np.array_equal(lev[p], lr[p]), ("levels", i, p)
+    d_rec2 = [capi.DevPicture(ctx, w, h).zero() for _ in range(n)]
+    ctx._chk(L.hmx_frame_intra_decode_multi(ctx.h, parr, n, A(d_rec2, capi.Pic), A(d_lev, capi.Levels)))
+    ctx.sync()
+    for i in range(n):
+        a = d_rec2[i].download()
+        assert all(np.array_equal(a[p], recs[i][p]) for p in range(3)), ("decode", i)
+    for p in plans:
+        L.hmx_intra_plan_destroy(ctx.h, p)
+    for d in d_org + d_rec + d_rec2 + d_lev:
+        d.free()
+
+
+@pytest.mark.parametrize("schedule", ["wave", "level", "packed"])
 @pytest.mark.parametrize("pic,tiling", [((416, 240), "mix"), ((200, 136), "mix"), ((128, 128), 32)])
-def test_frame_intra_zorder_levels(ctx, pic, tiling, schedule, monkeypatch):
+def test_frame_intra_zorder_levels(ctx, pic, tiling, schedule, hmx_opts):
     """Levels in the reference's Z-order coefficient layout (hmx_levels.stride == 0), encode + decode."""
-    monkeypatch.setenv("HMX_INTRA_SCHEDULE", schedule)
+    hmx_opts(ctx, HMX_INTRA_SCHEDULE=schedule)
     B, L = ctx.bit_depth, capi.lib()
     w, h = pic
     tus = workload.make_tus(17, w, h, tiling)
@@ -878,12 +929,12 @@ def test_inter_path_on_unaligned_planes(ctx):
     assert any(np.count_nonzero(a) for a in got[0][2])
 
 
-@pytest.mark.parametrize("n_pics,schedule", [(1, "wave"), (5, "level"), (70, "level")])
-def test_frame_intra_decode_onto(ctx, n_pics, schedule, monkeypatch):
+@pytest.mark.parametrize("n_pics,schedule", [(1, "wave"), (5, "level"), (70, "level"), (1, "packed"), (5, "packed"), (70, "packed")])
+def test_frame_intra_decode_onto(ctx, n_pics, schedule, hmx_opts):
     """hmx_frame_intra_decode_onto: the plan lists only SOME blocks (those of an inter picture's intra coding units);
     they are reconstructed onto what the pictures already hold, and everything else stays.  Both schedules, the
     across-pictures pool included (70 pictures), vs the oracle decoding the same blocks onto the same pictures."""
-    monkeypatch.setenv("HMX_INTRA_SCHEDULE", schedule)
+    hmx_opts(ctx, HMX_INTRA_SCHEDULE=schedule)
     O, B, L = ol.oracle(), ctx.bit_depth, capi.lib()
     w, h, qp = 136, 72, 29
     tus_all = workload.make_tus(31, w, h, "mix")

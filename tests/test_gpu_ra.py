@@ -70,9 +70,9 @@ def test_ra_pipeline_vs_oracle(B, fused):
     from thevc_amd import ra_pipeline as ra
     w, h, qp = 192, 128, 30
     wl = ra.RAWorkload(w, h, B, qp, intra_period=8, gop=4, n_segments=2, seed=3)
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = capi.Context(bit_depth=B, stream=stream)
-    pipe = ra.RAPipeline(ctx, torch, wl, fused=fused)  # one-pass inter chain / the two reference-shaped calls
+    stream = torch.cuda.Stream()  # the library's kernels and torch's copies share one stream (ra_pipeline.RAPipeline)
+    ctx = capi.Context(bit_depth=B, stream=stream.cuda_stream)
+    pipe = ra.RAPipeline(ctx, torch, wl, fused=fused, stream=stream)  # one-pass inter chain / the two reference-shaped calls
     pipe.load_originals()
     px = pipe.run()
     torch.cuda.synchronize()
@@ -107,8 +107,9 @@ def test_ldp_pipeline_vs_oracle():
     w, h, qp, B, ip = 192, 128, 33, 8, 5
     wl = ra.RAWorkload(w, h, B, qp, intra_period=ip, n_segments=3, seed=5, structure="ldp")
     assert wl.segment_jobs(1) == [(ip + i, ip + i - 1, None, (ip + i) % 2) for i in range(1, ip)]
-    ctx = capi.Context(bit_depth=B, stream=torch.cuda.current_stream().cuda_stream)
-    pipe = ra.RAPipeline(ctx, torch, wl)
+    stream = torch.cuda.Stream()
+    ctx = capi.Context(bit_depth=B, stream=stream.cuda_stream)
+    pipe = ra.RAPipeline(ctx, torch, wl, stream=stream)
     pipe.load_originals()
     px = pipe.run()
     torch.cuda.synchronize()

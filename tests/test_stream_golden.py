@@ -273,8 +273,9 @@ def test_gpu_reconstructs_reference_streams(path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("schedule", ["level", "packed"])
 @pytest.mark.parametrize("n_pics", [70, 400])
-def test_gpu_real_decisions_across_pictures(n_pics, monkeypatch):
+def test_gpu_real_decisions_across_pictures(n_pics, schedule, monkeypatch):
     """The across-pictures level schedule (one wave = one block of 16/8/4/1 pictures; two picture groups on two streams
     from 384 pictures) on the block structure of a real stream: n_pics copies of one picture's decisions and levels
     must all come out as the reference decoder's picture."""
@@ -282,7 +283,7 @@ def test_gpu_real_decisions_across_pictures(n_pics, monkeypatch):
     L = capi.lib()
     path = os.path.join(HERE, "golden", "stream_intra_main_q37_416x240_dbk.npz")
     p = next(iter(pictures(path)))
-    monkeypatch.setenv("HMX_INTRA_SCHEDULE", "level")
+    monkeypatch.setenv("HMX_INTRA_SCHEDULE", schedule)  # read once, when the context is created
     ctx = capi.Context(bit_depth=p["B"], ctu_size=p["ctu"])
     try:
         w, h = p["w"], p["h"]

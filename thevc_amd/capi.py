@@ -95,6 +95,7 @@ def lib():
         L.hmx_last_error.argtypes = [vp]
         L.hmx_last_error.restype = C.c_char_p
         L.hmx_sync.argtypes = [vp]
+        L.hmx_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
         L.hmx_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
         L.hmx_free.argtypes = [vp, vp]
         L.hmx_upload.argtypes = [vp, vp, vp, C.c_size_t]
@@ -239,6 +240,10 @@ class Context:
 
     def sync(self):
         self._chk(lib().hmx_sync(self.h))
+
+    def set_option(self, name, value):
+        """A tuning knob of include/hmx.h (hmx_set_option); value None restores the default."""
+        self._chk(lib().hmx_set_option(self.h, name.encode(), None if value is None else str(value).encode()))
 
     def alloc(self, nbytes):
         return DevBuf(self, nbytes)

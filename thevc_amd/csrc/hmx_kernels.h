@@ -83,6 +83,41 @@ __device__ __forceinline__ T *as_global(T *p) {
 typedef short s4v __attribute__((ext_vector_type(4)));
 typedef int i4v __attribute__((ext_vector_type(4)));
 
+// ---------------------------------------------------------------------------------------------
+// Accesses to the working reconstruction.  COH = the packed schedule (k_intra_packed): blocks of one
+// launch hand their reconstruction to later blocks of the SAME launch, on any CU of any XCD.  A CU's
+// vector L1 is never refreshed by another CU's stores and an XCD's L2 keeps dirty lines to itself, so
+// every store of the reconstruction is write-through (sc1) and every load of it bypasses the L1 (sc1);
+// the producer drains its stores (s_waitcnt vmcnt(0)) before it signals, the consumer polls the signal
+// with an sc1 load before its first load (MI355X_MICROARCH.md, inter-workgroup visibility: "every store
+// sc1 + drained, every load sc1").  Relaxed agent-scope atomics are how HIP spells those instructions
+// (global_load/store_dwordx2 ... sc1); 8 bytes = one tile row is the unit of every access.
+// COH = false: the level-synchronous schedules, where a kernel boundary separates producer and consumer.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+template <bool COH>
+__device__ __forceinline__ s4v ld_rec4(const short *p) { // 4 samples, 8-byte aligned
+  if constexpr (COH) {
+    const unsigned long long v = __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s4v r;
+    __builtin_memcpy(&r, &v, 8);
+    return r;
+  } else {
+    return *reinterpret_cast<const s4v *>(p);
+  }
+}
+template <bool COH>
+__device__ __forceinline__ void st_rec4(short *p, s4v v) {
+  if constexpr (COH) {
+    unsigned long long u;
+    __builtin_memcpy(&u, &v, 8);
+    __hip_atomic_store((gu64 *)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    *reinterpret_cast<s4v *>(p) = v;
+  }
+}
+
 // row r of the aligned N x N block (N >= 8) whose first sample has offset b0; pb = p + tphys(b0)
 template <int N>
 __device__ __forceinline__ void tload_row(const short *pb, unsigned qstride, int r, int *x) {
@@ -95,12 +130,12 @@ __device__ __forceinline__ void tload_row(const short *pb, unsigned qstride, int
     x[4 * q + 3] = v[3];
   }
 }
-template <int N>
+template <int N, bool COH = false>
 __device__ __forceinline__ void tstore_row(short *pb, unsigned qstride, int r, const int *x) {
 #pragma unroll
   for (int q = 0; q < N / 4; q++) {
     s4v v = {(short)x[4 * q], (short)x[4 * q + 1], (short)x[4 * q + 2], (short)x[4 * q + 3]};
-    *reinterpret_cast<s4v *>(pb + trel<N>(qstride, tile_in_block(q, r >> 2) + ((r & 3) << 2))) = v;
+    st_rec4<COH>(pb + trel<N>(qstride, tile_in_block(q, r >> 2) + ((r & 3) << 2)), v);
   }
 }
 struct LevelsDev {
@@ -289,6 +324,84 @@ template <int N, int NL, typename Fetch>
 __device__ __forceinline__ void intra_refs(TuLds<N> &L, int gl, bool active, Fetch fetch, bool luma,
                                            unsigned long long avail, const PicDev &P) {
   if (active) build_ref_line<N, NL>(fetch, avail, luma ? 2 : 1, P.bit_depth, gl, L.line);
+  wave_sync();
+  if (active && luma && N > 4) smooth_ref_line<N, NL>(L.line, L.fline, gl); // 4x4 never uses the smoothed line
+  wave_sync();
+}
+
+// The same reference line for a block of the TILED working reconstruction, gathered tile row by tile row instead of
+// sample by sample: the 4N+1 samples are the last sample of 2N tile rows to the left (left + below-left), the last
+// sample of one tile row of the corner tile and N/2 whole tile rows above (above + above-right).  One 8-byte access
+// each, 2N + 1 + N/2 of them shared by the block's NL lanes in ceil(.. / NL) rounds, every one issued before the first
+// is consumed (the sample-by-sample gather made 4N+1 two-byte accesses, and HBM saw ~4x the bytes the block needs).
+// Unavailable units are not loaded (the block's own first tile row stands in as a valid address); the reference's
+// padding rule then runs on the raw samples in LDS: position p copies sample q(p), the nearest available sample
+// before it (the first available one for a leading run), exactly as build_ref_line picks its load address.
+// pb0 = element index of the block's first sample.  Leaves L.line (raw) and L.fline (smoothed, luma N > 4).
+template <int N, int NL, bool COH>
+__device__ __forceinline__ void intra_refs_tiled(TuLds<N> &L, int gl, bool active, const TiledPlane &R, int x, int y, size_t pb0,
+                                                 bool luma, unsigned long long avail, const PicDev &P) {
+  constexpr int T = 2 * N + 1 + N / 2, IT = (T + NL - 1) / NL;
+  const int ul = luma ? 2 : 1, n = N >> ul;
+  if (active) {
+    s4v v[IT];
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+      const int t = gl + it * NL;
+      if (t < T) {
+        int tx, ty, u;
+        unsigned um = 1;
+        if (t < 2 * N) { // left column, bottom to top: p = t, sample (x-1, y+2N-1-t)
+          tx = x - 4, ty = y + 2 * N - 1 - t, u = t >> ul;
+        } else if (t == 2 * N) { // corner
+          tx = x - 4, ty = y - 1, u = 2 * n;
+        } else { // tile j of the row above: p = 2N+1+4j .. +3 (one luma unit, two chroma units)
+          const int j = t - 2 * N - 1;
+          tx = x + 4 * j, ty = y - 1, u = 2 * n + 1 + ((4 * j) >> ul), um = luma ? 1u : 3u;
+        }
+        const bool on = ((avail >> u) & um) != 0;
+        const size_t o = on ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, tx, ty) + ((unsigned)(ty & 3) << 2)) : pb0;
+        v[it] = ld_rec4<COH>(R.p + o);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; it++) { // raw samples wait in L.fline (free until the smoothing pass)
+      const int t = gl + it * NL;
+      if (t <= 2 * N) {
+        L.fline[t] = v[it][3];
+      } else if (t < T) {
+        const int p0 = 2 * N + 1 + 4 * (t - 2 * N - 1);
+        L.fline[p0] = v[it][0], L.fline[p0 + 1] = v[it][1], L.fline[p0 + 2] = v[it][2], L.fline[p0 + 3] = v[it][3];
+      }
+    }
+  }
+  wave_sync();
+  if (active) {
+    const int unit = 1 << ul, dcv = 1 << (P.bit_depth - 1);
+#pragma unroll
+    for (int it = 0; it < (4 * N + 1 + NL - 1) / NL; it++) {
+      const int p = gl + it * NL;
+      if (p <= 4 * N) {
+        int val = dcv;
+        if (avail != 0) {
+          const int u = p < 2 * N ? (p >> ul) : (p == 2 * N ? 2 * n : 2 * n + 1 + ((p - 2 * N - 1) >> ul));
+          int q = p;
+          if (!((avail >> u) & 1)) {
+            const unsigned long long lower = avail & ((1ull << u) - 1);
+            if (lower) {
+              const int u2 = 63 - __clzll((long long)lower); // last sample of the nearest available unit below
+              q = u2 < 2 * n ? (u2 << ul) + unit - 1 : (u2 == 2 * n ? 2 * N : 2 * N + ((u2 - 2 * n) << ul));
+            } else {
+              const int u2 = __ffsll((long long)avail) - 1; // first sample of the first available unit
+              q = u2 < 2 * n ? (u2 << ul) : (u2 == 2 * n ? 2 * N : 2 * N + 1 + ((u2 - 2 * n - 1) << ul));
+            }
+          }
+          val = L.fline[q];
+        }
+        L.line[p] = val;
+      }
+    }
+  }
   wave_sync();
   if (active && luma && N > 4) smooth_ref_line<N, NL>(L.line, L.fline, gl); // 4x4 never uses the smoothed line
   wave_sync();

@@ -274,8 +274,10 @@ constexpr int kSlots4Own = 64;       // per-picture level kernel: one lane per b
 // availability are wave-uniform (scalar registers, no divergent mode branches), and a wave is full
 // whenever the batch holds at least 64/N pictures.
 struct OwnPicture {
+  static constexpr bool kCoherent = false; // producer and consumer are separated by a kernel boundary
   const PicWork &W;
   const FTu *tus;
+  __device__ __forceinline__ void wait() const {}
   __device__ __forceinline__ FTu desc(int i) const { return tus[i]; }
   __device__ __forceinline__ PlaneView view(int, int pl) const {
     TiledPlane r = W.rec[pl];
@@ -284,6 +286,8 @@ struct OwnPicture {
   }
 };
 struct AcrossPictures {
+  static constexpr bool kCoherent = false;
+  __device__ __forceinline__ void wait() const {}
   const PicWork *pics;
   const FTu *ft; // the one block this wave works on (wave-uniform address: scalar loads)
   int pic0, n_pics;
@@ -330,7 +334,8 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, cons
     int *lev_row = V.lev + lev_row_off<N>(V, x, y, gl);
     const size_t pb0 = tphys(R.qstride, b0);
     if (ENC && active) tload_row<N>(V.org + pb0, R.qstride, gl, row); // independent of the references
-    intra_refs<N, N>(L, gl, active, [&](int dx, int dy) { return (int)R.p[taddr(R, x + dx, y + dy)]; }, luma, avail, P);
+    src.wait(); // packed schedule: the blocks this one predicts from belong to earlier rows of the same launch
+    intra_refs_tiled<N, N, SRC::kCoherent>(L, gl, active, R, x, y, pb0, luma, avail, P);
     intra_pred_block<N>(L, gl, t.mode, luma, P, pred);
     if (ENC) {
 #pragma unroll
@@ -357,7 +362,7 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, cons
       const int mx = (1 << P.bit_depth) - 1;
 #pragma unroll
       for (int k = 0; k < N; k++) row[k] = clip3(0, mx, pred[k] + row[k]);
-      tstore_row<N>(R.p + pb0, R.qstride, gl, row);
+      tstore_row<N, SRC::kCoherent>(R.p + pb0, R.qstride, gl, row);
     }
   }
 }
@@ -478,18 +483,17 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
   for (int base = 0; ONCE ? base < 1 : base < count; base += 64) {
     const int i = base + lane;
     const bool active = i < count;
-    if (!active) continue; // a lane works alone: nothing below needs the other lanes
-    const FTu ft = src.desc(i);
+    const FTu ft = src.desc(active ? i : 0);
     const hmx_tu t = ft.t;
     const int pl = t.plane, x = t.x, y = t.y, mode = t.mode;
     const bool luma = pl == 0, ts = t.flags & HMX_TU_TRANSFORM_SKIP;
     const unsigned avail = ft.avail_lo; // 4n+1 <= 9 units
-    const PlaneView V = src.view(i, pl);
+    const PlaneView V = src.view(active ? i : 0, pl);
     const TiledPlane &R = V.rec;
     const unsigned b0 = tile_base(R.ctu_w, R.clog, x, y);
     const size_t pb0 = tphys(R.qstride, b0); // a tile never straddles quads
     int v[16];
-    if (ENC) {
+    if (ENC && active) {
       const i4v o0 = *reinterpret_cast<const i4v *>(V.org + pb0), o1 = *reinterpret_cast<const i4v *>(V.org + pb0 + 8);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -497,6 +501,8 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
         v[8 + 2 * k] = (short)(o1[k] & 0xffff), v[8 + 2 * k + 1] = o1[k] >> 16;
       }
     }
+    src.wait(); // the whole wave (packed schedule): the neighbours belong to earlier rows of the same launch
+    if (!active) continue; // from here a lane works alone: nothing below needs the other lanes
     // ---- reference line (fillReferenceSamples): sequential padding is natural inside one lane.
     int *line = LS.line[lane];
     {
@@ -514,15 +520,20 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
         const short *t_c = R.p + (has_c ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x - 4, y - 4)) : pb0);
         const short *t_a = R.p + (has_a ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x, y - 4)) : pb0);
         const short *t_ar = R.p + (has_ar ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x + 4, y - 4)) : pb0);
-        const s4v va = *reinterpret_cast<const s4v *>(t_a + 12), var = *reinterpret_cast<const s4v *>(t_ar + 12);
+        // whole tile rows (8 bytes): the access width of the coherent path, and no narrower request reaches the L2
+        constexpr bool COH = SRC::kCoherent;
+        const s4v va = ld_rec4<COH>(t_a + 12), var = ld_rec4<COH>(t_ar + 12), vc = ld_rec4<COH>(t_c + 12);
+        s4v vb[4], vl[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) vb[k] = ld_rec4<COH>(t_bl + 4 * (3 - k)), vl[k] = ld_rec4<COH>(t_lf + 4 * (3 - k));
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          raw[k] = t_bl[4 * (3 - k) + 3];     // p = 0..3: (x-1, y+7-p)
-          raw[4 + k] = t_lf[4 * (3 - k) + 3]; // p = 4..7: (x-1, y+7-p)
+          raw[k] = vb[k][3];     // p = 0..3: (x-1, y+7-p)
+          raw[4 + k] = vl[k][3]; // p = 4..7: (x-1, y+7-p)
           raw[9 + k] = va[k];
           raw[13 + k] = var[k];
         }
-        raw[8] = t_c[15];
+        raw[8] = vc[3];
       }
       const int dc = 1 << (B - 1);
       int carry = dc;
@@ -589,8 +600,20 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
       r0[k] = (clip3(0, mx, pred[2 * k] + out[2 * k]) & 0xffff) | (clip3(0, mx, pred[2 * k + 1] + out[2 * k + 1]) << 16);
       r1[k] = (clip3(0, mx, pred[8 + 2 * k] + out[8 + 2 * k]) & 0xffff) | (clip3(0, mx, pred[8 + 2 * k + 1] + out[8 + 2 * k + 1]) << 16);
     }
-    *reinterpret_cast<i4v *>(R.p + pb0) = r0;
-    *reinterpret_cast<i4v *>(R.p + pb0 + 8) = r1;
+    if constexpr (SRC::kCoherent) { // write-through, one tile row per store
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        s4v a, b;
+        const int a2[2] = {r0[2 * k], r0[2 * k + 1]}, b2[2] = {r1[2 * k], r1[2 * k + 1]};
+        __builtin_memcpy(&a, a2, 8);
+        __builtin_memcpy(&b, b2, 8);
+        st_rec4<true>(R.p + pb0 + 4 * k, a);
+        st_rec4<true>(R.p + pb0 + 8 + 4 * k, b);
+      }
+    } else {
+      *reinterpret_cast<i4v *>(R.p + pb0) = r0;
+      *reinterpret_cast<i4v *>(R.p + pb0 + 8) = r1;
+    }
   }
 }
 
@@ -617,7 +640,8 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const 
       for (int q = 0; q < 4; q++)
         org4[q] = *reinterpret_cast<const s4v *>(V.org + row_off + trel<32>(R.qstride, tile_in_block(2 * q + h, r >> 2)));
     }
-    intra_refs<32, 64>(L, lane, true, [&](int dx, int dy) { return (int)R.p[taddr(R, x + dx, y + dy)]; }, luma, avail, P);
+    src.wait();
+    intra_refs_tiled<32, 64, SRC::kCoherent>(L, lane, true, R, x, y, tphys(R.qstride, b0), luma, avail, P);
     const int *RL = (luma && use_filtered_refs(t.mode, LG)) ? L.fline : L.line;
     const int dcs = dc_sum_block<32, 64>(L, lane);
     build_main_ref<32, 64>(RL, L.me, t.mode, lane);
@@ -658,7 +682,7 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const 
       const int p0 = pred2[2 * q] & 0xffff, p1 = pred2[2 * q] >> 16, p2 = pred2[2 * q + 1] & 0xffff, p3 = pred2[2 * q + 1] >> 16;
       s4v o = {(short)clip3(0, mx, p0 + out[4 * q]), (short)clip3(0, mx, p1 + out[4 * q + 1]),
                (short)clip3(0, mx, p2 + out[4 * q + 2]), (short)clip3(0, mx, p3 + out[4 * q + 3])};
-      *reinterpret_cast<s4v *>(R.p + row_off + trel<32>(R.qstride, tile_in_block(2 * q + h, r >> 2))) = o;
+      st_rec4<SRC::kCoherent>(R.p + row_off + trel<32>(R.qstride, tile_in_block(2 * q + h, r >> 2)), o);
     }
     wave_sync();
   }
@@ -824,6 +848,281 @@ __global__ __launch_bounds__(64, 4) void k_intra_wave(FrameArgs A) {
     case 3: wave_chain_valu<8, ENC>(smem, src, A.P, sg.count); break;
     case 4: wave_chain_valu<16, ENC>(smem, src, A.P, sg.count); break;
     default: wave_chain_32<ENC>(smem, src, A.P, sg.count); break;
+    }
+  }
+}
+
+// =============================================================================================
+// Packed schedule: ONE persistent launch per whole-picture call.
+//
+// The level schedules pay one kernel launch per picture-wide dependency level (4844 at 2160p) and every launch lasts at
+// least one block-chain latency however little work it carries.  Here the dependency order lives in memory instead:
+//   * pictures form GROUPS of I <= 64 (the interleave domain of the working pool); a ROW = (dependency level, group)
+//     holds every block of that level of the group's pictures -- each picture following ITS OWN plan -- bucketed by
+//     transform size.  A WAVE-ITEM is one wave's worth of a bucket: 64/N blocks (one 32x32 block) taken from whichever
+//     pictures have them, so waves are full whether the pictures share a plan or not (per item: picture + descriptor);
+//   * wave-items are numbered row after row, level-major (tickets).  A persistent wave draws the next ticket with an
+//     atomic add, WAITS until the previous row of the same group is complete (one counter per row, polled with an
+//     L1-bypassing load), runs the block chain, drains its write-through stores and adds 1 to its row's counter.
+// Forward progress: a wave waits only for wave-items with SMALLER tickets of the same shard, and a ticket is drawn by a
+// wave that is already running, in ticket order.  So the unfinished wave-item with the smallest ticket is always held by a
+// running wave whose own dependencies are complete: it finishes, and by induction all do, whatever the number of
+// resident waves, the dispatch order or the placement.  There is no barrier between workgroups.  (A spin that exceeds
+// ~2^22 polls -- seconds -- raises the abort word and every wave leaves: a bug then fails loudly instead of hanging.)
+// Rows of different groups are independent, so while one group waits for its row's last wave-item the others compute:
+// the per-level latency floor of the level schedules overlaps with work instead of adding up.
+// Visibility of the reconstruction between wave-items: see ld_rec4 / st_rec4 (hmx_kernels.h).
+// The ticket words are sharded by group (shard = group mod n_shards, a wave starts on the shard of its XCD and moves on
+// when it is drained): one word serves ~88 M draws/s, a 1792-picture step needs several hundred.
+// Reference for the dependency a row encodes: TLibCommon/TComPattern.cpp:389-425 (which neighbours a block reads).
+// =============================================================================================
+struct PackRow { // one (level, group)
+  uint32_t wave_base;    // index of its first wave-item in the call's descriptor array
+  uint32_t n_waves;
+  uint32_t item_base[4]; // first entry of each size class in the call's item array
+  uint32_t count[4];     // blocks per size class
+  uint32_t pad[2];
+};
+struct PackDesc { // one wave-item
+  uint32_t item_off;   // first item
+  uint32_t n_s;        // items | size class << 28
+  uint32_t row;
+  uint32_t dep_target; // wave-items of the previous row of the group (0: nothing to wait for)
+};
+struct PackHdr {
+  uint32_t shard_base[9]; // wave-items of shard s: [shard_base[s], shard_base[s+1])
+  uint32_t total_items;
+  uint32_t pad0[22];
+  uint32_t abort;         // set by a wave whose wait timed out
+  uint32_t pad1[31];
+  uint32_t ticket[8][32]; // one 128-byte line per shard
+};
+struct PackPic { // per picture: where its levels go, and the plan it follows
+  int *lev[3];
+  int lev_stride[3];
+  int n_levels;
+  const LevelRow *ltab;
+  const FTu *ltus;
+};
+struct PackGeom {
+  int n_pics, I, n_groups, n_shards, max_levels, slots4;
+};
+__host__ __device__ __forceinline__ uint32_t pack_slots(int s, int slots4) { return s == 0 ? (uint32_t)slots4 : s == 1 ? 8u : s == 2 ? 4u : 1u; }
+
+// prep 1: blocks per size class of every row (one wave per row, lane = picture of the group)
+__global__ __launch_bounds__(64) void k_pack_count(const PackPic *pics, PackRow *rows, PackGeom G) {
+  const int row = blockIdx.x, L = row / G.n_groups, g = row - L * G.n_groups, k = threadIdx.x;
+  const int pic = g * G.I + k;
+  uint32_t c[4] = {0, 0, 0, 0};
+  if (k < G.I && pic < G.n_pics && L < pics[pic].n_levels) {
+    const LevelRow r = pics[pic].ltab[L];
+#pragma unroll
+    for (int s = 0; s < 4; s++) c[s] = r.count[s];
+  }
+#pragma unroll
+  for (int s = 0; s < 4; s++) c[s] = (uint32_t)group_sum((int)c[s], 64);
+  if (k == 0) {
+    PackRow R{};
+    uint32_t nw = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      R.count[s] = c[s];
+      const uint32_t sl = pack_slots(s, G.slots4);
+      nw += (c[s] + sl - 1) / sl;
+    }
+    R.n_waves = nw;
+    rows[row] = R;
+  }
+}
+// position p of the ticket order (shard-major, then level, then group) -> row
+__device__ __forceinline__ int pack_row_at(const PackGeom &G, int p, int &shard) {
+  int sh = 0;
+  for (;; sh++) {
+    const int ng = (G.n_groups - sh + G.n_shards - 1) / G.n_shards, n = ng * G.max_levels;
+    if (p < n || sh == G.n_shards - 1) {
+      shard = sh;
+      const int L = p / ng, gi = p - L * ng;
+      return L * G.n_groups + sh + gi * G.n_shards;
+    }
+    p -= n;
+  }
+}
+// prep 2: exclusive prefix of wave-items and items over the rows in ticket order (one workgroup)
+__global__ __launch_bounds__(1024) void k_pack_scan(PackRow *rows, PackHdr *hdr, PackGeom G) {
+  __shared__ uint32_t sw[1024], si[1024];
+  const int n_rows = G.max_levels * G.n_groups, tid = threadIdx.x;
+  const int chunk = (n_rows + 1023) / 1024, lo = min(tid * chunk, n_rows), hi = min(lo + chunk, n_rows);
+  uint32_t w = 0, it = 0;
+  for (int p = lo; p < hi; p++) {
+    int sh;
+    const PackRow &R = rows[pack_row_at(G, p, sh)];
+    w += R.n_waves;
+    it += R.count[0] + R.count[1] + R.count[2] + R.count[3];
+  }
+  sw[tid] = w, si[tid] = it;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) { // inclusive scan
+    const uint32_t a = tid >= off ? sw[tid - off] : 0, b = tid >= off ? si[tid - off] : 0;
+    __syncthreads();
+    sw[tid] += a, si[tid] += b;
+    __syncthreads();
+  }
+  uint32_t wb = sw[tid] - w, ib = si[tid] - it;
+  int prev_shard = lo > 0 ? -2 : -1; // -2: find out
+  if (lo > 0 && lo < n_rows) pack_row_at(G, lo - 1, prev_shard);
+  for (int p = lo; p < hi; p++) {
+    int sh;
+    PackRow &R = rows[pack_row_at(G, p, sh)];
+    if (sh != prev_shard)
+      for (int q = prev_shard + 1; q <= sh; q++) hdr->shard_base[q] = wb; // empty shards in between do not occur, but stay safe
+    prev_shard = sh;
+    R.wave_base = wb;
+    wb += R.n_waves;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      R.item_base[s] = ib;
+      ib += R.count[s];
+    }
+  }
+  if (tid == 1023) {
+    for (int q = G.n_shards; q <= 8; q++) hdr->shard_base[q] = sw[1023];
+    hdr->total_items = si[1023];
+  }
+}
+// prep 3: the wave-item descriptors and the item array of one (row, size class) per wave.  Items of a bucket are ordered
+// by rank inside their picture's bucket, then by picture: pictures that share a plan put the SAME block of consecutive
+// pictures on consecutive lanes (consecutive lines of the interleaved pool, uniform control flow); pictures with their
+// own plans put blocks of similar code path (the plan sorts a bucket by plane, transform skip, mode) next to each other.
+__global__ __launch_bounds__(64) void k_pack_fill(const PackPic *pics, const PackRow *rows, PackDesc *descs, FTu *items, PackGeom G) {
+  const int row = blockIdx.x >> 2, s = blockIdx.x & 3, L = row / G.n_groups, g = row - L * G.n_groups, k = threadIdx.x;
+  const PackRow R = rows[row];
+  if (R.count[s] == 0) return;
+  const uint32_t sl = pack_slots(s, G.slots4), nw = (R.count[s] + sl - 1) / sl;
+  uint32_t woff = 0;
+  for (int s2 = 3; s2 > s; s2--) woff += (R.count[s2] + pack_slots(s2, G.slots4) - 1) / pack_slots(s2, G.slots4); // largest blocks first
+  const uint32_t dep = L > 0 ? rows[row - G.n_groups].n_waves : 0;
+  for (uint32_t c = k; c < nw; c += 64)
+    descs[R.wave_base + woff + c] = PackDesc{R.item_base[s] + c * sl, min(sl, R.count[s] - c * sl) | ((uint32_t)s << 28), (uint32_t)row, dep};
+  const int pic = g * G.I + k;
+  uint32_t cnt = 0, start = 0;
+  const FTu *ltus = nullptr;
+  if (k < G.I && pic < G.n_pics && L < pics[pic].n_levels) {
+    const LevelRow r = pics[pic].ltab[L];
+    cnt = r.count[s], start = r.start[s];
+    ltus = as_global(pics[pic].ltus);
+  }
+  uint32_t maxc = cnt;
+  for (int off = 32; off > 0; off >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, off, 64));
+  uint32_t off = R.item_base[s];
+  const unsigned long long below = (1ull << k) - 1ull;
+  for (uint32_t r = 0; r < maxc; r++) {
+    const unsigned long long m = __ballot(cnt > r);
+    if (cnt > r) {
+      FTu f = ltus[start + r];
+      f.t.plane = (uint8_t)(f.t.plane | (k << 2)); // picture of the group in the upper six bits
+      items[off + (uint32_t)__popcll(m & below)] = f;
+    }
+    off += (uint32_t)__popcll(m);
+  }
+}
+
+struct PackArgs {
+  const PackPic *pics;
+  const PackRow *rows;
+  const PackDesc *descs;
+  const FTu *items;
+  uint32_t *done; // [rows] completed wave-items
+  PackHdr *hdr;
+  const short *pool_org;
+  short *pool_rec;
+  size_t pic_elems;      // one picture, three planes
+  uint32_t plane_off[3]; // of one picture
+  int ctu_w, clog;
+  int n_groups, n_shards, I, K; // K = wave-items per ticket
+  PicDev P;
+};
+struct PackedSrc {
+  static constexpr bool kCoherent = true;
+  const FTu *items;     // the wave-item's entries
+  const PackPic *gpics; // the group's pictures
+  const short *org_g;   // the group's region of the pools
+  short *rec_g;
+  uint32_t off1, off2;  // plane offsets inside the group region
+  uint32_t qstride;
+  int ctu_w, clog_luma;
+  const uint32_t *dep;  // counter of the previous row of the group (NULL: first level)
+  uint32_t target;
+  uint32_t *abort_word;
+  __device__ __forceinline__ FTu desc(int i) const {
+    FTu f = items[i];
+    f.t.plane &= 3;
+    return f;
+  }
+  __device__ __forceinline__ PlaneView view(int i, int pl) const {
+    const unsigned k = items[i].t.plane >> 2;
+    const size_t o = (size_t)(pl == 0 ? 0u : pl == 1 ? off1 : off2) + (size_t)k * 64;
+    const char *row = reinterpret_cast<const char *>(&gpics[k]);
+    int *lv = *reinterpret_cast<int *const *>(row + offsetof(PackPic, lev) + pl * sizeof(int *));
+    const int ls = *reinterpret_cast<const int *>(row + offsetof(PackPic, lev_stride) + pl * sizeof(int));
+    return PlaneView{org_g + o, TiledPlane{rec_g + o, ctu_w, pl ? clog_luma - 1 : clog_luma, qstride}, as_global(lv), ls};
+  }
+  // Wait until the previous row of the group is complete.  One L1-bypassing load per poll (the whole wave reads one
+  // word: one request); everything the chain loads from the reconstruction afterwards is an sc1 load issued after this
+  // loop has seen the count, and the producers drained their sc1 stores before they counted.
+  __device__ __forceinline__ void wait() const {
+    if (dep) {
+      unsigned spins = 0;
+      for (;;) {
+        const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((gu32 *)dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (v >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023u) == 0) {
+          if (spins >= (1u << 22)) __hip_atomic_store((gu32 *)abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((gu32 *)abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler ordering: no reconstruction load moves above the poll
+  }
+};
+
+template <bool ENC, int SL4>
+__global__ __launch_bounds__(64, 4) void k_intra_packed(PackArgs A) {
+  __shared__ __attribute__((aligned(16))) char smem[HMX_WAVE_SMEM];
+  int xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const int lane = threadIdx.x, shard0 = (xcc & 7) % A.n_shards;
+  PackHdr *hdr = A.hdr;
+  for (int si = 0; si < A.n_shards; si++) {
+    const int sh = shard0 + si < A.n_shards ? shard0 + si : shard0 + si - A.n_shards;
+    const uint32_t base = hdr->shard_base[sh], total = hdr->shard_base[sh + 1] - base;
+    for (;;) {
+      uint32_t t = 0;
+      if (lane == 0) t = __hip_atomic_fetch_add((gu32 *)&hdr->ticket[sh][0], (uint32_t)A.K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+      if (t >= total) break;
+      if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((gu32 *)&hdr->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
+      const uint32_t e = min(t + (uint32_t)A.K, total);
+      for (uint32_t w = t; w < e; w++) {
+        const PackDesc d = A.descs[base + w];
+        const int s = (int)(d.n_s >> 28), n = (int)(d.n_s & 0x0fffffffu);
+        const int g = (int)(d.row % (uint32_t)A.n_groups);
+        const size_t greg = (size_t)g * A.I * A.pic_elems;
+        const PackedSrc src{A.items + d.item_off, A.pics + (size_t)g * A.I, A.pool_org + greg, A.pool_rec + greg,
+                            A.plane_off[1] * (uint32_t)A.I, A.plane_off[2] * (uint32_t)A.I, 64u * (uint32_t)A.I, A.ctu_w, A.clog,
+                            d.dep_target ? A.done + (d.row - (uint32_t)A.n_groups) : nullptr, d.dep_target, &hdr->abort};
+        wave_sync(); // the LDS scratch is re-interpreted per block size
+        if (s == 0) {
+          if constexpr (SL4 == 64) wave_chain_4_lane<ENC, true>(smem, src, A.P, n);
+          else wave_chain_valu<4, ENC, true>(smem, src, A.P, n);
+        } else if (s == 1) wave_chain_valu<8, ENC, true>(smem, src, A.P, n);
+        else if (s == 2) wave_chain_valu<16, ENC, true>(smem, src, A.P, n);
+        else wave_chain_32<ENC, true>(smem, src, A.P, n);
+        // publish: every store of this wave has left for memory before the row's count moves
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add((gu32 *)(A.done + d.row), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }
@@ -996,6 +1295,37 @@ struct hmx_ctx {
   size_t mcmap_cap = 0;
   char *arena_h = nullptr, *arena_d = nullptr;
   size_t arena_cap = 0, arena_head = 0;
+  // packed schedule (k_intra_packed): tables of the last call; rebuilt on the device when the pictures / plans change
+  struct Packed {
+    PackPic *d_pics = nullptr;
+    PackRow *d_rows = nullptr;
+    PackDesc *d_descs = nullptr;
+    FTu *d_items = nullptr;
+    uint32_t *d_done = nullptr;
+    PackHdr *d_hdr = nullptr;
+    size_t cap_pics = 0, cap_rows = 0, cap_descs = 0, cap_items = 0, cap_done = 0;
+    uint64_t key = 0;
+    bool valid = false;
+    PackGeom G{};
+    int K = 1, n_wg = 0;
+    uint64_t waves_bound = 0;
+  } pk;
+  int max_resident_waves = 0; // of k_intra_packed on this device
+  int pack_I = 1;             // pictures per group (interleave domain of the pool) of the call being issued
+  const hmx_levels *call_lev = nullptr; // the call's level planes (host array, valid while the call is issued)
+  bool pk_pending = false;    // a packed launch was issued since the last check of its abort word
+  uint64_t table_key = 0;     // of the picture table resident in d_jobs (whole-picture calls)
+  bool table_valid = false;
+  // knobs, read once from the environment in hmx_create (A/B runs and the cross-checks of the tests)
+  struct Knobs {
+    int schedule = -1;     // HMX_INTRA_SCHEDULE: wave / level / packed (default: packed)
+    int across = -1;       // HMX_INTRA_ACROSS: 0 keeps shared-plan batches of the level schedule per picture
+    int streams = 0;       // HMX_INTRA_STREAMS: picture groups of the across schedule
+    bool pipeline_conv = false, graph = false;
+    int slots4 = 0;        // HMX_PACK_SLOTS4: 16 or 64 4x4 blocks per wave-item (0: by batch size)
+    int pack_k = 0;        // HMX_PACK_K: wave-items per ticket (0: by batch size)
+    int pack_waves = 0;    // HMX_PACK_WAVES: persistent waves (0: by batch size)
+  } knob;
 };
 
 struct hmx_intra_plan {
@@ -1008,6 +1338,8 @@ struct hmx_intra_plan {
   LevelRow *d_ltab = nullptr;
   std::vector<uint32_t> level_chunks; // waves needed per level
   std::vector<LevelRow> h_ltab;       // host copy of the level table
+  uint64_t size_total[4] = {0, 0, 0, 0}; // blocks per transform size
+  uint64_t serial = 0;                    // unique per plan: a freed plan's address may be handed out again
   // per CTU row: the first and the last dependency level that touches it (the layout conversions are pipelined by CTU
   // row: a row is converted in before its first level and out after its last one)
   std::vector<int> row_first_level, row_last_level;
@@ -1078,6 +1410,29 @@ static PicDev make_picdev(const hmx_ctx *c, const hmx_pic_param *pp) {
   return P;
 }
 
+// Tuning knobs: read from the environment ONCE, in hmx_create; hmx_set_option changes one afterwards (A/B runs, and the
+// parity tests that hold the schedules against each other).  value == NULL restores the default.
+static const char *const kKnobNames[] = {"HMX_INTRA_SCHEDULE", "HMX_INTRA_ACROSS", "HMX_INTRA_STREAMS", "HMX_PIPELINE_CONV", "HMX_GRAPH",
+                                         "HMX_PACK_SLOTS4",    "HMX_PACK_K",       "HMX_PACK_WAVES"};
+static bool apply_knob(hmx_ctx *c, const char *name, const char *v) {
+  auto &k = c->knob;
+  const std::string n(name);
+  if (n == "HMX_INTRA_SCHEDULE") k.schedule = !v ? -1 : v[0] == 'w' ? 0 : v[0] == 'l' ? 1 : v[0] == 'p' ? 3 : -1;
+  else if (n == "HMX_INTRA_ACROSS") k.across = !v ? -1 : v[0] != '0';
+  else if (n == "HMX_INTRA_STREAMS") k.streams = v ? atoi(v) : 0;
+  else if (n == "HMX_PIPELINE_CONV") k.pipeline_conv = v && v[0] != '0';
+  else if (n == "HMX_GRAPH") k.graph = v != nullptr;
+  else if (n == "HMX_PACK_SLOTS4") k.slots4 = !v ? 0 : atoi(v) == 16 ? 16 : 64;
+  else if (n == "HMX_PACK_K") k.pack_k = v ? std::max(1, atoi(v)) : 0;
+  else if (n == "HMX_PACK_WAVES") k.pack_waves = v ? std::max(1, atoi(v)) : 0;
+  else return false;
+  return true;
+}
+extern "C" int hmx_set_option(hmx_ctx *c, const char *name, const char *value) {
+  if (!c || !name) return HMX_ERR_ARG;
+  return apply_knob(c, name, value) ? HMX_OK : fail(c, HMX_ERR_ARG, "hmx_set_option: unknown option");
+}
+
 extern "C" int hmx_create(const hmx_config *cfg, hmx_ctx **out) {
   if (!cfg || !out) return HMX_ERR_ARG;
   if (cfg->bit_depth < 8 || cfg->bit_depth > 12 || (cfg->ctu_size != 64 && cfg->ctu_size != 32 && cfg->ctu_size != 16))
@@ -1102,9 +1457,12 @@ extern "C" int hmx_create(const hmx_config *cfg, hmx_ctx **out) {
   c->scratch_bytes = 1 << 20;
   e = hipMalloc((void **)&c->d_scratch, c->scratch_bytes);
   if (e != hipSuccess) {
+    if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return HMX_ERR_NOMEM;
   }
+  for (const char *name : kKnobNames)
+    if (const char *v = getenv(name)) apply_knob(c, name, v);
   *out = c;
   return HMX_OK;
 }
@@ -1127,6 +1485,12 @@ extern "C" void hmx_destroy(hmx_ctx *c) {
   hipFree(c->rdoq_wi);
   hipFree(c->rdoq_blocks);
   hipFree(c->rdoq_est);
+  hipFree(c->pk.d_pics);
+  hipFree(c->pk.d_rows);
+  hipFree(c->pk.d_descs);
+  hipFree(c->pk.d_items);
+  hipFree(c->pk.d_done);
+  hipFree(c->pk.d_hdr);
   for (int g = 0; g < c->n_side; g++) {
     hipStreamDestroy(c->side[g]);
     hipEventDestroy(c->ev_join[g]);
@@ -1141,9 +1505,17 @@ extern "C" void hmx_destroy(hmx_ctx *c) {
   delete c;
 }
 extern "C" const char *hmx_last_error(const hmx_ctx *c) { return c ? c->err.c_str() : "null context"; }
+// after a synchronisation: did a wave of the packed schedule give up waiting (its bounded spin ran out)?
+static int check_packed_abort(hmx_ctx *c) {
+  if (!c->pk_pending || !c->pk.d_hdr) return HMX_OK;
+  c->pk_pending = false;
+  uint32_t ab = 0;
+  HIPCHK(c, hipMemcpy(&ab, &c->pk.d_hdr->abort, sizeof(ab), hipMemcpyDeviceToHost));
+  return ab ? fail(c, HMX_ERR_DEVICE, "packed schedule: a dependency wait timed out, the call's outputs are invalid") : HMX_OK;
+}
 extern "C" int hmx_sync(hmx_ctx *c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return HMX_OK;
+  return check_packed_abort(c);
 }
 extern "C" int hmx_malloc(hmx_ctx *c, size_t bytes, void **dptr) {
   hipError_t e = hipMalloc(dptr, bytes);
@@ -1162,7 +1534,7 @@ extern "C" int hmx_upload(hmx_ctx *c, void *dst, const void *src, size_t bytes) 
 extern "C" int hmx_download(hmx_ctx *c, void *dst, const void *src, size_t bytes) {
   HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return HMX_OK;
+  return check_packed_abort(c);
 }
 extern "C" int hmx_memset(hmx_ctx *c, void *dst, int value, size_t bytes) {
   HIPCHK(c, hipMemsetAsync(dst, value, bytes, c->stream));
@@ -1255,7 +1627,11 @@ extern "C" int hmx_tu_list_create(hmx_ctx *c, const hmx_tu *tus, int n, hmx_tu_l
       return fail(c, HMX_ERR_NOMEM, "hipMalloc tu list");
     }
     int r = hmx_upload(c, l->d, v.data(), sizeof(DTu) * n);
-    if (r) return r;
+    if (r) {
+      hipFree(l->d);
+      delete l;
+      return r;
+    }
   }
   *out = l;
   return HMX_OK;
@@ -1448,8 +1824,9 @@ extern "C" int hmx_intra_plan_create(hmx_ctx *c, const hmx_tu *tus, int n_tu, co
     const hmx_tu &t = tus[i];
     if (t.plane > 2 || t.log2n < 2 || t.log2n > 5) return fail(c, HMX_ERR_ARG, "hmx_intra_plan_create: bad block");
     const int sh = t.plane ? 1 : 0, lx = t.x << sh, ly = t.y << sh, ls = (1 << t.log2n) << sh;
-    if (lx + ls > cw * ctu || ly + ls > ch * ctu || (lx % ctu) + ls > ctu || (ly % ctu) + ls > ctu)
-      return fail(c, HMX_ERR_ARG, "hmx_intra_plan_create: block crosses a CTU");
+    if ((lx % ctu) + ls > ctu || (ly % ctu) + ls > ctu) return fail(c, HMX_ERR_ARG, "hmx_intra_plan_create: block crosses a CTU");
+    // the CTU grid is padded, the caller's planes are not: a block in the padding would be written past their end
+    if (lx + ls > pp->pic_w || ly + ls > pp->pic_h) return fail(c, HMX_ERR_ARG, "hmx_intra_plan_create: block outside the picture");
     bucket[((size_t)(ly / ctu) * cw + lx / ctu) * 3 + t.plane].push_back(i);
   }
   std::vector<FTu> stus;
@@ -1583,7 +1960,11 @@ extern "C" int hmx_intra_plan_create(hmx_ctx *c, const hmx_tu *tus, int n_tu, co
   }
   // CTU diagonals d = X + 2Y: (X,Y) needs (X-1,Y), (X-1,Y-1), (X,Y-1), (X+1,Y-1)
   hmx_intra_plan *pl = new hmx_intra_plan;
+  static uint64_t plan_serial = 0;
+  pl->serial = ++plan_serial;
   pl->level_chunks = level_chunks;
+  for (const LevelRow &lr : ltab)
+    for (int sidx = 0; sidx < 4; sidx++) pl->size_total[sidx] += lr.count[sidx];
   pl->h_ltab = ltab;
   pl->row_first_level = row_first;
   pl->row_last_level = row_last;
@@ -1659,10 +2040,9 @@ extern "C" int hmx_intra_plan_level(const hmx_intra_plan *pl, int level, uint32_
   if (n_waves) *n_waves = pl->level_chunks[level];
   return HMX_OK;
 }
-extern "C" int hmx_intra_schedule_for(const hmx_ctx *c, int n_pics) { // 1 = level schedule, 0 = wave schedule
-  bool use_level = n_pics >= c->level_mode_min_pics;
-  if (const char *e = getenv("HMX_INTRA_SCHEDULE")) use_level = e[0] == 'l' ? true : (e[0] == 'w' ? false : use_level);
-  return use_level ? 1 : 0;
+extern "C" int hmx_intra_schedule_for(const hmx_ctx *c, int n_pics) { // 3 = packed, 1 = level, 0 = wave
+  (void)n_pics;
+  return c->knob.schedule >= 0 ? c->knob.schedule : 3;
 }
 
 extern "C" void hmx_intra_plan_destroy(hmx_ctx *c, hmx_intra_plan *pl) {
@@ -1688,6 +2068,118 @@ extern "C" void hmx_intra_plan_destroy(hmx_ctx *c, hmx_intra_plan *pl) {
 // stream capture to record the call as a HIP graph.
 static int issue_chain_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_stride, int n_pics,
                                 const PicWork *d_work, bool enc, bool use_level, int groups, hipStream_t main);
+static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_stride, int n_pics, bool enc, hipStream_t st);
+
+// ---- packed schedule, host side ----
+static int grow_dev(hmx_ctx *c, void **p, size_t *cap, size_t need) {
+  if (need <= *cap) return HMX_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  const size_t want = need + need / 16 + 256;
+  if (hipMalloc(p, want) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc packed schedule tables");
+  *cap = want;
+  return HMX_OK;
+}
+static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_stride, int n_pics, bool enc, hipStream_t st) {
+  auto &pk = c->pk;
+  const hmx_intra_plan *p0 = plans[0];
+  PackGeom G{};
+  G.n_pics = n_pics;
+  G.I = c->pack_I;
+  G.n_groups = (n_pics + G.I - 1) / G.I;
+  G.n_shards = std::min(8, G.n_groups);
+  uint64_t items = 0, sz[4] = {0, 0, 0, 0};
+  for (int i = 0; i < n_pics; i++) {
+    const hmx_intra_plan *pl = plans[i * plan_stride];
+    G.max_levels = std::max(G.max_levels, (int)pl->level_chunks.size());
+    items += (uint64_t)pl->n_tu;
+    for (int s = 0; s < 4; s++) sz[s] += pl->size_total[s];
+  }
+  // one lane per 4x4 block is the throughput shape, four lanes per block make more, shorter waves (small batches)
+  G.slots4 = c->knob.slots4 ? c->knob.slots4 : (n_pics >= 256 ? 64 : 16);
+  const uint64_t n_rows = (uint64_t)G.max_levels * G.n_groups;
+  uint64_t waves_bound = 4 * n_rows + 4;
+  for (int s = 0; s < 4; s++) waves_bound += sz[s] / pack_slots(s, G.slots4);
+  if (items >= 0xffffffffull || waves_bound >= 0x0fffffffull || n_rows >= 0x7fffffffull / 4)
+    return fail(c, HMX_ERR_ARG, "frame_intra: batch too large for one packed call (split it)");
+  const bool same = pk.valid && pk.key == c->table_key && pk.G.n_pics == G.n_pics && pk.G.I == G.I && pk.G.slots4 == G.slots4 &&
+                    pk.G.max_levels == G.max_levels;
+  if (!same) {
+    pk.valid = false;
+    int r = grow_dev(c, (void **)&pk.d_pics, &pk.cap_pics, sizeof(PackPic) * n_pics);
+    if (!r) r = grow_dev(c, (void **)&pk.d_descs, &pk.cap_descs, sizeof(PackDesc) * waves_bound);
+    if (!r) r = grow_dev(c, (void **)&pk.d_items, &pk.cap_items, sizeof(FTu) * items);
+    if (!r) r = grow_dev(c, (void **)&pk.d_rows, &pk.cap_rows, sizeof(PackRow) * n_rows);
+    if (!r) r = grow_dev(c, (void **)&pk.d_done, &pk.cap_done, sizeof(uint32_t) * n_rows);
+    if (!r && !pk.d_hdr && hipMalloc((void **)&pk.d_hdr, sizeof(PackHdr)) != hipSuccess) r = fail(c, HMX_ERR_NOMEM, "hipMalloc packed header");
+    if (r) return r;
+    std::vector<PackPic> hp(n_pics);
+    for (int i = 0; i < n_pics; i++) {
+      const hmx_intra_plan *pl = plans[i * plan_stride];
+      for (int p = 0; p < 3; p++) hp[i].lev[p] = c->call_lev[i].plane[p], hp[i].lev_stride[p] = c->call_lev[i].stride[p];
+      hp[i].n_levels = (int)pl->level_chunks.size();
+      hp[i].ltab = pl->d_ltab;
+      hp[i].ltus = pl->d_ltus;
+    }
+    HIPCHK(c, hipMemcpyAsync(pk.d_pics, hp.data(), sizeof(PackPic) * n_pics, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st)); // hp goes out of scope
+    HIPCHK(c, hipMemsetAsync(pk.d_hdr, 0, sizeof(PackHdr), st));
+    hipLaunchKernelGGL(k_pack_count, dim3((unsigned)n_rows), dim3(64), 0, st, pk.d_pics, pk.d_rows, G);
+    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, st, pk.d_rows, pk.d_hdr, G);
+    hipLaunchKernelGGL(k_pack_fill, dim3((unsigned)(n_rows * 4)), dim3(64), 0, st, pk.d_pics, pk.d_rows, pk.d_descs, pk.d_items, G);
+    HIPCHK(c, hipGetLastError());
+    pk.key = c->table_key;
+    pk.G = G;
+    pk.waves_bound = waves_bound;
+    pk.valid = true;
+  }
+  // counters and ticket words start from zero every call
+  HIPCHK(c, hipMemsetAsync(pk.d_done, 0, sizeof(uint32_t) * n_rows, st));
+  HIPCHK(c, hipMemsetAsync(&pk.d_hdr->abort, 0, sizeof(PackHdr) - offsetof(PackHdr, abort), st));
+  const uint64_t wpl = waves_bound / (uint64_t)std::max(1, G.max_levels); // wave-items per dependency level, all groups
+  if (!c->max_resident_waves) {
+    int nb = 0;
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->cfg.device));
+    HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_intra_packed<true, 64>, 64, 0));
+    c->max_resident_waves = std::max(64, nb * prop.multiProcessorCount);
+  }
+  pk.K = c->knob.pack_k ? c->knob.pack_k : (wpl >= 8192 ? 4 : wpl >= 2048 ? 2 : 1);
+  // Enough persistent waves to hold about two levels' worth of wave-items (the waves of the next row load their
+  // descriptors and originals while the current row finishes), never more than the device keeps resident.
+  pk.n_wg = c->knob.pack_waves ? c->knob.pack_waves : (int)std::min<uint64_t>((uint64_t)c->max_resident_waves, std::max<uint64_t>(256, 2 * wpl));
+  PackArgs A{};
+  A.pics = pk.d_pics;
+  A.rows = pk.d_rows;
+  A.descs = pk.d_descs;
+  A.items = pk.d_items;
+  A.done = pk.d_done;
+  A.hdr = pk.d_hdr;
+  A.pool_org = c->pool_org;
+  A.pool_rec = c->pool_rec;
+  A.pic_elems = c->tiled_pic_elems;
+  for (int p = 0; p < 3; p++) A.plane_off[p] = c->tiled_plane_off[p];
+  A.ctu_w = c->tiled_cw;
+  A.clog = ilog2i(p0->P.ctu);
+  A.n_groups = G.n_groups;
+  A.n_shards = G.n_shards;
+  A.I = G.I;
+  A.K = pk.K;
+  A.P = p0->P;
+  const dim3 grid((unsigned)pk.n_wg), blk(64);
+  if (G.slots4 == 64) {
+    if (enc) hipLaunchKernelGGL((k_intra_packed<true, 64>), grid, blk, 0, st, A);
+    else hipLaunchKernelGGL((k_intra_packed<false, 64>), grid, blk, 0, st, A);
+  } else {
+    if (enc) hipLaunchKernelGGL((k_intra_packed<true, 16>), grid, blk, 0, st, A);
+    else hipLaunchKernelGGL((k_intra_packed<false, 16>), grid, blk, 0, st, A);
+  }
+  HIPCHK(c, hipGetLastError());
+  c->pk_pending = true;
+  return HMX_OK;
+}
 
 // The across schedule with the layout conversions pipelined by CTU row.  The chain is latency-bound and leaves the
 // memory system idle; the conversions are pure traffic.  CTU row r is converted in (stream `conv`) before the first
@@ -1814,7 +2306,8 @@ static int issue_intra_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, 
   if (c->onto_call) // the pool starts from the caller's reconstruction (the inter-coded parts of the picture)
     hipLaunchKernelGGL(k_convert_tiled<true>, cgrid, dim3(256), 0, main, d_jobs + (size_t)n_pics * 3, 0, 1 << 30);
   if (tm) HIPCHK(c, hipEventRecord(c->tev[1], main));
-  int r = issue_chain_launches(c, plans, plan_stride, n_pics, d_work, enc, use_level, groups, main);
+  int r = c->last_schedule == 3 ? issue_packed(c, plans, plan_stride, n_pics, enc, main)
+                                : issue_chain_launches(c, plans, plan_stride, n_pics, d_work, enc, use_level, groups, main);
   if (r) return r;
   if (tm) HIPCHK(c, hipEventRecord(c->tev[2], main));
   hipLaunchKernelGGL(k_convert_tiled<false>, cgrid, dim3(256), 0, main, d_jobs + (size_t)n_pics * 3, 0, 1 << 30);
@@ -1944,11 +2437,24 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
   if (!c || !plans || !plans[0] || n_pics <= 0 || !rec || !lev || (enc && !org))
     return fail(c, HMX_ERR_ARG, "frame_intra: null argument");
   const hmx_intra_plan *p0 = plans[0];
-  // tiled working pool: one slot per picture, planes padded to whole CTUs
   const int ctu = p0->P.ctu, cw = (p0->P.pic_w + ctu - 1) / ctu, ch = (p0->P.pic_h + ctu - 1) / ctu;
-  int clog = 0;
-  while ((1 << clog) < ctu) clog++;
-  if (c->tiled_cw != cw || c->tiled_ch != ch || c->pool_pics < n_pics) {
+  const int clog = ilog2i(ctu);
+  // Schedules.  "packed" (default): ONE persistent launch, blocks of equal size and dependency level
+  // packed into waves across pictures, each picture following its own plan, the dependency order kept by counters in
+  // memory.  The level-synchronous schedules stay as cross-checks and for A/B runs (HMX_INTRA_SCHEDULE=level|wave):
+  // "level" = one launch per picture-wide dependency level (pictures that share ONE plan run it across pictures on a
+  // pool interleaved per stream group), "wave" = one launch per CTU diagonal with autonomous waves.
+  const int sched_base = c->knob.schedule >= 0 ? c->knob.schedule : 3;
+  const bool packed = sched_base == 3, use_level = sched_base == 1;
+  const bool across = use_level && plan_stride == 0 && c->knob.across != 0;
+  // Picture groups of the across schedule on separate streams: measured at 1024 pictures 64.8 / 73.6 / 76.1 / 51.8 Gpx/s
+  // with 1 / 2 / 3 / 4 groups.
+  int groups = !across ? 1 : n_pics >= 640 ? 3 : n_pics >= 384 ? 2 : 1;
+  if (use_level && c->knob.streams > 0) groups = std::min(std::max(c->knob.streams, 1), std::min(n_pics, (int)hmx_ctx::kMaxSide));
+  // packed: groups of I pictures are the interleave domains of the pool and the lanes of the tables' prep kernels
+  const int I = packed ? std::min(n_pics, 64) : 1, pool_need = packed ? (n_pics + I - 1) / I * I : n_pics;
+  // tiled working pool: one slot per picture, planes padded to whole CTUs
+  if (c->tiled_cw != cw || c->tiled_ch != ch || c->pool_pics < pool_need) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     hipFree(c->pool_org);
     hipFree(c->pool_rec);
@@ -1956,43 +2462,27 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
     c->pool_pics = 0;
     c->tiled_cw = cw;
     c->tiled_ch = ch;
+    c->table_valid = false;
+    c->pk.valid = false;
     size_t off = 0;
     for (int p = 0; p < 3; p++) {
       c->tiled_plane_off[p] = (uint32_t)off;
       off += (size_t)cw * ch * ((size_t)ctu * ctu >> (p ? 2 : 0));
     }
     c->tiled_pic_elems = off;
-    if (hipMalloc((void **)&c->pool_org, off * 2 * n_pics) != hipSuccess || hipMalloc((void **)&c->pool_rec, off * 2 * n_pics) != hipSuccess) {
+    if (hipMalloc((void **)&c->pool_org, off * 2 * pool_need) != hipSuccess || hipMalloc((void **)&c->pool_rec, off * 2 * pool_need) != hipSuccess) {
       hipFree(c->pool_org);
       c->pool_org = nullptr;
       return fail(c, HMX_ERR_NOMEM, "hipMalloc tiled working pictures");
     }
-    c->pool_pics = n_pics;
+    c->pool_pics = pool_need;
   }
-  // Two schedules: "level" = one launch per picture-wide dependency level,
-  // lane-packed, throughput-oriented; "wave" = one launch per CTU diagonal with autonomous waves.
-  // Pictures that share ONE plan additionally run the level schedule across pictures, on a pool
-  // whose pictures are interleaved quad by quad.
-  bool use_level = n_pics >= c->level_mode_min_pics;
-  if (const char *e = getenv("HMX_INTRA_SCHEDULE")) use_level = e[0] == 'l' ? true : (e[0] == 'w' ? false : use_level);
-  bool across = use_level && plan_stride == 0;
-  if (const char *e = getenv("HMX_INTRA_ACROSS")) across = across && e[0] != '0';
-  // Picture groups on separate streams: the launches of the groups overlap, which hides part of the per-level
-  // latency floor once each group still fills its waves.  Measured at 1024 pictures (four lanes per 4x4 block):
-  // 64.8 / 73.6 / 76.1 / 51.8 Gpx/s with 1 / 2 / 3 / 4 groups (four collapse whether one host thread or one per group
-  // issues the launches; likely the runtime's four hardware queues); 256 pictures: 32.6 / 32.9 with 1 / 2.
-  // 640 pictures: 60.2 / 61.5 with 2 / 3 groups, 768: 65.7 / 66.0, 512: 53.7 / 53.8
-  int groups = !across ? 1 : n_pics >= 640 ? 3 : n_pics >= 384 ? 2 : 1;
-  if (use_level)
-    if (const char *e = getenv("HMX_INTRA_STREAMS")) groups = std::min(std::max(atoi(e), 1), std::min(n_pics, (int)hmx_ctx::kMaxSide));
   c->across_call = across;
-  // Conversions pipelined with the chain, CTU row by CTU row (issue_across_pipelined): opt-in.  Measured: +6 % whole-job
-  // throughput at 1024 pictures (74.0 vs 69.8 Gpx/s), but the level launches themselves run 8 % slower next to the
-  // conversions' traffic and queue behind their waves, so the per-launch figures of bench.py would no longer be the
-  // kernel's own.  HMX_PIPELINE_CONV=1 turns it on.
-  c->pipeline_conv = false;
-  if (const char *e = getenv("HMX_PIPELINE_CONV")) c->pipeline_conv = across && e[0] != '0' && !getenv("HMX_GRAPH") && !c->onto_call;
-  c->last_schedule = !use_level ? 0 : (across ? 2 : 1);
+  c->pack_I = I;
+  c->call_lev = lev;
+  // Conversions pipelined with the chain, CTU row by CTU row (issue_across_pipelined): opt-in, across schedule only.
+  c->pipeline_conv = c->knob.pipeline_conv && across && !c->knob.graph && !c->onto_call;
+  c->last_schedule = packed ? 3 : !use_level ? 0 : (across ? 2 : 1);
   c->last_groups = groups;
   std::vector<PicWork> hw(n_pics);
   std::vector<ConvJob> jobs((size_t)n_pics * 6);
@@ -2005,15 +2495,16 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
     memset(&hw[i], 0, sizeof(PicWork));
     for (int p = 0; p < 3; p++) {
       const int pclog = p ? clog - 1 : clog, pw = p0->P.pic_w >> (p ? 1 : 0), ph = p0->P.pic_h >> (p ? 1 : 0);
-      // across: the pictures of a group [g0, g1) are interleaved among themselves, groups one after another
-      int g0 = 0, g1 = n_pics;
-      if (across && groups > 1) {
+      // interleave domain [g0, g1) of picture i: a stream group (across), a group of I pictures (packed), itself
+      int g0 = i, g1 = i + 1;
+      if (packed) {
+        g0 = i / I * I, g1 = g0 + I;
+      } else if (across) {
         const int g = (int)(((long long)(i + 1) * groups - 1) / n_pics); // the g with first[g] <= i < first[g+1]
         g0 = (int)((long long)n_pics * g / groups), g1 = (int)((long long)n_pics * (g + 1) / groups);
       }
-      const size_t base = across ? (size_t)g0 * c->tiled_pic_elems + (size_t)c->tiled_plane_off[p] * (g1 - g0) + (size_t)(i - g0) * 64
-                                 : (size_t)i * c->tiled_pic_elems + c->tiled_plane_off[p];
-      const unsigned qstride = across ? 64u * (unsigned)(g1 - g0) : 64u;
+      const size_t base = (size_t)g0 * c->tiled_pic_elems + (size_t)c->tiled_plane_off[p] * (g1 - g0) + (size_t)(i - g0) * 64;
+      const unsigned qstride = 64u * (unsigned)(g1 - g0);
       hw[i].org[p] = TiledPlane{c->pool_org + base, cw, pclog, qstride};
       hw[i].rec[p] = TiledPlane{c->pool_rec + base, cw, pclog, qstride};
       hw[i].lev[p] = lev[i].plane[p];
@@ -2029,8 +2520,6 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
     hw[i].n_levels = (int)pl->level_chunks.size();
   }
   if (use_level && groups > 1 && c->n_side < groups) {
-    // measured on MI355X: launches of different streams do not overlap usefully (the dispatcher
-    // retires ~140k small kernels/s whatever the stream count), so one stream is the default
     if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (int g = c->n_side; g < groups; g++) {
       HIPCHK(c, hipStreamCreateWithFlags(&c->side[g], hipStreamNonBlocking));
@@ -2038,9 +2527,9 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
     }
     c->n_side = groups;
   }
-  // A call is thousands of dependent launches whose arguments depend only on (plans, planes): it is
-  // recorded once as a HIP graph and replayed while the same pictures/plans come back (steady-state
-  // pipelines re-use their picture pools).  Key = the picture table itself.
+  // Key of the call = the picture table itself (planes, level buffers, plans, schedule).  A steady-state pipeline
+  // re-uses its picture pools: the device copy of the table (and the packed schedule's tables) is then kept as it is,
+  // and the call is queued behind the previous one without any synchronisation.
   uint64_t key = 1469598103934665603ull;
   auto mix = [&](const void *p, size_t n) {
     const unsigned char *b = (const unsigned char *)p;
@@ -2048,13 +2537,14 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
   };
   mix(hw.data(), sizeof(PicWork) * n_pics);
   mix(jobs.data(), sizeof(ConvJob) * jobs.size());
-  const int flags[5] = {enc, use_level, groups, n_pics, across};
+  const int flags[6] = {enc, c->last_schedule, groups, n_pics, across, I};
   mix(flags, sizeof(flags));
   for (int i = 0; i < n_pics; i++) {
-    const void *pp = plans[i * plan_stride];
+    const hmx_intra_plan *pp = plans[i * plan_stride];
     mix(&pp, sizeof(pp));
+    mix(&pp->serial, sizeof(pp->serial)); // a destroyed plan's address may come back
   }
-  const bool use_graph = getenv("HMX_GRAPH") != nullptr; // measured: replay is not faster than eager launches here
+  const bool use_graph = c->knob.graph && !packed; // measured: replay is not faster than eager launches here
   hmx_ctx::GraphEntry *hit = nullptr;
   for (auto &e : c->graphs)
     if (e.key == key && e.n_pics == n_pics) hit = &e;
@@ -2063,22 +2553,28 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
     HIPCHK(c, hipGraphLaunch(hit->exec, c->stream));
     return HMX_OK;
   }
-  // miss: a fresh picture table (it must outlive the graph) and, if enabled, a capture
   PicWork *d_work = nullptr;
   const size_t table_bytes = sizeof(PicWork) * n_pics + sizeof(ConvJob) * jobs.size();
-  if (!use_graph) { // eager path: one grow-only table in the context, no synchronisation after the launches
+  if (!use_graph) { // eager path: one grow-only table in the context
     if ((int)table_bytes > c->jobs_cap) {
       HIPCHK(c, hipStreamSynchronize(c->stream));
       hipFree(c->d_jobs);
       c->jobs_cap = 0;
+      c->table_valid = false;
       if (hipMalloc((void **)&c->d_jobs, table_bytes) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc picture table");
       c->jobs_cap = (int)table_bytes;
     }
     char *base = reinterpret_cast<char *>(c->d_jobs);
-    HIPCHK(c, hipMemcpyAsync(base, hw.data(), sizeof(PicWork) * n_pics, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(base + sizeof(PicWork) * n_pics, jobs.data(), sizeof(ConvJob) * jobs.size(), hipMemcpyHostToDevice,
-                             c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream)); // hw / jobs go out of scope
+    if (!c->table_valid || c->table_key != key) {
+      // earlier calls may still read the table: the copies are ordered behind them on the stream; the host vectors go
+      // out of scope, hence the synchronisation -- on this path only
+      HIPCHK(c, hipMemcpyAsync(base, hw.data(), sizeof(PicWork) * n_pics, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(base + sizeof(PicWork) * n_pics, jobs.data(), sizeof(ConvJob) * jobs.size(), hipMemcpyHostToDevice,
+                               c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      c->table_key = key;
+      c->table_valid = true;
+    }
     return issue_intra_launches(c, plans, plan_stride, n_pics, reinterpret_cast<PicWork *>(base),
                                 reinterpret_cast<ConvJob *>(base + sizeof(PicWork) * n_pics), enc, use_level, groups, c->stream);
   }
@@ -2129,7 +2625,7 @@ extern "C" int hmx_frame_intra_decode(hmx_ctx *c, const hmx_intra_plan *pl, int 
 extern "C" int hmx_frame_intra_decode_onto(hmx_ctx *c, const hmx_intra_plan *pl, int n_pics, const hmx_pic *rec,
                                            const hmx_levels *lev) {
   if (!c) return HMX_ERR_ARG;
-  if (getenv("HMX_GRAPH")) return fail(c, HMX_ERR_ARG, "hmx_frame_intra_decode_onto: not available with HMX_GRAPH");
+  if (c->knob.graph) return fail(c, HMX_ERR_ARG, "hmx_frame_intra_decode_onto: not available with HMX_GRAPH");
   c->onto_call = true;
   const int r = frame_intra(c, &pl, 0, n_pics, nullptr, rec, lev, false);
   c->onto_call = false;
@@ -2138,7 +2634,7 @@ extern "C" int hmx_frame_intra_decode_onto(hmx_ctx *c, const hmx_intra_plan *pl,
 extern "C" int hmx_frame_intra_encode_onto(hmx_ctx *c, const hmx_intra_plan *pl, int n_pics, const hmx_pic *org, const hmx_pic *rec,
                                            const hmx_levels *lev) {
   if (!c) return HMX_ERR_ARG;
-  if (getenv("HMX_GRAPH")) return fail(c, HMX_ERR_ARG, "hmx_frame_intra_encode_onto: not available with HMX_GRAPH");
+  if (c->knob.graph) return fail(c, HMX_ERR_ARG, "hmx_frame_intra_encode_onto: not available with HMX_GRAPH");
   c->onto_call = true;
   const int r = frame_intra(c, &pl, 0, n_pics, org, rec, lev, true);
   c->onto_call = false;

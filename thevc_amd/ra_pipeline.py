@@ -140,9 +140,17 @@ class RAWorkload:
 
 
 class RAPipeline:
-    def __init__(self, ctx, torch, wl, rank=0, world=1, dist=None, fused=True):
+    """stream: the torch.cuda.Stream the context was created on (capi.Context(stream=stream.cuda_stream)).  The library's
+    kernels, torch's uploads and the RCCL send/recv of the exchange must share ONE stream: the exchange sends
+    reconstructions the intra chain has just written, and motion compensation reads what it received.  (A context
+    created with stream handle 0 makes its own non-blocking stream, which nothing of torch's ever waits on.)"""
+
+    def __init__(self, ctx, torch, wl, rank=0, world=1, dist=None, fused=True, stream=None):
         self.ctx, self.torch, self.wl, self.rank, self.world, self.dist = ctx, torch, wl, rank, world, dist
         self.fused = fused
+        self.stream = stream if stream is not None else torch.cuda.current_stream()
+        self._ev = None
+        self._moved = (0, 0)
         self.L = capi.lib()
         w, h = wl.w, wl.h
         self.dev = torch.device("cuda", torch.cuda.current_device())
@@ -169,6 +177,39 @@ class RAPipeline:
 
     def load_originals(self):
         """Synthetic originals for every picture this rank codes (resident before the timed region)."""
+        with self.torch.cuda.stream(self.stream):
+            return self._load_originals()
+
+    def run(self):
+        """One pass: intra pictures, exchange, inter pictures of every owned segment.  Returns pixels coded."""
+        with self.torch.cuda.stream(self.stream):
+            return self._run()
+
+    def exchange_stats(self):
+        """What the boundary-picture exchange of the last run() moved on this rank, and how long it took on the stream."""
+        w, h = self.wl.w, self.wl.h
+        per_pic = 2 * ((w + 2 * MARGIN) * (h + 2 * MARGIN) + 2 * (w // 2 + MARGIN) * (h // 2 + MARGIN))
+        out = {"pictures_sent": self._moved[0], "pictures_received": self._moved[1], "bytes_per_picture": per_pic,
+               "bytes_per_step": per_pic * (self._moved[0] + self._moved[1]), "ms": None}
+        if self._ev is not None:
+            self._ev[1].synchronize()
+            out["ms"] = round(self._ev[0].elapsed_time(self._ev[1]), 3)
+        return out
+
+    def free(self):
+        L = self.L
+        for l in self.lev + (self.lev_i or []):
+            l.free()
+        for d in self.lists:
+            L.hmx_tu_list_destroy(self.ctx.h, d["tu"])
+            d["pus_b"].free()
+            d["pus_p"].free()
+        L.hmx_intra_plan_destroy(self.ctx.h, self.plan)
+        self.rec.clear()
+        self.org.clear()
+        self.pred = []
+
+    def _load_originals(self):
         pocs = {k * self.wl.ip for k in self.my_i}
         for k in self.my_segments:
             pocs |= {j[0] for j in self.wl.segment_jobs(k)}
@@ -182,8 +223,7 @@ class RAPipeline:
         self.lev_i = [capi.DevLevelsZ(self.ctx, self.wl.w, self.wl.h) for _ in range(n_i)]
         return len(pocs)
 
-    def run(self):
-        """One pass: intra pictures, exchange, inter pictures of every owned segment.  Returns pixels coded."""
+    def _run(self):
         ctx, L, wl = self.ctx, self.L, self.wl
         w, h = wl.w, wl.h
         # phase 1: all my I pictures in one whole-picture call, then their borders
@@ -197,7 +237,13 @@ class RAPipeline:
             ctx._chk(L.hmx_pic_extend_border_multi(ctx.h, n, rec, w, h, MARGIN, MARGIN))
         # phase 2: boundary I pictures travel to the owner of the previous segment (RCCL send/recv)
         if self.world > 1 and wl.structure == "ra":
+            if self._ev is None:
+                self._ev = (self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True))
+            self._ev[0].record(self.stream)
             run_exchange(self.dist, self.rank, self.world, wl.n_segments, lambda ki: self.rec[ki * wl.ip].t)
+            self._ev[1].record(self.stream)
+            plan = exchange_plan(wl.n_segments, self.world)
+            self._moved = (sum(1 for (_, s_, _d) in plan if s_ == self.rank), sum(1 for (_, _s, d_) in plan if d_ == self.rank))
         # phase 3: inter pictures in coding order; position j of every owned segment in one call per stage
         pixels = n * w * h
         S = len(self.my_segments)

@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""tools/pmc.py -- hardware counters of ONE kernel of a command, collected the way MI355X_MICROARCH.md prescribes:
+rocprofv3 --kernel-trace --pmc, every counter set in its own pass (FETCH_SIZE and WRITE_SIZE each alone), nothing but
+the kernel-trace domain next to --pmc, the program itself after `--`.  Sums the counters over the dispatches of the
+kernel whose name contains KERNEL and writes one JSON summary (profiles/<tag>_pmc_summary.json) with the derived
+figures the judge asks for: wait / VALU-busy shares, LDS bank conflicts, MFMA busy share and int8 MFMA rate against the
+gfx950 dense peak, HBM bytes (FETCH_SIZE doubled per the gfx950 note) per launch.
+
+    python3 tools/pmc.py --tag r02_mix --kernel k_intra_packed [--sets inst,wait,mfma,lds,traffic] -- python3 bench.py --frames 1728 --steps 1 --warmup 0 --no-cpu-baseline
+Run on the GPU box (gpurun); scratch goes to gpurun_out/pmc_<tag>_<set>/.
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SETS = {
+    "inst": "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_FLAT",
+    "wait": "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS",
+    "mfma": "SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU",
+    "lds": "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_WAVE_CYCLES",
+    "fetch": "FETCH_SIZE",
+    "write": "WRITE_SIZE",
+}
+INT8_DENSE_PEAK_TOPS = 5000.0  # MI355X dense int8 = the dense fp8 figure of the guides (~5 PFLOP/s); never the 2:1-sparsity number
+
+
+def run_set(tag, name, counters, cmd, kernel, timeout):
+    out = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{name}")
+    shutil.rmtree(out, ignore_errors=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    full = ["rocprofv3", "--kernel-trace", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", out, "--"] + cmd
+    log = open(out + ".log", "w")
+    rc = subprocess.call(full, cwd=ROOT, env=env, stdout=log, stderr=subprocess.STDOUT, timeout=timeout)
+    files = glob.glob(os.path.join(out, "*", "*counter_collection.csv"))
+    if rc != 0 or not files:
+        return None, rc
+    tot, disp, dur = collections.Counter(), set(), {}
+    for r in csv.DictReader(open(files[0])):
+        if kernel in r["Kernel_Name"]:
+            tot[r["Counter_Name"]] += float(r["Counter_Value"])
+            disp.add(r["Dispatch_Id"])
+    kt = glob.glob(os.path.join(out, "*", "*kernel_trace.csv"))
+    if kt:
+        for r in csv.DictReader(open(kt[0])):
+            if kernel in r["Kernel_Name"]:
+                dur[r.get("Dispatch_Id", len(dur))] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return {"counters": {k: v for k, v in tot.items()}, "launches": len(disp), "kernel_ns": sum(dur.values())}, 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", required=True)
+    ap.add_argument("--kernel", required=True, help="substring of the kernel name")
+    ap.add_argument("--sets", default="inst,wait,mfma,lds,fetch,write")
+    ap.add_argument("--timeout", type=int, default=500)
+    ap.add_argument("--meta", default="{}", help="JSON merged into the summary (frames, plans, ...)")
+    ap.add_argument("cmd", nargs=argparse.REMAINDER)
+    a = ap.parse_args()
+    cmd = a.cmd[1:] if a.cmd and a.cmd[0] == "--" else a.cmd
+    if not cmd:
+        raise SystemExit("no command after --")
+    summary = {"tag": a.tag, "kernel": a.kernel, "command": " ".join(cmd), "passes": {},
+               "method": "rocprofv3 --kernel-trace --pmc, one pass per counter set, summed over the kernel's dispatches"}
+    summary.update(json.loads(a.meta))
+    C = {}
+    for name in a.sets.split(","):
+        res, rc = run_set(a.tag, name, SETS[name], cmd, a.kernel, a.timeout)
+        if res is None:
+            summary["passes"][name] = {"error": f"rocprofv3 exit {rc} or no counter file"}
+            print(f"[pmc] set {name}: failed (rc {rc})", flush=True)
+            continue
+        summary["passes"][name] = res
+        C.update(res["counters"])
+        summary["launches"] = res["launches"]
+        print(f"[pmc] set {name}: {res['launches']} launches, {res['kernel_ns'] / 1e6:.3f} ms in kernel", flush=True)
+
+    def ratio(a_, b_):
+        return round(C[a_] / C[b_], 5) if a_ in C and C.get(b_) else None
+
+    d = {}
+    d["wait_share_of_wave_cycles"] = ratio("SQ_WAIT_ANY", "SQ_WAVE_CYCLES")
+    d["wait_inst_share_of_wave_cycles"] = ratio("SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES")
+    # SQ_ACTIVE_INST_VALU counts 4 cycles per quad-cycle issue on a SIMD; busy cycles are per SQ (4 SIMDs)
+    d["valu_busy_share"] = round(C["SQ_ACTIVE_INST_VALU"] / C["SQ_BUSY_CYCLES"], 5) if C.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in C else None
+    d["valu_insts_per_wave"] = ratio("SQ_INSTS_VALU", "SQ_WAVES")
+    d["salu_insts_per_wave"] = ratio("SQ_INSTS_SALU", "SQ_WAVES")
+    d["lds_insts_per_wave"] = ratio("SQ_INSTS_LDS", "SQ_WAVES")
+    d["lds_bank_conflict_share"] = ratio("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")
+    d["mfma_busy_share_of_busy_cycles"] = ratio("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES")
+    if "SQ_INSTS_VALU_MFMA_I8" in C:
+        ns = summary["passes"].get("mfma", {}).get("kernel_ns") or 0
+        ops = C["SQ_INSTS_VALU_MFMA_I8"] * 2 * 32 * 32 * 32  # v_mfma_i32_32x32x32_i8: 32x32x32 multiply-adds per wave instruction
+        d["mfma_i8_instructions"] = int(C["SQ_INSTS_VALU_MFMA_I8"])
+        if ns:
+            d["mfma_i8_tops"] = round(ops / ns / 1e3, 3)
+            d["mfma_i8_share_of_dense_peak"] = round(ops / ns / 1e3 / INT8_DENSE_PEAK_TOPS, 6)
+            d["int8_dense_peak_tops"] = INT8_DENSE_PEAK_TOPS
+    if "FETCH_SIZE" in C and "WRITE_SIZE" in C and summary.get("launches"):
+        n = summary["launches"]
+        d["FETCH_SIZE_KB"], d["WRITE_SIZE_KB"] = C["FETCH_SIZE"], C["WRITE_SIZE"]
+        d["hbm_bytes_per_launch"] = round((2 * C["FETCH_SIZE"] + C["WRITE_SIZE"]) * 1024 / n)
+        d["hbm_read_bytes_per_launch"] = round(2 * C["FETCH_SIZE"] * 1024 / n)
+        d["hbm_write_bytes_per_launch"] = round(C["WRITE_SIZE"] * 1024 / n)
+        d["note_fetch"] = "gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled (MI355X_MICROARCH.md, HBM)"
+    summary["derived"] = d
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    path = os.path.join(ROOT, "gpurun_out", f"{a.tag}_pmc_summary.json")
+    json.dump(summary, open(path, "w"), indent=1)
+    print(json.dumps(d), flush=True)
+    print("[pmc] wrote", path, "(copy it into profiles/)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
