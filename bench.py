@@ -259,6 +259,9 @@ def main():
     ap.add_argument("--decode", action="store_true",
                     help="time the decoder direction of the chain (levels -> reconstruction, DEC/TDecCu.cpp:469-687) instead of the "
                          "encoder direction; the levels come from one untimed encode")
+    ap.add_argument("--planar", action="store_true",
+                    help="hand the pictures over in the reference's plane geometry (TComPicYuv): every call converts them into and out "
+                         "of the working layout; default: pictures resident in the working layout (hmx_tpool)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--one-core-only", action="store_true", help="cpu_baseline: skip the all-cores leg")
     ap.add_argument("--no-ra", action="store_true", help="N > 1: skip the random-access leg (ra2160p8 with the RCCL exchange) after the all-intra line")
@@ -313,7 +316,7 @@ def main():
     # tiled working pool 6.2 bytes per luma sample, plus 16 B per block of the packed schedule's item table).
     F = args.frames if args.frames else (1728 if w >= 3840 else 4096)
     free_b, _total_b = torch.cuda.mem_get_info()
-    per_pic = int(18.3 * w * h_c) + 18 * max(len(t) for t in tus_list)
+    per_pic = int((18.3 if args.planar else 12.3) * w * h_c) + 18 * max(len(t) for t in tus_list)
     if not args.frames and F * per_pic > 0.92 * free_b:
         F = max(8, int(0.92 * free_b / per_pic) // 64 * 64 or 8)
     n_plans = min(n_plans, F)
@@ -323,27 +326,55 @@ def main():
         if sd not in cache:
             cache[sd] = workload.make_planes(sd, w, h_c, B, "texture")
     src = [cache[sd] for sd in seeds]
-    d_org = [capi.DevPicture(ctx, w, h_c).upload(src[i]) for i in range(F)]
-    d_rec = [capi.DevPicture(ctx, w, h_c).zero() for _ in range(F)]
     d_lev = [capi.DevLevelsZ(ctx, w, h_c).zero() for _ in range(F)]  # the reference's own coefficient layout
-    org_arr = (capi.Pic * F)(*[d.as_pic() for d in d_org])
-    rec_arr = (capi.Pic * F)(*[d.as_pic() for d in d_rec])
     lev_arr = (capi.Levels * F)(*[d.as_pic() for d in d_lev])
     plan_arr = (C.c_void_p * F)(*[plans[i % n_plans].value for i in range(F)])
+    stride = 0 if n_plans == 1 else 1
+    if args.planar:
+        # the reference's plane geometry at the boundary: every call converts the originals into the working layout and
+        # the reconstruction out of it (two extra passes over the pictures, reported as layout_conversion_ms)
+        d_org = [capi.DevPicture(ctx, w, h_c).upload(src[i]) for i in range(F)]
+        d_rec = [capi.DevPicture(ctx, w, h_c).zero() for _ in range(F)]
+        org_arr = (capi.Pic * F)(*[d.as_pic() for d in d_org])
+        rec_arr = (capi.Pic * F)(*[d.as_pic() for d in d_rec])
+        p_org = p_rec = None
+    else:
+        # pictures RESIDENT in the working layout (hmx_tpool): originals are brought in once, before the timed region
+        # (in a pipeline: hmx_yuv_unpack_resident straight from the file's bytes); the reconstruction stays resident
+        d_org = d_rec = []
+        p_org, p_rec = capi.ResidentPool(ctx, w, h_c, F), capi.ResidentPool(ctx, w, h_c, F)
+        stage = [capi.DevPicture(ctx, w, h_c) for _ in range(min(F, 16))]
+        for i0 in range(0, F, len(stage)):
+            part = stage[:min(len(stage), F - i0)]
+            for k, d in enumerate(part):
+                d.upload(src[i0 + k])
+            p_org.import_planes(i0, part)
+        ctx.sync()
+
+    def call(enc):
+        if args.planar:
+            if enc:
+                ctx._chk(L.hmx_frame_intra_encode_multi(ctx.h, plan_arr, F, org_arr, rec_arr, lev_arr) if stride else
+                         L.hmx_frame_intra_encode(ctx.h, plans[0], F, org_arr, rec_arr, lev_arr))
+            else:
+                ctx._chk(L.hmx_frame_intra_decode_multi(ctx.h, plan_arr, F, rec_arr, lev_arr) if stride else
+                         L.hmx_frame_intra_decode(ctx.h, plans[0], F, rec_arr, lev_arr))
+        elif enc:
+            ctx._chk(L.hmx_frame_intra_encode_resident(ctx.h, plan_arr, stride, F, p_org.h_, p_rec.h_, lev_arr))
+        else:
+            ctx._chk(L.hmx_frame_intra_decode_resident(ctx.h, plan_arr, stride, F, p_rec.h_, lev_arr))
 
     def encode():
-        if n_plans == 1:
-            ctx._chk(L.hmx_frame_intra_encode(ctx.h, plans[0], F, org_arr, rec_arr, lev_arr))
-        else:
-            ctx._chk(L.hmx_frame_intra_encode_multi(ctx.h, plan_arr, F, org_arr, rec_arr, lev_arr))
+        call(True)
 
     def step():
-        if not args.decode:
-            return encode()
-        if n_plans == 1:
-            ctx._chk(L.hmx_frame_intra_decode(ctx.h, plans[0], F, rec_arr, lev_arr))
-        else:
-            ctx._chk(L.hmx_frame_intra_decode_multi(ctx.h, plan_arr, F, rec_arr, lev_arr))
+        call(not args.decode)
+
+    def reconstruction(i):
+        if args.planar:
+            return d_rec[i].download()
+        p_rec.export_planes(i, stage[:1])
+        return stage[0].download()
 
     if args.decode:  # produce the levels the decoder direction consumes
         encode()
@@ -419,7 +450,8 @@ def main():
                                    f"{min(levels)}-{max(levels)} dependency levels per picture), "
                                    f"{len(cache)} distinct source pictures, frames sharded over ranks, no collective",
                        "pictures_per_gpu": F, "width": w, "height": h_c, "bit_depth": B, "qp": qp, "tiling": str(args.tiling),
-                       "distinct_plans": n_plans, "distinct_pictures": len(cache), "shared_decisions": n_plans == 1},
+                       "distinct_plans": n_plans, "distinct_pictures": len(cache), "shared_decisions": n_plans == 1,
+                       "pictures": "plane geometry, converted per call" if args.planar else "resident in the working layout (hmx_tpool)"},
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": kernel, "launches_per_step": n_launch, "concurrent_launches": groups.value,
@@ -434,15 +466,18 @@ def main():
             # --verify: one picture of every few packing groups, first and last included
             idx = sorted({0, F - 1} | set(range(0, F, max(64, F // 6 // 64 * 64 or 64)))) if args.verify else [0]
             checks = [(i, tus_list[i % n_plans], plan_seeds[i % n_plans], seeds[i], src[i],
-                       (d_rec[i].download(), d_lev[i].to_planes(tus_list[i % n_plans]))) for i in idx]
+                       (reconstruction(i), d_lev[i].to_planes(tus_list[i % n_plans]))) for i in idx]
             out["cpu_baseline"] = cpu_baseline(w, h_c, B, qp, args.tiling, checks, 0.0 if args.no_cpu_baseline else 10.0,
                                                all_cores=not args.one_core_only)
             if args.verify:
                 cb = out["cpu_baseline"]
                 out["verified_bit_exact_vs_oracle"] = cb.get("gpu_pictures_identical", cb["gpu_picture_0_identical"])
     # free the batch before the optional random-access leg
-    for d in d_org + d_rec + d_lev:
+    for d in d_org + d_rec + d_lev + ([] if args.planar else stage):
         d.free()
+    for x in (p_org, p_rec):
+        if x is not None:
+            x.free()
     for p in plans:
         L.hmx_intra_plan_destroy(ctx.h, p)
     ctx.close()

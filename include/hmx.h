@@ -61,7 +61,7 @@ int hmx_sync(hmx_ctx *ctx);
  * cross-checks).  Each is read once from the environment variable of the same name in hmx_create; hmx_set_option
  * changes one afterwards, value NULL restores the default.  HMX_INTRA_SCHEDULE = packed (default) | level | wave,
  * HMX_INTRA_ACROSS, HMX_INTRA_STREAMS, HMX_PIPELINE_CONV, HMX_GRAPH (level schedules), HMX_PACK_SLOTS4 = 16 | 64,
- * HMX_PACK_K, HMX_PACK_WAVES (packed schedule). */
+ * HMX_PACK_GROUP, HMX_PACK_WAVES, HMX_PACK_SLEEP0, HMX_PACK_SLEEP1 (packed schedule). */
 int hmx_set_option(hmx_ctx *ctx, const char *name, const char *value);
 /* device memory + timing plumbing so that callers need no HIP headers */
 int hmx_malloc(hmx_ctx *ctx, size_t bytes, void **dptr);
@@ -195,6 +195,15 @@ int hmx_filterVerChroma(hmx_ctx *ctx, const hmx_pel *src, int src_stride, int16_
                         int h, int frac, int is_first, int is_last);
 int hmx_addAvg(hmx_ctx *ctx, const hmx_pel *src0, int s0_stride, const hmx_pel *src1, int s1_stride,
                hmx_pel *dst, int dst_stride, int w, int h);
+/* TComPrediction::xPredInterLumaBlk / xPredInterChromaBlk (TLibCommon/TComPrediction.cpp:554-585, :599-642) for one block:
+ * ref = the reference plane at the block's own position (refPic->getLumaAddr(cuAddr, zorder + partAddr); the reference
+ * adds the vector's integer part itself), mv in quarter-pel luma units, bi = the block is one half of a bi-prediction
+ * (output = the 14-bit intermediate, not clipped).  w, h: LUMA size of the block (the chroma form halves it, like the
+ * reference); dst stride in elements.  The planes must be readable 3 (1) samples before and 4 (2) after the moved block. */
+int hmx_xPredInterLumaBlk(hmx_ctx *ctx, const hmx_pel *ref, int ref_stride, int mv_hor, int mv_ver, int w, int h, hmx_pel *dst,
+                          int dst_stride, int bi);
+int hmx_xPredInterChromaBlk(hmx_ctx *ctx, const hmx_pel *ref, int ref_stride, int mv_hor, int mv_ver, int w, int h, hmx_pel *dst,
+                            int dst_stride, int bi);
 
 /* ------------------------------------------------------------------------------------------------
  * Batched device path
@@ -328,6 +337,38 @@ int hmx_frame_intra_encode_onto(hmx_ctx *ctx, const hmx_intra_plan *plan, int n_
                                 const hmx_levels *lev);
 int hmx_frame_intra_decode_multi(hmx_ctx *ctx, const hmx_intra_plan *const *plans, int n_pics, const hmx_pic *rec,
                                  const hmx_levels *lev);
+
+/* Pictures RESIDENT in the library's working layout: CTU blocks in raster order, 4x4 tiles in
+ * Z-order inside a CTU, groups of up to 64 pictures interleaved 8x8 quad by quad.  The whole-picture entry points above
+ * take pictures in the reference's plane geometry (TComPicYuv) and convert them into and out of this layout around
+ * every call; an application that keeps its pictures here pays that once, or never: hmx_yuv_unpack_resident writes a
+ * file's frame straight into a pool picture, hmx_yuv_pack_resident reads one back, hmx_tpool_import / _export convert
+ * from / to planes (e.g. a reconstruction that motion compensation needs with the reference's margins).
+ * A pool holds n_pics pictures of one size; picture indices are positions in the pool. */
+typedef struct hmx_tpool hmx_tpool;
+int hmx_tpool_create(hmx_ctx *ctx, int pic_w, int pic_h, int n_pics, hmx_tpool **pool);
+void hmx_tpool_destroy(hmx_ctx *ctx, hmx_tpool *pool);
+int hmx_tpool_import(hmx_ctx *ctx, hmx_tpool *pool, int first, int n, const hmx_pic *src);       /* planes -> pictures first..first+n-1 */
+int hmx_tpool_export(hmx_ctx *ctx, const hmx_tpool *pool, int first, int n, const hmx_pic *dst); /* and back */
+/* TVideoIOYuv::read / write (TLibVideoIO/TVideoIOYuv.cpp:226-480) on a pool picture; arguments as hmx_yuv_unpack /
+ * hmx_yuv_pack with the picture size taken from the pool (w_full x h_full = the pool's picture size). */
+int hmx_yuv_unpack_resident(hmx_ctx *ctx, const void *d_file, int file_bits, hmx_tpool *pool, int index, int pad_x, int pad_y);
+int hmx_yuv_pack_resident(hmx_ctx *ctx, const hmx_tpool *pool, int index, int crop_right, int crop_bottom, int file_bits, void *d_file);
+/* hmx_frame_intra_encode_multi / _decode_multi on pictures 0..n_pics-1 of resident pools: no layout conversion inside the
+ * call.  plan_stride 1: picture i follows plans[i]; 0: every picture follows plans[0].  org and rec must be pools of the
+ * plans' picture size and of EQUAL picture count (the count fixes how many pictures form a group of the layout). */
+int hmx_frame_intra_encode_resident(hmx_ctx *ctx, const hmx_intra_plan *const *plans, int plan_stride, int n_pics,
+                                    const hmx_tpool *org, hmx_tpool *rec, const hmx_levels *lev);
+int hmx_frame_intra_decode_resident(hmx_ctx *ctx, const hmx_intra_plan *const *plans, int plan_stride, int n_pics,
+                                    hmx_tpool *rec, const hmx_levels *lev);
+
+/* TComPrediction::motionCompensation for one prediction unit (TComPrediction.cpp:410-552 -> xPredInterUni / xPredInterBi
+ * -> the two functions above -> TComYuv::addAvg), the call TEncCu.cpp:1299 and TDecCu.cpp:452 make per coding unit.
+ * ref0 / ref1: the reference pictures of list 0 / 1 as HOST planes (plane[i] at sample (0,0), margins readable), NULL =
+ * list unused; mv0 / mv1: {hor, ver} in quarter-pel, clipped (hmx_clipMv); (x, y, w, h): the unit in luma samples;
+ * dst: HOST planes, plane[i] at the unit's first sample of that plane (a TComYuv part address). */
+int hmx_motionCompensation(hmx_ctx *ctx, const hmx_pic *ref0, const int *mv0, const hmx_pic *ref1, const int *mv1, int x, int y,
+                           int w, int h, const hmx_pic *dst);
 
 /* Motion compensation of a list of PUs against reference pictures resident in HBM with the
  * reference's margin layout (TLibCommon/TComPicYuv.cpp:82-94): motionCompensation -> xPredInterUni/Bi ->

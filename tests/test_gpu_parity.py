@@ -534,16 +534,16 @@ def test_frame_intra_multi_plan(ctx, schedule, hmx_opts):
         L.hmx_intra_plan_destroy(ctx.h, p)
 
 
-@pytest.mark.parametrize("knobs", [{}, {"HMX_PACK_SLOTS4": "64"}, {"HMX_PACK_SLOTS4": "16", "HMX_PACK_K": "3"},
-                                   {"HMX_PACK_WAVES": "3", "HMX_PACK_K": "2"}, {"HMX_PACK_WAVES": "4096", "HMX_PACK_SLOTS4": "64"}])
+@pytest.mark.parametrize("knobs", [{}, {"HMX_PACK_SLOTS4": "64"}, {"HMX_PACK_SLOTS4": "16", "HMX_PACK_GROUP": "64"},
+                                   {"HMX_PACK_WAVES": "3", "HMX_PACK_GROUP": "7"}, {"HMX_PACK_WAVES": "4096", "HMX_PACK_SLOTS4": "64", "HMX_PACK_GROUP": "3"}])
 @pytest.mark.parametrize("pic,n", [((136, 72), 70), ((256, 192), 9), ((64, 64), 130)])
 def test_frame_intra_packed_own_plans(ctx, pic, n, knobs, hmx_opts):
     """The packed schedule (one persistent launch, k_intra_packed): n pictures, EVERY ONE with its own block structure
     and modes, packed into waves across pictures -- more pictures than a group holds (70 and 130 > 64: a full group
-    plus a ragged one), plans with different numbers of dependency levels (uniform 4x4 / 16x16 / 32x32 tilings next to
-    mixed ones), both 4x4 wave shapes, several wave-items per ticket, three persistent waves only (every wave-item
-    then waits behind tickets drawn much earlier) and far more waves than work.  Bit-exact vs the oracle, encoder and
-    decoder direction, both level layouts."""
+    plus a ragged one with 64-picture groups; groups of 3, 7, 9 and 17 pictures otherwise), plans with different numbers
+    of dependency levels (uniform 4x4 / 16x16 / 32x32 tilings next to mixed ones), both 4x4 wave shapes, three
+    persistent waves only (at most three XCDs own all the shards; every wave-item waits behind tickets drawn much
+    earlier) and far more waves than work.  Bit-exact vs the oracle, encoder and decoder direction, both level layouts."""
     hmx_opts(ctx, HMX_INTRA_SCHEDULE="packed", **knobs)
     B, L = ctx.bit_depth, capi.lib()
     w, h = pic
@@ -732,6 +732,175 @@ def test_yuv_files_on_device(ctx, tmp_path):
         rd.close(), wr.close()
         assert open(str(tmp_path / f"out{file_bits}.yuv"), "rb").read() == want_bytes, ("pack", file_bits)
         pic.free()
+
+
+@pytest.mark.parametrize("pic,n", [((136, 72), 70), ((416, 240), 5), ((64, 64), 1)])
+def test_resident_pictures(ctx, pic, n):
+    """Pictures resident in the working layout (hmx_tpool): planes -> pool -> planes is the identity (a ragged last
+    group, pictures that cut the last CTU), and the all-intra chain on resident pools -- no layout conversion inside the
+    call -- writes the oracle's levels and, exported, its reconstruction; decoder direction too."""
+    B, L = ctx.bit_depth, capi.lib()
+    w, h = pic
+    qp = 31
+    pp = capi.PicParam(w, h, qp, 0, capi.I_SLICE, 1)
+    tus = [workload.make_tus(900 + i, w, h, "mix") for i in range(min(n, 7))]
+    plans = [ctx.intra_plan(t, pp) for t in tus]
+    orgs = [workload.make_planes(950 + i, w, h, B, "texture" if i % 2 else "noise") for i in range(n)]
+    d_org = [capi.DevPicture(ctx, w, h, pad=(i % 2)).upload(o) for i, o in enumerate(orgs)]
+    d_out = [capi.DevPicture(ctx, w, h).zero() for _ in range(n)]
+    p_org, p_rec = capi.ResidentPool(ctx, w, h, n), capi.ResidentPool(ctx, w, h, n)
+    p_org.import_planes(0, d_org)
+    p_org.export_planes(0, d_out)
+    ctx.sync()
+    for i in range(n):
+        got = d_out[i].download()
+        assert all(np.array_equal(got[p], orgs[i][p]) for p in range(3)), ("round trip", i)
+    d_lev = [capi.DevLevelsZ(ctx, w, h) for _ in range(n)]
+    lev_arr = (capi.Levels * n)(*[d.as_pic() for d in d_lev])
+    parr = (C.c_void_p * n)(*[plans[i % len(plans)].value for i in range(n)])
+    ctx._chk(L.hmx_frame_intra_encode_resident(ctx.h, parr, 1, n, p_org.h_, p_rec.h_, lev_arr))
+    p_rec.export_planes(0, d_out)
+    ctx.sync()
+    recs = []
+    for i in range(n):
+        rr, lr = ol.o_intra_frame_encode(tus[i % len(tus)], w, h, B, qp, orgs[i])
+        rec, lev = d_out[i].download(), d_lev[i].to_planes(tus[i % len(tus)])
+        recs.append(rec)
+        for p in range(3):
+            assert np.array_equal(rec[p], rr[p]), ("recon", i, p)
+            assert np.array_equal(lev[p], lr[p]), ("levels", i, p)
+    p_dec = capi.ResidentPool(ctx, w, h, n)
+    ctx._chk(L.hmx_frame_intra_decode_resident(ctx.h, parr, 1, n, p_dec.h_, lev_arr))
+    for d in d_out:
+        d.zero()
+    p_dec.export_planes(0, d_out)
+    ctx.sync()
+    for i in range(n):
+        got = d_out[i].download()
+        assert all(np.array_equal(got[p], recs[i][p]) for p in range(3)), ("decode", i)
+    # a pool of another size is refused, not mis-addressed
+    p_bad = capi.ResidentPool(ctx, w + 64, h, n)
+    assert L.hmx_frame_intra_decode_resident(ctx.h, parr, 1, n, p_bad.h_, lev_arr) != 0
+    for x in (p_org, p_rec, p_dec, p_bad):
+        x.free()
+    for pl in plans:
+        L.hmx_intra_plan_destroy(ctx.h, pl)
+    for d in d_org + d_out + d_lev:
+        d.free()
+
+
+def test_yuv_resident(ctx):
+    """hmx_yuv_unpack_resident / hmx_yuv_pack_resident: a file's frame straight into a pool picture and back, vs the
+    plane-geometry entry points (which are held against the oracle's TVideoIOYuv restatement above)."""
+    B, L = ctx.bit_depth, capi.lib()
+    rng = np.random.default_rng(77 + B)
+    for file_bits in (8, 10):
+        w, h, px, py = 72, 40, 24, 8
+        wf, hf = w + px, h + py
+        wide = file_bits > 8
+        pool = capi.ResidentPool(ctx, wf, hf, 3)
+        pic, pic2 = capi.DevPicture(ctx, wf, hf), capi.DevPicture(ctx, wf, hf).zero()
+        for k in range(3):
+            vals = rng.integers(0, 1 << file_bits, w * h * 3 // 2)
+            raw = np.frombuffer(vals.astype("<u2").tobytes() if wide else vals.astype(np.uint8).tobytes(), np.uint8)
+            d_file = ctx.to_device(raw)
+            p = pic.as_pic()
+            ctx._chk(L.hmx_yuv_unpack(ctx.h, d_file.ptr, file_bits, C.byref(p), wf, hf, px, py))
+            ctx._chk(L.hmx_yuv_unpack_resident(ctx.h, d_file.ptr, file_bits, pool.h_, k, px, py))
+            pool.export_planes(k, [pic2])
+            ctx.sync()
+            a, b = pic.download(), pic2.download()
+            assert all(np.array_equal(a[q], b[q]) for q in range(3)), ("unpack", file_bits, k)
+            n_out = L.hmx_yuv_frame_bytes(w, h, file_bits)
+            o1, o2 = ctx.alloc(n_out), ctx.alloc(n_out)
+            ctx._chk(L.hmx_yuv_pack(ctx.h, C.byref(p), wf, hf, px, py, file_bits, o1.ptr))
+            ctx._chk(L.hmx_yuv_pack_resident(ctx.h, pool.h_, k, px, py, file_bits, o2.ptr))
+            assert np.array_equal(o1.download(np.uint8, n_out), o2.download(np.uint8, n_out)), ("pack", file_bits, k)
+            assert np.array_equal(o1.download(np.uint8, n_out), raw) or file_bits != B  # same depth: the file comes back as it was
+            for x in (d_file, o1, o2):
+                x.free()
+        pool.free(), pic.free(), pic2.free()
+
+
+def test_scalar_motion_compensation_dropins(ctx):
+    """hmx_xPredInterLumaBlk / hmx_xPredInterChromaBlk / hmx_motionCompensation (host pointers, one prediction unit per
+    call: what TEncCu.cpp:1299 / TDecCu.cpp:452 reach through TComPrediction::motionCompensation) vs the oracle's
+    restatement of TComPrediction.cpp:410-642: all 16 luma / 64 chroma phases, uni- and bi-prediction, AMP shapes."""
+    O, B, L = ol.oracle(), ctx.bit_depth, capi.lib()
+    rng = np.random.default_rng(4100 + B)
+    mx = (1 << B) - 1
+    W, H, M = 160, 96, 16
+    st, stc = W + 2 * M, W // 2 + M
+    refs = []
+    for _ in range(2):
+        y = rng.integers(0, mx + 1, (H + 2 * M, st)).astype(np.int16)
+        cb = rng.integers(0, mx + 1, (H // 2 + M, stc)).astype(np.int16)
+        cr = rng.integers(0, mx + 1, (H // 2 + M, stc)).astype(np.int16)
+        refs.append((y, cb, cr))
+
+    def pic_of(planes):
+        p = capi.Pic()
+        for k, a in enumerate(planes):
+            m = M if k == 0 else M // 2
+            p.plane[k] = a.ctypes.data + 2 * (m * a.shape[1] + m)
+            p.stride[k] = a.shape[1]
+        return p
+
+    shapes = [(8, 8), (16, 4), (4, 16), (32, 24), (64, 16), (12, 16), (16, 64), (8, 4)]
+    n = 0
+    for it in range(48):
+        w, h = shapes[it % len(shapes)]
+        x, y = int(rng.integers(0, (W - w) // 4 + 1)) * 4, int(rng.integers(0, (H - h) // 4 + 1)) * 4
+        mv = [[int(rng.integers(-4 * (M - 8), 4 * (M - 8) + 1)) for _ in range(2)] for _ in range(2)]
+        if it < 16:
+            mv[0] = [(mv[0][0] & ~3) | (it & 3), (mv[0][1] & ~3) | (it >> 2)]  # every luma phase once
+        use = [(1, 0), (0, 1), (1, 1)][it % 3]
+        # the two block functions, list 0, both values of bi
+        for bi in (0, 1):
+            ry = refs[0][0]
+            o = M * st + M + y * st + x
+            want = np.zeros((h, w), np.int16)
+            O.hmo_predInterLumaBlk(ol.ptr(ry.reshape(-1), o), st, mv[0][0], mv[0][1], w, h, want.reshape(-1), w, bi, B)
+            got = np.zeros((h, w + 3), np.int16)
+            ctx._chk(L.hmx_xPredInterLumaBlk(ctx.h, ry.ctypes.data + 2 * o, st, mv[0][0], mv[0][1], w, h, got.ctypes.data, w + 3, bi))
+            assert np.array_equal(got[:, :w], want), ("luma", it, bi)
+            rc = refs[0][1]
+            oc = (M // 2) * stc + M // 2 + (y // 2) * stc + x // 2
+            wantc = np.zeros((h // 2, w // 2), np.int16)
+            O.hmo_predInterChromaBlk(ol.ptr(rc.reshape(-1), oc), stc, mv[0][0], mv[0][1], w, h, wantc.reshape(-1), w // 2, bi, B)
+            gotc = np.zeros((h // 2, w // 2), np.int16)
+            ctx._chk(L.hmx_xPredInterChromaBlk(ctx.h, rc.ctypes.data + 2 * oc, stc, mv[0][0], mv[0][1], w, h, gotc.ctypes.data, w // 2, bi))
+            assert np.array_equal(gotc, wantc), ("chroma", it, bi)
+        # the whole unit
+        dst = [np.zeros((h, w), np.int16), np.zeros((h // 2, w // 2), np.int16), np.zeros((h // 2, w // 2), np.int16)]
+        dp = capi.Pic()
+        for k in range(3):
+            dp.plane[k], dp.stride[k] = dst[k].ctypes.data, dst[k].shape[1]
+        r0, r1 = pic_of(refs[0]), pic_of(refs[1])
+        m0, m1 = (C.c_int * 2)(*mv[0]), (C.c_int * 2)(*mv[1])
+        ctx._chk(L.hmx_motionCompensation(ctx.h, C.byref(r0) if use[0] else None, m0 if use[0] else None,
+                                          C.byref(r1) if use[1] else None, m1 if use[1] else None, x, y, w, h, C.byref(dp)))
+        bi = int(use[0] and use[1])
+        for k in range(3):
+            ch = 1 if k else 0
+            pw, ph, sk, mk = w >> ch, h >> ch, (stc if k else st), (M // 2 if k else M)
+            parts = []
+            for l in range(2):
+                if not use[l]:
+                    continue
+                a = refs[l][k]
+                o = mk * sk + mk + (y >> ch) * sk + (x >> ch)
+                t = np.zeros((ph, pw), np.int16)
+                (O.hmo_predInterChromaBlk if k else O.hmo_predInterLumaBlk)(ol.ptr(a.reshape(-1), o), sk, mv[l][0], mv[l][1], w, h,
+                                                                            t.reshape(-1), pw, bi, B)
+                parts.append(t)
+            want = parts[0]
+            if bi:
+                want = np.zeros((ph, pw), np.int16)
+                O.hmo_addAvg(parts[0].reshape(-1), pw, parts[1].reshape(-1), pw, want.reshape(-1), pw, pw, ph, B)
+            assert np.array_equal(dst[k], want), ("motionCompensation", it, k, use)
+        n += 1
+    assert n == 48
 
 
 def test_deblock_picture_vs_oracle(ctx):

@@ -130,6 +130,9 @@ def lib():
         for n in ("hmx_filterVerLuma", "hmx_filterVerChroma"):
             getattr(L, n).argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, ci]
         L.hmx_addAvg.argtypes = [vp, vp, ci, vp, ci, vp, ci, ci, ci]
+        L.hmx_xPredInterLumaBlk.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, ci, ci]
+        L.hmx_xPredInterChromaBlk.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, ci, ci]
+        L.hmx_motionCompensation.argtypes = [vp, C.POINTER(Pic), C.POINTER(ci), C.POINTER(Pic), C.POINTER(ci), ci, ci, ci, ci, C.POINTER(Pic)]
         L.hmx_tu_list_create.argtypes = [vp, vp, ci, C.POINTER(vp)]
         L.hmx_tu_list_destroy.argtypes = [vp, vp]
         L.hmx_tu_list_destroy.restype = None
@@ -175,6 +178,15 @@ def lib():
         L.hmx_yuv_frame_bytes.restype = C.c_size_t
         L.hmx_yuv_unpack.argtypes = [vp, vp, ci, C.POINTER(Pic), ci, ci, ci, ci]
         L.hmx_yuv_pack.argtypes = [vp, C.POINTER(Pic), ci, ci, ci, ci, ci, vp]
+        L.hmx_tpool_create.argtypes = [vp, ci, ci, ci, C.POINTER(vp)]
+        L.hmx_tpool_destroy.argtypes = [vp, vp]
+        L.hmx_tpool_destroy.restype = None
+        L.hmx_tpool_import.argtypes = [vp, vp, ci, ci, C.POINTER(Pic)]
+        L.hmx_tpool_export.argtypes = [vp, vp, ci, ci, C.POINTER(Pic)]
+        L.hmx_yuv_unpack_resident.argtypes = [vp, vp, ci, vp, ci, ci, ci]
+        L.hmx_yuv_pack_resident.argtypes = [vp, vp, ci, ci, ci, ci, vp]
+        L.hmx_frame_intra_encode_resident.argtypes = [vp, vp, ci, ci, vp, vp, C.POINTER(Levels)]
+        L.hmx_frame_intra_decode_resident.argtypes = [vp, vp, ci, ci, vp, C.POINTER(Levels)]
         L.hmx_clipMv.argtypes = [C.POINTER(ci), C.POINTER(ci), ci, ci, ci, ci, ci]
         L.hmx_clipMv.restype = None
         _lib = L
@@ -513,3 +525,30 @@ class DevLevelsZ:
         for p in range(3):
             self.bufs[p].upload(raw[p])
         return self
+
+
+class ResidentPool:
+    """hmx_tpool: n pictures of one size resident in the library's working layout (include/hmx.h)."""
+
+    def __init__(self, ctx, w, h, n):
+        self.ctx, self.w, self.h, self.n = ctx, w, h, n
+        h_ = C.c_void_p()
+        ctx._chk(lib().hmx_tpool_create(ctx.h, w, h, n, C.byref(h_)))
+        self.h_ = h_
+
+    def import_planes(self, first, dev_pictures):
+        n = len(dev_pictures)
+        arr = (Pic * n)(*[d.as_pic() for d in dev_pictures])
+        self.ctx._chk(lib().hmx_tpool_import(self.ctx.h, self.h_, first, n, arr))
+        return self
+
+    def export_planes(self, first, dev_pictures):
+        n = len(dev_pictures)
+        arr = (Pic * n)(*[d.as_pic() for d in dev_pictures])
+        self.ctx._chk(lib().hmx_tpool_export(self.ctx.h, self.h_, first, n, arr))
+        return self
+
+    def free(self):
+        if self.h_:
+            lib().hmx_tpool_destroy(self.ctx.h, self.h_)
+            self.h_ = None

@@ -273,8 +273,17 @@ constexpr int kSlots4Own = 64;       // per-picture level kernel: one lane per b
 // follow one plan (same decisions) run in SIMD across pictures: the descriptor, its mode, position and
 // availability are wave-uniform (scalar registers, no divergent mode branches), and a wave is full
 // whenever the batch holds at least 64/N pictures.
+// The lane index as a value the optimiser cannot see through.  Inside a persistent loop (k_intra_packed) everything
+// derived from threadIdx.x is loop-invariant: the compiler hoists all of it -- slot, row, LDS addresses of four chains --
+// out of the loop and, out of registers, parks it in scratch memory (176 bytes per lane, reloaded every iteration).
+__device__ __forceinline__ int lane_id() {
+  int l = threadIdx.x;
+  asm volatile("" : "+v"(l));
+  return l;
+}
 struct OwnPicture {
   static constexpr bool kCoherent = false; // producer and consumer are separated by a kernel boundary
+  static constexpr bool kWriteThrough = false;
   const PicWork &W;
   const FTu *tus;
   __device__ __forceinline__ void wait() const {}
@@ -287,6 +296,7 @@ struct OwnPicture {
 };
 struct AcrossPictures {
   static constexpr bool kCoherent = false;
+  static constexpr bool kWriteThrough = false;
   __device__ __forceinline__ void wait() const {}
   const PicWork *pics;
   const FTu *ft; // the one block this wave works on (wave-uniform address: scalar loads)
@@ -316,7 +326,7 @@ __device__ __forceinline__ unsigned lev_row_off(const PlaneView &V, int x, int y
 template <int N, bool ENC, bool ONCE = false, typename SRC>
 __device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, const PicDev &P, int count) {
   constexpr int SL = 64 / N;
-  const int lane = threadIdx.x, slot = lane / N, gl = lane % N;
+  const int lane = lane_id(), slot = lane / N, gl = lane % N;
   TuLds<N> &L = reinterpret_cast<TuLds<N> *>(smem)[slot];
   for (int base = 0; ONCE ? base < 1 : base < count; base += SL) { // ONCE: the level schedule hands a wave at most one pass
     const int i = base + slot;
@@ -362,7 +372,7 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, cons
       const int mx = (1 << P.bit_depth) - 1;
 #pragma unroll
       for (int k = 0; k < N; k++) row[k] = clip3(0, mx, pred[k] + row[k]);
-      tstore_row<N, SRC::kCoherent>(R.p + pb0, R.qstride, gl, row);
+      tstore_row<N, SRC::kWriteThrough>(R.p + pb0, R.qstride, gl, row);
     }
   }
 }
@@ -478,7 +488,7 @@ __device__ __forceinline__ void lane4_inverse(const int *lv, bool use_dst, bool 
 template <bool ENC, bool ONCE = false, typename SRC>
 __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, const PicDev &P, int count) {
   Lane4Lds &LS = *reinterpret_cast<Lane4Lds *>(smem);
-  const int lane = threadIdx.x;
+  const int lane = lane_id();
   const int B = P.bit_depth, mx = (1 << B) - 1;
   for (int base = 0; ONCE ? base < 1 : base < count; base += 64) {
     const int i = base + lane;
@@ -600,7 +610,7 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
       r0[k] = (clip3(0, mx, pred[2 * k] + out[2 * k]) & 0xffff) | (clip3(0, mx, pred[2 * k + 1] + out[2 * k + 1]) << 16);
       r1[k] = (clip3(0, mx, pred[8 + 2 * k] + out[8 + 2 * k]) & 0xffff) | (clip3(0, mx, pred[8 + 2 * k + 1] + out[8 + 2 * k + 1]) << 16);
     }
-    if constexpr (SRC::kCoherent) { // write-through, one tile row per store
+    if constexpr (SRC::kWriteThrough) { // write-through, one tile row per store
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         s4v a, b;
@@ -619,7 +629,7 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
 
 template <bool ENC, bool ONCE = false, typename SRC>
 __device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const PicDev &P, int count) {
-  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int lane = lane_id(), r = lane & 31, h = lane >> 5;
   TuLds<32> &L = *reinterpret_cast<TuLds<32> *>(smem);
   constexpr int LG = 5;
   for (int i = 0; ONCE ? i < 1 : i < count; i++) {
@@ -682,7 +692,7 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const 
       const int p0 = pred2[2 * q] & 0xffff, p1 = pred2[2 * q] >> 16, p2 = pred2[2 * q + 1] & 0xffff, p3 = pred2[2 * q + 1] >> 16;
       s4v o = {(short)clip3(0, mx, p0 + out[4 * q]), (short)clip3(0, mx, p1 + out[4 * q + 1]),
                (short)clip3(0, mx, p2 + out[4 * q + 2]), (short)clip3(0, mx, p3 + out[4 * q + 3])};
-      st_rec4<SRC::kCoherent>(R.p + row_off + trel<32>(R.qstride, tile_in_block(2 * q + h, r >> 2)), o);
+      st_rec4<SRC::kWriteThrough>(R.p + row_off + trel<32>(R.qstride, tile_in_block(2 * q + h, r >> 2)), o);
     }
     wave_sync();
   }
@@ -861,19 +871,28 @@ __global__ __launch_bounds__(64, 4) void k_intra_wave(FrameArgs A) {
 //     holds every block of that level of the group's pictures -- each picture following ITS OWN plan -- bucketed by
 //     transform size.  A WAVE-ITEM is one wave's worth of a bucket: 64/N blocks (one 32x32 block) taken from whichever
 //     pictures have them, so waves are full whether the pictures share a plan or not (per item: picture + descriptor);
-//   * wave-items are numbered row after row, level-major (tickets).  A persistent wave draws the next ticket with an
-//     atomic add, WAITS until the previous row of the same group is complete (one counter per row, polled with an
-//     L1-bypassing load), runs the block chain, drains its write-through stores and adds 1 to its row's counter.
+//   * groups are dealt to SHARDS (group mod n_shards, at most 8); the wave-items of a shard are numbered row after row,
+//     level-major (tickets).  A persistent wave draws the next ticket of its shard with an atomic add, WAITS until the
+//     previous row of the same group is complete (one counter per row, polled with an L1-bypassing load), runs the
+//     block chain, drains its stores and adds 1 to its row's counter.
+// A shard belongs to ONE XCD: the first wave that touches it claims it for the XCD it runs on (compare-and-swap on the
+// shard's owner word with the hardware's XCC id; a wave starts at the shard with its XCD's number, moves on to shards its
+// XCD already owns or that nobody owns when those are drained, and never works on another XCD's).  So every producer and
+// every consumer of a group's reconstruction runs on the same XCD BY CONSTRUCTION -- read from the hardware, not assumed
+// from the dispatch order -- and the hand-off stays inside that XCD's L2: plain stores (the vector L1 is write-through;
+// a store whose vmcnt has drained is in the L2), loads that bypass the L1 (sc1), no write-through to HBM and no round
+// trip to it on the dependency path.  An XCD is a 32-CU machine with its own L2; this schedule runs eight of them side
+// by side on independent pictures.
 // Forward progress: a wave waits only for wave-items with SMALLER tickets of the same shard, and a ticket is drawn by a
-// wave that is already running, in ticket order.  So the unfinished wave-item with the smallest ticket is always held by a
-// running wave whose own dependencies are complete: it finishes, and by induction all do, whatever the number of
-// resident waves, the dispatch order or the placement.  There is no barrier between workgroups.  (A spin that exceeds
-// ~2^22 polls -- seconds -- raises the abort word and every wave leaves: a bug then fails loudly instead of hanging.)
-// Rows of different groups are independent, so while one group waits for its row's last wave-item the others compute:
-// the per-level latency floor of the level schedules overlaps with work instead of adding up.
-// Visibility of the reconstruction between wave-items: see ld_rec4 / st_rec4 (hmx_kernels.h).
-// The ticket words are sharded by group (shard = group mod n_shards, a wave starts on the shard of its XCD and moves on
-// when it is drained): one word serves ~88 M draws/s, a 1792-picture step needs several hundred.
+// wave that is already running, in ticket order.  So the unfinished wave-item with the smallest ticket of a shard is always
+// held by a running wave whose own dependencies are complete: it finishes, and by induction all do, whatever the number of
+// resident waves, the dispatch order or the placement (an XCD that gets no wave of the launch owns nothing: its shards
+// are claimed by the waves of another XCD once those have drained their own).  There is no barrier between workgroups.
+// (A spin that exceeds ~2^22 polls -- seconds -- raises the abort word and every wave leaves: a bug fails loudly.)
+// Rows of different groups are independent, so while one group waits for its row's last wave-item the others compute.
+// Latency hiding inside a wave: the ticket, the descriptor and the items of the NEXT wave-item are fetched while the current
+// one runs (ticket drawn before the chain, descriptor loaded behind the dependency poll, items loaded behind the chain's
+// stores), so that a wave-item starts with its block descriptors in registers.
 // Reference for the dependency a row encodes: TLibCommon/TComPattern.cpp:389-425 (which neighbours a block reads).
 // =============================================================================================
 struct PackRow { // one (level, group)
@@ -896,6 +915,11 @@ struct PackHdr {
   uint32_t abort;         // set by a wave whose wait timed out
   uint32_t pad1[31];
   uint32_t ticket[8][32]; // one 128-byte line per shard
+  uint32_t owner[8][32];  // 0: unclaimed, x + 1: claimed by XCD x
+  // -DHMX_PACK_PROFILE builds only: phases of a wave-item in ticks of the 100 MHz wall clock, summed over all wave-items
+  // [0] draw a ticket [1] descriptor [2] item loads issued up to the wait [3] wait for the previous row [4] references +
+  // arithmetic + stores issued [5] drain of the stores [6] count; [7] wave-items; [8] polls; [9] waves' lifetimes
+  unsigned long long prof[16];
 };
 struct PackPic { // per picture: where its levels go, and the plan it follows
   int *lev[3];
@@ -1026,24 +1050,38 @@ __global__ __launch_bounds__(64) void k_pack_fill(const PackPic *pics, const Pac
   }
 }
 
+// The completion counters of different rows live on different 128-byte lines: the adds of a row's wave-items serialise
+// on their word anyway (~12 ns each), but with neighbouring rows on one line every add and every poll of a whole level --
+// all groups -- queued on ONE L2 channel (measured: the first cut ran 5x slower than the level schedule it replaces).
+constexpr uint32_t kDoneStride = 32;
 struct PackArgs {
   const PackPic *pics;
   const PackRow *rows;
   const PackDesc *descs;
   const FTu *items;
-  uint32_t *done; // [rows] completed wave-items
+  uint32_t *done; // [rows][kDoneStride] completed wave-items, one 128-byte line per row (see kDoneStride)
+  int sleep0, sleep1; // poll back-off in units of 64 clocks: previous row not started / in progress
   PackHdr *hdr;
   const short *pool_org;
   short *pool_rec;
   size_t pic_elems;      // one picture, three planes
   uint32_t plane_off[3]; // of one picture
   int ctu_w, clog;
-  int n_groups, n_shards, I, K; // K = wave-items per ticket
+  int n_groups, n_shards, I;
   PicDev P;
 };
+// what a wave-item of the packed schedule prefetches for its successor (see k_intra_packed)
+struct PackNext {
+  uint32_t ticket_raw; // lane 0: the ticket drawn for the next wave-item (the atomic's return value)
+  uint32_t base, total;
+  const PackDesc *descs;
+  uint32_t t;          // the next ticket, wave-uniform (valid after the dependency wait)
+  PackDesc d;          // its descriptor (in flight after the dependency wait)
+};
 struct PackedSrc {
-  static constexpr bool kCoherent = true;
-  const FTu *items;     // the wave-item's entries
+  static constexpr bool kCoherent = true;      // reconstruction loads bypass the vector L1 (sc1)
+  static constexpr bool kWriteThrough = false; // producers and consumers share an XCD's L2: plain stores
+  FTu ft;               // this lane's item, fetched during the previous wave-item
   const PackPic *gpics; // the group's pictures
   const short *org_g;   // the group's region of the pools
   short *rec_g;
@@ -1053,13 +1091,18 @@ struct PackedSrc {
   const uint32_t *dep;  // counter of the previous row of the group (NULL: first level)
   uint32_t target;
   uint32_t *abort_word;
-  __device__ __forceinline__ FTu desc(int i) const {
-    FTu f = items[i];
+  int sleep0, sleep1;
+  PackNext *nx;
+#ifdef HMX_PACK_PROFILE
+  unsigned long long *pt; // [0] wait entry, [1] wait exit, [2] polls
+#endif
+  __device__ __forceinline__ FTu desc(int) const { // the chains ask for item i = lane / (lanes per block): that is what was fetched
+    FTu f = ft;
     f.t.plane &= 3;
     return f;
   }
-  __device__ __forceinline__ PlaneView view(int i, int pl) const {
-    const unsigned k = items[i].t.plane >> 2;
+  __device__ __forceinline__ PlaneView view(int, int pl) const {
+    const unsigned k = ft.t.plane >> 2;
     const size_t o = (size_t)(pl == 0 ? 0u : pl == 1 ? off1 : off2) + (size_t)k * 64;
     const char *row = reinterpret_cast<const char *>(&gpics[k]);
     int *lv = *reinterpret_cast<int *const *>(row + offsetof(PackPic, lev) + pl * sizeof(int *));
@@ -1068,14 +1111,22 @@ struct PackedSrc {
   }
   // Wait until the previous row of the group is complete.  One L1-bypassing load per poll (the whole wave reads one
   // word: one request); everything the chain loads from the reconstruction afterwards is an sc1 load issued after this
-  // loop has seen the count, and the producers drained their sc1 stores before they counted.
+  // loop has seen the count, and the producers' stores had reached the L2 (vmcnt drained) before they counted.
   __device__ __forceinline__ void wait() const {
+#ifdef HMX_PACK_PROFILE
+    pt[0] = wall_clock64();
+#endif
     if (dep) {
       unsigned spins = 0;
       for (;;) {
+#ifdef HMX_PACK_PROFILE
+        pt[2]++;
+#endif
         const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((gu32 *)dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if (v >= target) break;
-        __builtin_amdgcn_s_sleep(1);
+        // back off: a row that has not finished a single wave-item is at least one block chain away, one in progress
+        // completes within a few hundred nanoseconds; every poll is a request to the L2 channel the producers add on
+        for (int q = v == 0 ? sleep0 : sleep1; q > 0; q--) __builtin_amdgcn_s_sleep(1);
         if ((++spins & 1023u) == 0) {
           if (spins >= (1u << 22)) __hip_atomic_store((gu32 *)abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((gu32 *)abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
@@ -1083,48 +1134,125 @@ struct PackedSrc {
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler ordering: no reconstruction load moves above the poll
+    // the next wave-item's ticket has long returned: fetch its descriptor behind the reference loads that follow
+    nx->t = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx->ticket_raw);
+    if (nx->t < nx->total) nx->d = nx->descs[nx->base + nx->t];
+#ifdef HMX_PACK_PROFILE
+    pt[1] = wall_clock64();
+#endif
   }
 };
+
+// item index of a lane inside a wave-item of size class s: lane / (lanes per block)
+template <int SL4>
+__device__ __forceinline__ int pack_lane_item(int lane, int s) {
+  return s == 0 ? (SL4 == 64 ? lane : lane >> 2) : s == 1 ? lane >> 3 : s == 2 ? lane >> 4 : 0;
+}
 
 template <bool ENC, int SL4>
 __global__ __launch_bounds__(64, 4) void k_intra_packed(PackArgs A) {
   __shared__ __attribute__((aligned(16))) char smem[HMX_WAVE_SMEM];
   int xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  const int lane = threadIdx.x, shard0 = (xcc & 7) % A.n_shards;
+  xcc &= 15;
   PackHdr *hdr = A.hdr;
+#ifdef HMX_PACK_PROFILE
+  unsigned long long acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt[3] = {0, 0, 0};
+  const unsigned long long t_start = wall_clock64();
+#define PROF_T(v) const unsigned long long v = wall_clock64()
+#else
+#define PROF_T(v)
+#endif
   for (int si = 0; si < A.n_shards; si++) {
-    const int sh = shard0 + si < A.n_shards ? shard0 + si : shard0 + si - A.n_shards;
-    const uint32_t base = hdr->shard_base[sh], total = hdr->shard_base[sh + 1] - base;
-    for (;;) {
-      uint32_t t = 0;
-      if (lane == 0) t = __hip_atomic_fetch_add((gu32 *)&hdr->ticket[sh][0], (uint32_t)A.K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-      if (t >= total) break;
-      if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((gu32 *)&hdr->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
-      const uint32_t e = min(t + (uint32_t)A.K, total);
-      for (uint32_t w = t; w < e; w++) {
-        const PackDesc d = A.descs[base + w];
-        const int s = (int)(d.n_s >> 28), n = (int)(d.n_s & 0x0fffffffu);
-        const int g = (int)(d.row % (uint32_t)A.n_groups);
-        const size_t greg = (size_t)g * A.I * A.pic_elems;
-        const PackedSrc src{A.items + d.item_off, A.pics + (size_t)g * A.I, A.pool_org + greg, A.pool_rec + greg,
-                            A.plane_off[1] * (uint32_t)A.I, A.plane_off[2] * (uint32_t)A.I, 64u * (uint32_t)A.I, A.ctu_w, A.clog,
-                            d.dep_target ? A.done + (d.row - (uint32_t)A.n_groups) : nullptr, d.dep_target, &hdr->abort};
-        wave_sync(); // the LDS scratch is re-interpreted per block size
-        if (s == 0) {
-          if constexpr (SL4 == 64) wave_chain_4_lane<ENC, true>(smem, src, A.P, n);
-          else wave_chain_valu<4, ENC, true>(smem, src, A.P, n);
-        } else if (s == 1) wave_chain_valu<8, ENC, true>(smem, src, A.P, n);
-        else if (s == 2) wave_chain_valu<16, ENC, true>(smem, src, A.P, n);
-        else wave_chain_32<ENC, true>(smem, src, A.P, n);
-        // publish: every store of this wave has left for memory before the row's count moves
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add((gu32 *)(A.done + d.row), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int s0 = xcc % A.n_shards, sh = s0 + si < A.n_shards ? s0 + si : s0 + si - A.n_shards;
+    // whose shard?  mine if my XCD claimed it or nobody has yet (then it is mine from now on)
+    uint32_t own = 0;
+    if (lane_id() == 0) {
+      own = __hip_atomic_load((gu32 *)&hdr->owner[sh][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (own == 0) {
+        uint32_t expect = 0;
+        own = __hip_atomic_compare_exchange_strong((gu32 *)&hdr->owner[sh][0], &expect, (uint32_t)xcc + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT)
+                  ? (uint32_t)xcc + 1u
+                  : expect;
       }
     }
+    own = (uint32_t)__builtin_amdgcn_readfirstlane((int)own);
+    if (own != (uint32_t)xcc + 1u) continue;
+    if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((gu32 *)&hdr->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
+    PackNext nx;
+    nx.base = hdr->shard_base[sh], nx.total = hdr->shard_base[sh + 1] - nx.base;
+    nx.descs = A.descs;
+    gu32 *ticket = (gu32 *)&hdr->ticket[sh][0];
+    // prologue: the first wave-item's ticket, descriptor and items, unhidden
+    PROF_T(p0);
+    uint32_t t = 0;
+    if (lane_id() == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (t >= nx.total) continue;
+    PackDesc d = A.descs[nx.base + t];
+    FTu ft;
+    {
+      const int s = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)d.n_s) >> 28), n = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)d.n_s) & 0x0fffffffu);
+      ft = A.items[(uint32_t)__builtin_amdgcn_readfirstlane((int)d.item_off) + (uint32_t)min(pack_lane_item<SL4>(lane_id(), s), n - 1)];
+    }
+    PROF_T(p1);
+#ifdef HMX_PACK_PROFILE
+    acc[0] += p1 - p0;
+#endif
+    for (;;) {
+      PROF_T(p2);
+      // draw the NEXT ticket now: its latency hides behind this wave-item
+      nx.ticket_raw = 0;
+      if (lane_id() == 0) nx.ticket_raw = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      d.item_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.item_off), d.n_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.n_s);
+      d.row = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.row), d.dep_target = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.dep_target);
+      const int s = (int)(d.n_s >> 28), n = (int)(d.n_s & 0x0fffffffu);
+      const int g = (int)(d.row % (uint32_t)A.n_groups);
+      const size_t greg = (size_t)g * A.I * A.pic_elems;
+      const PackedSrc src{ft, A.pics + (size_t)g * A.I, A.pool_org + greg, A.pool_rec + greg,
+                          A.plane_off[1] * (uint32_t)A.I, A.plane_off[2] * (uint32_t)A.I, 64u * (uint32_t)A.I, A.ctu_w, A.clog,
+                          d.dep_target ? A.done + (size_t)(d.row - (uint32_t)A.n_groups) * kDoneStride : nullptr, d.dep_target, &hdr->abort,
+                          A.sleep0, A.sleep1, &nx
+#ifdef HMX_PACK_PROFILE
+                          , pt
+#endif
+      };
+      wave_sync(); // the LDS scratch is re-interpreted per block size
+      PROF_T(p3);
+      if (s == 0) {
+        if constexpr (SL4 == 64) wave_chain_4_lane<ENC, true>(smem, src, A.P, n);
+        else wave_chain_valu<4, ENC, true>(smem, src, A.P, n);
+      } else if (s == 1) wave_chain_valu<8, ENC, true>(smem, src, A.P, n);
+      else if (s == 2) wave_chain_valu<16, ENC, true>(smem, src, A.P, n);
+      else wave_chain_32<ENC, true>(smem, src, A.P, n);
+      // the next wave-item's items, behind this one's stores (its descriptor was fetched behind the dependency poll)
+      const bool more = nx.t < nx.total;
+      FTu ftn = ft;
+      if (more) {
+        const uint32_t ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx.d.n_s);
+        ftn = A.items[(uint32_t)__builtin_amdgcn_readfirstlane((int)nx.d.item_off) +
+                      (uint32_t)min(pack_lane_item<SL4>(lane_id(), (int)(ns >> 28)), (int)(ns & 0x0fffffffu) - 1)];
+      }
+      // publish: every store of this wave has reached the L2 before the row's count moves
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      PROF_T(p4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PROF_T(p5);
+      if (lane_id() == 0) __hip_atomic_fetch_add((gu32 *)(A.done + (size_t)d.row * kDoneStride), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef HMX_PACK_PROFILE
+      const unsigned long long p6 = wall_clock64();
+      acc[1] += p3 - p2, acc[2] += pt[0] - p3, acc[3] += pt[1] - pt[0], acc[4] += p4 - pt[1], acc[5] += p5 - p4, acc[6] += p6 - p5, acc[7] += 1;
+#endif
+      if (!more) break;
+      d = nx.d, ft = ftn;
+    }
   }
+#ifdef HMX_PACK_PROFILE
+  acc[8] = pt[2], acc[9] = wall_clock64() - t_start;
+  if (lane_id() == 0)
+    for (int q = 0; q < 10; q++) atomicAdd(&hdr->prof[q], acc[q]);
+#endif
 }
 
 // The inter block chain for 32x32 blocks on the matrix cores, ONE WAVE PER BLOCK (k_list<32> spends 32 lanes on a
@@ -1248,11 +1376,14 @@ struct hmx_ctx {
   // working pictures of the whole-picture path in tiled layout (grow-only pool, one slot per picture)
   // ONE allocation per direction, picture i at element offset i * tiled_pic_elems, its planes at
   // tiled_plane_off[]: a wave that works across pictures reaches any picture with a multiply-add
-  short *pool_org = nullptr, *pool_rec = nullptr;
+  short *pool_org = nullptr, *pool_rec = nullptr; // pools of the call being issued: the context's own or the caller's (hmx_tpool)
+  short *own_pool_org = nullptr, *own_pool_rec = nullptr; // allocations behind the plane-geometry entry points
   int pool_pics = 0;
   size_t tiled_pic_elems = 0;
   uint32_t tiled_plane_off[3] = {0, 0, 0};
-  int tiled_cw = 0, tiled_ch = 0; // CTU grid the pool was sized for
+  int tiled_cw = 0, tiled_ch = 0; // CTU grid of the call being issued
+  int own_cw = 0, own_ch = 0;     // CTU grid the context's own pools were sized for
+  bool resident_call = false;     // the call works on the caller's resident pools: no layout conversion
   ConvJob *d_jobs = nullptr;      // [2][n_pics*3]: to-tiled jobs, then from-tiled jobs
   int jobs_cap = 0;
   // whole-picture calls recorded as HIP graphs (see frame_intra)
@@ -1307,7 +1438,7 @@ struct hmx_ctx {
     uint64_t key = 0;
     bool valid = false;
     PackGeom G{};
-    int K = 1, n_wg = 0;
+    int n_wg = 0;
     uint64_t waves_bound = 0;
   } pk;
   int max_resident_waves = 0; // of k_intra_packed on this device
@@ -1323,8 +1454,9 @@ struct hmx_ctx {
     int streams = 0;       // HMX_INTRA_STREAMS: picture groups of the across schedule
     bool pipeline_conv = false, graph = false;
     int slots4 = 0;        // HMX_PACK_SLOTS4: 16 or 64 4x4 blocks per wave-item (0: by batch size)
-    int pack_k = 0;        // HMX_PACK_K: wave-items per ticket (0: by batch size)
+    int pack_group = 0;    // HMX_PACK_GROUP: pictures per group, 1..64 (0: by batch size, see pack_group_size)
     int pack_waves = 0;    // HMX_PACK_WAVES: persistent waves (0: by batch size)
+    int pack_sleep0 = -1, pack_sleep1 = -1; // HMX_PACK_SLEEP0 / 1: poll back-off, units of 64 clocks (-1: default)
   } knob;
 };
 
@@ -1413,7 +1545,7 @@ static PicDev make_picdev(const hmx_ctx *c, const hmx_pic_param *pp) {
 // Tuning knobs: read from the environment ONCE, in hmx_create; hmx_set_option changes one afterwards (A/B runs, and the
 // parity tests that hold the schedules against each other).  value == NULL restores the default.
 static const char *const kKnobNames[] = {"HMX_INTRA_SCHEDULE", "HMX_INTRA_ACROSS", "HMX_INTRA_STREAMS", "HMX_PIPELINE_CONV", "HMX_GRAPH",
-                                         "HMX_PACK_SLOTS4",    "HMX_PACK_K",       "HMX_PACK_WAVES"};
+                                         "HMX_PACK_SLOTS4",    "HMX_PACK_GROUP",      "HMX_PACK_WAVES",    "HMX_PACK_SLEEP0",   "HMX_PACK_SLEEP1"};
 static bool apply_knob(hmx_ctx *c, const char *name, const char *v) {
   auto &k = c->knob;
   const std::string n(name);
@@ -1423,8 +1555,10 @@ static bool apply_knob(hmx_ctx *c, const char *name, const char *v) {
   else if (n == "HMX_PIPELINE_CONV") k.pipeline_conv = v && v[0] != '0';
   else if (n == "HMX_GRAPH") k.graph = v != nullptr;
   else if (n == "HMX_PACK_SLOTS4") k.slots4 = !v ? 0 : atoi(v) == 16 ? 16 : 64;
-  else if (n == "HMX_PACK_K") k.pack_k = v ? std::max(1, atoi(v)) : 0;
+  else if (n == "HMX_PACK_GROUP") k.pack_group = v ? std::min(64, std::max(1, atoi(v))) : 0;
   else if (n == "HMX_PACK_WAVES") k.pack_waves = v ? std::max(1, atoi(v)) : 0;
+  else if (n == "HMX_PACK_SLEEP0") k.pack_sleep0 = v ? std::max(0, atoi(v)) : -1;
+  else if (n == "HMX_PACK_SLEEP1") k.pack_sleep1 = v ? std::max(0, atoi(v)) : -1;
   else return false;
   return true;
 }
@@ -1475,8 +1609,8 @@ extern "C" void hmx_destroy(hmx_ctx *c) {
     hipGraphExecDestroy(e.exec);
     hipFree(e.d_work);
   }
-  hipFree(c->pool_org);
-  hipFree(c->pool_rec);
+  hipFree(c->own_pool_org);
+  hipFree(c->own_pool_rec);
   hipFree(c->d_jobs);
   if (c->arena_h) hipHostFree(c->arena_h);
   hipFree(c->arena_d);
@@ -1509,6 +1643,16 @@ extern "C" const char *hmx_last_error(const hmx_ctx *c) { return c ? c->err.c_st
 static int check_packed_abort(hmx_ctx *c) {
   if (!c->pk_pending || !c->pk.d_hdr) return HMX_OK;
   c->pk_pending = false;
+#ifdef HMX_PACK_PROFILE
+  {
+    unsigned long long pr[16];
+    HIPCHK(c, hipMemcpy(pr, c->pk.d_hdr->prof, sizeof(pr), hipMemcpyDeviceToHost));
+    const double n = pr[7] ? (double)pr[7] : 1.0;
+    fprintf(stderr, "[pack profile] last call: %llu wave-items, per item (us): ticket %.2f desc %.2f pre-wait %.2f wait %.2f (%.1f polls) chain %.2f drain %.2f count %.2f; "
+                    "wave lifetime %.1f us avg over %d waves\n", pr[7], pr[0] / n / 100, pr[1] / n / 100, pr[2] / n / 100, pr[3] / n / 100, pr[8] / n, pr[4] / n / 100,
+            pr[5] / n / 100, pr[6] / n / 100, c->pk.n_wg ? pr[9] / 100.0 / c->pk.n_wg : 0.0, c->pk.n_wg);
+  }
+#endif
   uint32_t ab = 0;
   HIPCHK(c, hipMemcpy(&ab, &c->pk.d_hdr->abort, sizeof(ab), hipMemcpyDeviceToHost));
   return ab ? fail(c, HMX_ERR_DEVICE, "packed schedule: a dependency wait timed out, the call's outputs are invalid") : HMX_OK;
@@ -2112,7 +2256,7 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
     if (!r) r = grow_dev(c, (void **)&pk.d_descs, &pk.cap_descs, sizeof(PackDesc) * waves_bound);
     if (!r) r = grow_dev(c, (void **)&pk.d_items, &pk.cap_items, sizeof(FTu) * items);
     if (!r) r = grow_dev(c, (void **)&pk.d_rows, &pk.cap_rows, sizeof(PackRow) * n_rows);
-    if (!r) r = grow_dev(c, (void **)&pk.d_done, &pk.cap_done, sizeof(uint32_t) * n_rows);
+    if (!r) r = grow_dev(c, (void **)&pk.d_done, &pk.cap_done, sizeof(uint32_t) * kDoneStride * n_rows);
     if (!r && !pk.d_hdr && hipMalloc((void **)&pk.d_hdr, sizeof(PackHdr)) != hipSuccess) r = fail(c, HMX_ERR_NOMEM, "hipMalloc packed header");
     if (r) return r;
     std::vector<PackPic> hp(n_pics);
@@ -2136,7 +2280,7 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
     pk.valid = true;
   }
   // counters and ticket words start from zero every call
-  HIPCHK(c, hipMemsetAsync(pk.d_done, 0, sizeof(uint32_t) * n_rows, st));
+  HIPCHK(c, hipMemsetAsync(pk.d_done, 0, sizeof(uint32_t) * kDoneStride * n_rows, st));
   HIPCHK(c, hipMemsetAsync(&pk.d_hdr->abort, 0, sizeof(PackHdr) - offsetof(PackHdr, abort), st));
   const uint64_t wpl = waves_bound / (uint64_t)std::max(1, G.max_levels); // wave-items per dependency level, all groups
   if (!c->max_resident_waves) {
@@ -2146,7 +2290,6 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
     HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_intra_packed<true, 64>, 64, 0));
     c->max_resident_waves = std::max(64, nb * prop.multiProcessorCount);
   }
-  pk.K = c->knob.pack_k ? c->knob.pack_k : (wpl >= 8192 ? 4 : wpl >= 2048 ? 2 : 1);
   // Enough persistent waves to hold about two levels' worth of wave-items (the waves of the next row load their
   // descriptors and originals while the current row finishes), never more than the device keeps resident.
   pk.n_wg = c->knob.pack_waves ? c->knob.pack_waves : (int)std::min<uint64_t>((uint64_t)c->max_resident_waves, std::max<uint64_t>(256, 2 * wpl));
@@ -2166,7 +2309,8 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
   A.n_groups = G.n_groups;
   A.n_shards = G.n_shards;
   A.I = G.I;
-  A.K = pk.K;
+  A.sleep0 = c->knob.pack_sleep0 >= 0 ? c->knob.pack_sleep0 : 16;
+  A.sleep1 = c->knob.pack_sleep1 >= 0 ? c->knob.pack_sleep1 : 2;
   A.P = p0->P;
   const dim3 grid((unsigned)pk.n_wg), blk(64);
   if (G.slots4 == 64) {
@@ -2302,15 +2446,16 @@ static int issue_intra_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, 
     HIPCHK(c, hipGetLastError());
     return HMX_OK;
   }
-  if (enc) hipLaunchKernelGGL(k_convert_tiled<true>, cgrid, dim3(256), 0, main, d_jobs, 0, 1 << 30);
-  if (c->onto_call) // the pool starts from the caller's reconstruction (the inter-coded parts of the picture)
+  const bool conv = !c->resident_call;
+  if (conv && enc) hipLaunchKernelGGL(k_convert_tiled<true>, cgrid, dim3(256), 0, main, d_jobs, 0, 1 << 30);
+  if (conv && c->onto_call) // the pool starts from the caller's reconstruction (the inter-coded parts of the picture)
     hipLaunchKernelGGL(k_convert_tiled<true>, cgrid, dim3(256), 0, main, d_jobs + (size_t)n_pics * 3, 0, 1 << 30);
   if (tm) HIPCHK(c, hipEventRecord(c->tev[1], main));
   int r = c->last_schedule == 3 ? issue_packed(c, plans, plan_stride, n_pics, enc, main)
                                 : issue_chain_launches(c, plans, plan_stride, n_pics, d_work, enc, use_level, groups, main);
   if (r) return r;
   if (tm) HIPCHK(c, hipEventRecord(c->tev[2], main));
-  hipLaunchKernelGGL(k_convert_tiled<false>, cgrid, dim3(256), 0, main, d_jobs + (size_t)n_pics * 3, 0, 1 << 30);
+  if (conv) hipLaunchKernelGGL(k_convert_tiled<false>, cgrid, dim3(256), 0, main, d_jobs + (size_t)n_pics * 3, 0, 1 << 30);
   if (tm) {
     HIPCHK(c, hipEventRecord(c->tev[3], main));
     c->tev_valid = true;
@@ -2432,9 +2577,89 @@ static int issue_chain_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, 
   return HMX_OK;
 }
 
+// Pictures per group of the packed schedule.  A group is an interleave domain of the pool, the unit that advances level by
+// level, and it lives on one XCD: at most 64 pictures (the lanes of the prep kernels), and as many groups as a multiple of
+// the 8 XCDs allows, so that every XCD gets the same number of groups (1728 pictures: 32 groups of 54, not 27 of 64;
+// 64 pictures: 8 groups of 8; 5 pictures: 5 groups of 1).
+static int pack_group_size(const hmx_ctx *c, int n_pics) {
+  if (c && c->knob.pack_group > 0) return std::min(c->knob.pack_group, n_pics);
+  const int g64 = (n_pics + 63) / 64, groups = (g64 + 7) / 8 * 8;
+  return std::max(1, (n_pics + groups - 1) / groups);
+}
+// ---- pictures resident in the working layout (include/hmx.h: hmx_tpool) ----
+struct hmx_tpool {
+  short *base = nullptr;
+  int n_pics = 0, I = 1;   // groups of I pictures are interleaved quad by quad
+  int cw = 0, ch = 0, ctu = 64, pic_w = 0, pic_h = 0;
+  size_t pic_elems = 0;
+  uint32_t plane_off[3] = {0, 0, 0};
+};
+static TiledPlane tpool_plane(const hmx_tpool *t, int i, int p) {
+  const int g0 = i / t->I * t->I, clog = ilog2i(t->ctu);
+  const size_t base = (size_t)g0 * t->pic_elems + (size_t)t->plane_off[p] * t->I + (size_t)(i - g0) * 64;
+  return TiledPlane{t->base + base, t->cw, p ? clog - 1 : clog, 64u * (unsigned)t->I};
+}
+extern "C" int hmx_tpool_create(hmx_ctx *c, int pic_w, int pic_h, int n_pics, hmx_tpool **out) {
+  if (!c || !out || pic_w <= 0 || pic_h <= 0 || n_pics <= 0) return fail(c, HMX_ERR_ARG, "hmx_tpool_create: bad argument");
+  hmx_tpool *t = new hmx_tpool;
+  t->ctu = c->cfg.ctu_size;
+  t->pic_w = pic_w, t->pic_h = pic_h;
+  t->cw = (pic_w + t->ctu - 1) / t->ctu, t->ch = (pic_h + t->ctu - 1) / t->ctu;
+  t->n_pics = n_pics;
+  t->I = pack_group_size(c, n_pics);
+  size_t off = 0;
+  for (int p = 0; p < 3; p++) {
+    t->plane_off[p] = (uint32_t)off;
+    off += (size_t)t->cw * t->ch * ((size_t)t->ctu * t->ctu >> (p ? 2 : 0));
+  }
+  t->pic_elems = off;
+  const size_t slots = (size_t)(n_pics + t->I - 1) / t->I * t->I;
+  if (hipMalloc((void **)&t->base, off * 2 * slots) != hipSuccess) {
+    delete t;
+    return fail(c, HMX_ERR_NOMEM, "hipMalloc resident pictures");
+  }
+  *out = t;
+  return HMX_OK;
+}
+extern "C" void hmx_tpool_destroy(hmx_ctx *c, hmx_tpool *t) {
+  if (!t) return;
+  if (c) {
+    hipStreamSynchronize(c->stream);
+    c->table_valid = false; // a later pool may get the same address
+    c->pk.valid = false;
+  }
+  hipFree(t->base);
+  delete t;
+}
+static int tpool_convert(hmx_ctx *c, const hmx_tpool *t, int first, int n, const hmx_pic *planes, bool to_tiled) {
+  if (!c || !t || !planes || first < 0 || n <= 0 || first + n > t->n_pics) return fail(c, HMX_ERR_ARG, "hmx_tpool import/export: bad argument");
+  std::vector<ConvJob> jobs((size_t)n * 3);
+  for (int i = 0; i < n; i++)
+    for (int p = 0; p < 3; p++)
+      jobs[(size_t)i * 3 + p] = ConvJob{planes[i].plane[p], planes[i].stride[p], t->pic_w >> (p ? 1 : 0), t->pic_h >> (p ? 1 : 0), tpool_plane(t, first + i, p)};
+  for (size_t done = 0; done < jobs.size();) { // through the argument arena, a few thousand jobs at a time
+    const size_t part = std::min(jobs.size() - done, (size_t)3 * 8192);
+    const ConvJob *d = static_cast<const ConvJob *>(arena_push(c, jobs.data() + done, sizeof(ConvJob) * part));
+    if (!d) return fail(c, HMX_ERR_NOMEM, "argument arena");
+    const unsigned spr = (unsigned)(t->cw * t->ctu + 63) / 64, rows = (unsigned)(t->ch * t->ctu + 63) / 64;
+    const dim3 grid((unsigned)(part / 3), spr * rows, 3);
+    if (to_tiled) hipLaunchKernelGGL(k_convert_tiled<true>, grid, dim3(256), 0, c->stream, d, 0, 1 << 30);
+    else hipLaunchKernelGGL(k_convert_tiled<false>, grid, dim3(256), 0, c->stream, d, 0, 1 << 30);
+    done += part;
+  }
+  HIPCHK(c, hipGetLastError());
+  return HMX_OK;
+}
+extern "C" int hmx_tpool_import(hmx_ctx *c, hmx_tpool *t, int first, int n, const hmx_pic *src) { return tpool_convert(c, t, first, n, src, true); }
+extern "C" int hmx_tpool_export(hmx_ctx *c, const hmx_tpool *t, int first, int n, const hmx_pic *dst) { return tpool_convert(c, t, first, n, dst, false); }
+
+// org / rec: pictures in plane geometry (converted into / out of the context's own working pools around the chain), or
+// NULL with torg / trec: pictures resident in the working layout (no conversion; packed schedule only)
 static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_stride, int n_pics, const hmx_pic *org,
-                       const hmx_pic *rec, const hmx_levels *lev, bool enc) {
-  if (!c || !plans || !plans[0] || n_pics <= 0 || !rec || !lev || (enc && !org))
+                       const hmx_pic *rec, const hmx_levels *lev, bool enc, const hmx_tpool *torg = nullptr,
+                       const hmx_tpool *trec = nullptr) {
+  const bool resident = trec != nullptr;
+  if (!c || !plans || !plans[0] || n_pics <= 0 || !lev || (!resident && (!rec || (enc && !org))) || (resident && enc && !torg))
     return fail(c, HMX_ERR_ARG, "frame_intra: null argument");
   const hmx_intra_plan *p0 = plans[0];
   const int ctu = p0->P.ctu, cw = (p0->P.pic_w + ctu - 1) / ctu, ch = (p0->P.pic_h + ctu - 1) / ctu;
@@ -2444,7 +2669,7 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
   // memory.  The level-synchronous schedules stay as cross-checks and for A/B runs (HMX_INTRA_SCHEDULE=level|wave):
   // "level" = one launch per picture-wide dependency level (pictures that share ONE plan run it across pictures on a
   // pool interleaved per stream group), "wave" = one launch per CTU diagonal with autonomous waves.
-  const int sched_base = c->knob.schedule >= 0 ? c->knob.schedule : 3;
+  const int sched_base = resident ? 3 : c->knob.schedule >= 0 ? c->knob.schedule : 3;
   const bool packed = sched_base == 3, use_level = sched_base == 1;
   const bool across = use_level && plan_stride == 0 && c->knob.across != 0;
   // Picture groups of the across schedule on separate streams: measured at 1024 pictures 64.8 / 73.6 / 76.1 / 51.8 Gpx/s
@@ -2452,31 +2677,45 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
   int groups = !across ? 1 : n_pics >= 640 ? 3 : n_pics >= 384 ? 2 : 1;
   if (use_level && c->knob.streams > 0) groups = std::min(std::max(c->knob.streams, 1), std::min(n_pics, (int)hmx_ctx::kMaxSide));
   // packed: groups of I pictures are the interleave domains of the pool and the lanes of the tables' prep kernels
-  const int I = packed ? std::min(n_pics, 64) : 1, pool_need = packed ? (n_pics + I - 1) / I * I : n_pics;
-  // tiled working pool: one slot per picture, planes padded to whole CTUs
-  if (c->tiled_cw != cw || c->tiled_ch != ch || c->pool_pics < pool_need) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    hipFree(c->pool_org);
-    hipFree(c->pool_rec);
-    c->pool_org = c->pool_rec = nullptr;
-    c->pool_pics = 0;
-    c->tiled_cw = cw;
-    c->tiled_ch = ch;
-    c->table_valid = false;
-    c->pk.valid = false;
+  const int I = resident ? trec->I : packed ? pack_group_size(c, n_pics) : 1, pool_need = packed ? (n_pics + I - 1) / I * I : n_pics;
+  {
     size_t off = 0;
     for (int p = 0; p < 3; p++) {
       c->tiled_plane_off[p] = (uint32_t)off;
       off += (size_t)cw * ch * ((size_t)ctu * ctu >> (p ? 2 : 0));
     }
     c->tiled_pic_elems = off;
-    if (hipMalloc((void **)&c->pool_org, off * 2 * pool_need) != hipSuccess || hipMalloc((void **)&c->pool_rec, off * 2 * pool_need) != hipSuccess) {
-      hipFree(c->pool_org);
-      c->pool_org = nullptr;
-      return fail(c, HMX_ERR_NOMEM, "hipMalloc tiled working pictures");
-    }
-    c->pool_pics = pool_need;
   }
+  if (resident) { // the caller's pools: same geometry as the plans, at least n_pics pictures, one interleave
+    for (const hmx_tpool *t : {trec, enc ? torg : trec})
+      if (t->cw != cw || t->ch != ch || t->ctu != ctu || t->pic_w != p0->P.pic_w || t->pic_h != p0->P.pic_h || t->n_pics < n_pics || t->I != I)
+        return fail(c, HMX_ERR_ARG, "frame_intra: resident pool does not match the call (picture size, CTU size, pictures, group size)");
+    c->pool_org = enc ? torg->base : nullptr;
+    c->pool_rec = trec->base;
+    c->tiled_cw = cw, c->tiled_ch = ch;
+  } else {
+    // the context's own working pools: one slot per picture, planes padded to whole CTUs
+    if (c->own_cw != cw || c->own_ch != ch || c->pool_pics < pool_need) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      hipFree(c->own_pool_org);
+      hipFree(c->own_pool_rec);
+      c->own_pool_org = c->own_pool_rec = nullptr;
+      c->pool_pics = 0;
+      c->own_cw = cw, c->own_ch = ch;
+      c->table_valid = false;
+      c->pk.valid = false;
+      if (hipMalloc((void **)&c->own_pool_org, c->tiled_pic_elems * 2 * pool_need) != hipSuccess ||
+          hipMalloc((void **)&c->own_pool_rec, c->tiled_pic_elems * 2 * pool_need) != hipSuccess) {
+        hipFree(c->own_pool_org);
+        c->own_pool_org = nullptr;
+        return fail(c, HMX_ERR_NOMEM, "hipMalloc tiled working pictures");
+      }
+      c->pool_pics = pool_need;
+    }
+    c->pool_org = c->own_pool_org, c->pool_rec = c->own_pool_rec;
+    c->tiled_cw = cw, c->tiled_ch = ch;
+  }
+  c->resident_call = resident;
   c->across_call = across;
   c->pack_I = I;
   c->call_lev = lev;
@@ -2505,12 +2744,14 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
       }
       const size_t base = (size_t)g0 * c->tiled_pic_elems + (size_t)c->tiled_plane_off[p] * (g1 - g0) + (size_t)(i - g0) * 64;
       const unsigned qstride = 64u * (unsigned)(g1 - g0);
-      hw[i].org[p] = TiledPlane{c->pool_org + base, cw, pclog, qstride};
+      hw[i].org[p] = TiledPlane{c->pool_org ? c->pool_org + base : nullptr, cw, pclog, qstride};
       hw[i].rec[p] = TiledPlane{c->pool_rec + base, cw, pclog, qstride};
       hw[i].lev[p] = lev[i].plane[p];
       hw[i].lev_stride[p] = lev[i].stride[p];
-      if (enc) jobs[(size_t)i * 3 + p] = ConvJob{org[i].plane[p], org[i].stride[p], pw, ph, hw[i].org[p]};
-      jobs[(size_t)(n_pics + i) * 3 + p] = ConvJob{rec[i].plane[p], rec[i].stride[p], pw, ph, hw[i].rec[p]};
+      if (!resident) {
+        if (enc) jobs[(size_t)i * 3 + p] = ConvJob{org[i].plane[p], org[i].stride[p], pw, ph, hw[i].org[p]};
+        jobs[(size_t)(n_pics + i) * 3 + p] = ConvJob{rec[i].plane[p], rec[i].stride[p], pw, ph, hw[i].rec[p]};
+      }
     }
     hw[i].tus = pl->d_tus;
     hw[i].segs = pl->d_segs;
@@ -2647,6 +2888,16 @@ extern "C" int hmx_frame_intra_encode_multi(hmx_ctx *c, const hmx_intra_plan *co
 extern "C" int hmx_frame_intra_decode_multi(hmx_ctx *c, const hmx_intra_plan *const *plans, int n_pics, const hmx_pic *rec,
                                             const hmx_levels *lev) {
   return frame_intra(c, plans, 1, n_pics, nullptr, rec, lev, false);
+}
+extern "C" int hmx_frame_intra_encode_resident(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_stride, int n_pics,
+                                               const hmx_tpool *org, hmx_tpool *rec, const hmx_levels *lev) {
+  if (!org || !rec || (plan_stride != 0 && plan_stride != 1)) return fail(c, HMX_ERR_ARG, "hmx_frame_intra_encode_resident: bad argument");
+  return frame_intra(c, plans, plan_stride, n_pics, nullptr, nullptr, lev, true, org, rec);
+}
+extern "C" int hmx_frame_intra_decode_resident(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_stride, int n_pics,
+                                               hmx_tpool *rec, const hmx_levels *lev) {
+  if (!rec || (plan_stride != 0 && plan_stride != 1)) return fail(c, HMX_ERR_ARG, "hmx_frame_intra_decode_resident: bad argument");
+  return frame_intra(c, plans, plan_stride, n_pics, nullptr, nullptr, lev, false, nullptr, rec);
 }
 
 // =============================================================================================
@@ -3340,6 +3591,79 @@ extern "C" int hmx_filterVerChroma(hmx_ctx *c, const hmx_pel *src, int ss, int16
   return filter_scalar(c, src, ss, dst, ds, w, h, frac, 1, 1, is_first, is_last);
 }
 
+// ---- scalar drop-ins of the inter prediction of ONE block (host pointers) ----
+// xPredInterLumaBlk / xPredInterChromaBlk (TComPrediction.cpp:554-642): the window the filters reach goes up once, the
+// one or two filter stages run on the device (the reference's three cases: horizontal only, vertical only, horizontal
+// into the 14-bit intermediate then vertical), the block comes back.  w, h: the block IN ITS PLANE.
+static int pred_inter_blk(hmx_ctx *c, const hmx_pel *ref, int ref_stride, int mvx, int mvy, int w, int h, hmx_pel *dst, int dst_stride, int bi,
+                          int chroma, short *d_keep = nullptr) {
+  if (!c || !ref || (!dst && !d_keep) || w <= 0 || h <= 0 || w > 64 || h > 64) return fail(c, HMX_ERR_ARG, "xPredInterBlk: bad argument");
+  const int fb = chroma ? 3 : 2, fm = (1 << fb) - 1, xf = mvx & fm, yf = mvy & fm;
+  const int before = chroma ? 1 : 3, after = chroma ? 2 : 4, ww = w + before + after, wh = h + before + after;
+  Scratch s{c};
+  short *d_in = s.take<short>((size_t)ww * wh), *d_tmp = s.take<short>((size_t)w * wh), *d_out = d_keep ? d_keep : s.take<short>((size_t)w * h);
+  const hmx_pel *h0 = ref + (ptrdiff_t)((mvy >> fb) - before) * ref_stride + ((mvx >> fb) - before);
+  int r = up2d(c, d_in, h0, 2, ww, wh, ref_stride);
+  if (r) return r;
+  const short *d_blk = d_in + before * ww + before; // the block's first sample inside the window
+  const int B = c->cfg.bit_depth, last = !bi;
+  const dim3 g1((w * h + 255) / 256), g2((w * wh + 255) / 256), blk(256);
+  if (yf == 0) {
+    hipLaunchKernelGGL(k_filter, g1, blk, 0, c->stream, d_blk, ww, d_out, w, w, h, xf, chroma, 0, 1, last, B);
+  } else if (xf == 0) {
+    hipLaunchKernelGGL(k_filter, g1, blk, 0, c->stream, d_blk, ww, d_out, w, w, h, yf, chroma, 1, 1, last, B);
+  } else { // rows -before .. h+after-1 through the horizontal stage (isLast = false), then the vertical one (isFirst = false)
+    hipLaunchKernelGGL(k_filter, g2, blk, 0, c->stream, d_in + before, ww, d_tmp, w, w, wh, xf, chroma, 0, 1, 0, B);
+    hipLaunchKernelGGL(k_filter, g1, blk, 0, c->stream, d_tmp + before * w, w, d_out, w, w, h, yf, chroma, 1, 0, last, B);
+  }
+  HIPCHK(c, hipGetLastError());
+  return d_keep ? HMX_OK : down2d(c, dst, dst_stride, d_out, 2, w, h);
+}
+extern "C" int hmx_xPredInterLumaBlk(hmx_ctx *c, const hmx_pel *ref, int ref_stride, int mv_hor, int mv_ver, int w, int h, hmx_pel *dst,
+                                     int dst_stride, int bi) {
+  return pred_inter_blk(c, ref, ref_stride, mv_hor, mv_ver, w, h, dst, dst_stride, bi, 0);
+}
+extern "C" int hmx_xPredInterChromaBlk(hmx_ctx *c, const hmx_pel *ref, int ref_stride, int mv_hor, int mv_ver, int w, int h, hmx_pel *dst,
+                                       int dst_stride, int bi) {
+  if ((w & 1) || (h & 1)) return fail(c, HMX_ERR_ARG, "hmx_xPredInterChromaBlk: odd luma size");
+  return pred_inter_blk(c, ref, ref_stride, mv_hor, mv_ver, w >> 1, h >> 1, dst, dst_stride, bi, 1);
+}
+__global__ void k_addavg(const short *a, const short *b, short *d, int n, int B);
+// motionCompensation of ONE prediction unit (TComPrediction.cpp:410-552): xPredInterUni per used list (isLast = uni-prediction),
+// TComYuv::addAvg when both lists are used.  ref0 / ref1: planes of the reference pictures (plane[i] at sample (0,0), margins
+// readable), NULL = list unused; (x, y, w, h): the unit in luma samples; dst: plane[i] at the unit's first sample.
+extern "C" int hmx_motionCompensation(hmx_ctx *c, const hmx_pic *ref0, const int *mv0, const hmx_pic *ref1, const int *mv1, int x, int y, int w,
+                                      int h, const hmx_pic *dst) {
+  if (!c || !dst || (!ref0 && !ref1) || (ref0 && !mv0) || (ref1 && !mv1) || w <= 0 || h <= 0 || w > 64 || h > 64 || (w & 1) || (h & 1))
+    return fail(c, HMX_ERR_ARG, "hmx_motionCompensation: bad argument");
+  const bool bi = ref0 && ref1;
+  for (int p = 0; p < 3; p++) {
+    const int ch = p ? 1 : 0, pw = w >> ch, ph = h >> ch;
+    short *d_pred[2] = {nullptr, nullptr};
+    if (bi) { // both 14-bit intermediates stay on the device (the tail of the scratch area), addAvg there
+      d_pred[0] = reinterpret_cast<short *>(c->d_scratch + c->scratch_bytes) - 2 * 64 * 64;
+      d_pred[1] = d_pred[0] + 64 * 64;
+    }
+    for (int l = 0; l < 2; l++) {
+      const hmx_pic *rp = l ? ref1 : ref0;
+      const int *mv = l ? mv1 : mv0;
+      if (!rp) continue;
+      const hmx_pel *r0 = rp->plane[p] + (ptrdiff_t)(y >> ch) * rp->stride[p] + (x >> ch);
+      int r = pred_inter_blk(c, r0, rp->stride[p], mv[0], mv[1], pw, ph, dst->plane[p], dst->stride[p], bi, ch, bi ? d_pred[l] : nullptr);
+      if (r) return r;
+    }
+    if (bi) {
+      Scratch s{c};
+      short *d_out = s.take<short>((size_t)pw * ph);
+      hipLaunchKernelGGL(k_addavg, dim3((pw * ph + 255) / 256), dim3(256), 0, c->stream, d_pred[0], d_pred[1], d_out, pw * ph, c->cfg.bit_depth);
+      HIPCHK(c, hipGetLastError());
+      int r = down2d(c, dst->plane[p], dst->stride[p], d_out, 2, pw, ph);
+      if (r) return r;
+    }
+  }
+  return HMX_OK;
+}
+
 __device__ __forceinline__ int add_avg(int a, int b, int B) { // TComYuv.cpp:539-540
   const int sh = 15 - B, off = (1 << (sh - 1)) + 2 * 8192;
   return clip3(0, (1 << B) - 1, (a + b + off) >> sh);
@@ -3998,8 +4322,12 @@ __device__ __forceinline__ short yuv_rescale(short v, int shift, int bits) { // 
   return (short)min(max((int)r, 0), (1 << bits) - 1);
 }
 // 8 consecutive samples of a row per thread (16-byte plane accesses when aligned)
+struct TiledPic { // the three planes of one resident picture
+  TiledPlane T[3];
+};
+template <bool TILED>
 __global__ __launch_bounds__(256) void k_yuv_unpack(const unsigned char *file, int wide, int shift, int bits, int w_full, int h_full,
-                                                    int pad_x, int pad_y, PlanesDev D) {
+                                                    int pad_x, int pad_y, PlanesDev D, TiledPic TP) {
   const int p = blockIdx.y, c = p ? 1 : 0;
   const int wf = w_full >> c, hf = h_full >> c, w = wf - (pad_x >> c), h = hf - (pad_y >> c), w8 = (wf + 7) >> 3;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -4015,6 +4343,19 @@ __global__ __launch_bounds__(256) void k_yuv_unpack(const unsigned char *file, i
     const short t = wide ? (short)((row[2 * sx + 1] << 8) | row[2 * sx]) : (short)row[sx];
     v[k] = yuv_rescale(t, shift, bits);
   }
+  if constexpr (TILED) { // eight samples of a row = one row of two neighbouring tiles (widths are even: n is 2, 4, 6 or 8)
+    const TiledPlane T = p == 0 ? TP.T[0] : p == 1 ? TP.T[1] : TP.T[2];
+#pragma unroll
+    for (int k = 0; k < 8; k += 4) {
+      if (k + 4 <= n) {
+        s4v o = {v[k], v[k + 1], v[k + 2], v[k + 3]};
+        *reinterpret_cast<s4v *>(T.p + taddr(T, x0 + k, y)) = o;
+      } else {
+        for (int q = k; q < n; q++) T.p[taddr(T, x0 + q, y)] = v[q];
+      }
+    }
+    return;
+  }
   short *d = D.p[p] + (size_t)y * D.s[p] + x0;
   if (n == 8 && (((uintptr_t)d) & 15) == 0) {
     s8v ov;
@@ -4025,16 +4366,28 @@ __global__ __launch_bounds__(256) void k_yuv_unpack(const unsigned char *file, i
     for (int k = 0; k < n; k++) d[k] = v[k];
   }
 }
-__global__ __launch_bounds__(256) void k_yuv_pack(PlanesDev S, int wide, int shift, int bits, int ww, int hh, unsigned char *file) {
+template <bool TILED>
+__global__ __launch_bounds__(256) void k_yuv_pack(PlanesDev S, TiledPic TP, int wide, int shift, int bits, int ww, int hh, unsigned char *file) {
   const int p = blockIdx.y, c = p ? 1 : 0, w = ww >> c, h = hh >> c, w8 = (w + 7) >> 3;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w8 * h) return;
   const int x0 = (i % w8) << 3, y = i / w8, n = min(8, w - x0);
   const size_t luma = (size_t)ww * hh, chroma = (size_t)w * h;
   unsigned char *d = file + ((p == 0 ? 0 : luma + (p == 2 ? chroma : 0)) + (size_t)y * w + x0) * (wide ? 2 : 1);
-  const short *s = S.p[p] + (size_t)y * S.s[p] + x0;
+  const short *s = TILED ? nullptr : S.p[p] + (size_t)y * S.s[p] + x0;
   short v[8];
-  if (n == 8 && (((uintptr_t)s) & 15) == 0) {
+  if constexpr (TILED) {
+    const TiledPlane T = p == 0 ? TP.T[0] : p == 1 ? TP.T[1] : TP.T[2];
+#pragma unroll
+    for (int k = 0; k < 8; k += 4) {
+      if (k + 4 <= n) {
+        const s4v iv = *reinterpret_cast<const s4v *>(T.p + taddr(T, x0 + k, y));
+        v[k] = iv[0], v[k + 1] = iv[1], v[k + 2] = iv[2], v[k + 3] = iv[3];
+      } else {
+        for (int q = k; q < k + 4; q++) v[q] = T.p[taddr(T, x0 + min(q, n - 1), y)];
+      }
+    }
+  } else if (n == 8 && (((uintptr_t)s) & 15) == 0) {
     const s8v iv = *reinterpret_cast<const s8v *>(s);
 #pragma unroll
     for (int k = 0; k < 8; k++) v[k] = iv[k];
@@ -4069,9 +4422,9 @@ extern "C" int hmx_yuv_unpack(hmx_ctx *c, const void *d_file, int file_bits, con
   if (!c || !d_file || !dst || file_bits < 8 || file_bits > 16 || w_full <= 0 || h_full <= 0 || (w_full & 1) || (h_full & 1) ||
       pad_x < 0 || pad_y < 0 || (pad_x & 1) || (pad_y & 1) || pad_x >= w_full || pad_y >= h_full)
     return fail(c, HMX_ERR_ARG, "hmx_yuv_unpack: bad argument");
-  hipLaunchKernelGGL(k_yuv_unpack, dim3((unsigned)(((size_t)((w_full + 7) / 8) * h_full + 255) / 256), 3), dim3(256), 0, c->stream,
+  hipLaunchKernelGGL(k_yuv_unpack<false>, dim3((unsigned)(((size_t)((w_full + 7) / 8) * h_full + 255) / 256), 3), dim3(256), 0, c->stream,
                      static_cast<const unsigned char *>(d_file), file_bits > 8 ? 1 : 0, c->cfg.bit_depth - file_bits, c->cfg.bit_depth,
-                     w_full, h_full, pad_x, pad_y, to_dev(dst));
+                     w_full, h_full, pad_x, pad_y, to_dev(dst), TiledPic{});
   HIPCHK(c, hipGetLastError());
   return HMX_OK;
 }
@@ -4080,7 +4433,33 @@ extern "C" int hmx_yuv_pack(hmx_ctx *c, const hmx_pic *src, int w, int h, int cr
       crop_bottom >= h || ((w - crop_right) & 1) || ((h - crop_bottom) & 1))
     return fail(c, HMX_ERR_ARG, "hmx_yuv_pack: bad argument");
   const int ww = w - crop_right, hh = h - crop_bottom;
-  hipLaunchKernelGGL(k_yuv_pack, dim3((unsigned)(((size_t)((ww + 7) / 8) * hh + 255) / 256), 3), dim3(256), 0, c->stream, to_dev(src),
+  hipLaunchKernelGGL(k_yuv_pack<false>, dim3((unsigned)(((size_t)((ww + 7) / 8) * hh + 255) / 256), 3), dim3(256), 0, c->stream, to_dev(src),
+                     TiledPic{}, file_bits > 8 ? 1 : 0, file_bits - c->cfg.bit_depth, file_bits, ww, hh, static_cast<unsigned char *>(d_file));
+  HIPCHK(c, hipGetLastError());
+  return HMX_OK;
+}
+// The same straight into / out of a resident picture: the frame crosses PCIe as file bytes and is widened, scaled, padded and
+// laid out for the block kernels in ONE pass over it; no plane-geometry copy exists on the device.
+extern "C" int hmx_yuv_unpack_resident(hmx_ctx *c, const void *d_file, int file_bits, hmx_tpool *t, int index, int pad_x, int pad_y) {
+  if (!c || !d_file || !t || index < 0 || index >= t->n_pics || file_bits < 8 || file_bits > 16 || (t->pic_w & 1) || (t->pic_h & 1) || pad_x < 0 ||
+      pad_y < 0 || (pad_x & 1) || (pad_y & 1) || pad_x >= t->pic_w || pad_y >= t->pic_h)
+    return fail(c, HMX_ERR_ARG, "hmx_yuv_unpack_resident: bad argument");
+  TiledPic TP;
+  for (int p = 0; p < 3; p++) TP.T[p] = tpool_plane(t, index, p);
+  hipLaunchKernelGGL(k_yuv_unpack<true>, dim3((unsigned)(((size_t)((t->pic_w + 7) / 8) * t->pic_h + 255) / 256), 3), dim3(256), 0, c->stream,
+                     static_cast<const unsigned char *>(d_file), file_bits > 8 ? 1 : 0, c->cfg.bit_depth - file_bits, c->cfg.bit_depth,
+                     t->pic_w, t->pic_h, pad_x, pad_y, PlanesDev{}, TP);
+  HIPCHK(c, hipGetLastError());
+  return HMX_OK;
+}
+extern "C" int hmx_yuv_pack_resident(hmx_ctx *c, const hmx_tpool *t, int index, int crop_right, int crop_bottom, int file_bits, void *d_file) {
+  if (!c || !d_file || !t || index < 0 || index >= t->n_pics || file_bits < 8 || file_bits > 16 || crop_right < 0 || crop_bottom < 0 ||
+      crop_right >= t->pic_w || crop_bottom >= t->pic_h || ((t->pic_w - crop_right) & 1) || ((t->pic_h - crop_bottom) & 1))
+    return fail(c, HMX_ERR_ARG, "hmx_yuv_pack_resident: bad argument");
+  const int ww = t->pic_w - crop_right, hh = t->pic_h - crop_bottom;
+  TiledPic TP;
+  for (int p = 0; p < 3; p++) TP.T[p] = tpool_plane(t, index, p);
+  hipLaunchKernelGGL(k_yuv_pack<true>, dim3((unsigned)(((size_t)((ww + 7) / 8) * hh + 255) / 256), 3), dim3(256), 0, c->stream, PlanesDev{}, TP,
                      file_bits > 8 ? 1 : 0, file_bits - c->cfg.bit_depth, file_bits, ww, hh, static_cast<unsigned char *>(d_file));
   HIPCHK(c, hipGetLastError());
   return HMX_OK;

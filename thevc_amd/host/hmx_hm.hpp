@@ -173,6 +173,20 @@ public:
   void predIntraChromaAng(const Int *piSrc, UInt uiDirMode, Pel *piPred, UInt uiStride, Int iWidth, Int iHeight) {
     m_c.check(hmx_predIntraChromaAng(m_c.get(), piSrc, uiDirMode, piPred, uiStride, iWidth, iHeight), "predIntraChromaAng");
   }
+  // xPredInterLumaBlk / xPredInterChromaBlk (TComPrediction.cpp:554-642): refBlock = refPic->getLumaAddr(cuAddr, zorder + partAddr),
+  // the TComMv as its two components, dst = dstPic->getLumaAddr(partAddr) with dstPic's stride
+  void xPredInterLumaBlk(const Pel *refBlock, Int refStride, Int mvHor, Int mvVer, Int width, Int height, Pel *dst, Int dstStride, Bool bi) {
+    m_c.check(hmx_xPredInterLumaBlk(m_c.get(), refBlock, refStride, mvHor, mvVer, width, height, dst, dstStride, bi), "xPredInterLumaBlk");
+  }
+  void xPredInterChromaBlk(const Pel *refBlock, Int refStride, Int mvHor, Int mvVer, Int width, Int height, Pel *dst, Int dstStride, Bool bi) {
+    m_c.check(hmx_xPredInterChromaBlk(m_c.get(), refBlock, refStride, mvHor, mvVer, width, height, dst, dstStride, bi), "xPredInterChromaBlk");
+  }
+  // motionCompensation (TComPrediction.cpp:410-552) of one prediction unit: the reference pictures of the two lists (NULL = unused),
+  // their vectors, the unit's luma rectangle, the prediction planes at the unit's first sample
+  void motionCompensation(const hmx_pic *ref0, const Int mv0[2], const hmx_pic *ref1, const Int mv1[2], Int x, Int y, Int width, Int height,
+                          const hmx_pic *pred) {
+    m_c.check(hmx_motionCompensation(m_c.get(), ref0, mv0, ref1, mv1, x, y, width, height, pred), "motionCompensation");
+  }
 
 private:
   Context &m_c;
