@@ -237,6 +237,56 @@ def run_random_access(args, torch, dist, rank, local_rank, world, workload_name,
     return out
 
 
+def rehearse_cpu(args):
+    """`bench.py --gpus N --rehearse-cpu`: the multi-rank plumbing of this file WITHOUT a GPU -- the launcher above, one
+    process per rank, gloo instead of RCCL, the CPU oracle standing in for the device step.  Every rank codes its own
+    all-intra pictures (rank_picture_seeds), the ranks exchange the boundary I pictures of a random-access split
+    (ra_pipeline.exchange_plan / run_exchange, the calls the GPU path makes) and agree on the slowest rank's time; rank 0
+    prints the same one-line JSON.  What the driver's N-GPU run exercises, minus the kernels (tests/test_abi_and_ranks.py)."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from thevc_amd import ra_pipeline as ra
+    from thevc_amd import workload
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo")
+    w, h, B, qp, F = 128, 64, 8, 32, 3
+    tus = workload.make_tus(1, w, h, "mix")
+    seeds = rank_picture_seeds(rank, F)
+    pics = [workload.make_planes(sd, w, h, B, "texture") for sd in seeds]
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    recs = [ol.o_intra_frame_encode(tus, w, h, B, qp, p)[0] for p in pics]
+    # the random-access split: segment k on rank k mod N, I picture k+1 travels to the owner of segment k
+    n_seg = 2 * world + 1
+    i_pics = {k: [torch.from_numpy(np.ascontiguousarray(recs[k % F][p])).clone() if k % world == rank else
+                  torch.zeros(recs[0][p].shape, dtype=torch.int16) for p in range(3)] for k in range(n_seg + 1)}
+    moved = ra.run_exchange(dist, rank, world, n_seg, lambda ki: i_pics[ki]) if world > 1 else 0
+    if world > 1:
+        dist.barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, world, "cpu")
+    ok = all(int(i_pics[ki][0].abs().sum()) > 0 for k in range(n_seg) if k % world == rank for ki in (k, k + 1))
+    if world > 1:
+        t = torch.tensor([1.0 if ok else 0.0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": round(whole_job_value(w * h * F, 1, world, dt), 3), "unit": "Mpixels/s", "n_gpus": world,
+                          "steps": 1, "warmup": 0, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+                          "config": {"workload": "CPU rehearsal of the rank plumbing (gloo, CPU oracle): NOT a measurement"},
+                          "rehearsal": {"ranks": world, "exchange_ops_rank0": moved, "boundary_pictures_arrived": ok}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         return cpu_worker(sys.argv[2:])
@@ -267,10 +317,13 @@ def main():
     ap.add_argument("--no-ra", action="store_true", help="N > 1: skip the random-access leg (ra2160p8 with the RCCL exchange) after the all-intra line")
     ap.add_argument("--ra-segments", type=int, default=4, help="segments per GPU of the random-access leg of a multi-GPU run")
     ap.add_argument("--verify", action="store_true", help="the cpu_baseline leg also checks a picture of every packing group")
+    ap.add_argument("--rehearse-cpu", action="store_true", help="no GPU: run the rank launcher, sharding, exchange and reporting with gloo and the CPU oracle")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))  # before anything touches the GPU
+    if args.rehearse_cpu:
+        return rehearse_cpu(args)
 
     import torch
     import torch.distributed as dist
@@ -321,13 +374,13 @@ def main():
         F = max(8, int(0.92 * free_b / per_pic) // 64 * 64 or 8)
     n_plans = min(n_plans, F)
     seeds = rank_picture_seeds(rank, F, max(1, args.distinct))  # distinct synthetic pictures, cycled over the batch
-    cache = {}
-    for sd in seeds:
-        if sd not in cache:
-            cache[sd] = workload.make_planes(sd, w, h_c, B, "texture")
+    from concurrent.futures import ThreadPoolExecutor
+    uniq = sorted(set(seeds))
+    with ThreadPoolExecutor(max_workers=min(16, len(uniq), os.cpu_count() or 1)) as ex:  # numpy releases the GIL in the large array ops
+        cache = dict(zip(uniq, ex.map(lambda sd: workload.make_planes(sd, w, h_c, B, "texture"), uniq)))
     src = [cache[sd] for sd in seeds]
-    d_lev = [capi.DevLevelsZ(ctx, w, h_c).zero() for _ in range(F)]  # the reference's own coefficient layout
-    lev_arr = (capi.Levels * F)(*[d.as_pic() for d in d_lev])
+    lev_slab = capi.DevLevelsZSlab(ctx, w, h_c, F).zero()  # the reference's own coefficient layout, one slab per plane
+    lev_arr = (capi.Levels * F)(*[lev_slab.as_pic(i) for i in range(F)])
     plan_arr = (C.c_void_p * F)(*[plans[i % n_plans].value for i in range(F)])
     stride = 0 if n_plans == 1 else 1
     if args.planar:
@@ -466,15 +519,16 @@ def main():
             # --verify: one picture of every few packing groups, first and last included
             idx = sorted({0, F - 1} | set(range(0, F, max(64, F // 6 // 64 * 64 or 64)))) if args.verify else [0]
             checks = [(i, tus_list[i % n_plans], plan_seeds[i % n_plans], seeds[i], src[i],
-                       (reconstruction(i), d_lev[i].to_planes(tus_list[i % n_plans]))) for i in idx]
+                       (reconstruction(i), lev_slab.picture(i).to_planes(tus_list[i % n_plans]))) for i in idx]
             out["cpu_baseline"] = cpu_baseline(w, h_c, B, qp, args.tiling, checks, 0.0 if args.no_cpu_baseline else 10.0,
                                                all_cores=not args.one_core_only)
             if args.verify:
                 cb = out["cpu_baseline"]
                 out["verified_bit_exact_vs_oracle"] = cb.get("gpu_pictures_identical", cb["gpu_picture_0_identical"])
     # free the batch before the optional random-access leg
-    for d in d_org + d_rec + d_lev + ([] if args.planar else stage):
+    for d in d_org + d_rec + ([] if args.planar else stage):
         d.free()
+    lev_slab.free()
     for x in (p_org, p_rec):
         if x is not None:
             x.free()

@@ -338,6 +338,19 @@ int hmx_frame_intra_encode_onto(hmx_ctx *ctx, const hmx_intra_plan *plan, int n_
 int hmx_frame_intra_decode_multi(hmx_ctx *ctx, const hmx_intra_plan *const *plans, int n_pics, const hmx_pic *rec,
                                  const hmx_levels *lev);
 
+/* Distortion next to the chain: the encoder calls TComRdCost::getDistPart(rec, org, DF_SSE) right after every
+ * reconstruction (TLibEncoder/TEncSearch.cpp:1163, :1381).  After hmx_set_sse_output(ctx, sse, n) the whole-picture
+ * ENCODE calls (any of the hmx_frame_intra_encode* entry points, packed schedule) with at most n pictures also write,
+ * for picture i and plane p, xGetSSE(org, rec) of every block -- sum of (org - rec)^2 >> 2 * (B - 8),
+ * TLibCommon/TComRdCost.cpp:1313-1657 -- into sse[i].plane[p][u], u = the block's first 4x4 unit in the reference's
+ * partition order (CTU blocks in raster order over the CTU-padded plane, Z-order inside a CTU: 1/16 of the block's
+ * offset in the stride-0 level layout).  Device arrays of (CTU-padded plane samples / 16) entries; sse == NULL
+ * switches the output off.  The sums are formed in the kernel that reconstructs the block. */
+typedef struct {
+  uint32_t *plane[3];
+} hmx_sse;
+int hmx_set_sse_output(hmx_ctx *ctx, const hmx_sse *sse, int n_pics);
+
 /* Pictures RESIDENT in the library's working layout: CTU blocks in raster order, 4x4 tiles in
  * Z-order inside a CTU, groups of up to 64 pictures interleaved 8x8 quad by quad.  The whole-picture entry points above
  * take pictures in the reference's plane geometry (TComPicYuv) and convert them into and out of this layout around

@@ -114,3 +114,21 @@ def test_two_rank_rehearsal_gloo():
     assert d0 >= max(l0, l1) - 1e-9
     assert abs(v0 - 2 * 128 * 64 * 3 / d0 / 1e6) < 1e-6  # value is the whole-job aggregate
     assert g0 != g1                          # different pictures were really processed
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts its ranks itself (a child torch.distributed.run, before the
+    parent touches any GPU).  Rehearsed on the CPU: gloo, the CPU oracle for the device step, the random-access
+    boundary-picture exchange through the same ra_pipeline.run_exchange the GPU path calls; rank 0 prints ONE JSON line."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-cpu"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["rehearsal"] == {"ranks": 2, "exchange_ops_rank0": d["rehearsal"]["exchange_ops_rank0"], "boundary_pictures_arrived": True}
+    assert d["rehearsal"]["exchange_ops_rank0"] > 0

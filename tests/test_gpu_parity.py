@@ -789,6 +789,63 @@ def test_resident_pictures(ctx, pic, n):
         d.free()
 
 
+@pytest.mark.parametrize("slots4", ["16", "64"])
+def test_frame_intra_sse_output(ctx, slots4, hmx_opts):
+    """hmx_set_sse_output: the whole-picture encode also writes xGetSSE(org, rec) of every block (getDistPart right
+    behind the reconstruction, TEncSearch.cpp:1163) at the block's first 4x4 unit in partition order.  All four block
+    sizes, both 4x4 wave shapes, pictures with their own plans; vs the oracle's getSSE on the oracle's reconstruction
+    (which the GPU's equals).  Switching the output off restores the plain kernel."""
+    hmx_opts(ctx, HMX_PACK_SLOTS4=slots4)
+    O, B, L = ol.oracle(), ctx.bit_depth, capi.lib()
+    O.hmo_getSSE.restype = C.c_uint32
+    w, h, n, qp = 200, 136, 5, 30
+    pp = capi.PicParam(w, h, qp, 0, capi.I_SLICE, 1)
+    tus = [workload.make_tus(1300 + i, w, h, "mix") for i in range(n)]
+    plans = [ctx.intra_plan(t, pp) for t in tus]
+    orgs = [workload.make_planes(1400 + i, w, h, B, "texture" if i % 2 else "noise") for i in range(n)]
+    d_org = [capi.DevPicture(ctx, w, h).upload(o) for o in orgs]
+    d_rec = [capi.DevPicture(ctx, w, h).zero() for _ in range(n)]
+    d_lev = [capi.DevLevelsZ(ctx, w, h) for _ in range(n)]
+    cw, ch = -(-w // 64), -(-h // 64)
+    units = [cw * ch * 256, cw * ch * 64, cw * ch * 64]
+    d_sse = [[ctx.alloc(4 * u).zero() for u in units] for _ in range(n)]
+    sse_arr = (capi.Sse * n)()
+    for i in range(n):
+        for p in range(3):
+            sse_arr[i].plane[p] = d_sse[i][p].ptr
+    A = lambda lst, T: (T * n)(*[x.as_pic() for x in lst])
+    parr = (C.c_void_p * n)(*[p.value for p in plans])
+    ctx._chk(L.hmx_set_sse_output(ctx.h, sse_arr, n))
+    ctx._chk(L.hmx_frame_intra_encode_multi(ctx.h, parr, n, A(d_org, capi.Pic), A(d_rec, capi.Pic), A(d_lev, capi.Levels)))
+    ctx.sync()
+    checked = 0
+    for i in range(n):
+        rr, _ = ol.o_intra_frame_encode(tus[i], w, h, B, qp, orgs[i])
+        rec = d_rec[i].download()
+        got = [d_sse[i][p].download(np.uint32) for p in range(3)]
+        for p in range(3):
+            assert np.array_equal(rec[p], rr[p])
+        for t in tus[i]:
+            N, p, x, y = 1 << int(t["log2n"]), int(t["plane"]), int(t["x"]), int(t["y"])
+            o = np.ascontiguousarray(orgs[i][p][y:y + N, x:x + N])
+            r = np.ascontiguousarray(rr[p][y:y + N, x:x + N])
+            want = O.hmo_getSSE(o.ctypes.data_as(C.c_void_p), N, r.ctypes.data_as(C.c_void_p), N, N, N, B)
+            u = d_lev[i].block_offset(p, x, y) // 16
+            assert int(got[p][u]) == want, ("sse", i, p, x, y, N)
+            checked += 1
+    assert checked == sum(len(t) for t in tus)
+    ctx._chk(L.hmx_set_sse_output(ctx.h, None, 0))
+    for b in d_sse[0]:
+        b.zero()
+    ctx._chk(L.hmx_frame_intra_encode_multi(ctx.h, parr, n, A(d_org, capi.Pic), A(d_rec, capi.Pic), A(d_lev, capi.Levels)))
+    ctx.sync()
+    assert not d_sse[0][0].download(np.uint32).any()
+    for pl in plans:
+        L.hmx_intra_plan_destroy(ctx.h, pl)
+    for d in d_org + d_rec + d_lev + [b for row in d_sse for b in row]:
+        d.free()
+
+
 def test_yuv_resident(ctx):
     """hmx_yuv_unpack_resident / hmx_yuv_pack_resident: a file's frame straight into a pool picture and back, vs the
     plane-geometry entry points (which are held against the oracle's TVideoIOYuv restatement above)."""

@@ -56,6 +56,10 @@ class Levels(C.Structure):
     _fields_ = [("plane", C.c_void_p * 3), ("stride", C.c_int * 3)]
 
 
+class Sse(C.Structure):  # hmx_sse
+    _fields_ = [("plane", C.c_void_p * 3)]
+
+
 class EstBits(C.Structure):  # hmx_est_bits == estBitsSbacStruct (TComTrQuant.h:59-72)
     _fields_ = [("significantCoeffGroupBits", (C.c_int32 * 2) * 2), ("significantBits", (C.c_int32 * 2) * 42),
                 ("lastXBits", C.c_int32 * 32), ("lastYBits", C.c_int32 * 32), ("greaterOneBits", (C.c_int32 * 2) * 24),
@@ -178,6 +182,7 @@ def lib():
         L.hmx_yuv_frame_bytes.restype = C.c_size_t
         L.hmx_yuv_unpack.argtypes = [vp, vp, ci, C.POINTER(Pic), ci, ci, ci, ci]
         L.hmx_yuv_pack.argtypes = [vp, C.POINTER(Pic), ci, ci, ci, ci, ci, vp]
+        L.hmx_set_sse_output.argtypes = [vp, vp, ci]
         L.hmx_tpool_create.argtypes = [vp, ci, ci, ci, C.POINTER(vp)]
         L.hmx_tpool_destroy.argtypes = [vp, vp]
         L.hmx_tpool_destroy.restype = None
@@ -552,3 +557,49 @@ class ResidentPool:
         if self.h_:
             lib().hmx_tpool_destroy(self.ctx.h, self.h_)
             self.h_ = None
+
+
+class DevLevelsZSlab:
+    """The levels of n pictures in the reference's coefficient layout (DevLevelsZ) as ONE allocation per plane, picture i
+    at offset i * elems: what a pipeline that owns its level buffers would allocate (and the whole-picture calls then
+    address by arithmetic instead of through the picture table)."""
+
+    def __init__(self, ctx, w, h, n, ctu=64):
+        self.ctx, self.w, self.h, self.n, self.ctu = ctx, w, h, n, ctu
+        self.cw, self.ch = -(-w // ctu), -(-h // ctu)
+        self.elems = [self.cw * self.ch * ctu * ctu, self.cw * self.ch * ctu * ctu // 4, self.cw * self.ch * ctu * ctu // 4]
+        self.bufs = [ctx.alloc(4 * e * n) for e in self.elems]
+
+    def zero(self):
+        for b in self.bufs:
+            b.zero()
+        return self
+
+    def as_pic(self, i):
+        s = Levels()
+        for p in range(3):
+            s.plane[p] = self.bufs[p].ptr + 4 * self.elems[p] * i
+            s.stride[p] = 0
+        return s
+
+    def picture(self, i):
+        """A DevLevelsZ-like view of picture i (to_planes)."""
+        v = DevLevelsZ.__new__(DevLevelsZ)
+        v.ctx, v.w, v.h, v.ctu, v.cw, v.ch, v.elems = self.ctx, self.w, self.h, self.ctu, self.cw, self.ch, self.elems
+        parent = self
+
+        class _View:
+            def __init__(self, p):
+                self.p = p
+
+            def download(self, dtype, count=None):
+                out = np.empty(parent.elems[self.p], np.int32)
+                parent.ctx._chk(lib().hmx_download(parent.ctx.h, _hp(out), parent.bufs[self.p].ptr + 4 * parent.elems[self.p] * i, out.nbytes))
+                return out
+
+        v.bufs = [_View(p) for p in range(3)]
+        return v
+
+    def free(self):
+        for b in self.bufs:
+            b.free()

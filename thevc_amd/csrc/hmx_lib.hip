@@ -259,7 +259,20 @@ struct PlaneView {
   TiledPlane rec;   // tiled working reconstruction
   int *lev;
   int lev_stride;   // > 0: plane geometry; 0: the reference's Z-order coefficient layout
+  uint32_t *sse = nullptr; // != NULL (encoder direction): xGetSSE(org, rec) of every block, at the index of its first 4x4 unit
 };
+// distortion of NS samples: sum of (org - rec)^2 >> 2 * (B - 8), TComRdCost::xGetSSE* with IBDI_DISTORTION 0 (TComRdCost.cpp:1313-1657)
+template <int NS>
+__device__ __forceinline__ unsigned sse_samples(const int *org, const int *rec, int B) {
+  const unsigned sh = (unsigned)(B - 8) << 1;
+  unsigned s = 0;
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const int d = org[k] - rec[k];
+    s += (unsigned)mul24(d, d) >> sh; // |d| < 2^12
+  }
+  return s;
+}
 // 4x4 blocks per wave in the across-pictures level schedule: 16 = four lanes per block (one row each, through LDS like the 8x8 and
 // 16x16 blocks), 64 = one lane per block (wave_chain_4_lane).  Measured at 1024 pictures of the 2160p mix: four lanes
 // +3 % encoder direction, +16 % decoder direction (more, shorter waves); the one-lane form stays for A/B builds.
@@ -284,6 +297,7 @@ __device__ __forceinline__ int lane_id() {
 struct OwnPicture {
   static constexpr bool kCoherent = false; // producer and consumer are separated by a kernel boundary
   static constexpr bool kWriteThrough = false;
+  static constexpr bool kSse = false; // distortion output: packed schedule only
   const PicWork &W;
   const FTu *tus;
   __device__ __forceinline__ void wait() const {}
@@ -297,6 +311,7 @@ struct OwnPicture {
 struct AcrossPictures {
   static constexpr bool kCoherent = false;
   static constexpr bool kWriteThrough = false;
+  static constexpr bool kSse = false;
   __device__ __forceinline__ void wait() const {}
   const PicWork *pics;
   const FTu *ft; // the one block this wave works on (wave-uniform address: scalar loads)
@@ -373,6 +388,18 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, cons
 #pragma unroll
       for (int k = 0; k < N; k++) row[k] = clip3(0, mx, pred[k] + row[k]);
       tstore_row<N, SRC::kWriteThrough>(R.p + pb0, R.qstride, gl, row);
+    }
+    if constexpr (ENC && SRC::kSse) {
+      if (src.want_sse()) { // wave-uniform: getDistPart right behind the reconstruction (TEncSearch.cpp:1163), fused
+        int o[N];
+        unsigned d = 0;
+        if (active) {
+          tload_row<N>(V.org + pb0, R.qstride, gl, o); // the original row again (it went into the residual): an L2 hit
+          d = sse_samples<N>(o, row, P.bit_depth);
+        }
+        d = (unsigned)group_sum((int)d, N);
+        if (active && gl == 0) V.sse[b0 >> 4] = d;
+      }
     }
   }
 }
@@ -610,6 +637,20 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
       r0[k] = (clip3(0, mx, pred[2 * k] + out[2 * k]) & 0xffff) | (clip3(0, mx, pred[2 * k + 1] + out[2 * k + 1]) << 16);
       r1[k] = (clip3(0, mx, pred[8 + 2 * k] + out[8 + 2 * k]) & 0xffff) | (clip3(0, mx, pred[8 + 2 * k + 1] + out[8 + 2 * k + 1]) << 16);
     }
+    if constexpr (ENC && SRC::kSse) {
+      if (src.want_sse()) {
+        const i4v o0 = *reinterpret_cast<const i4v *>(V.org + pb0), o1 = *reinterpret_cast<const i4v *>(V.org + pb0 + 8);
+        int o[16], rc[16];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          o[2 * k] = (short)(o0[k] & 0xffff), o[2 * k + 1] = o0[k] >> 16;
+          o[8 + 2 * k] = (short)(o1[k] & 0xffff), o[8 + 2 * k + 1] = o1[k] >> 16;
+          rc[2 * k] = r0[k] & 0xffff, rc[2 * k + 1] = (int)((unsigned)r0[k] >> 16);
+          rc[8 + 2 * k] = r1[k] & 0xffff, rc[8 + 2 * k + 1] = (int)((unsigned)r1[k] >> 16);
+        }
+        V.sse[b0 >> 4] = sse_samples<16>(o, rc, B);
+      }
+    }
     if constexpr (SRC::kWriteThrough) { // write-through, one tile row per store
 #pragma unroll
       for (int k = 0; k < 2; k++) {
@@ -693,6 +734,21 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const 
       s4v o = {(short)clip3(0, mx, p0 + out[4 * q]), (short)clip3(0, mx, p1 + out[4 * q + 1]),
                (short)clip3(0, mx, p2 + out[4 * q + 2]), (short)clip3(0, mx, p3 + out[4 * q + 3])};
       st_rec4<SRC::kWriteThrough>(R.p + row_off + trel<32>(R.qstride, tile_in_block(2 * q + h, r >> 2)), o);
+    }
+    if constexpr (ENC && SRC::kSse) {
+      if (src.want_sse()) {
+        int o[16], rc[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const s4v ov = *reinterpret_cast<const s4v *>(V.org + row_off + trel<32>(R.qstride, tile_in_block(2 * q + h, r >> 2)));
+          const int p0 = pred2[2 * q] & 0xffff, p1 = pred2[2 * q] >> 16, p2 = pred2[2 * q + 1] & 0xffff, p3 = pred2[2 * q + 1] >> 16;
+          const int pr4[4] = {p0, p1, p2, p3};
+#pragma unroll
+          for (int k = 0; k < 4; k++) o[4 * q + k] = ov[k], rc[4 * q + k] = clip3(0, mx, pr4[k] + out[4 * q + k]);
+        }
+        const unsigned d = (unsigned)group_sum((int)sse_samples<16>(o, rc, P.bit_depth), 64);
+        if (lane == 0) V.sse[b0 >> 4] = d;
+      }
     }
     wave_sync();
   }
@@ -927,6 +983,7 @@ struct PackPic { // per picture: where its levels go, and the plan it follows
   int n_levels;
   const LevelRow *ltab;
   const FTu *ltus;
+  uint32_t *sse[3]; // distortion output per plane (hmx_set_sse_output), NULL = none
 };
 struct PackGeom {
   int n_pics, I, n_groups, n_shards, max_levels, slots4;
@@ -1068,6 +1125,13 @@ struct PackArgs {
   uint32_t plane_off[3]; // of one picture
   int ctu_w, clog;
   int n_groups, n_shards, I;
+  // level buffers of the call laid out as ONE slab per plane (picture i at lev_base[p] + i * lev_pic_elems[p], one stride):
+  // a wave-item then addresses its levels by arithmetic instead of a load from the picture table on its way to the wait
+  int want_sse; // encoder direction: write xGetSSE(org, rec) of every block through PackPic::sse
+  int lev_slab;
+  int *lev_base[3];
+  long long lev_pic_elems[3];
+  int lev_stride[3];
   PicDev P;
 };
 // what a wave-item of the packed schedule prefetches for its successor (see k_intra_packed)
@@ -1078,9 +1142,12 @@ struct PackNext {
   uint32_t t;          // the next ticket, wave-uniform (valid after the dependency wait)
   PackDesc d;          // its descriptor (in flight after the dependency wait)
 };
+template <bool SSE>
 struct PackedSrc {
   static constexpr bool kCoherent = true;      // reconstruction loads bypass the vector L1 (sc1)
   static constexpr bool kWriteThrough = false; // producers and consumers share an XCD's L2: plain stores
+  static constexpr bool kSse = SSE;            // a kernel variant of its own: the extra live registers would spill in the common one
+  __device__ __forceinline__ bool want_sse() const { return SSE; }
   FTu ft;               // this lane's item, fetched during the previous wave-item
   const PackPic *gpics; // the group's pictures
   const short *org_g;   // the group's region of the pools
@@ -1093,6 +1160,8 @@ struct PackedSrc {
   uint32_t *abort_word;
   int sleep0, sleep1;
   PackNext *nx;
+  const PackArgs *A;
+  int pic0; // first picture of the group
 #ifdef HMX_PACK_PROFILE
   unsigned long long *pt; // [0] wait entry, [1] wait exit, [2] polls
 #endif
@@ -1104,10 +1173,21 @@ struct PackedSrc {
   __device__ __forceinline__ PlaneView view(int, int pl) const {
     const unsigned k = ft.t.plane >> 2;
     const size_t o = (size_t)(pl == 0 ? 0u : pl == 1 ? off1 : off2) + (size_t)k * 64;
-    const char *row = reinterpret_cast<const char *>(&gpics[k]);
-    int *lv = *reinterpret_cast<int *const *>(row + offsetof(PackPic, lev) + pl * sizeof(int *));
-    const int ls = *reinterpret_cast<const int *>(row + offsetof(PackPic, lev_stride) + pl * sizeof(int));
-    return PlaneView{org_g + o, TiledPlane{rec_g + o, ctu_w, pl ? clog_luma - 1 : clog_luma, qstride}, as_global(lv), ls};
+    int *lv;
+    int ls;
+    if (A->lev_slab) {
+      int *const b = pl == 0 ? A->lev_base[0] : pl == 1 ? A->lev_base[1] : A->lev_base[2];
+      const long long e = pl == 0 ? A->lev_pic_elems[0] : pl == 1 ? A->lev_pic_elems[1] : A->lev_pic_elems[2];
+      lv = b + (long long)(pic0 + (int)k) * e;
+      ls = pl == 0 ? A->lev_stride[0] : pl == 1 ? A->lev_stride[1] : A->lev_stride[2];
+    } else {
+      const char *row = reinterpret_cast<const char *>(&gpics[k]);
+      lv = *reinterpret_cast<int *const *>(row + offsetof(PackPic, lev) + pl * sizeof(int *));
+      ls = *reinterpret_cast<const int *>(row + offsetof(PackPic, lev_stride) + pl * sizeof(int));
+    }
+    uint32_t *sp = nullptr;
+    if constexpr (SSE) sp = as_global(*reinterpret_cast<uint32_t *const *>(reinterpret_cast<const char *>(&gpics[k]) + offsetof(PackPic, sse) + pl * sizeof(uint32_t *)));
+    return PlaneView{org_g + o, TiledPlane{rec_g + o, ctu_w, pl ? clog_luma - 1 : clog_luma, qstride}, as_global(lv), ls, sp};
   }
   // Wait until the previous row of the group is complete.  One L1-bypassing load per poll (the whole wave reads one
   // word: one request); everything the chain loads from the reconstruction afterwards is an sc1 load issued after this
@@ -1149,7 +1229,7 @@ __device__ __forceinline__ int pack_lane_item(int lane, int s) {
   return s == 0 ? (SL4 == 64 ? lane : lane >> 2) : s == 1 ? lane >> 3 : s == 2 ? lane >> 4 : 0;
 }
 
-template <bool ENC, int SL4>
+template <bool ENC, int SL4, bool SSE = false>
 __global__ __launch_bounds__(64, 4) void k_intra_packed(PackArgs A) {
   __shared__ __attribute__((aligned(16))) char smem[HMX_WAVE_SMEM];
   int xcc;
@@ -1210,10 +1290,10 @@ __global__ __launch_bounds__(64, 4) void k_intra_packed(PackArgs A) {
       const int s = (int)(d.n_s >> 28), n = (int)(d.n_s & 0x0fffffffu);
       const int g = (int)(d.row % (uint32_t)A.n_groups);
       const size_t greg = (size_t)g * A.I * A.pic_elems;
-      const PackedSrc src{ft, A.pics + (size_t)g * A.I, A.pool_org + greg, A.pool_rec + greg,
+      const PackedSrc<SSE> src{ft, A.pics + (size_t)g * A.I, A.pool_org + greg, A.pool_rec + greg,
                           A.plane_off[1] * (uint32_t)A.I, A.plane_off[2] * (uint32_t)A.I, 64u * (uint32_t)A.I, A.ctu_w, A.clog,
                           d.dep_target ? A.done + (size_t)(d.row - (uint32_t)A.n_groups) * kDoneStride : nullptr, d.dep_target, &hdr->abort,
-                          A.sleep0, A.sleep1, &nx
+                          A.sleep0, A.sleep1, &nx, &A, g * A.I
 #ifdef HMX_PACK_PROFILE
                           , pt
 #endif
@@ -1445,6 +1525,7 @@ struct hmx_ctx {
   int pack_I = 1;             // pictures per group (interleave domain of the pool) of the call being issued
   const hmx_levels *call_lev = nullptr; // the call's level planes (host array, valid while the call is issued)
   bool pk_pending = false;    // a packed launch was issued since the last check of its abort word
+  std::vector<hmx_sse> sse_out; // hmx_set_sse_output: per-picture distortion arrays of the next whole-picture encode calls
   uint64_t table_key = 0;     // of the picture table resident in d_jobs (whole-picture calls)
   bool table_valid = false;
   // knobs, read once from the environment in hmx_create (A/B runs and the cross-checks of the tests)
@@ -2266,6 +2347,7 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
       hp[i].n_levels = (int)pl->level_chunks.size();
       hp[i].ltab = pl->d_ltab;
       hp[i].ltus = pl->d_ltus;
+      for (int p = 0; p < 3; p++) hp[i].sse[p] = (enc && (int)c->sse_out.size() >= n_pics) ? c->sse_out[i].plane[p] : nullptr;
     }
     HIPCHK(c, hipMemcpyAsync(pk.d_pics, hp.data(), sizeof(PackPic) * n_pics, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st)); // hp goes out of scope
@@ -2309,11 +2391,29 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
   A.n_groups = G.n_groups;
   A.n_shards = G.n_shards;
   A.I = G.I;
+  A.want_sse = enc && (int)c->sse_out.size() >= n_pics;
+  {
+    const hmx_levels *lv = c->call_lev;
+    bool slab = true;
+    for (int p = 0; p < 3 && slab; p++) {
+      const ptrdiff_t d = n_pics > 1 ? (const char *)lv[1].plane[p] - (const char *)lv[0].plane[p] : 0;
+      slab = d >= 0 && d % (ptrdiff_t)sizeof(int) == 0;
+      for (int i = 0; i < n_pics && slab; i++)
+        slab = (const char *)lv[i].plane[p] == (const char *)lv[0].plane[p] + (ptrdiff_t)i * d && lv[i].stride[p] == lv[0].stride[p];
+      A.lev_base[p] = lv[0].plane[p];
+      A.lev_pic_elems[p] = d / (ptrdiff_t)sizeof(int);
+      A.lev_stride[p] = lv[0].stride[p];
+    }
+    A.lev_slab = slab ? 1 : 0;
+  }
   A.sleep0 = c->knob.pack_sleep0 >= 0 ? c->knob.pack_sleep0 : 16;
   A.sleep1 = c->knob.pack_sleep1 >= 0 ? c->knob.pack_sleep1 : 2;
   A.P = p0->P;
   const dim3 grid((unsigned)pk.n_wg), blk(64);
-  if (G.slots4 == 64) {
+  if (A.want_sse) {
+    if (G.slots4 == 64) hipLaunchKernelGGL((k_intra_packed<true, 64, true>), grid, blk, 0, st, A);
+    else hipLaunchKernelGGL((k_intra_packed<true, 16, true>), grid, blk, 0, st, A);
+  } else if (G.slots4 == 64) {
     if (enc) hipLaunchKernelGGL((k_intra_packed<true, 64>), grid, blk, 0, st, A);
     else hipLaunchKernelGGL((k_intra_packed<false, 64>), grid, blk, 0, st, A);
   } else {
@@ -2577,14 +2677,15 @@ static int issue_chain_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, 
   return HMX_OK;
 }
 
-// Pictures per group of the packed schedule.  A group is an interleave domain of the pool, the unit that advances level by
-// level, and it lives on one XCD: at most 64 pictures (the lanes of the prep kernels), and as many groups as a multiple of
-// the 8 XCDs allows, so that every XCD gets the same number of groups (1728 pictures: 32 groups of 54, not 27 of 64;
-// 64 pictures: 8 groups of 8; 5 pictures: 5 groups of 1).
+// Pictures per group of the packed schedule.  A group is an interleave domain of the pool and the unit that advances level
+// by level: its pictures move in lockstep, and a row is complete only when its slowest wave-item is.  Small groups keep
+// that coupling small (measured at 2048 pictures of 2160p, 64 distinct plans: 70 / 79 / 86 / 93 / 94 / 93 Gpx/s with groups
+// of 64 / 32 / 16 / 8 / 4 / 2); what is left of "packing across pictures" at 4 is enough to fill the waves of the large
+// batches, and small batches are latency-bound whatever the packing (256 pictures: 29 / 32 Gpx/s with 4 / 2; 64
+// pictures: 9.5 / 9.9 with 2 / 1).  Groups are dealt to the 8 XCDs round-robin.
 static int pack_group_size(const hmx_ctx *c, int n_pics) {
   if (c && c->knob.pack_group > 0) return std::min(c->knob.pack_group, n_pics);
-  const int g64 = (n_pics + 63) / 64, groups = (g64 + 7) / 8 * 8;
-  return std::max(1, (n_pics + groups - 1) / groups);
+  return n_pics >= 1536 ? 4 : n_pics >= 512 ? 2 : 1;
 }
 // ---- pictures resident in the working layout (include/hmx.h: hmx_tpool) ----
 struct hmx_tpool {
@@ -2780,6 +2881,10 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
   mix(jobs.data(), sizeof(ConvJob) * jobs.size());
   const int flags[6] = {enc, c->last_schedule, groups, n_pics, across, I};
   mix(flags, sizeof(flags));
+  if (enc && (int)c->sse_out.size() >= n_pics) {
+    if (!packed) return fail(c, HMX_ERR_ARG, "frame_intra: the distortion output (hmx_set_sse_output) needs the packed schedule");
+    mix(c->sse_out.data(), sizeof(hmx_sse) * n_pics);
+  }
   for (int i = 0; i < n_pics; i++) {
     const hmx_intra_plan *pp = plans[i * plan_stride];
     mix(&pp, sizeof(pp));
@@ -2888,6 +2993,12 @@ extern "C" int hmx_frame_intra_encode_multi(hmx_ctx *c, const hmx_intra_plan *co
 extern "C" int hmx_frame_intra_decode_multi(hmx_ctx *c, const hmx_intra_plan *const *plans, int n_pics, const hmx_pic *rec,
                                             const hmx_levels *lev) {
   return frame_intra(c, plans, 1, n_pics, nullptr, rec, lev, false);
+}
+extern "C" int hmx_set_sse_output(hmx_ctx *c, const hmx_sse *sse, int n_pics) {
+  if (!c || (sse && n_pics <= 0)) return HMX_ERR_ARG;
+  c->sse_out.clear();
+  if (sse) c->sse_out.assign(sse, sse + n_pics);
+  return HMX_OK;
 }
 extern "C" int hmx_frame_intra_encode_resident(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_stride, int n_pics,
                                                const hmx_tpool *org, hmx_tpool *rec, const hmx_levels *lev) {

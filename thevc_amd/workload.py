@@ -113,8 +113,11 @@ def make_planes(seed, w, h, bit_depth, kind="noise"):
         if kind == "noise":
             p = rng.integers(0, mx + 1, (ph, pw))
         else:
-            yy, xx = np.mgrid[0:ph, 0:pw]
-            p = (mx / 2) * (1 + 0.6 * np.sin(xx / 23.0 + seed) * np.cos(yy / 17.0)) + rng.normal(0, 6 * mx / 255, (ph, pw))
+            # sin(x / 23 + seed) * cos(y / 17) as an outer product of the two 1-D factors: the same doubles multiplied,
+            # the same samples as the element-wise form over a 2-D grid, at a fraction of the time for a 2160p picture
+            sx = np.sin(np.arange(pw) / 23.0 + seed)[None, :]
+            cy = np.cos(np.arange(ph) / 17.0)[:, None]
+            p = (mx / 2) * (1 + 0.6 * sx * cy) + rng.normal(0, 6 * mx / 255, (ph, pw))
             p = np.clip(np.rint(p), 0, mx)
         out.append(p.astype(np.int16))
     return out
