@@ -474,6 +474,12 @@ int hmx_batch_residual_transformNxN_multi(hmx_ctx *ctx, const hmx_tu_list *list,
 int hmx_batch_residual_transform_recon_multi(hmx_ctx *ctx, const hmx_tu_list *list, int n_pics, const hmx_pic *org,
                                              const hmx_pic *pred, const hmx_levels *lev, const hmx_pic *rec,
                                              uint32_t *d_abs_sum, const hmx_pic_param *pp);
+/* The same with the distortion the encoder takes right behind it (getDistPart(rec, org, DF_SSE), TEncSearch.cpp:4990 ->
+ * TComRdCost::xGetSSE*, TComRdCost.cpp:1313-1657): d_sse[picture * blocks + i] = sum of (org - rec)^2 >> 2 * (B - 8) over
+ * block i (the caller's order, like d_abs_sum; device, may be NULL), formed in the pass that reconstructs the block. */
+int hmx_batch_residual_transform_recon_sse_multi(hmx_ctx *ctx, const hmx_tu_list *list, int n_pics, const hmx_pic *org,
+                                                 const hmx_pic *pred, const hmx_levels *lev, const hmx_pic *rec,
+                                                 uint32_t *d_abs_sum, uint32_t *d_sse, const hmx_pic_param *pp);
 int hmx_batch_invtransformNxN_multi(hmx_ctx *ctx, const hmx_tu_list *list, int n_pics, const hmx_levels *lev,
                                     const hmx_pic *pred, const hmx_pic *out, const hmx_pic_param *pp);
 int hmx_pic_extend_border_multi(hmx_ctx *ctx, int n_pics, const hmx_pic *pics, int pic_w, int pic_h, int margin_x,

@@ -846,6 +846,54 @@ def test_frame_intra_sse_output(ctx, slots4, hmx_opts):
         d.free()
 
 
+def test_inter_chain_sse(ctx):
+    """hmx_batch_residual_transform_recon_sse_multi: the fused inter chain also returns getDistPart(rec, org, DF_SSE) per
+    block (all four block sizes: lane-per-block 4x4 kernel, list kernels, one wave per 32x32 block), in the caller's
+    block order, for every picture of the call; same levels and reconstruction as the call without it."""
+    O, B, L = ol.oracle(), ctx.bit_depth, capi.lib()
+    O.hmo_getSSE.restype = C.c_uint32
+    w, h, n = 192, 128, 2
+    mx = (1 << B) - 1
+    rng = np.random.default_rng(640 + B)
+    tus = workload.make_tus(41, w, h, "mix", ts_prob=0.0)
+    tus["flags"] = capi.TU_INTER
+    tl = ctx.tu_list(tus)
+    pp = capi.PicParam(w, h, 29, 0, capi.P_SLICE, 1)
+    orgs = [workload.make_planes(80 + i, w, h, B, "texture") for i in range(n)]
+    preds = [[np.clip(o.astype(np.int32) + rng.integers(-40, 41, o.shape), 0, mx).astype(np.int16) for o in orgs[i]] for i in range(n)]
+    d_org = [capi.DevPicture(ctx, w, h).upload(o) for o in orgs]
+    d_pred = [capi.DevPicture(ctx, w, h).upload(p) for p in preds]
+    outs = []
+    for with_sse in (True, False):
+        d_rec = [capi.DevPicture(ctx, w, h).zero() for _ in range(n)]
+        d_lev = [capi.DevPicture(ctx, w, h, dtype=np.int32).zero() for _ in range(n)]
+        A = lambda lst, T: (T * n)(*[x.as_pic() for x in lst])
+        d_sse = ctx.alloc(4 * n * len(tus)).zero()
+        if with_sse:
+            ctx._chk(L.hmx_batch_residual_transform_recon_sse_multi(ctx.h, tl, n, A(d_org, capi.Pic), A(d_pred, capi.Pic), A(d_lev, capi.Levels),
+                                                                    A(d_rec, capi.Pic), None, d_sse.ptr, C.byref(pp)))
+        else:
+            ctx._chk(L.hmx_batch_residual_transform_recon_multi(ctx.h, tl, n, A(d_org, capi.Pic), A(d_pred, capi.Pic), A(d_lev, capi.Levels),
+                                                                A(d_rec, capi.Pic), None, C.byref(pp)))
+        ctx.sync()
+        outs.append(([d.download() for d in d_rec], [d.download() for d in d_lev], d_sse.download(np.uint32)))
+        for d in d_rec + d_lev + [d_sse]:
+            d.free()
+    (rec, lev, sse), (rec0, lev0, _) = outs
+    for i in range(n):
+        for p in range(3):
+            assert np.array_equal(rec[i][p], rec0[i][p]) and np.array_equal(lev[i][p], lev0[i][p]), (i, p)
+        for k, t in enumerate(tus):
+            N, p, x, y = 1 << int(t["log2n"]), int(t["plane"]), int(t["x"]), int(t["y"])
+            o = np.ascontiguousarray(orgs[i][p][y:y + N, x:x + N])
+            r = np.ascontiguousarray(rec[i][p][y:y + N, x:x + N])
+            assert int(sse[i * len(tus) + k]) == O.hmo_getSSE(o.ctypes.data_as(C.c_void_p), N, r.ctypes.data_as(C.c_void_p), N, N, N, B), (i, k, N)
+    assert sse.any()
+    L.hmx_tu_list_destroy(ctx.h, tl)
+    for d in d_org + d_pred:
+        d.free()
+
+
 def test_yuv_resident(ctx):
     """hmx_yuv_unpack_resident / hmx_yuv_pack_resident: a file's frame straight into a pool picture and back, vs the
     plane-geometry entry points (which are held against the oracle's TVideoIOYuv restatement above)."""

@@ -172,6 +172,8 @@ def lib():
                                                             C.POINTER(PicParam)]
         L.hmx_batch_residual_transform_recon_multi.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(Levels),
                                                                C.POINTER(Pic), vp, C.POINTER(PicParam)]
+        L.hmx_batch_residual_transform_recon_sse_multi.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(Levels),
+                                                                   C.POINTER(Pic), vp, vp, C.POINTER(PicParam)]
         L.hmx_batch_invtransformNxN_multi.argtypes = [vp, vp, ci, C.POINTER(Levels), C.POINTER(Pic), C.POINTER(Pic),
                                                       C.POINTER(PicParam)]
         L.hmx_pic_extend_border_multi.argtypes = [vp, ci, C.POINTER(Pic), ci, ci, ci, ci]

@@ -160,6 +160,19 @@ __device__ __forceinline__ int group_sum(int v, int width) { // sum over `width`
   return v;
 }
 
+// distortion of NS samples: sum of (org - rec)^2 >> 2 * (B - 8), TComRdCost::xGetSSE* with IBDI_DISTORTION 0 (TComRdCost.cpp:1313-1657)
+template <int NS>
+__device__ __forceinline__ unsigned sse_samples(const int *org, const int *rec, int B) {
+  const unsigned sh = (unsigned)(B - 8) << 1;
+  unsigned s = 0;
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const int d = org[k] - rec[k];
+    s += (unsigned)mul24(d, d) >> sh; // |d| < 2^12
+  }
+  return s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Quantise the coefficients a lane holds and run sign-bit hiding on the block (TComTrQuant.cpp
 // :1130-1267, :977-1100).  coef[k] sits at (row, col) = pos(k); NL lanes own the block, NCOEF per lane.

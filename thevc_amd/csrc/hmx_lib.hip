@@ -56,6 +56,7 @@ struct ListArgs {
   LevelsDev lev; // levels / coefficients (Int)
   LevelsDev lev2;
   uint32_t *abs_sum;
+  uint32_t *sse; // OP_TRANSFORM_RECON: xGetSSE(org, rec) per block, indexed like abs_sum (NULL = none)
   int have_pred;
   PlanesDev org;        // OP_PRED with cost: the original the predictions are costed against
   uint32_t *cost;       // OP_PRED: calcHAD of every (block, mode), [block idx][n_modes]; NULL = none
@@ -138,6 +139,16 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
 #pragma unroll
         for (int k = 0; k < N; k++) row[k] = clip3(0, mx, pr[k] + row[k]);
         store_row16<N>(uniform3(Q->rec.p, pl) + (size_t)(y + gl) * uniform3(Q->rec.s, pl) + x, row);
+      }
+      if (A.sse) { // getDistPart(rec, org, DF_SSE) behind the reconstruction (TEncSearch.cpp:4990), in the same pass
+        unsigned dsum = 0;
+        if (active) {
+          int o[N];
+          load_row16<N>(a_p + (size_t)(y + gl) * a_s + x, o); // the original row again: it went into the residual
+          dsum = sse_samples<N>(o, row, A.P.bit_depth);
+        }
+        dsum = (unsigned)group_sum((int)dsum, N);
+        if (active && gl == 0) A.sse[(size_t)blockIdx.y * A.abs_stride + d.idx] = dsum;
       }
     }
   } else if constexpr (OP == OP_XQUANT) {
@@ -261,18 +272,6 @@ struct PlaneView {
   int lev_stride;   // > 0: plane geometry; 0: the reference's Z-order coefficient layout
   uint32_t *sse = nullptr; // != NULL (encoder direction): xGetSSE(org, rec) of every block, at the index of its first 4x4 unit
 };
-// distortion of NS samples: sum of (org - rec)^2 >> 2 * (B - 8), TComRdCost::xGetSSE* with IBDI_DISTORTION 0 (TComRdCost.cpp:1313-1657)
-template <int NS>
-__device__ __forceinline__ unsigned sse_samples(const int *org, const int *rec, int B) {
-  const unsigned sh = (unsigned)(B - 8) << 1;
-  unsigned s = 0;
-#pragma unroll
-  for (int k = 0; k < NS; k++) {
-    const int d = org[k] - rec[k];
-    s += (unsigned)mul24(d, d) >> sh; // |d| < 2^12
-  }
-  return s;
-}
 // 4x4 blocks per wave in the across-pictures level schedule: 16 = four lanes per block (one row each, through LDS like the 8x8 and
 // 16x16 blocks), 64 = one lane per block (wave_chain_4_lane).  Measured at 1024 pictures of the 2160p mix: four lanes
 // +3 % encoder direction, +16 % decoder direction (more, shorter waves); the one-lane form stays for A/B builds.
@@ -1390,6 +1389,20 @@ __global__ __launch_bounds__(64) void k_inter32(ListArgs A) {
     short r4[4] = {(short)clip3(0, mx, p0 + out[4 * q]), (short)clip3(0, mx, p1 + out[4 * q + 1]),
                    (short)clip3(0, mx, p2 + out[4 * q + 2]), (short)clip3(0, mx, p3 + out[4 * q + 3])};
     __builtin_memcpy(rec + 8 * q, r4, 8);
+    if (A.sse) { // v[] becomes org - rec for the distortion
+      short o4[4];
+      __builtin_memcpy(o4, org + 8 * q, 8);
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[4 * q + k] = o4[k] - r4[k];
+    }
+  }
+  if (A.sse) {
+    const unsigned sh = (unsigned)(A.P.bit_depth - 8) << 1;
+    unsigned dsum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) dsum += (unsigned)mul24(v[k], v[k]) >> sh;
+    dsum = (unsigned)group_sum((int)dsum, 64);
+    if (lane == 0) A.sse[(size_t)blockIdx.y * A.abs_stride + d.idx] = dsum;
   }
 }
 
@@ -1439,6 +1452,15 @@ __global__ __launch_bounds__(256) void k_inter4(ListArgs A) {
 #pragma unroll
     for (int k = 0; k < 4; k++) r4[k] = (short)clip3(0, mx, pred[4 * r + k] + out[4 * r + k]);
     __builtin_memcpy(rec + (size_t)r * r_s, r4, 8);
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[4 * r + k] = v[4 * r + k] + pred[4 * r + k] - r4[k]; // org - rec (org = residual + prediction)
+  }
+  if (A.sse) {
+    const unsigned sh = (unsigned)(A.P.bit_depth - 8) << 1;
+    unsigned dsum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) dsum += (unsigned)mul24(out[k], out[k]) >> sh;
+    A.sse[(size_t)blockIdx.y * A.abs_stride + d.idx] = dsum;
   }
 }
 
@@ -1966,7 +1988,7 @@ extern "C" int hmx_batch_invtransformNxN(hmx_ctx *c, const hmx_tu_list *l, const
 
 static int run_list_multi(hmx_ctx *c, int op, const hmx_tu_list *l, int n_pics, const hmx_pic *a, const hmx_pic *b,
                           const hmx_levels *lev, uint32_t *d_abs_sum, const hmx_pic_param *pp, bool have_pred,
-                          const hmx_pic *rec = nullptr) {
+                          const hmx_pic *rec = nullptr, uint32_t *d_sse = nullptr) {
   std::vector<ListPic> t(n_pics);
   for (int i = 0; i < n_pics; i++) {
     t[i].a = to_dev(a ? &a[i] : nullptr);
@@ -1979,6 +2001,7 @@ static int run_list_multi(hmx_ctx *c, int op, const hmx_tu_list *l, int n_pics, 
   if (!A.pics) return fail(c, HMX_ERR_NOMEM, "argument arena");
   A.n_pics = n_pics;
   A.abs_sum = d_abs_sum;
+  A.sse = d_sse;
   A.abs_stride = l->n;
   A.have_pred = have_pred;
   A.P = make_picdev(c, pp);
@@ -1999,6 +2022,14 @@ extern "C" int hmx_batch_residual_transform_recon_multi(hmx_ctx *c, const hmx_tu
   if (!c || !l || !org || !pred || !lev || !rec || !pp || n_pics <= 0 || n_pics > 65535)
     return fail(c, HMX_ERR_ARG, "hmx_batch_residual_transform_recon_multi: bad argument");
   return run_list_multi(c, OP_TRANSFORM_RECON, l, n_pics, org, pred, lev, d_abs_sum, pp, true, rec);
+}
+
+extern "C" int hmx_batch_residual_transform_recon_sse_multi(hmx_ctx *c, const hmx_tu_list *l, int n_pics, const hmx_pic *org,
+                                                           const hmx_pic *pred, const hmx_levels *lev, const hmx_pic *rec,
+                                                           uint32_t *d_abs_sum, uint32_t *d_sse, const hmx_pic_param *pp) {
+  if (!c || !l || !org || !pred || !lev || !rec || !pp || n_pics <= 0 || n_pics > 65535)
+    return fail(c, HMX_ERR_ARG, "hmx_batch_residual_transform_recon_sse_multi: bad argument");
+  return run_list_multi(c, OP_TRANSFORM_RECON, l, n_pics, org, pred, lev, d_abs_sum, pp, true, rec, d_sse);
 }
 
 extern "C" int hmx_batch_invtransformNxN_multi(hmx_ctx *c, const hmx_tu_list *l, int n_pics, const hmx_levels *lev,
