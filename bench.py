@@ -296,8 +296,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="ai2160p10", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=None,
-                    help="pictures per GPU per step (157 MB of HBM each at 2160p: planes, levels, the working pool and the packed "
-                         "schedule's tables); default 1728 at 2160p (27 groups of 64) and 4096 at 1080p, reduced to what the free HBM holds")
+                    help="pictures per GPU per step (110 MB of HBM each at 2160p: resident original and reconstruction, levels and the "
+                         "packed schedule's tables); default 2048 at 2160p and 8192 at 1080p, reduced to what the free HBM holds")
     ap.add_argument("--plans", type=int, default=64,
                     help="distinct decision structures (block quadtrees + modes) in the batch; picture i follows plan i mod PLANS. "
                          "1 = every picture shares one structure (the best case of round 1's headline)")
@@ -367,7 +367,7 @@ def main():
 
     # Batch size: throughput comes from pictures in flight; the default fills most of the HBM (planes 6 + levels 6 +
     # tiled working pool 6.2 bytes per luma sample, plus 16 B per block of the packed schedule's item table).
-    F = args.frames if args.frames else (1728 if w >= 3840 else 4096)
+    F = args.frames if args.frames else ((2048 if w >= 3840 else 8192) if not args.planar else (1536 if w >= 3840 else 4096))
     free_b, _total_b = torch.cuda.mem_get_info()
     per_pic = int((18.3 if args.planar else 12.3) * w * h_c) + 18 * max(len(t) for t in tus_list)
     if not args.frames and F * per_pic > 0.92 * free_b:
