@@ -87,7 +87,7 @@ def cpu_worker(argv):
     print(json.dumps({"pictures": n, "seconds": dt}), flush=True)
 
 
-def cpu_baseline(w, h, B, qp, tiling, checks, seconds_target=10.0, all_cores=True):
+def cpu_baseline(w, h, B, qp, tiling, checks, seconds_target=10.0, all_cores=True, max_cores=16):
     """checks = [(picture index, decisions (tus), plan seed, picture seed, original planes, (GPU reconstruction planes,
     GPU level planes))].  Leg 1: ONE core, in this process, codes the first entry over and over for seconds_target (what
     the CPU computes doubles as a check of what the GPU wrote; further entries -- --verify: a picture of every packing
@@ -121,6 +121,7 @@ def cpu_baseline(w, h, B, qp, tiling, checks, seconds_target=10.0, all_cores=Tru
         out["gpu_pictures_identical"] = bool(same)
     if all_cores and seconds_target > 0:
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = min(cores, max_cores)  # a one-GPU box of the pool is granted 16 host cores, whatever the affinity mask shows
         procs = []
         for k in range(cores):
             cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(w), str(h), str(B), str(qp), str(tiling),
@@ -314,6 +315,7 @@ def main():
                          "of the working layout; default: pictures resident in the working layout (hmx_tpool)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--one-core-only", action="store_true", help="cpu_baseline: skip the all-cores leg")
+    ap.add_argument("--cpu-cores", type=int, default=16, help="cpu_baseline: worker processes of the all-cores leg (the host-core share of one GPU)")
     ap.add_argument("--no-ra", action="store_true", help="N > 1: skip the random-access leg (ra2160p8 with the RCCL exchange) after the all-intra line")
     ap.add_argument("--ra-segments", type=int, default=4, help="segments per GPU of the random-access leg of a multi-GPU run")
     ap.add_argument("--verify", action="store_true", help="the cpu_baseline leg also checks a picture of every packing group")
@@ -521,7 +523,7 @@ def main():
             checks = [(i, tus_list[i % n_plans], plan_seeds[i % n_plans], seeds[i], src[i],
                        (reconstruction(i), lev_slab.picture(i).to_planes(tus_list[i % n_plans]))) for i in idx]
             out["cpu_baseline"] = cpu_baseline(w, h_c, B, qp, args.tiling, checks, 0.0 if args.no_cpu_baseline else 10.0,
-                                               all_cores=not args.one_core_only)
+                                               all_cores=not args.one_core_only, max_cores=args.cpu_cores)
             if args.verify:
                 cb = out["cpu_baseline"]
                 out["verified_bit_exact_vs_oracle"] = cb.get("gpu_pictures_identical", cb["gpu_picture_0_identical"])

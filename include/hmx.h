@@ -394,6 +394,21 @@ typedef struct {
 } hmx_pu;
 int hmx_batch_motionCompensation(hmx_ctx *ctx, const hmx_pu *d_pus, int n, const hmx_pic *refs, int n_refs,
                                  const hmx_pic *dst);
+/* The encoder's sub-pel refinement fan-out (HOT LOOP C): TEncSearch::xPatternSearchFracDIF (TLibEncoder/TEncSearch.cpp:
+ * 4480-4514) builds the half- and quarter-sample planes around a unit's integer vector (xExtDIFUpSamplingH / Q, :5982-6165:
+ * 2 + 4, then 2 + 8 interpolation calls) and costs nine candidates per stage (xPatternRefinement :711-760) with
+ * TComRdCost::xGetHADs (UseHADME, TComRdCost.cpp:2186-2283) or xGetSAD (:488-516).  Here: for every unit i of `pus` (HOST
+ * array; ref0 and mv0 = the INTEGER vector in quarter samples, a multiple of 4) and every candidate k the distortion between
+ * the original block and the two-stage prediction (filterHorLuma isLast = false, then filterVerLuma isFirst = false, isLast =
+ * true -- what the reference's m_filteredBlock planes hold, zero fractions included) at mv0 + offs[k] quarter samples
+ * (offs: host array of n_cand {dx, dy} pairs, |dx|, |dy| <= 3; n_cand <= 49: both stages of the reference's search, or the
+ * whole 7 x 7 neighbourhood at once): d_cost[i * n_cand + k] (device) = sum over the unit's 8x8 (4x4 when a side is not a
+ * multiple of 8) sub-blocks of the Hadamard sum (use_had) or the SAD, >> (bit depth - 8).  The vector-bits term of
+ * xPatternRefinement (TComRdCost::getCost(x, y)) and the choice among candidates stay with the caller.
+ * refs / org: device pictures; the references with the reference's margins. */
+int hmx_batch_subpel_cost(hmx_ctx *ctx, const hmx_pu *pus, int n, const hmx_pic *refs, int n_refs, const hmx_pic *org,
+                          const int8_t *offs, int n_cand, int use_had, uint32_t *d_cost);
+
 /* Deblocking filter, the application part (TLibCommon/TComLoopFilter.cpp:571-922: xEdgeFilterLuma, xEdgeFilterChroma,
  * the pel filters, the strong/weak decision), in place on a reconstructed picture whose size
  * is a multiple of 8.  Maps (device) hold one entry per 4x4 luma unit in raster order: d_bs_ver[u] = boundary

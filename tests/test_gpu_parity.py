@@ -894,6 +894,60 @@ def test_inter_chain_sse(ctx):
         d.free()
 
 
+@pytest.mark.parametrize("use_had", [1, 0])
+def test_batch_subpel_cost(ctx, use_had):
+    """hmx_batch_subpel_cost, the encoder's sub-pel refinement fan-out (xExtDIFUpSamplingH / Q + xPatternRefinement): the
+    distortion of every unit at every candidate displacement -- the reference's two search stages (nine half-sample,
+    nine quarter-sample candidates) and the whole 7 x 7 neighbourhood -- vs the same made with the oracle's filters the
+    way the reference makes its planes: filterHorLuma(isLast = false) over height + 7 rows, filterVerLuma(isFirst = false,
+    isLast = true), then calcHAD / SAD.  All unit shapes (8x8 and 4x4 Hadamard sub-blocks), two references."""
+    O, B, L = ol.oracle(), ctx.bit_depth, capi.lib()
+    O.hmo_calcHAD.restype = C.c_uint32
+    rng = np.random.default_rng(9000 + B + use_had)
+    w, h, m = 192, 128, 80
+    refs_h = [workload.make_planes(70 + i, w, h, B, "texture") for i in range(2)]
+    org_h = workload.make_planes(75, w, h, B, "texture")
+    refs = [capi.DevPicture(ctx, w, h, m, m).upload(r) for r in refs_h]
+    for r in refs:
+        ctx._chk(L.hmx_pic_extend_border(ctx.h, C.byref(r.as_pic()), w, h, m, m))
+    org = capi.DevPicture(ctx, w, h).upload(org_h)
+    ctx.sync()
+    full = [r.download(with_margins=True)[0] for r in refs]  # luma with margins, as the device holds it
+    pus = workload.make_pus(77, w, h, n_refs=2, bi_frac=0.0, mv_range=12)
+    pus = pus[::3][:40].copy()
+    pus["mv0x"] &= ~3
+    pus["mv0y"] &= ~3
+    half = [(0, 0), (0, -2), (0, 2), (-2, 0), (2, 0), (-2, -2), (2, -2), (-2, 2), (2, 2)]           # s_acMvRefineH x 2
+    quarter = [(2 + dx, -2 + dy) for (dx, dy) in ((0, 0), (0, -1), (0, 1), (-1, -1), (1, -1), (-1, 0), (1, 0), (-1, 1), (1, 1))]  # around one half-sample winner
+    allpos = [(dx, dy) for dy in range(-3, 4) for dx in range(-3, 4)]
+    ref_arr = (capi.Pic * 2)(*[r.as_pic() for r in refs])
+    for cands in (half, quarter, allpos):
+        offs = np.array(cands, np.int8)
+        d_cost = ctx.alloc(4 * len(pus) * len(cands))
+        ctx._chk(L.hmx_batch_subpel_cost(ctx.h, pus.ctypes.data, len(pus), ref_arr, 2, C.byref(org.as_pic()), offs.ctypes.data, len(cands), use_had, d_cost.ptr))
+        got = d_cost.download(np.uint32).reshape(len(pus), len(cands))
+        d_cost.free()
+        st = w + 2 * m
+        for i, u in enumerate(pus[:12] if cands is allpos else pus):
+            x, y, pw, ph = int(u["x"]), int(u["y"]), int(u["w"]), int(u["h"])
+            plane = full[int(u["ref0"])].reshape(-1)
+            ob = np.ascontiguousarray(org_h[0][y:y + ph, x:x + pw])
+            for k, (dx, dy) in enumerate(cands):
+                mvx, mvy = int(u["mv0x"]) + dx, int(u["mv0y"]) + dy
+                o0 = (m + y + (mvy >> 2) - 3) * st + m + x + (mvx >> 2)
+                tmp = np.zeros((ph + 7, pw), np.int16)
+                O.hmo_filterHorLuma(ol.ptr(plane, o0), st, ol.ptr(tmp.reshape(-1)), pw, pw, ph + 7, mvx & 3, 0, B)
+                pred = np.zeros((ph, pw), np.int16)
+                O.hmo_filterVerLuma(ol.ptr(tmp.reshape(-1), 3 * pw), pw, ol.ptr(pred.reshape(-1)), pw, pw, ph, mvy & 3, 0, 1, B)
+                if use_had:
+                    want = O.hmo_calcHAD(ob.ctypes.data_as(C.c_void_p), pw, pred.ctypes.data_as(C.c_void_p), pw, pw, ph, B)
+                else:
+                    want = int(np.abs(ob.astype(np.int32) - pred).sum()) >> (B - 8)
+                assert int(got[i, k]) == want, ("subpel", i, (pw, ph), (dx, dy))
+    for d in refs + [org]:
+        d.free()
+
+
 def test_yuv_resident(ctx):
     """hmx_yuv_unpack_resident / hmx_yuv_pack_resident: a file's frame straight into a pool picture and back, vs the
     plane-geometry entry points (which are held against the oracle's TVideoIOYuv restatement above)."""

@@ -163,6 +163,7 @@ def lib():
         L.hmx_frame_intra_decode_onto.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Levels)]
         L.hmx_frame_intra_encode_onto.argtypes = [vp, vp, ci, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(Levels)]
         L.hmx_batch_motionCompensation.argtypes = [vp, vp, ci, C.POINTER(Pic), ci, C.POINTER(Pic)]
+        L.hmx_batch_subpel_cost.argtypes = [vp, vp, ci, C.POINTER(Pic), ci, C.POINTER(Pic), vp, ci, ci, vp]
         L.hmx_pic_extend_border.argtypes = [vp, C.POINTER(Pic), ci, ci, ci, ci]
         L.hmx_batch_motionCompensation_multi.argtypes = [vp, ci, C.POINTER(McJob)]
         L.hmx_xRateDistOptQuant.argtypes = [vp, vp, vp, ci, ci, C.POINTER(C.c_uint32), ci, C.POINTER(RdoqParam), C.POINTER(EstBits)]

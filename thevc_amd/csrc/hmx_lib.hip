@@ -3806,6 +3806,127 @@ extern "C" int hmx_motionCompensation(hmx_ctx *c, const hmx_pic *ref0, const int
   return HMX_OK;
 }
 
+// ---- the encoder's sub-pel refinement fan-out (HOT LOOP C) ----
+// xPatternSearchFracDIF (TEncSearch.cpp:4480-4514) makes the half- and quarter-sample planes of a prediction unit
+// (xExtDIFUpSamplingH / Q, :5982-6165: filterHorLuma(frac x, isLast = false) into the 14-bit intermediate, then
+// filterVerLuma(frac y, isFirst = false, isLast = true), zero fractions included) and costs nine candidates per stage
+// (xPatternRefinement, :711-760) with xGetHADs / xGetSAD (TComRdCost.cpp:2186-2283, :488-516).  The sample a plane holds
+// at a candidate's position depends on the position alone, so the fan-out is: for every unit and every candidate
+// displacement (integer vector + up to 3 quarter samples either way) the distortion of the displaced two-stage
+// prediction against the original.  One thread = one 8x8 (4x4) sub-block of one unit at one candidate: column by column
+// the horizontal stage of the 15 (11) rows it needs, the vertical stage, the difference; then the Hadamard sum of the
+// sub-block (rounded per sub-block as the reference does) or its SAD, added to the unit's candidate.
+struct SubpelArgs {
+  const hmx_pu *pus;
+  const uint32_t *first; // [n + 1] prefix of sub-blocks per unit
+  int n;
+  PlanesDev refs[4];
+  PlanesDev org;
+  const signed char *offs; // [n_cand][2]
+  int n_cand, use_had, B;
+  uint32_t *cost; // [n][n_cand]
+};
+__global__ __launch_bounds__(64) void k_subpel_cost(SubpelArgs A) {
+  const uint32_t sb = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cand = blockIdx.y;
+  if (sb >= A.first[A.n]) return;
+  int lo = 0, hi = A.n; // the unit this sub-block belongs to
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (A.first[mid] <= sb) lo = mid;
+    else hi = mid;
+  }
+  const hmx_pu pu = A.pus[lo];
+  const int w = pu.w, h = pu.h, n = (w % 8 == 0 && h % 8 == 0) ? 8 : 4, bw = w / n, k = (int)(sb - A.first[lo]);
+  const int bx = pu.x + (k % bw) * n, by = pu.y + (k / bw) * n;
+  const int mvx = pu.mv0x + A.offs[2 * cand], mvy = pu.mv0y + A.offs[2 * cand + 1];
+  const int xf = mvx & 3, yf = mvy & 3, B = A.B, head = 14 - B, maxv = (1 << B) - 1;
+  const PlanesDev &R = A.refs[pu.ref0 < 4 ? pu.ref0 : 0];
+  const short *ref = R.p[0] + (ptrdiff_t)(by + (mvy >> 2)) * R.s[0] + bx + (mvx >> 2);
+  const short *org = A.org.p[0] + (size_t)by * A.org.s[0] + bx;
+  int d[64];
+  for (int c = 0; c < n; c++) {
+    int t[15]; // horizontal stage of rows -3 .. n+3 of this column (isFirst = true, isLast = false)
+    for (int r = 0; r < n + 7; r++) t[r] = interp_sample<8>(ref + (ptrdiff_t)(r - 3) * R.s[0] + c, 1, xf, true, false, B);
+    for (int r = 0; r < n; r++) {
+      int v;
+      if (yf == 0) { // filterCopy, last only (:124-145)
+        const int off = wrap16(8192 + (head ? (1 << (head - 1)) : 0));
+        v = clip3(0, maxv, wrap16((t[r + 3] + off) >> head));
+      } else {
+        const int shift = 6 + head, offset = (1 << (shift - 1)) + (8192 << 6);
+        int sum = 0;
+        for (int q = 0; q < 8; q++) sum += t[r + q] * luma_tap(yf, q);
+        v = clip3(0, maxv, wrap16((sum + offset) >> shift));
+      }
+      d[r * 8 + c] = org[(size_t)r * A.org.s[0] + c] - v;
+    }
+  }
+  int sum = 0;
+  if (!A.use_had) {
+    for (int r = 0; r < n; r++)
+      for (int c = 0; c < n; c++) sum += abs(d[r * 8 + c]);
+  } else if (n == 8) {
+    for (int r = 0; r < 8; r++) wht_regs<8>(d + r * 8);
+    for (int c = 0; c < 8; c++) {
+      int col[8];
+      for (int r = 0; r < 8; r++) col[r] = d[r * 8 + c];
+      wht_regs<8>(col);
+      for (int r = 0; r < 8; r++) sum += abs(col[r]);
+    }
+    sum = (sum + 2) >> 2;
+  } else {
+    for (int r = 0; r < 4; r++) wht_regs<4>(d + r * 8);
+    for (int c = 0; c < 4; c++) {
+      int col[4];
+      for (int r = 0; r < 4; r++) col[r] = d[r * 8 + c];
+      wht_regs<4>(col);
+      for (int r = 0; r < 4; r++) sum += abs(col[r]);
+    }
+    sum = (sum + 1) >> 1;
+  }
+  atomicAdd(&A.cost[(size_t)lo * A.n_cand + cand], (unsigned)sum);
+}
+__global__ void k_shift_u32(uint32_t *v, size_t n, int sh) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] >>= sh;
+}
+extern "C" int hmx_batch_subpel_cost(hmx_ctx *c, const hmx_pu *pus, int n, const hmx_pic *refs, int n_refs, const hmx_pic *org,
+                                     const int8_t *offs, int n_cand, int use_had, uint32_t *d_cost) {
+  if (!c || !pus || n <= 0 || !refs || n_refs <= 0 || n_refs > 4 || !org || !offs || n_cand <= 0 || n_cand > 49 || !d_cost)
+    return fail(c, HMX_ERR_ARG, "hmx_batch_subpel_cost: bad argument");
+  std::vector<uint32_t> first((size_t)n + 1, 0);
+  for (int i = 0; i < n; i++) {
+    const int w = pus[i].w, h = pus[i].h;
+    if (w <= 0 || h <= 0 || w > 64 || h > 64 || ((w | h) & 3) || pus[i].ref0 >= n_refs || ((pus[i].mv0x | pus[i].mv0y) & 3))
+      return fail(c, HMX_ERR_ARG, "hmx_batch_subpel_cost: unit size not a multiple of 4, reference index, or a vector that is not integer");
+    const int nb = (w % 8 == 0 && h % 8 == 0) ? 8 : 4;
+    first[i + 1] = first[i] + (uint32_t)((w / nb) * (h / nb));
+  }
+  for (int k = 0; k < 2 * n_cand; k++)
+    if (offs[k] < -3 || offs[k] > 3) return fail(c, HMX_ERR_ARG, "hmx_batch_subpel_cost: candidate further than 3 quarter samples");
+  SubpelArgs A{};
+  const size_t pu_bytes = sizeof(hmx_pu) * (size_t)n, first_bytes = sizeof(uint32_t) * ((size_t)n + 1);
+  // unit list and prefix through the argument arena (they are the caller's host arrays)
+  A.pus = static_cast<const hmx_pu *>(arena_push(c, pus, pu_bytes));
+  A.first = static_cast<const uint32_t *>(arena_push(c, first.data(), first_bytes));
+  A.offs = static_cast<const signed char *>(arena_push(c, offs, (size_t)2 * n_cand));
+  if (!A.pus || !A.first || !A.offs) return fail(c, HMX_ERR_NOMEM, "argument arena (unit list too long: split the call)");
+  A.n = n;
+  for (int r = 0; r < n_refs; r++) A.refs[r] = to_dev(&refs[r]);
+  A.org = to_dev(org);
+  A.n_cand = n_cand;
+  A.use_had = use_had;
+  A.B = c->cfg.bit_depth;
+  A.cost = d_cost;
+  HIPCHK(c, hipMemsetAsync(d_cost, 0, sizeof(uint32_t) * (size_t)n * n_cand, c->stream));
+  hipLaunchKernelGGL(k_subpel_cost, dim3((first[n] + 63) / 64, (unsigned)n_cand), dim3(64), 0, c->stream, A);
+  if (c->cfg.bit_depth > 8) // xGetHADs / xGetSAD return uiSum >> g_uiBitIncrement
+    hipLaunchKernelGGL(k_shift_u32, dim3((unsigned)(((size_t)n * n_cand + 255) / 256)), dim3(256), 0, c->stream, d_cost, (size_t)n * n_cand, c->cfg.bit_depth - 8);
+  HIPCHK(c, hipGetLastError());
+  return HMX_OK;
+}
+
 __device__ __forceinline__ int add_avg(int a, int b, int B) { // TComYuv.cpp:539-540
   const int sh = 15 - B, off = (1 << (sh - 1)) + 2 * 8192;
   return clip3(0, (1 << B) - 1, (a + b + off) >> sh);

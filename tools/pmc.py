@@ -87,8 +87,11 @@ def main():
     d = {}
     d["wait_share_of_wave_cycles"] = ratio("SQ_WAIT_ANY", "SQ_WAVE_CYCLES")
     d["wait_inst_share_of_wave_cycles"] = ratio("SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES")
-    # SQ_ACTIVE_INST_VALU counts 4 cycles per quad-cycle issue on a SIMD; busy cycles are per SQ (4 SIMDs)
-    d["valu_busy_share"] = round(C["SQ_ACTIVE_INST_VALU"] / C["SQ_BUSY_CYCLES"], 5) if C.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in C else None
+    # VALU utilisation of the chip: a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles; 256 CUs x 4 SIMDs; the
+    # clock is taken as 2.4 GHz (the counters carry no clock), the kernel time is the trace's
+    ns_inst = summary["passes"].get("inst", {}).get("kernel_ns") or 0
+    d["valu_utilisation"] = round(C["SQ_INSTS_VALU"] * 4 / (ns_inst * 2.4 * 1024), 4) if ns_inst and "SQ_INSTS_VALU" in C else None
+    d["valu_share_of_wave_cycles"] = ratio("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES")
     d["valu_insts_per_wave"] = ratio("SQ_INSTS_VALU", "SQ_WAVES")
     d["salu_insts_per_wave"] = ratio("SQ_INSTS_SALU", "SQ_WAVES")
     d["lds_insts_per_wave"] = ratio("SQ_INSTS_LDS", "SQ_WAVES")
