@@ -22,11 +22,14 @@ static inline hmx_ctx *hmx_shim_ctx() {
   }
   return ctx;
 }
-static unsigned long g_hmx_shim_calls = 0; /* per translation unit; printed at exit */
+namespace { /* internal linkage: every translation unit has ITS OWN counter and ITS OWN report (an inline destructor with
+               external linkage would be merged across the four units and print one unit's counter four times) */
+unsigned long g_hmx_shim_calls = 0;
 struct HmxShimReport {
   const char *unit;
   ~HmxShimReport() { fprintf(stderr, "libhmx shim: %lu calls from %s\n", g_hmx_shim_calls, unit); }
 };
+} // namespace
 #define HMX_SHIM_CHECK(call)                                                                   \
   do {                                                                                         \
     ++g_hmx_shim_calls;                                                                        \

@@ -84,13 +84,18 @@ typedef short s4v __attribute__((ext_vector_type(4)));
 typedef int i4v __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------
-// Accesses to the working reconstruction.  COH = the packed schedule (k_intra_packed): blocks of one
-// launch hand their reconstruction to later blocks of the SAME launch, on any CU of any XCD.  A CU's
-// vector L1 is never refreshed by another CU's stores and an XCD's L2 keeps dirty lines to itself, so
-// every store of the reconstruction is write-through (sc1) and every load of it bypasses the L1 (sc1);
-// the producer drains its stores (s_waitcnt vmcnt(0)) before it signals, the consumer polls the signal
-// with an sc1 load before its first load (MI355X_MICROARCH.md, inter-workgroup visibility: "every store
-// sc1 + drained, every load sc1").  Relaxed agent-scope atomics are how HIP spells those instructions
+// Accesses to the working reconstruction.  In the packed schedule (k_intra_packed) blocks of one launch hand their
+// reconstruction to later blocks of the SAME launch.  A CU's vector L1 is never refreshed by another CU's stores, so
+// every LOAD of the reconstruction there bypasses the L1 (COH loads: sc1, served by the L2).  STORES come in two
+// flavours:
+//   plain          the producer and every consumer run on ONE XCD (the packed schedule binds a picture group to the XCD
+//                  that claimed it, read from the hardware's XCC id): the L1 is write-through, a store whose vmcnt has
+//                  drained is in that XCD's L2, and the L2 is the one cache all its CUs share -- nothing has to reach HBM;
+//   write-through  (COH stores: sc1) for producers and consumers on different XCDs, whose L2s keep dirty lines to
+//                  themselves (MI355X_MICROARCH.md, inter-workgroup visibility: "every store sc1 + drained, every load
+//                  sc1").  The first cut of the packed schedule used this form; it is kept for A/B builds.
+// In both the producer drains its stores (s_waitcnt vmcnt(0)) before it signals, and the consumer polls the signal with
+// an sc1 load before its first load.  Relaxed agent-scope atomics are how HIP spells those instructions
 // (global_load/store_dwordx2 ... sc1); 8 bytes = one tile row is the unit of every access.
 // COH = false: the level-synchronous schedules, where a kernel boundary separates producer and consumer.
 // ---------------------------------------------------------------------------------------------
@@ -118,12 +123,29 @@ __device__ __forceinline__ void st_rec4(short *p, s4v v) {
   }
 }
 
+// Streams of the whole-picture chain that are touched once -- originals in, levels out -- can carry the non-temporal
+// hint, so that they do not push the reconstruction lines the next dependency level gathers from out of the XCD's L2
+// (2048 pictures of 2160p: 97.5 vs 93.4 Gpx/s; no difference at 256).  -DHMX_STREAM_PLAIN builds without the hint.
+#ifndef HMX_STREAM_PLAIN
+#define HMX_STREAM_NT 1
+#endif
+#ifdef HMX_STREAM_NT
+template <typename T>
+__device__ __forceinline__ T stream_load(const T *p) { return __builtin_nontemporal_load(p); }
+template <typename T>
+__device__ __forceinline__ void stream_store(T *p, T v) { __builtin_nontemporal_store(v, p); }
+#else
+template <typename T>
+__device__ __forceinline__ T stream_load(const T *p) { return *p; }
+template <typename T>
+__device__ __forceinline__ void stream_store(T *p, T v) { *p = v; }
+#endif
 // row r of the aligned N x N block (N >= 8) whose first sample has offset b0; pb = p + tphys(b0)
 template <int N>
 __device__ __forceinline__ void tload_row(const short *pb, unsigned qstride, int r, int *x) {
 #pragma unroll
   for (int q = 0; q < N / 4; q++) {
-    const s4v v = *reinterpret_cast<const s4v *>(pb + trel<N>(qstride, tile_in_block(q, r >> 2) + ((r & 3) << 2)));
+    const s4v v = stream_load(reinterpret_cast<const s4v *>(pb + trel<N>(qstride, tile_in_block(q, r >> 2) + ((r & 3) << 2))));
     x[4 * q] = v[0];
     x[4 * q + 1] = v[1];
     x[4 * q + 2] = v[2];
@@ -504,6 +526,14 @@ template <int N>
 __device__ __forceinline__ void store_row32(int *dst, const int *x) {
 #pragma unroll
   for (int k = 0; k < N; k++) dst[k] = x[k];
+}
+template <int N>
+__device__ __forceinline__ void stream_store_row32(int *dst, const int *x) { // 16-byte aligned rows of levels (frame path)
+#pragma unroll
+  for (int k = 0; k < N; k += 4) {
+    const i4v v = {x[k], x[k + 1], x[k + 2], x[k + 3]};
+    stream_store(reinterpret_cast<i4v *>(dst + k), v);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -369,7 +369,11 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, cons
         load_row32<N>(&L.tile[gl][0], row);
 #pragma unroll
         for (int k = 0; k < N; k++) row[k] = level_of(row[k]);
-        store_row32<N>(lev_row, row);
+#ifdef HMX_STREAM_NT
+        if (V.lev_stride == 0) stream_store_row32<N>(lev_row, row); // the reference's coefficient layout: 16-byte aligned rows
+        else
+#endif
+          store_row32<N>(lev_row, row);
       }
     } else {
       if (active) {
@@ -530,7 +534,7 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
     const size_t pb0 = tphys(R.qstride, b0); // a tile never straddles quads
     int v[16];
     if (ENC && active) {
-      const i4v o0 = *reinterpret_cast<const i4v *>(V.org + pb0), o1 = *reinterpret_cast<const i4v *>(V.org + pb0 + 8);
+      const i4v o0 = stream_load(reinterpret_cast<const i4v *>(V.org + pb0)), o1 = stream_load(reinterpret_cast<const i4v *>(V.org + pb0 + 8));
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         v[2 * k] = (short)(o0[k] & 0xffff), v[2 * k + 1] = o0[k] >> 16;
@@ -619,7 +623,7 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         i4v o = {w[4 * r], w[4 * r + 1], w[4 * r + 2], w[4 * r + 3]};
-        *reinterpret_cast<i4v *>(lev_ptr + l0 + (unsigned)r * (unsigned)lrow) = o;
+        stream_store(reinterpret_cast<i4v *>(lev_ptr + l0 + (unsigned)r * (unsigned)lrow), o);
       }
     } else {
 #pragma unroll
@@ -688,7 +692,7 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const 
     if (ENC) {
 #pragma unroll
       for (int q = 0; q < 4; q++)
-        org4[q] = *reinterpret_cast<const s4v *>(V.org + row_off + trel<32>(R.qstride, tile_in_block(2 * q + h, r >> 2)));
+        org4[q] = stream_load(reinterpret_cast<const s4v *>(V.org + row_off + trel<32>(R.qstride, tile_in_block(2 * q + h, r >> 2))));
     }
     src.wait();
     intra_refs_tiled<32, 64, SRC::kCoherent>(L, lane, true, R, x, y, tphys(R.qstride, b0), luma, avail, P);
@@ -714,7 +718,7 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const 
 #pragma unroll
       for (int g = 0; g < 16; g++) {
         v[g] = level_of(L.tile[mrow(g, h)][r]);
-        lev0[__umul24((unsigned)mrow(g, h), (unsigned)lstep)] = v[g];
+        stream_store(&lev0[__umul24((unsigned)mrow(g, h), (unsigned)lstep)], v[g]);
       }
     } else {
 #pragma unroll

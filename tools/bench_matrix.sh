@@ -8,8 +8,8 @@ OUT=gpurun_out/${TAG}_bench_matrix.txt
 run() { echo "## $*" >> $OUT; timeout -k 10 400 "$@" >> $OUT 2>gpurun_out/${TAG}_bm.err || { echo "FAILED rc=$?" >> $OUT; tail -5 gpurun_out/${TAG}_bm.err >> $OUT; }; }
 for spec in "$@"; do
   IFS=: read F P S X <<< "$spec"
-  if [ "$S" = "packed" ] || [ -z "$S" ]; then run python3 bench.py --frames $F --plans $P --no-cpu-baseline $X
-  else echo "## HMX_INTRA_SCHEDULE=$S" >> $OUT; HMX_INTRA_SCHEDULE=$S run python3 bench.py --frames $F --plans $P --no-cpu-baseline $X; fi
+  if [ "$S" = "packed" ] || [ -z "$S" ]; then run python3 bench.py --frames $F --plans $P --no-cpu-baseline --no-ra $X
+  else echo "## HMX_INTRA_SCHEDULE=$S" >> $OUT; HMX_INTRA_SCHEDULE=$S run python3 bench.py --frames $F --plans $P --no-cpu-baseline --no-ra $X; fi
 done
 grep -E '^(##|\{|FAILED)' $OUT | python3 -c "
 import sys, json

@@ -7,7 +7,7 @@ OUT=gpurun_out/${TAG}_pack_sweep.txt
 for spec in "$@"; do
   set -- $spec
   F=$1; P=$2; shift 2
-  line=$(env "$@" timeout -k 10 300 python3 bench.py --frames $F --plans $P --distinct 4 --steps 3 --warmup 1 --no-cpu-baseline $EXTRA 2>gpurun_out/${TAG}_sweep.err | tail -1)
+  line=$(env "$@" timeout -k 10 300 python3 bench.py --frames $F --plans $P --distinct 4 --steps 3 --warmup 1 --no-cpu-baseline --no-ra $EXTRA 2>gpurun_out/${TAG}_sweep.err | tail -1)
   echo "$F $P $* :: $(echo "$line" | python3 -c "
 import sys, json
 try:
