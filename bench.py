@@ -318,7 +318,7 @@ def main():
     ap.add_argument("--cpu-cores", type=int, default=16, help="cpu_baseline: worker processes of the all-cores leg (the host-core share of one GPU)")
     ap.add_argument("--no-ra", action="store_true", help="skip the random-access leg (ra2160p8, segments sharded over the ranks, RCCL exchange of the "
                                                          "boundary I pictures when N > 1) that follows the all-intra measurement")
-    ap.add_argument("--ra-segments", type=int, default=4, help="segments per GPU of the random-access leg of a multi-GPU run")
+    ap.add_argument("--ra-segments", type=int, default=16, help="segments (32 pictures each) per GPU of the random-access leg")
     ap.add_argument("--verify", action="store_true", help="the cpu_baseline leg also checks a picture of every packing group")
     ap.add_argument("--rehearse-cpu", action="store_true", help="no GPU: run the rank launcher, sharding, exchange and reporting with gloo and the CPU oracle")
     args = ap.parse_args()
