@@ -1,0 +1,190 @@
+// tests/native/rdoq_core_host.cpp -- TEST INFRASTRUCTURE.  The lane decomposition of thevc_amd/csrc/hmx_rdoq_core.h run on
+// the CPU, one "lane" after the other in exactly the steps k_rdoq_wave takes on the device, against the oracle's sequential
+// restatement (oracle/hmx_oracle.c hmo_xRateDistOptQuant) on random blocks: every size, scan, texture type, cbf branch,
+// bit depth, with coefficient statistics from sparse to dense.  Built and run by tests/test_rdoq_core.py:
+//   g++ -O2 -ffp-contract=off -I thevc_amd/csrc -I oracle tests/native/rdoq_core_host.cpp -L oracle -lhmx_oracle
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "hmx_oracle.h"
+#include "hmx_rdoq_core.h"
+
+using namespace hmx;
+
+static int diag_xy(int W, int i) {
+  int c = 0;
+  for (int d = 0; d <= 2 * W - 2; d++)
+    for (int x = (d < W ? 0 : d - W + 1); x <= d && x < W; x++) {
+      if (c == i) return (d - x) * W + x;
+      c++;
+    }
+  return 0;
+}
+static std::vector<unsigned> make_scan(int N, int sc) { // the library's ScanTab (hmx_device.h), host side
+  const int G = N / 4;
+  std::vector<unsigned> t(N * N);
+  for (int g = 0; g < G * G; g++)
+    for (int i = 0; i < 16; i++) {
+      int gy, gx, y, x;
+      if (sc == 1) gy = g / G, gx = g % G, y = i >> 2, x = i & 3;
+      else if (sc == 2) gx = g / G, gy = g % G, x = i >> 2, y = i & 3;
+      else {
+        int gp = diag_xy(G, g), ip = diag_xy(4, i);
+        gy = gp / G, gx = gp % G, y = ip >> 2, x = ip & 3;
+      }
+      t[g * 16 + i] = (unsigned)((gy * 4 + y) * N + gx * 4 + x);
+    }
+  return t;
+}
+
+static long g_zeroed_groups = 0, g_carried_groups = 0, g_sign_hidden = 0; // coverage of the harness
+static const int kQuantScales[6] = {26214, 23302, 20560, 18396, 16384, 14564};
+static const int kInvQuantScales[6] = {40, 45, 51, 57, 64, 72};
+
+// the decomposition, lane by lane
+static void rdoq_block_lanes(const int *src, int *dst, int N, int B, const hmo_rdoq_cfg &cfg, const EstBitsDev &E, uint32_t *abs_sum) {
+  const int lg = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5, nn = N * N, n_cg = nn / 16, inc = B - 8;
+  const int tshift = 15 - B - lg;
+  RdoqConst C{};
+  C.lg = lg, C.scan_idx = cfg.scan_idx == 3 ? 0 : cfg.scan_idx, C.is_luma = cfg.is_luma;
+  C.q = kQuantScales[cfg.rem], C.qbits = 14 + cfg.per + tshift;
+  C.root_cbf = cfg.root_cbf, C.cbf_ctx = cfg.cbf_ctx, C.sign_hide = cfg.sign_hide;
+  C.lambda = cfg.lambda;
+  double e = (double)(1 << 15);
+  e = e * ldexp(1.0, -2 * tshift);
+  e = e / (double)C.q / (double)C.q / (double)(1 << (2 * inc));
+  C.err_scale = e;
+  const int iq = kInvQuantScales[cfg.rem];
+  C.rd_factor = (long long)((double)iq * (double)iq * (double)(1 << (2 * cfg.per)) / cfg.lambda / 16 / (double)(1 << (2 * inc)) + 0.5);
+  const std::vector<unsigned> scan = make_scan(N, C.scan_idx);
+  auto bp_of = [&](int sp) { return scan[sp]; };
+  auto gpos_of = [&](int cg) { const unsigned p0 = scan[cg * 16]; return ((p0 & (unsigned)(N - 1)) >> 2) | (((p0 >> lg) >> 2) << 8); };
+  std::vector<int> ld(nn), lev(nn), ru(nn), rd(nn), sd(nn), du(nn);
+  std::vector<double> cz(nn), cc(nn), cs(nn), cgs(64);
+  int last_pos = -1;
+  for (int sp = 0; sp < nn; sp++) { // step 0: one lane per position
+    rdoq_prep(src[scan[sp]], C, ld[sp], cz[sp]);
+    if (rdoq_max_level(ld[sp], C.qbits) > 0) last_pos = sp;
+  }
+  memset(dst, 0, sizeof(int) * nn);
+  *abs_sum = 0;
+  if (last_pos < 0) return;
+  const int last_cg = last_pos >> 4;
+  std::vector<RdoqSpec> spec((size_t)n_cg * 8);
+  for (int task = 0; task < (last_cg + 1) * 8; task++) { // step 1: one lane per (group, carry, pattern)
+    const int cg = task >> 3, v = task & 7;
+    RdoqSpecSink sink{&spec[task]};
+    spec[task].S = rdoq_walk_cg(C, E, cg, bp_of, &ld[cg * 16], &cz[cg * 16], v & 3, v >> 2, last_pos, sink);
+  }
+  std::vector<unsigned char> sel(n_cg);
+  RdoqRun R;
+  rdoq_resolve(C, E, n_cg, last_cg, gpos_of, cz.data(), spec.data(), sel.data(), cgs.data(), R); // step 2: one lane
+  for (int cg = 0; cg <= last_cg; cg++) g_zeroed_groups += (R.zeroed >> cg) & 1, g_carried_groups += cg < last_cg && (sel[cg] >> 2);
+  for (int cg = 0; cg < n_cg; cg++) { // step 3: one lane per group
+    if (cg > last_cg) {
+      for (int k = 0; k < 16; k++) lev[cg * 16 + k] = 0, cc[cg * 16 + k] = 0, cs[cg * 16 + k] = 0, ru[cg * 16 + k] = rd[cg * 16 + k] = sd[cg * 16 + k] = du[cg * 16 + k] = 0;
+      continue;
+    }
+    RdoqFullSink sink{lev.data(), cc.data(), cs.data(), ru.data(), rd.data(), sd.data(), du.data(), cg * 16};
+    rdoq_walk_cg(C, E, cg, bp_of, &ld[cg * 16], &cz[cg * 16], sel[cg] & 3, sel[cg] >> 2, last_pos, sink);
+    if ((R.zeroed >> cg) & 1) rdoq_apply_zeroed_cg(cg, cz.data(), lev.data(), cc.data(), cs.data());
+  }
+  const int best_last_p1 = rdoq_phase_b(C, E, last_pos, last_cg, gpos_of, bp_of, R, cz.data(), lev.data(), cc.data(), cs.data(), cgs.data()); // one lane
+  uint32_t sum = 0;
+  for (int sp = 0; sp < nn; sp++) { // final levels: one lane per position
+    int l = sp < best_last_p1 ? lev[sp] : 0;
+    sum += (uint32_t)l;
+    lev[sp] = src[scan[sp]] < 0 ? -l : l;
+  }
+  *abs_sum = sum;
+  if (C.sign_hide && sum >= 2) {
+    int top = -1; // the highest group that holds a level
+    for (int cg = n_cg - 1; cg >= 0 && top < 0; cg--)
+      for (int k = 0; k < 16; k++)
+        if (lev[cg * 16 + k]) top = cg;
+    for (int cg = 0; cg < n_cg; cg++) { // one lane per group
+      unsigned neg = 0;
+      for (int k = 0; k < 16; k++) neg |= (src[scan[cg * 16 + k]] < 0 ? 1u : 0u) << k;
+      int before[16];
+      memcpy(before, &lev[cg * 16], sizeof(before));
+      rdoq_phase_c_cg(C, cg == top, &lev[cg * 16], neg, &ru[cg * 16], &rd[cg * 16], &sd[cg * 16], &du[cg * 16]);
+      g_sign_hidden += memcmp(before, &lev[cg * 16], sizeof(before)) != 0;
+    }
+  }
+  for (int sp = 0; sp < nn; sp++) dst[scan[sp]] = lev[sp];
+}
+
+int main(int argc, char **argv) {
+  const int rounds = argc > 1 ? atoi(argv[1]) : 400;
+  std::mt19937_64 rng(20260101);
+  long checked = 0, nonzero = 0, zeroed_like = 0;
+  for (int it = 0; it < rounds; it++)
+    for (int lg = 2; lg <= 5; lg++) {
+      const int N = 1 << lg, B = (it & 1) ? 10 : 8;
+      hmo_est_bits est;
+      auto pair = [&](int32_t *d) {
+        const double p = 0.03 + 0.94 * (rng() % 10000) / 10000.0;
+        d[0] = (int32_t)lround(-log2(1 - p) * 32768), d[1] = (int32_t)lround(-log2(p) * 32768);
+      };
+      for (auto &x : est.sig_cg) pair(x);
+      for (auto &x : est.sig) pair(x);
+      for (auto &x : est.greater1) pair(x);
+      for (auto &x : est.greater2) pair(x);
+      for (auto &x : est.cbf) pair(x);
+      for (auto &x : est.root_cbf) pair(x);
+      for (int i = 0; i < 32; i++) est.last_x[i] = (int32_t)((8000 + rng() % 52000) * (1 + i / 4)), est.last_y[i] = (int32_t)((8000 + rng() % 52000) * (1 + i / 4));
+      pair(est.scan_zigzag), pair(est.scan_nonzigzag);
+      hmo_rdoq_cfg cfg;
+      const int qp = (int)(rng() % 52) + 6 * (B - 8);
+      cfg.per = qp / 6, cfg.rem = qp % 6;
+      cfg.is_luma = (int)(rng() % 3 != 0);
+      cfg.is_intra = (int)(rng() & 1);
+      const bool multi = cfg.is_intra && (cfg.is_luma ? (N == 4 || N == 8) : N == 4);
+      cfg.scan_idx = multi ? (int)(rng() % 3) : 0;
+      cfg.root_cbf = (int)(rng() % 4 == 0);
+      cfg.cbf_ctx = (int)(rng() % 15);
+      cfg.sign_hide = (int)(rng() % 4 != 0);
+      cfg.lambda = 4.0 + (rng() % 200000) / 1000.0;
+      std::vector<int32_t> src(N * N), want(N * N), got(N * N);
+      const int style = (int)(rng() % 5); // sparse, decaying, dense small, dense large, mostly zero with outliers
+      for (int y = 0; y < N; y++)
+        for (int x = 0; x < N; x++) {
+          int amp = style == 0 ? 60 : style == 1 ? 4000 / (1 + x + y) : style == 2 ? 90 : style == 3 ? 30000 : 8;
+          int v = (int)(rng() % (2 * amp + 1)) - amp;
+          if (style == 0 && rng() % 8) v = 0;
+          if (style == 4 && rng() % 50 == 0) v = (int)(rng() % 2001) - 1000;
+          src[y * N + x] = v;
+        }
+      if (it % 17 == 3) std::fill(src.begin(), src.end(), 0);
+      uint32_t s_want = 0, s_got = 0;
+      hmo_xRateDistOptQuant(src.data(), want.data(), N, B, &cfg, &est, &s_want);
+      EstBitsDev E;
+      static_assert(sizeof(EstBitsDev) == sizeof(hmo_est_bits), "bit-estimate tables");
+      memcpy(&E, &est, sizeof(E));
+      rdoq_block_lanes(src.data(), got.data(), N, B, cfg, E, &s_got);
+      if (s_want != s_got || memcmp(want.data(), got.data(), sizeof(int32_t) * N * N)) {
+        printf("MISMATCH round %d N %d B %d luma %d scan %d root %d lambda %.3f style %d: abs sum %u vs %u\n", it, N, B, cfg.is_luma, cfg.scan_idx,
+               cfg.root_cbf, cfg.lambda, style, s_want, s_got);
+        for (int i = 0; i < N * N; i++)
+          if (want[i] != got[i]) {
+            printf("  first difference at (%d,%d): %d vs %d\n", i / N, i % N, want[i], got[i]);
+            break;
+          }
+        return 1;
+      }
+      checked++;
+      nonzero += s_want > 0;
+      (void)zeroed_like;
+    }
+  printf("rdoq_core_host: %ld blocks identical to the oracle (%ld with levels; %ld groups zeroed by the group decision, %ld entered with a carry, "
+         "%ld changed by sign hiding)\n", checked, nonzero, g_zeroed_groups, g_carried_groups, g_sign_hidden);
+  if (!g_zeroed_groups || !g_carried_groups || !g_sign_hidden) {
+    printf("coverage hole\n");
+    return 2;
+  }
+  return 0;
+}
