@@ -61,7 +61,8 @@ int hmx_sync(hmx_ctx *ctx);
  * cross-checks).  Each is read once from the environment variable of the same name in hmx_create; hmx_set_option
  * changes one afterwards, value NULL restores the default.  HMX_INTRA_SCHEDULE = packed (default) | level | wave,
  * HMX_INTRA_ACROSS, HMX_INTRA_STREAMS, HMX_PIPELINE_CONV, HMX_GRAPH (level schedules), HMX_PACK_SLOTS4 = 16 | 64,
- * HMX_PACK_GROUP, HMX_PACK_WAVES, HMX_PACK_SLEEP0, HMX_PACK_SLEEP1 (packed schedule). */
+ * HMX_PACK_GROUP, HMX_PACK_WAVES, HMX_PACK_SLEEP0, HMX_PACK_SLEEP1 (packed schedule), HMX_RDOQ_LANE (RDOQ: every block
+ * through the one-lane-per-block kernel). */
 int hmx_set_option(hmx_ctx *ctx, const char *name, const char *value);
 /* device memory + timing plumbing so that callers need no HIP headers */
 int hmx_malloc(hmx_ctx *ctx, size_t bytes, void **dptr);
@@ -264,7 +265,8 @@ int hmx_batch_invtransformNxN(hmx_ctx *ctx, const hmx_tu_list *list, const hmx_l
 /* RDOQ over a list of blocks (host list): Int coefficients in `coef` (plane geometry, e.g. the output of the
  * xT drop-in or of a batch transform without quantisation) -> levels in `lev`; d_abs_sum[i] (device, may be
  * NULL) receives block i's absolute sum.  side[i] carries what the reference reads from the CU for block i
- * and which bit-estimate table (est[side[i].est_idx], host array) applies.  One lane per block. */
+ * and which bit-estimate table (est[side[i].est_idx], host array) applies.  8x8 and larger blocks: one wave per block,
+ * coefficient groups walked in parallel (thevc_amd/csrc/hmx_rdoq_core.h); 4x4 blocks: one lane per block. */
 typedef struct hmx_rdoq_side {
   uint16_t est_idx;
   uint8_t root_cbf, cbf_ctx;

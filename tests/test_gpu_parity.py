@@ -1168,6 +1168,13 @@ def test_example_end_to_end(tmp_path):
     assert got.tobytes() == want
 
 
+def test_rdoq_lane_kernel_still_agrees(ctx, hmx_opts):
+    """The block-list RDOQ runs 8x8 and larger blocks one WAVE per block (k_rdoq_wave, hmx_rdoq_core.h) since round 2;
+    round 1's one-lane-per-block kernel (all sizes; HMX_RDOQ_LANE) is kept as a cross-check of the same vectors."""
+    hmx_opts(ctx, HMX_RDOQ_LANE="1")
+    test_rdoq_batch_vs_oracle(ctx)
+
+
 def test_cell_map_growth_keeps_rdoq_workspace(ctx):
     """Regression: growing the motion-compensation cell map once released the RDOQ workspace of the same context.
     RDOQ, then a mapped MC call on a picture larger than any before it (the map is re-allocated), then RDOQ again."""

@@ -1527,7 +1527,9 @@ struct hmx_ctx {
   int *rdoq_wi = nullptr;
   RdoqBlock *rdoq_blocks = nullptr;
   EstBitsDev *rdoq_est = nullptr;
-  int rdoq_T = 0, rdoq_est_cap = 0;
+  int rdoq_T = 0, rdoq_est_cap = 0, rdoq_blocks_cap = 0;
+  char *rdoq_ws = nullptr; // k_rdoq_wave: per-block workspace of a launch chunk
+  size_t rdoq_ws_bytes = 0;
   int *d_mcmap = nullptr; // cell -> PU maps of the last motion-compensation call
   size_t mcmap_cap = 0;
   char *arena_h = nullptr, *arena_d = nullptr;
@@ -1564,6 +1566,7 @@ struct hmx_ctx {
     int pack_group = 0;    // HMX_PACK_GROUP: pictures per group, 1..64 (0: by batch size, see pack_group_size)
     int pack_waves = 0;    // HMX_PACK_WAVES: persistent waves (0: by batch size)
     int pack_sleep0 = -1, pack_sleep1 = -1; // HMX_PACK_SLEEP0 / 1: poll back-off, units of 64 clocks (-1: default)
+    bool rdoq_lane_only = false; // HMX_RDOQ_LANE: every block through the one-lane-per-block kernel (round 1's, A/B and cross-check)
   } knob;
 };
 
@@ -1652,7 +1655,8 @@ static PicDev make_picdev(const hmx_ctx *c, const hmx_pic_param *pp) {
 // Tuning knobs: read from the environment ONCE, in hmx_create; hmx_set_option changes one afterwards (A/B runs, and the
 // parity tests that hold the schedules against each other).  value == NULL restores the default.
 static const char *const kKnobNames[] = {"HMX_INTRA_SCHEDULE", "HMX_INTRA_ACROSS", "HMX_INTRA_STREAMS", "HMX_PIPELINE_CONV", "HMX_GRAPH",
-                                         "HMX_PACK_SLOTS4",    "HMX_PACK_GROUP",      "HMX_PACK_WAVES",    "HMX_PACK_SLEEP0",   "HMX_PACK_SLEEP1"};
+                                         "HMX_PACK_SLOTS4",    "HMX_PACK_GROUP",      "HMX_PACK_WAVES",    "HMX_PACK_SLEEP0",   "HMX_PACK_SLEEP1",
+                                         "HMX_RDOQ_LANE"};
 static bool apply_knob(hmx_ctx *c, const char *name, const char *v) {
   auto &k = c->knob;
   const std::string n(name);
@@ -1666,6 +1670,7 @@ static bool apply_knob(hmx_ctx *c, const char *name, const char *v) {
   else if (n == "HMX_PACK_WAVES") k.pack_waves = v ? std::max(1, atoi(v)) : 0;
   else if (n == "HMX_PACK_SLEEP0") k.pack_sleep0 = v ? std::max(0, atoi(v)) : -1;
   else if (n == "HMX_PACK_SLEEP1") k.pack_sleep1 = v ? std::max(0, atoi(v)) : -1;
+  else if (n == "HMX_RDOQ_LANE") k.rdoq_lane_only = v && v[0] != '0';
   else return false;
   return true;
 }
@@ -1726,6 +1731,7 @@ extern "C" void hmx_destroy(hmx_ctx *c) {
   hipFree(c->rdoq_wi);
   hipFree(c->rdoq_blocks);
   hipFree(c->rdoq_est);
+  hipFree(c->rdoq_ws);
   hipFree(c->pk.d_pics);
   hipFree(c->pk.d_rows);
   hipFree(c->pk.d_descs);
@@ -3252,24 +3258,51 @@ static int rdoq_launch(hmx_ctx *c, RdoqArgs A, const std::vector<RdoqBlock> &blo
   if (!c->rdoq_wd) {
     const size_t T = kRdoqChunk;
     if (hipMalloc((void **)&c->rdoq_wd, sizeof(double) * (3 * 1024 + 64) * T) != hipSuccess ||
-        hipMalloc((void **)&c->rdoq_wi, sizeof(int) * 4 * 1024 * T) != hipSuccess ||
-        hipMalloc((void **)&c->rdoq_blocks, sizeof(RdoqBlock) * T) != hipSuccess)
+        hipMalloc((void **)&c->rdoq_wi, sizeof(int) * 4 * 1024 * T) != hipSuccess)
       return fail(c, HMX_ERR_NOMEM, "hipMalloc RDOQ workspace");
     c->rdoq_T = (int)T;
   }
+  if ((int)blocks.size() > c->rdoq_blocks_cap) { // the whole list goes up once; the launches below follow without a synchronisation
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(c->rdoq_blocks);
+    c->rdoq_blocks = nullptr;
+    c->rdoq_blocks_cap = 0;
+    const size_t cap = blocks.size() + blocks.size() / 8 + 1024;
+    if (hipMalloc((void **)&c->rdoq_blocks, sizeof(RdoqBlock) * cap) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc RDOQ block list");
+    c->rdoq_blocks_cap = (int)cap;
+  }
   HIPCHK(c, hipMemcpyAsync(c->rdoq_est, est, sizeof(EstBitsDev) * n_est, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->rdoq_blocks, blocks.data(), sizeof(RdoqBlock) * blocks.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream)); // pageable sources
   A.est = c->rdoq_est;
   A.wd = c->rdoq_wd;
   A.wi = c->rdoq_wi;
   A.T = c->rdoq_T;
-  A.blocks = c->rdoq_blocks;
-  for (size_t o = 0; o < blocks.size(); o += kRdoqChunk) {
-    const int n = (int)std::min(blocks.size() - o, (size_t)kRdoqChunk);
-    HIPCHK(c, hipMemcpyAsync(c->rdoq_blocks, blocks.data() + o, sizeof(RdoqBlock) * n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream)); // pageable source
-    A.n = n;
-    hipLaunchKernelGGL(k_rdoq, dim3((n + 63) / 64), dim3(64), 0, c->stream, A);
+  // blocks arrive sorted by size, largest first: 8x8 and larger go one WAVE per block (k_rdoq_wave, the lane decomposition
+  // of hmx_rdoq_core.h), 4x4 blocks -- a single coefficient group, nothing to decompose -- one LANE per block (k_rdoq)
+  size_t n_wave = 0;
+  while (n_wave < blocks.size() && blocks[n_wave].log2n > 2) n_wave++;
+  const bool lane_only = c->knob.rdoq_lane_only;
+  if (n_wave && !lane_only && !c->rdoq_ws) {
+    c->rdoq_ws_bytes = (size_t)2048 * ((rdoq_wave_ws_bytes(5) + 255) & ~(size_t)255);
+    if (hipMalloc((void **)&c->rdoq_ws, c->rdoq_ws_bytes) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc RDOQ wave workspace");
+  }
+  for (size_t o = 0; o < blocks.size();) { // chunks share the workspaces: launches of one stream run one after the other
+    const bool wave = o < n_wave && !lane_only;
+    size_t n = std::min(blocks.size() - o, (size_t)kRdoqChunk);
+    if (wave) {
+      A.ws = c->rdoq_ws;
+      A.ws_stride = (rdoq_wave_ws_bytes(blocks[o].log2n) + 255) & ~(size_t)255; // the largest block of the chunk comes first
+      n = std::min({blocks.size() - o, n_wave - o, c->rdoq_ws_bytes / A.ws_stride});
+    } else if (!lane_only && o < n_wave) {
+      n = std::min(n, n_wave - o);
+    }
+    A.blocks = c->rdoq_blocks + o;
+    A.n = (int)n;
+    if (wave) hipLaunchKernelGGL(k_rdoq_wave, dim3((unsigned)n), dim3(64), 0, c->stream, A);
+    else hipLaunchKernelGGL(k_rdoq, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, A);
     HIPCHK(c, hipGetLastError());
+    o += n;
   }
   return HMX_OK;
 }

@@ -18,21 +18,11 @@
 // formed on the host.
 #pragma once
 #include "hmx_device.h"
+#include "hmx_rdoq_core.h"
 
 #pragma clang fp contract(off)
 
 namespace hmx {
-
-struct EstBitsDev { // estBitsSbacStruct (TComTrQuant.h:59-72), 1/32768 bit
-  int sig_cg[2][2];
-  int sig[42][2];
-  int last_x[32], last_y[32];
-  int greater1[24][2];
-  int greater2[6][2];
-  int cbf[15][2];
-  int root_cbf[4][2];
-  int scan_zigzag[2], scan_nonzigzag[2];
-};
 
 struct RdoqBlock { // one block of a launch
   const int *src;  // coefficients (Int), row stride src_stride
@@ -47,113 +37,19 @@ struct RdoqArgs {
   const RdoqBlock *blocks;
   int n;
   const EstBitsDev *est; // tables, RdoqBlock::est_idx selects
-  // workspace, n_threads = T lanes: doubles [3 * 1024 + 64] * T, ints [4 * 1024] * T
+  // workspace of k_rdoq (one lane per block), n_threads = T lanes: doubles [3 * 1024 + 64] * T, ints [4 * 1024] * T
   double *wd;
   int *wi;
   int T;
+  // workspace of k_rdoq_wave (one wave per block): ws_stride bytes per block of the launch
+  char *ws;
+  size_t ws_stride;
   int bit_depth, sign_hide;
   int per[2], rem[2], q[2];
   double lambda[2];
   double err_scale[2][4]; // [plane type][log2n - 2]: 2^15 * 2^(-2 tshift) / q / q / 2^(2 inc)
   long long rd_factor[2]; // (Int64)(invq * invq * 2^(2 per) / lambda / 16 / 2^(2 inc) + 0.5)
 };
-
-__device__ __forceinline__ int rdoq_base_level(unsigned c1i, unsigned c2i) { return c1i < 8 ? (2 + (c2i < 1)) : 1; }
-
-// rate of |level| beyond the significance flag as a COST (xGetICRateCost)
-__device__ __forceinline__ double rdoq_level_cost(const EstBitsDev &e, double lambda, unsigned lvl, unsigned ctx1, unsigned ctx2,
-                                                  unsigned rice, unsigned c1i, unsigned c2i) {
-  double rate = 32768;
-  const unsigned base = (unsigned)rdoq_base_level(c1i, c2i);
-  if (lvl >= base) {
-    unsigned sym = lvl - base, len;
-    if (sym < (3u << rice)) {
-      len = sym >> rice;
-      rate += (double)((len + 1 + rice) << 15);
-    } else {
-      len = rice;
-      sym -= 3u << rice;
-      while (sym >= (1u << len)) sym -= 1u << (len++);
-      rate += (double)((3 + len + 1 - rice + len) << 15);
-    }
-    if (c1i < 8) {
-      rate += e.greater1[ctx1][1];
-      if (c2i < 1) rate += e.greater2[ctx2][1];
-    }
-  } else if (lvl == 1) {
-    rate += e.greater1[ctx1][0];
-  } else {
-    rate += e.greater1[ctx1][1];
-    rate += e.greater2[ctx2][0];
-  }
-  return lambda * rate;
-}
-
-// integer rate of |level| (xGetICRate): only for the sign-hiding deltas
-__device__ __forceinline__ int rdoq_level_rate(const EstBitsDev &e, unsigned lvl, unsigned ctx1, unsigned ctx2, unsigned rice,
-                                               unsigned c1i, unsigned c2i) {
-  int rate = 0;
-  const unsigned base = (unsigned)rdoq_base_level(c1i, c2i);
-  if (lvl >= base) {
-    unsigned sym = lvl - base;
-    const unsigned max_vlc = rice == 0 ? 7u : rice == 1 ? 14u : rice == 2 ? 26u : rice == 3 ? 46u : 78u;
-    const unsigned pre_max = 8u - rice;
-    if (sym > max_vlc) {
-      const unsigned a = sym - max_vlc;
-      int egs = 1;
-      for (unsigned m = 2; a >= m; m <<= 1) egs += 2;
-      rate += egs << 15;
-      sym = min(sym, max_vlc + 1);
-    }
-    const unsigned pre = ((sym >> rice) & 0xffffu) + 1;
-    const unsigned bins = min(pre, pre_max) + rice;
-    rate += (int)((bins & 0xffffu) << 15);
-    if (c1i < 8) {
-      rate += e.greater1[ctx1][1];
-      if (c2i < 1) rate += e.greater2[ctx2][1];
-    }
-  } else if (lvl == 0) {
-    return 0;
-  } else if (lvl == 1) {
-    rate += e.greater1[ctx1][0];
-  } else {
-    rate += e.greater1[ctx1][1];
-    rate += e.greater2[ctx2][0];
-  }
-  return rate;
-}
-
-// significance context (getSigCtxInc, REMOVAL_8x2_2x8_CG branch); scan_idx 0 = diagonal
-__device__ __forceinline__ int rdoq_sig_ctx(int pattern, int scan_idx, int px, int py, int log2n, bool is_luma) {
-  if (px + py == 0) return 0;
-  if (log2n == 2) {
-    const unsigned long long map4 = 0x8877886654325410ull; // {0,1,4,5, 2,3,4,5, 6,6,8,8, 7,7,8,8}, one nibble each
-    return (int)((map4 >> (4 * (4 * py + px))) & 15);
-  }
-  const int offset = log2n == 3 ? (scan_idx == 0 ? 9 : 15) : (is_luma ? 21 : 12);
-  const int sx = px & 3, sy = py & 3;
-  int cnt;
-  if (pattern == 0)
-    cnt = sx + sy <= 2 ? (sx + sy == 0 ? 2 : 1) : 0;
-  else if (pattern == 1)
-    cnt = sy <= 1 ? (sy == 0 ? 2 : 1) : 0;
-  else if (pattern == 2)
-    cnt = sx <= 1 ? (sx == 0 ? 2 : 1) : 0;
-  else
-    cnt = 2;
-  return ((is_luma && ((px >> 2) + (py >> 2)) > 0) ? 3 : 0) + offset + cnt;
-}
-
-__device__ __forceinline__ unsigned rdoq_group_idx(unsigned p) { // g_uiGroupIdx
-  return p < 4 ? p : p < 6 ? 4 : p < 8 ? 5 : p < 12 ? 6 : p < 16 ? 7 : p < 24 ? 8 : 9;
-}
-__device__ __forceinline__ double rdoq_last_cost(const EstBitsDev &e, double lambda, unsigned px, unsigned py) {
-  const unsigned cx = rdoq_group_idx(px), cy = rdoq_group_idx(py);
-  double cost = e.last_x[cx] + e.last_y[cy];
-  if (cx > 3) cost += 32768.0 * ((cx - 2) >> 1);
-  if (cy > 3) cost += 32768.0 * ((cy - 2) >> 1);
-  return lambda * cost;
-}
 
 __device__ __forceinline__ unsigned rdoq_scan_pos(int log2n, int scan_idx, int sp) {
   return log2n == 2 ? kScan4.t[scan_idx][sp] : log2n == 3 ? kScan8.t[scan_idx][sp] : log2n == 4 ? kScan16.t[scan_idx][sp] : kScan32.t[scan_idx][sp];
@@ -455,6 +351,141 @@ __global__ __launch_bounds__(64) void k_rdoq(RdoqArgs A) {
 #undef WS
 #undef SRC
 #undef DST
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ONE WAVE PER BLOCK (8x8, 16x16, 32x32): the lane decomposition of hmx_rdoq_core.h.
+//   step 0  a lane per scan position: |coef| * q, cost of zero; the last position with a non-zero candidate (wave max)
+//   step 1  a lane per (coefficient group, carry, neighbour pattern): the group walked under that assumption
+//   step 2  lane 0: the groups in the reference's order -- variant picked, its 16 cost terms added one by one, group decision
+//   step 3  a lane per group: the chosen variant walked again for levels, per-coefficient costs and rate deltas
+//   step 4  lane 0: last position; a lane per position: final levels; a lane per group: rate-aware sign hiding
+// The steps hand their results on through the block's workspace in global memory (the lanes of one wave: a drained store is
+// visible to the wave's own later loads).  Workspace per block: rdoq_wave_ws_bytes(log2n).
+// ---------------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t rdoq_wave_ws_bytes(int lg) {
+  const size_t nn = (size_t)1 << (2 * lg), n_cg = nn >> 4;
+  return nn * (6 * sizeof(int) + 3 * sizeof(double)) + n_cg * 8 * sizeof(RdoqSpec) + 64 * sizeof(double) + 64 + sizeof(RdoqRun) + 64;
+}
+__device__ __forceinline__ void rdoq_wave_fence() { // this wave's global stores before its later loads by other lanes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__global__ __launch_bounds__(64) void k_rdoq_wave(RdoqArgs A) {
+  const int lane = threadIdx.x;
+  const RdoqBlock K = A.blocks[blockIdx.x];
+  const EstBitsDev &E = A.est[K.est_idx];
+  const int lg = K.log2n, N = 1 << lg, nn = N * N, n_cg = nn >> 4;
+  const int pt = K.plane_type, B = A.bit_depth, scan_idx = K.scan_idx;
+  RdoqConst C;
+  C.lg = lg, C.scan_idx = scan_idx, C.is_luma = K.is_luma;
+  C.q = A.q[pt], C.qbits = 14 + A.per[pt] + (15 - B - lg);
+  C.root_cbf = K.root_cbf, C.cbf_ctx = K.cbf_ctx, C.sign_hide = A.sign_hide;
+  C.lambda = A.lambda[pt], C.err_scale = A.err_scale[pt][lg - 2], C.rd_factor = A.rd_factor[pt];
+  // carve the workspace
+  char *w = A.ws + (size_t)blockIdx.x * A.ws_stride;
+  double *cz = reinterpret_cast<double *>(w), *cc = cz + nn, *cs = cc + nn, *cgs = cs + nn;
+  RdoqSpec *spec = reinterpret_cast<RdoqSpec *>(cgs + 64);
+  RdoqRun *run = reinterpret_cast<RdoqRun *>(spec + (size_t)n_cg * 8);
+  int *ld = reinterpret_cast<int *>(run + 1), *lev = ld + nn, *ru = lev + nn, *rd = ru + nn, *sd = rd + nn, *du = sd + nn;
+  unsigned char *sel = reinterpret_cast<unsigned char *>(du + nn);
+  const int *src = K.src;
+  int *dst = K.dst;
+  const int ss = K.src_stride, ds = K.dst_stride;
+  auto bp_of = [&](int sp) { return rdoq_scan_pos(lg, scan_idx, sp); };
+  auto gpos_of = [&](int cg) {
+    const unsigned p0 = rdoq_scan_pos(lg, scan_idx, cg * 16);
+    return ((p0 & (unsigned)(N - 1)) >> 2) | (((p0 >> lg) >> 2) << 8);
+  };
+  // step 0
+  int last_pos = -1;
+  for (int sp = lane; sp < nn; sp += 64) {
+    const unsigned bp = bp_of(sp);
+    int l;
+    double z;
+    rdoq_prep(src[(bp >> lg) * ss + (bp & (unsigned)(N - 1))], C, l, z);
+    ld[sp] = l, cz[sp] = z;
+    if (rdoq_max_level(l, C.qbits) > 0) last_pos = sp;
+  }
+  for (int off = 32; off > 0; off >>= 1) last_pos = max(last_pos, __shfl_xor(last_pos, off, 64));
+  if (last_pos < 0) { // nothing survives quantisation
+    for (int sp = lane; sp < nn; sp += 64) dst[(sp >> lg) * ds + (sp & (N - 1))] = 0;
+    if (lane == 0 && K.abs_sum) *K.abs_sum = 0;
+    return;
+  }
+  const int last_cg = last_pos >> 4;
+  rdoq_wave_fence();
+  // step 1
+  for (int task = lane; task < (last_cg + 1) * 8; task += 64) {
+    const int cg = task >> 3, v = task & 7;
+    RdoqSpecSink sink{&spec[task]};
+    spec[task].S = rdoq_walk_cg(C, E, cg, bp_of, ld + cg * 16, cz + cg * 16, v & 3, v >> 2, last_pos, sink);
+  }
+  rdoq_wave_fence();
+  // step 2
+  if (lane == 0) {
+    RdoqRun R;
+    rdoq_resolve(C, E, n_cg, last_cg, gpos_of, cz, spec, sel, cgs, R);
+    *run = R;
+  }
+  rdoq_wave_fence();
+  // step 3
+  if (lane < n_cg) {
+    const int cg = lane;
+    if (cg > last_cg) {
+      for (int k = 0; k < 16; k++) {
+        const int sp = cg * 16 + k;
+        lev[sp] = 0, cc[sp] = 0, cs[sp] = 0, ru[sp] = 0, rd[sp] = 0, sd[sp] = 0, du[sp] = 0;
+      }
+    } else {
+      RdoqFullSink sink{lev, cc, cs, ru, rd, sd, du, cg * 16};
+      const int v = sel[cg];
+      rdoq_walk_cg(C, E, cg, bp_of, ld + cg * 16, cz + cg * 16, v & 3, v >> 2, last_pos, sink);
+      if ((run->zeroed >> cg) & 1) rdoq_apply_zeroed_cg(cg, cz, lev, cc, cs);
+    }
+  }
+  rdoq_wave_fence();
+  // step 4a
+  int blp1 = 0;
+  if (lane == 0) blp1 = rdoq_phase_b(C, E, last_pos, last_cg, gpos_of, bp_of, *run, cz, lev, cc, cs, cgs);
+  blp1 = __shfl(blp1, 0, 64);
+  // final levels
+  uint32_t sum = 0;
+  unsigned neg = 0; // for lanes that are a group: the signs of the group's unquantised coefficients
+  for (int sp = lane; sp < nn; sp += 64) {
+    const unsigned bp = bp_of(sp);
+    const int l = sp < blp1 ? lev[sp] : 0;
+    sum += (uint32_t)l;
+    lev[sp] = src[(bp >> lg) * ss + (bp & (unsigned)(N - 1))] < 0 ? -l : l;
+  }
+  for (int off = 32; off > 0; off >>= 1) sum += (uint32_t)__shfl_xor((int)sum, off, 64);
+  if (lane == 0 && K.abs_sum) *K.abs_sum = sum;
+  rdoq_wave_fence();
+  // step 4c
+  if (A.sign_hide && sum >= 2) {
+    bool any = false;
+    int l16[16];
+    if (lane < n_cg) {
+      for (int k = 0; k < 16; k++) {
+        l16[k] = lev[lane * 16 + k];
+        any |= l16[k] != 0;
+        const unsigned bp = bp_of(lane * 16 + k);
+        neg |= (src[(bp >> lg) * ss + (bp & (unsigned)(N - 1))] < 0 ? 1u : 0u) << k;
+      }
+    }
+    const unsigned long long mask = __ballot(any);
+    const int top = mask ? 63 - __clzll((long long)mask) : -1;
+    if (lane < n_cg && any) {
+      rdoq_phase_c_cg(C, lane == top, l16, neg, ru + lane * 16, rd + lane * 16, sd + lane * 16, du + lane * 16);
+      for (int k = 0; k < 16; k++) lev[lane * 16 + k] = l16[k];
+    }
+    rdoq_wave_fence();
+  }
+  for (int sp = lane; sp < nn; sp += 64) {
+    const unsigned bp = bp_of(sp);
+    dst[(bp >> lg) * ds + (bp & (unsigned)(N - 1))] = lev[sp];
+  }
 }
 
 } // namespace hmx
