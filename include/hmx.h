@@ -219,6 +219,7 @@ typedef struct {
 } hmx_tu;
 #define HMX_TU_TRANSFORM_SKIP 1u
 #define HMX_TU_INTER 2u /* non-intra CU: REG_DCT, diagonal scan, no DST */
+#define HMX_TU_CBF_CTX(ctx) (((unsigned)(ctx) & 15u) << 4) /* bits 4..7: context of the coded-block flag (hmx_set_rdoq) */
 
 typedef struct {
   int pic_w, pic_h;      /* luma size of the picture */
@@ -340,6 +341,20 @@ int hmx_frame_intra_encode_onto(hmx_ctx *ctx, const hmx_intra_plan *plan, int n_
 int hmx_frame_intra_decode_multi(hmx_ctx *ctx, const hmx_intra_plan *const *plans, int n_pics, const hmx_pic *rec,
                                  const hmx_levels *lev);
 
+/* RDOQ as the quantiser of the whole-picture encode calls (the encoder's default: TEncSearch::xIntraCodingLumaBlk /
+ * ChromaBlk call transformNxN, which runs xRateDistOptQuant when m_useRDOQ, TComTrQuant.cpp:1395-1404).  What the
+ * encoder takes from its live state is an input, per picture: the bit estimates m_pcEstBitsSbac as estBit leaves them
+ * for [luma, chroma] x [4x4, 8x8, 16x16, 32x32] (TEncSbac.cpp:1507-1667), and m_dLambda for luma and chroma blocks
+ * (setLambda per component, TEncSlice.cpp:380-395).  The context of a block's coded-block flag travels in
+ * hmx_tu::flags, bits 4..7 (= getCtxQtCbf: the transform depth for luma, + NUM_QT_CBF_CTX for chroma).
+ * n_pics = the pictures of the following calls, or 1 = one set for every picture.  pics = NULL turns RDOQ off again.
+ * Transform-skip blocks keep the flat quantiser (TComTrQuant.cpp:1121-1122 with TransformSkipFast, which every shipped
+ * cfg that enables transform skip sets); packed schedule only; 154 KB of device workspace per resident wave. */
+typedef struct hmx_rdoq_pic {
+  hmx_est_bits est[8]; /* [luma, chroma][log2(size) - 2] */
+  double lambda_luma, lambda_chroma;
+} hmx_rdoq_pic;
+int hmx_set_rdoq(hmx_ctx *ctx, const hmx_rdoq_pic *pics, int n_pics);
 /* Distortion next to the chain: the encoder calls TComRdCost::getDistPart(rec, org, DF_SSE) right after every
  * reconstruction (TLibEncoder/TEncSearch.cpp:1163, :1381).  After hmx_set_sse_output(ctx, sse, n) the whole-picture
  * ENCODE calls (any of the hmx_frame_intra_encode* entry points, packed schedule) with at most n pictures also write,

@@ -1223,6 +1223,47 @@ void hmo_intra_frame_encode(const hmo_frame_cfg *cfg, const hmo_tu *tus, int n_t
   }
 }
 
+/* The same with the quantiser every shipped cfg selects (RDOQ : 1): xRateDistOptQuant for every block that is not a
+ * transform-skip block (TSFast: those keep the flat quantiser, COM/TComTrQuant.cpp:1121-1128), as xIntraCodingLumaBlk /
+ * ChromaBlk (ENC/TEncSearch.cpp:1006-1390) reach it.  What the encoder takes from its live state is an input here: est[8] =
+ * the bit estimates TEncSbac::estBit gives for [luma, chroma][4x4 .. 32x32], lambda[2] = m_dLambda for luma / chroma blocks
+ * (selectLambda), the block's cbf context (getCtxQtCbf + texture offset) in bits 4..7 of hmo_tu::flags. */
+void hmo_intra_frame_encode_rdoq(const hmo_frame_cfg *cfg, const hmo_tu *tus, int n_tu,
+                                 const int16_t *const org[3], const int org_stride[3],
+                                 int16_t *const rec[3], const int rec_stride[3],
+                                 int32_t *const level[3], const hmo_est_bits *est, const double *lambda) {
+  int16_t pred[32 * 32], resi[32 * 32];
+  int32_t lvl[32 * 32], coef[32 * 32];
+  for (int i = 0; i < n_tu; i++) {
+    const hmo_tu *t = &tus[i];
+    int p = t->plane, N = 1 << t->log2n, ts = t->flags & 1;
+    int pw = p ? cfg->pic_w / 2 : cfg->pic_w;
+    hmo_qp qp;
+    hmo_quant_cfg qc;
+    tu_predict(cfg, t, rec[p], rec_stride[p], pred);
+    tu_quant_cfg(cfg, t, &qp, &qc);
+    hmo_subtract(org[p] + t->y * org_stride[p] + t->x, org_stride[p], pred, N, resi, N, N, N);
+    unsigned tmode = p ? HMO_REG_DCT : t->mode;
+    uint32_t abs_sum = 0;
+    if (ts) {
+      hmo_transformNxN(resi, N, lvl, N, cfg->B, tmode, ts, 0, &qc, &abs_sum);
+    } else {
+      hmo_rdoq_cfg rc;
+      rc.per = qp.per, rc.rem = qp.rem, rc.is_luma = p == 0, rc.is_intra = 1;
+      rc.scan_idx = qc.scan_idx, rc.root_cbf = 0, rc.cbf_ctx = (t->flags >> 4) & 15, rc.sign_hide = cfg->sign_hide;
+      rc.lambda = lambda[p ? 1 : 0];
+      hmo_xT(tmode, resi, N, coef, N, cfg->B);
+      hmo_xRateDistOptQuant(coef, lvl, N, cfg->B, &rc, &est[(p ? 4 : 0) + t->log2n - 2], &abs_sum);
+    }
+    if (abs_sum)
+      hmo_invtransformNxN(0, tmode, resi, N, lvl, N, cfg->B, qp.per, qp.rem, ts);
+    else
+      memset(resi, 0, sizeof(resi));
+    hmo_addClip(pred, N, resi, N, rec[p] + t->y * rec_stride[p] + t->x, rec_stride[p], N, N, cfg->B);
+    for (int r = 0; r < N; r++) memcpy(level[p] + (t->y + r) * pw + t->x, lvl + r * N, sizeof(int32_t) * N);
+  }
+}
+
 void hmo_intra_frame_decode(const hmo_frame_cfg *cfg, const hmo_tu *tus, int n_tu,
                             int16_t *const rec[3], const int rec_stride[3],
                             const int32_t *const level[3]) {

@@ -185,6 +185,11 @@ void hmo_intra_frame_encode(const hmo_frame_cfg *cfg, const hmo_tu *tus, int n_t
                             const int16_t *const org[3], const int org_stride[3],
                             int16_t *const rec[3], const int rec_stride[3], int32_t *const level[3]);
 /* Decoder-side (DEC/TDecCu.cpp:469-687): levels + modes -> recon. */
+void hmo_intra_frame_encode_rdoq(const hmo_frame_cfg *cfg, const hmo_tu *tus, int n_tu,
+                                 const int16_t *const org[3], const int org_stride[3],
+                                 int16_t *const rec[3], const int rec_stride[3],
+                                 int32_t *const level[3], const hmo_est_bits *est /* [luma, chroma][4 sizes] */,
+                                 const double *lambda /* [luma, chroma] */);
 void hmo_intra_frame_decode(const hmo_frame_cfg *cfg, const hmo_tu *tus, int n_tu,
                             int16_t *const rec[3], const int rec_stride[3],
                             const int32_t *const level[3]);

@@ -130,6 +130,8 @@ def oracle():
         P3 = C.c_void_p * 3
         I3 = ci * 3
         L.hmo_intra_frame_encode.argtypes = [C.POINTER(FrameCfg), C.c_void_p, ci, P3, I3, P3, I3, P3]
+        L.hmo_intra_frame_encode_rdoq.argtypes = [C.POINTER(FrameCfg), C.c_void_p, ci, P3, I3, P3, I3, P3, C.POINTER(EstBits),
+                                                  C.POINTER(C.c_double)]
         L.hmo_intra_frame_decode.argtypes = [C.POINTER(FrameCfg), C.c_void_p, ci, P3, I3, P3]
         L.hmo_mc_frame.argtypes = [C.c_void_p, ci, ci, C.c_void_p, I3, P3, I3]
         _oracle = L
@@ -242,6 +244,22 @@ def o_intra_frame_encode(tus, w, h, B, qp, org, sign_hide=1):
     t = np.ascontiguousarray(tus, TU_DTYPE)
     oracle().hmo_intra_frame_encode(C.byref(cfg), t.ctypes.data, len(t), P3(*[p.ctypes.data for p in org]), st,
                                     P3(*[p.ctypes.data for p in rec]), st, P3(*[p.ctypes.data for p in lev]))
+    return rec, lev
+
+
+def o_intra_frame_encode_rdoq(tus, w, h, B, qp, org, ests, lambdas, sign_hide=1):
+    """oracle: the same chain with xRateDistOptQuant as the quantiser; ests = 8 EstBits [luma, chroma][4 sizes], lambdas = (luma,
+    chroma); the blocks' cbf contexts ride in bits 4..7 of tus['flags']"""
+    cfg = frame_cfg(w, h, B, qp, sign_hide)
+    rec = [np.zeros_like(p) for p in org]
+    lev = [np.zeros(p.shape, np.int32) for p in org]
+    P3, I3 = C.c_void_p * 3, C.c_int * 3
+    st = I3(w, w // 2, w // 2)
+    t = np.ascontiguousarray(tus, TU_DTYPE)
+    est_arr = (EstBits * 8)(*ests)
+    lam = (C.c_double * 2)(*lambdas)
+    oracle().hmo_intra_frame_encode_rdoq(C.byref(cfg), t.ctypes.data, len(t), P3(*[p.ctypes.data for p in org]), st,
+                                         P3(*[p.ctypes.data for p in rec]), st, P3(*[p.ctypes.data for p in lev]), est_arr, lam)
     return rec, lev
 
 

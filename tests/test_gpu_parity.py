@@ -1327,3 +1327,55 @@ def test_frame_intra_decode_onto(ctx, n_pics, schedule, hmx_opts):
     L.hmx_intra_plan_destroy(ctx.h, plan)
     for d in d_rec + d_lev + d_org + d_rec2 + d_lev2:
         d.free()
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_frame_intra_rdoq_in_chain(ctx, shared):
+    """hmx_set_rdoq: xRateDistOptQuant as the quantiser INSIDE the whole-picture chain (what TEncSearch::xIntraCodingLumaBlk /
+    ChromaBlk run with RDOQ on, TComTrQuant.cpp:1121-1122): the levels of a block decide its reconstruction, which later
+    blocks predict from.  All four block sizes, transform-skip blocks (flat quantiser), own plans, per-picture tables and
+    multipliers (or one set for all), cbf contexts in the flags; levels and reconstruction vs the oracle's chain."""
+    B, L = ctx.bit_depth, capi.lib()
+    w, h, n, qp = 200, 136, 4, 27
+    rng = np.random.default_rng(77)
+    pp = capi.PicParam(w, h, qp, 0, capi.I_SLICE, 1)
+    tus = []
+    for i in range(n):
+        t = workload.make_tus(2300 + i, w, h, "mix")
+        depth = rng.integers(0, 3, len(t))
+        t["flags"] = (t["flags"] & 1) | (np.where(t["plane"] == 0, np.minimum(depth, 1), 5 + depth).astype(np.uint8) << 4)
+        tus.append(t)
+    assert any((t["flags"] & 1).any() for t in tus) and all(len({int(x) for x in t["log2n"]}) == 4 for t in tus)
+    plans = [ctx.intra_plan(t, pp) for t in tus]
+    orgs = [workload.make_planes(2400 + i, w, h, B, "texture" if i % 2 else "noise") for i in range(n)]
+    n_sets = 1 if shared else n
+    ests = [[ol.make_est_bits(rng) for _ in range(8)] for _ in range(n_sets)]
+    lams = [(float(rng.uniform(20, 120)), float(rng.uniform(15, 90))) for _ in range(n_sets)]
+    d_org = [capi.DevPicture(ctx, w, h).upload(o) for o in orgs]
+    d_rec = [capi.DevPicture(ctx, w, h).zero() for _ in range(n)]
+    d_lev = [capi.DevPicture(ctx, w, h, dtype=np.int32).zero() for _ in range(n)]
+    A = lambda lst, T: (T * n)(*[x.as_pic() for x in lst])
+    parr = (C.c_void_p * n)(*[p.value for p in plans])
+    ctx.set_rdoq([(ests[i], lams[i][0], lams[i][1]) for i in range(n_sets)])
+    ctx._chk(L.hmx_frame_intra_encode_multi(ctx.h, parr, n, A(d_org, capi.Pic), A(d_rec, capi.Pic), A(d_lev, capi.Levels)))
+    ctx.sync()
+    flat_differs = 0
+    for i in range(n):
+        k = 0 if shared else i
+        rr, ll = ol.o_intra_frame_encode_rdoq(tus[i], w, h, B, qp, orgs[i], ests[k], lams[k])
+        _, lf = ol.o_intra_frame_encode(tus[i], w, h, B, qp, orgs[i])
+        rec, lev = d_rec[i].download(), d_lev[i].download()
+        for p in range(3):
+            assert np.array_equal(lev[p], ll[p]), ("levels", i, p, np.argwhere(lev[p] != ll[p])[:4])
+            assert np.array_equal(rec[p], rr[p]), ("rec", i, p)
+            flat_differs += int((ll[p] != lf[p]).sum())
+    assert flat_differs > 100  # RDOQ did take other decisions than the flat quantiser
+    ctx.set_rdoq(None)  # off again: the flat quantiser's result
+    ctx._chk(L.hmx_frame_intra_encode_multi(ctx.h, parr, n, A(d_org, capi.Pic), A(d_rec, capi.Pic), A(d_lev, capi.Levels)))
+    ctx.sync()
+    _, lf = ol.o_intra_frame_encode(tus[0], w, h, B, qp, orgs[0])
+    assert all(np.array_equal(d_lev[0].download()[p], lf[p]) for p in range(3))
+    for pl in plans:
+        L.hmx_intra_plan_destroy(ctx.h, pl)
+    for d in d_org + d_rec + d_lev:
+        d.free()

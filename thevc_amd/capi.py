@@ -67,6 +67,10 @@ class EstBits(C.Structure):  # hmx_est_bits == estBitsSbacStruct (TComTrQuant.h:
                 ("blockRootCbpBits", (C.c_int32 * 2) * 4), ("scanZigzag", C.c_int32 * 2), ("scanNonZigzag", C.c_int32 * 2)]
 
 
+class RdoqPic(C.Structure):  # hmx_rdoq_pic
+    _fields_ = [("est", EstBits * 8), ("lambda_luma", C.c_double), ("lambda_chroma", C.c_double)]
+
+
 class RdoqSide(C.Structure):  # hmx_rdoq_side
     _fields_ = [("est_idx", C.c_uint16), ("root_cbf", C.c_uint8), ("cbf_ctx", C.c_uint8)]
 
@@ -186,6 +190,7 @@ def lib():
         L.hmx_yuv_unpack.argtypes = [vp, vp, ci, C.POINTER(Pic), ci, ci, ci, ci]
         L.hmx_yuv_pack.argtypes = [vp, C.POINTER(Pic), ci, ci, ci, ci, ci, vp]
         L.hmx_set_sse_output.argtypes = [vp, vp, ci]
+        L.hmx_set_rdoq.argtypes = [vp, C.POINTER(RdoqPic), ci]
         L.hmx_tpool_create.argtypes = [vp, ci, ci, ci, C.POINTER(vp)]
         L.hmx_tpool_destroy.argtypes = [vp, vp]
         L.hmx_tpool_destroy.restype = None
@@ -264,6 +269,19 @@ class Context:
     def set_option(self, name, value):
         """A tuning knob of include/hmx.h (hmx_set_option); value None restores the default."""
         self._chk(lib().hmx_set_option(self.h, name.encode(), None if value is None else str(value).encode()))
+
+    def set_rdoq(self, pics):
+        """hmx_set_rdoq: pics = [(eight EstBits [luma, chroma][4 sizes], lambda_luma, lambda_chroma), ...] for the pictures
+        of the next whole-picture encode calls (one entry = the same for all); None turns RDOQ off."""
+        if not pics:
+            self._chk(lib().hmx_set_rdoq(self.h, None, 0))
+            return
+        arr = (RdoqPic * len(pics))()
+        for i, (ests, ll, lc) in enumerate(pics):
+            for k in range(8):
+                C.memmove(C.byref(arr[i].est[k]), C.byref(ests[k]), C.sizeof(EstBits))
+            arr[i].lambda_luma, arr[i].lambda_chroma = ll, lc
+        self._chk(lib().hmx_set_rdoq(self.h, arr, len(pics)))
 
     def alloc(self, nbytes):
         return DevBuf(self, nbytes)

@@ -297,6 +297,7 @@ struct OwnPicture {
   static constexpr bool kCoherent = false; // producer and consumer are separated by a kernel boundary
   static constexpr bool kWriteThrough = false;
   static constexpr bool kSse = false; // distortion output: packed schedule only
+  static constexpr bool kRdoq = false; // RDOQ as the chain's quantiser: packed schedule only
   const PicWork &W;
   const FTu *tus;
   __device__ __forceinline__ void wait() const {}
@@ -311,6 +312,7 @@ struct AcrossPictures {
   static constexpr bool kCoherent = false;
   static constexpr bool kWriteThrough = false;
   static constexpr bool kSse = false;
+  static constexpr bool kRdoq = false;
   __device__ __forceinline__ void wait() const {}
   const PicWork *pics;
   const FTu *ft; // the one block this wave works on (wave-uniform address: scalar loads)
@@ -364,7 +366,15 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, cons
     if (ENC) {
 #pragma unroll
       for (int k = 0; k < N; k++) row[k] = wrap16(row[k] - pred[k]);
-      fwd_tq_block<N>(L, gl, active, row, ts, luma, luma, scan_idx, true, P);
+      if constexpr (SRC::kRdoq) { // xRateDistOptQuant in the quantiser's place (transform-skip blocks keep the flat one)
+        static_assert(N >= 8, "4x4 blocks with RDOQ run in the lane-per-block chain");
+        wave_sync(); // the prediction has read the reference line
+        if (gl == 0) L.line[0] = active && !ts, L.line[1] = src.picture(), L.line[2] = luma, L.line[3] = scan_idx, L.line[4] = src.cbf_ctx();
+        fwd_tq_block<N>(L, gl, active, row, ts, luma, luma, scan_idx, ts, P);
+        rdoq_wave_tiles<N, SL>(reinterpret_cast<TuLds<N> *>(smem), src.rdoq_ws(), src.rdoq(), P, lane);
+      } else {
+        fwd_tq_block<N>(L, gl, active, row, ts, luma, luma, scan_idx, true, P);
+      }
       if (active) {
         load_row32<N>(&L.tile[gl][0], row);
 #pragma unroll
@@ -427,9 +437,8 @@ __device__ __forceinline__ int scan4_pos(int scan_idx, int i) { // raster positi
 
 // The transform half of a 4x4 block held by ONE lane (used by the lane-per-block chain and by the inter list kernel).
 // lane4_forward: residual (row-major) -> packed words (level | neg << 16 | deltaU << 17) after sign-bit hiding.
-__device__ __forceinline__ void lane4_forward(const int *resid, bool use_dst, bool ts, bool luma, int scan_idx, const PicDev &P, int *w) {
+__device__ __forceinline__ void lane4_coef(const int *resid, bool use_dst, bool ts, const PicDev &P, int *coef) {
   const int B = P.bit_depth, tshift = 15 - B - 2;
-  int coef[16];
   if (ts) {
 #pragma unroll
     for (int k = 0; k < 16; k++) coef[k] = resid[k] << tshift; // tshift >= 1 for B <= 12
@@ -450,6 +459,11 @@ __device__ __forceinline__ void lane4_forward(const int *resid, bool use_dst, bo
       for (int k = 0; k < 4; k++) coef[4 * k + r] = yk[k];
     }
   }
+}
+__device__ __forceinline__ void lane4_forward(const int *resid, bool use_dst, bool ts, bool luma, int scan_idx, const PicDev &P, int *w) {
+  const int B = P.bit_depth, tshift = 15 - B - 2;
+  int coef[16];
+  lane4_coef(resid, use_dst, ts, P, coef);
   const QuantDev qd = pick_qd(P, luma);
   const int qbits = 14 + qd.per_qbits + tshift;
   int sum = 0;
@@ -617,9 +631,20 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
     if (ENC) {
 #pragma unroll
       for (int k = 0; k < 16; k++) v[k] = wrap16(v[k] - pred[k]);
-      lane4_forward(v, luma, ts, luma, coef_scan_idx(4, luma, true, mode), P, w);
+      bool flat = true;
+      if constexpr (SRC::kRdoq) {
+        if (!ts) { // transform-skip blocks keep the flat quantiser
+          int coef[16];
+          lane4_coef(v, luma, false, P, coef);
+          rdoq_lane_4x4(coef, w, src.picture(), luma, coef_scan_idx(4, luma, true, mode), src.cbf_ctx(), src.rdoq(), P);
+          flat = false;
+        }
+      }
+      if (flat) {
+        lane4_forward(v, luma, ts, luma, coef_scan_idx(4, luma, true, mode), P, w);
 #pragma unroll
-      for (int k = 0; k < 16; k++) w[k] = level_of(w[k]);
+        for (int k = 0; k < 16; k++) w[k] = level_of(w[k]);
+      }
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         i4v o = {w[4 * r], w[4 * r + 1], w[4 * r + 2], w[4 * r + 3]};
@@ -713,8 +738,17 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const 
 #pragma unroll
       for (int s = 0; s < 16; s++) v[s] = wrap16((int)org4[s >> 2][s & 3] - pred[s]);
       fwd32_mfma(v, r, h, P.bit_depth, coef);
-      quant_sbh_block<32, 64, 16, false>(
-          L, lane, true, coef, [&](int k) { return mrow(k, h); }, [&](int) { return r; }, luma, 0, P);
+      if constexpr (SRC::kRdoq) {
+        wave_sync();
+        if (lane == 0) L.line[0] = 1, L.line[1] = src.picture(), L.line[2] = luma, L.line[3] = 0, L.line[4] = src.cbf_ctx();
+#pragma unroll
+        for (int g = 0; g < 16; g++) L.tile[mrow(g, h)][r] = coef[g];
+        wave_sync();
+        rdoq_wave_tiles<32, 1>(&L, src.rdoq_ws(), src.rdoq(), P, lane);
+      } else {
+        quant_sbh_block<32, 64, 16, false>(
+            L, lane, true, coef, [&](int k) { return mrow(k, h); }, [&](int) { return r; }, luma, 0, P);
+      }
 #pragma unroll
       for (int g = 0; g < 16; g++) {
         v[g] = level_of(L.tile[mrow(g, h)][r]);
@@ -1136,6 +1170,7 @@ struct PackArgs {
   long long lev_pic_elems[3];
   int lev_stride[3];
   PicDev P;
+  RdoqChain rq; // RDOQ variant of the kernel only
 };
 // what a wave-item of the packed schedule prefetches for its successor (see k_intra_packed)
 struct PackNext {
@@ -1145,12 +1180,17 @@ struct PackNext {
   uint32_t t;          // the next ticket, wave-uniform (valid after the dependency wait)
   PackDesc d;          // its descriptor (in flight after the dependency wait)
 };
-template <bool SSE>
+template <bool SSE, bool RDOQ = false>
 struct PackedSrc {
   static constexpr bool kCoherent = true;      // reconstruction loads bypass the vector L1 (sc1)
   static constexpr bool kWriteThrough = false; // producers and consumers share an XCD's L2: plain stores
   static constexpr bool kSse = SSE;            // a kernel variant of its own: the extra live registers would spill in the common one
+  static constexpr bool kRdoq = RDOQ;          // likewise (doubles, and the 4x4 lane's private arrays)
   __device__ __forceinline__ bool want_sse() const { return SSE; }
+  __device__ __forceinline__ int picture() const { return pic0 + (int)(ft.t.plane >> 2); }
+  __device__ __forceinline__ int cbf_ctx() const { return (ft.t.flags >> 4) & 15; } // hmx_tu::flags bits 4..7
+  __device__ __forceinline__ const RdoqChain &rdoq() const { return A->rq; }
+  __device__ __forceinline__ char *rdoq_ws() const { return A->rq.ws + (size_t)blockIdx.x * A->rq.ws_stride; }
   FTu ft;               // this lane's item, fetched during the previous wave-item
   const PackPic *gpics; // the group's pictures
   const short *org_g;   // the group's region of the pools
@@ -1232,8 +1272,9 @@ __device__ __forceinline__ int pack_lane_item(int lane, int s) {
   return s == 0 ? (SL4 == 64 ? lane : lane >> 2) : s == 1 ? lane >> 3 : s == 2 ? lane >> 4 : 0;
 }
 
-template <bool ENC, int SL4, bool SSE = false>
-__global__ __launch_bounds__(64, 4) void k_intra_packed(PackArgs A) {
+template <bool ENC, int SL4, bool SSE = false, bool RDOQ = false>
+__global__ __launch_bounds__(64, RDOQ ? 2 : 4) void k_intra_packed(PackArgs A) {
+  static_assert(!RDOQ || (ENC && SL4 == 64), "RDOQ: encoder direction, 4x4 blocks one per lane");
   __shared__ __attribute__((aligned(16))) char smem[HMX_WAVE_SMEM];
   int xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1293,7 +1334,7 @@ __global__ __launch_bounds__(64, 4) void k_intra_packed(PackArgs A) {
       const int s = (int)(d.n_s >> 28), n = (int)(d.n_s & 0x0fffffffu);
       const int g = (int)(d.row % (uint32_t)A.n_groups);
       const size_t greg = (size_t)g * A.I * A.pic_elems;
-      const PackedSrc<SSE> src{ft, A.pics + (size_t)g * A.I, A.pool_org + greg, A.pool_rec + greg,
+      const PackedSrc<SSE, RDOQ> src{ft, A.pics + (size_t)g * A.I, A.pool_org + greg, A.pool_rec + greg,
                           A.plane_off[1] * (uint32_t)A.I, A.plane_off[2] * (uint32_t)A.I, 64u * (uint32_t)A.I, A.ctu_w, A.clog,
                           d.dep_target ? A.done + (size_t)(d.row - (uint32_t)A.n_groups) * kDoneStride : nullptr, d.dep_target, &hdr->abort,
                           A.sleep0, A.sleep1, &nx, &A, g * A.I
@@ -1555,6 +1596,19 @@ struct hmx_ctx {
   int pack_I = 1;             // pictures per group (interleave domain of the pool) of the call being issued
   const hmx_levels *call_lev = nullptr; // the call's level planes (host array, valid while the call is issued)
   bool pk_pending = false;    // a packed launch was issued since the last check of its abort word
+  // hmx_set_rdoq: xRateDistOptQuant as the quantiser of the next whole-picture encode calls
+  struct ChainRdoq {
+    int n = 0;                    // pictures described (1: one set for all pictures of a call); 0 = off
+    EstBitsDev *d_est = nullptr;  // [n][2][4]
+    size_t cap_est = 0;
+    std::vector<double> lambda;   // [n][2]
+    double *d_lambda = nullptr;   // [n][2], then the Int64 factors [n][2]
+    size_t cap_lambda = 0;
+    char *ws = nullptr;
+    size_t cap_ws = 0;
+    int max_waves = 0;            // resident waves of the RDOQ kernel variant
+    uint64_t serial = 0;          // counts hmx_set_rdoq calls (part of the schedule key)
+  } crq;
   std::vector<hmx_sse> sse_out; // hmx_set_sse_output: per-picture distortion arrays of the next whole-picture encode calls
   uint64_t table_key = 0;     // of the picture table resident in d_jobs (whole-picture calls)
   bool table_valid = false;
@@ -1734,6 +1788,9 @@ extern "C" void hmx_destroy(hmx_ctx *c) {
   hipFree(c->rdoq_blocks);
   hipFree(c->rdoq_est);
   hipFree(c->rdoq_ws);
+  hipFree(c->crq.d_est);
+  hipFree(c->crq.d_lambda);
+  hipFree(c->crq.ws);
   hipFree(c->pk.d_pics);
   hipFree(c->pk.d_rows);
   hipFree(c->pk.d_descs);
@@ -2367,6 +2424,11 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
   }
   // one lane per 4x4 block is the throughput shape, four lanes per block make more, shorter waves (small batches)
   G.slots4 = c->knob.slots4 ? c->knob.slots4 : (n_pics >= 256 ? 64 : 16);
+  const bool rdoq = enc && c->crq.n > 0;
+  if (rdoq) {
+    if (c->crq.n != 1 && c->crq.n != n_pics) return fail(c, HMX_ERR_ARG, "frame_intra: hmx_set_rdoq described another number of pictures");
+    G.slots4 = 64; // a 4x4 block's RDOQ runs inside one lane
+  }
   const uint64_t n_rows = (uint64_t)G.max_levels * G.n_groups;
   uint64_t waves_bound = 4 * n_rows + 4;
   for (int s = 0; s < 4; s++) waves_bound += sz[s] / pack_slots(s, G.slots4);
@@ -2417,7 +2479,18 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
   }
   // Enough persistent waves to hold about two levels' worth of wave-items (the waves of the next row load their
   // descriptors and originals while the current row finishes), never more than the device keeps resident.
-  pk.n_wg = c->knob.pack_waves ? c->knob.pack_waves : (int)std::min<uint64_t>((uint64_t)c->max_resident_waves, std::max<uint64_t>(256, 2 * wpl));
+  int resident = c->max_resident_waves;
+  if (rdoq) {
+    if (!c->crq.max_waves) {
+      int nb = 0;
+      hipDeviceProp_t prop;
+      HIPCHK(c, hipGetDeviceProperties(&prop, c->cfg.device));
+      HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_intra_packed<true, 64, true, true>, 64, 0));
+      c->crq.max_waves = std::max(64, nb * prop.multiProcessorCount);
+    }
+    resident = c->crq.max_waves;
+  }
+  pk.n_wg = c->knob.pack_waves ? std::min(c->knob.pack_waves, resident) : (int)std::min<uint64_t>((uint64_t)resident, std::max<uint64_t>(256, 2 * wpl));
   PackArgs A{};
   A.pics = pk.d_pics;
   A.rows = pk.d_rows;
@@ -2452,8 +2525,46 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
   A.sleep0 = c->knob.pack_sleep0 >= 0 ? c->knob.pack_sleep0 : 16;
   A.sleep1 = c->knob.pack_sleep1 >= 0 ? c->knob.pack_sleep1 : 2;
   A.P = p0->P;
+  if (rdoq) {
+#pragma clang fp contract(off)
+    auto &q = c->crq;
+    const size_t per_wave = rdoq_chain_ws_bytes();
+    int r = grow_dev(c, (void **)&q.ws, &q.cap_ws, per_wave * (size_t)pk.n_wg);
+    if (r) return r;
+    // lambda and the factor of the sign-hiding cost per picture, the error scale per size: the quotients are formed here, in
+    // the reference's operation order (setErrScaleCoeff TComTrQuant.cpp:2794-2818, :2205)
+    const int B = A.P.bit_depth, inc = B - 8;
+    std::vector<double> up((size_t)q.n * 4);
+    for (int t = 0; t < 2; t++) {
+      const int qs = A.P.qd[t].q, per = A.P.qd[t].per_qbits, iq = A.P.qd[t].iq_scale >> per;
+      for (int lg = 2; lg <= 5; lg++) {
+        const int tshift = 15 - B - lg;
+        double e = (double)(1 << 15);
+        e = e * ldexp(1.0, -2 * tshift);
+        e = e / (double)qs / (double)qs / (double)(1 << (2 * inc));
+        A.rq.err_scale[t][lg - 2] = e;
+      }
+      for (int i = 0; i < q.n; i++) {
+        const double lam = q.lambda[(size_t)i * 2 + t];
+        up[(size_t)i * 2 + t] = lam;
+        const long long f = (long long)((double)iq * (double)iq * (double)(1 << (2 * per)) / lam / 16 / (double)(1 << (2 * inc)) + 0.5);
+        memcpy(&up[(size_t)q.n * 2 + (size_t)i * 2 + t], &f, sizeof(f));
+      }
+    }
+    HIPCHK(c, hipMemcpyAsync(q.d_lambda, up.data(), up.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st)); // `up` goes out of scope
+    A.rq.est = q.d_est;
+    A.rq.lambda = q.d_lambda;
+    A.rq.rd_factor = reinterpret_cast<const long long *>(q.d_lambda + (size_t)q.n * 2);
+    A.rq.ws = q.ws;
+    A.rq.ws_stride = per_wave;
+    A.rq.pic_mul = q.n == 1 ? 0 : 1;
+  }
   const dim3 grid((unsigned)pk.n_wg), blk(64);
-  if (A.want_sse) {
+  if (rdoq) {
+    if (A.want_sse) hipLaunchKernelGGL((k_intra_packed<true, 64, true, true>), grid, blk, 0, st, A);
+    else hipLaunchKernelGGL((k_intra_packed<true, 64, false, true>), grid, blk, 0, st, A);
+  } else if (A.want_sse) {
     if (G.slots4 == 64) hipLaunchKernelGGL((k_intra_packed<true, 64, true>), grid, blk, 0, st, A);
     else hipLaunchKernelGGL((k_intra_packed<true, 16, true>), grid, blk, 0, st, A);
   } else if (G.slots4 == 64) {
@@ -2924,6 +3035,10 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
   mix(jobs.data(), sizeof(ConvJob) * jobs.size());
   const int flags[6] = {enc, c->last_schedule, groups, n_pics, across, I};
   mix(flags, sizeof(flags));
+  if (enc && c->crq.n > 0) {
+    if (!packed) return fail(c, HMX_ERR_ARG, "frame_intra: RDOQ as the quantiser (hmx_set_rdoq) needs the packed schedule");
+    mix(&c->crq.serial, sizeof(c->crq.serial)); // 4x4 blocks then always go one per lane: another table
+  }
   if (enc && (int)c->sse_out.size() >= n_pics) {
     if (!packed) return fail(c, HMX_ERR_ARG, "frame_intra: the distortion output (hmx_set_sse_output) needs the packed schedule");
     mix(c->sse_out.data(), sizeof(hmx_sse) * n_pics);
@@ -3036,6 +3151,29 @@ extern "C" int hmx_frame_intra_encode_multi(hmx_ctx *c, const hmx_intra_plan *co
 extern "C" int hmx_frame_intra_decode_multi(hmx_ctx *c, const hmx_intra_plan *const *plans, int n_pics, const hmx_pic *rec,
                                             const hmx_levels *lev) {
   return frame_intra(c, plans, 1, n_pics, nullptr, rec, lev, false);
+}
+extern "C" int hmx_set_rdoq(hmx_ctx *c, const hmx_rdoq_pic *pics, int n_pics) {
+  if (!c || (pics && n_pics <= 0)) return HMX_ERR_ARG;
+  auto &q = c->crq;
+  q.serial++;
+  if (!pics) {
+    q.n = 0;
+    return HMX_OK;
+  }
+  static_assert(sizeof(hmx_rdoq_pic) == 8 * sizeof(EstBitsDev) + 2 * sizeof(double), "hmx_rdoq_pic: eight tables and two multipliers");
+  HIPCHK(c, hipStreamSynchronize(c->stream)); // a queued call may still read the previous tables
+  int r = grow_dev(c, (void **)&q.d_est, &q.cap_est, sizeof(EstBitsDev) * 8 * (size_t)n_pics);
+  if (!r) r = grow_dev(c, (void **)&q.d_lambda, &q.cap_lambda, sizeof(double) * 4 * (size_t)n_pics);
+  if (r) return r;
+  q.lambda.resize((size_t)n_pics * 2);
+  for (int i = 0; i < n_pics; i++) {
+    if (!(pics[i].lambda_luma > 0) || !(pics[i].lambda_chroma > 0)) return fail(c, HMX_ERR_ARG, "hmx_set_rdoq: lambda must be positive");
+    q.lambda[(size_t)i * 2] = pics[i].lambda_luma, q.lambda[(size_t)i * 2 + 1] = pics[i].lambda_chroma;
+    HIPCHK(c, hipMemcpyAsync(q.d_est + (size_t)i * 8, pics[i].est, sizeof(EstBitsDev) * 8, hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  q.n = n_pics;
+  return HMX_OK;
 }
 extern "C" int hmx_set_sse_output(hmx_ctx *c, const hmx_sse *sse, int n_pics) {
   if (!c || (sse && n_pics <= 0)) return HMX_ERR_ARG;

@@ -367,6 +367,22 @@ __host__ __device__ inline size_t rdoq_wave_ws_bytes(int lg) {
   const size_t nn = (size_t)1 << (2 * lg), n_cg = nn >> 4;
   return nn * (6 * sizeof(int) + 3 * sizeof(double)) + n_cg * 8 * sizeof(RdoqSpec) + 64 * sizeof(double) + 64 + sizeof(RdoqRun) + 64;
 }
+struct RdoqWs { // a block's workspace, carved
+  double *cz, *cc, *cs, *cgs;
+  RdoqSpec *spec;
+  RdoqRun *run;
+  int *ld, *lev, *ru, *rd, *sd, *du;
+  unsigned char *sel;
+};
+__device__ __forceinline__ RdoqWs rdoq_ws_carve(char *w, int nn) {
+  RdoqWs W;
+  W.cz = reinterpret_cast<double *>(w), W.cc = W.cz + nn, W.cs = W.cc + nn, W.cgs = W.cs + nn;
+  W.spec = reinterpret_cast<RdoqSpec *>(W.cgs + 64);
+  W.run = reinterpret_cast<RdoqRun *>(W.spec + (size_t)(nn >> 4) * 8);
+  W.ld = reinterpret_cast<int *>(W.run + 1), W.lev = W.ld + nn, W.ru = W.lev + nn, W.rd = W.ru + nn, W.sd = W.rd + nn, W.du = W.sd + nn;
+  W.sel = reinterpret_cast<unsigned char *>(W.du + nn);
+  return W;
+}
 __device__ __forceinline__ void rdoq_wave_fence() { // this wave's global stores before its later loads by other lanes
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
@@ -486,6 +502,229 @@ __global__ __launch_bounds__(64) void k_rdoq_wave(RdoqArgs A) {
     const unsigned bp = bp_of(sp);
     dst[(bp >> lg) * ds + (bp & (unsigned)(N - 1))] = lev[sp];
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RDOQ as the quantiser of the whole-picture chain (k_intra_packed): the same lane decomposition over the SL blocks a chain
+// wave holds in LDS.  On entry Ls[b].tile[row][col] holds block b's Int coefficients (fwd_tq_block without the quantiser)
+// and Ls[b].line[0..4] = {active, picture, is_luma, scan_idx, cbf_ctx}; on exit the tile holds the levels.
+// What the encoder takes from its live state is an input of the call (hmx_set_rdoq): per picture the bit estimates for
+// [luma, chroma][4 sizes] and lambda for luma / chroma blocks.
+// ---------------------------------------------------------------------------------------------------------------------
+struct RdoqChain {
+  const EstBitsDev *est;      // [picture][luma, chroma][log2n - 2]
+  const double *lambda;       // [picture][luma, chroma]
+  const long long *rd_factor; // [picture][luma, chroma]
+  char *ws;                   // workspace: ws_stride bytes per persistent wave
+  size_t ws_stride;
+  int pic_mul;                // 0: one set of tables for every picture of the call, 1: a set per picture
+  double err_scale[2][4];
+};
+__host__ __device__ inline size_t rdoq_chain_ws_bytes() { // the largest of 8 x 8x8, 4 x 16x16, 1 x 32x32 blocks
+  const size_t a = 8 * ((rdoq_wave_ws_bytes(3) + 255) & ~(size_t)255), b = 4 * ((rdoq_wave_ws_bytes(4) + 255) & ~(size_t)255),
+               c = (rdoq_wave_ws_bytes(5) + 255) & ~(size_t)255;
+  return a > b ? (a > c ? a : c) : (b > c ? b : c);
+}
+template <int N>
+__device__ __forceinline__ RdoqConst rdoq_chain_const(const TuLds<N> &L, const RdoqChain &RC, const PicDev &P, const EstBitsDev *&E) {
+  constexpr int LG = N == 8 ? 3 : N == 16 ? 4 : N == 32 ? 5 : 2;
+  const int pic = L.line[1] * RC.pic_mul, luma = L.line[2], pt = luma ? 0 : 1;
+  RdoqConst C;
+  C.lg = LG, C.scan_idx = L.line[3], C.is_luma = luma;
+  C.q = pt ? P.qd[1].q : P.qd[0].q;
+  C.qbits = 14 + (pt ? P.qd[1].per_qbits : P.qd[0].per_qbits) + (15 - P.bit_depth - LG);
+  C.root_cbf = 0, C.cbf_ctx = L.line[4], C.sign_hide = P.sign_hide;
+  C.lambda = RC.lambda[pic * 2 + pt], C.err_scale = RC.err_scale[pt][LG - 2], C.rd_factor = RC.rd_factor[pic * 2 + pt];
+  E = RC.est + ((size_t)pic * 2 + pt) * 4 + (LG - 2);
+  return C;
+}
+template <int N, int SL>
+__device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, char *ws, const RdoqChain &RC, const PicDev &P, int lane) {
+  constexpr int LG = N == 8 ? 3 : N == 16 ? 4 : 5, NN = N * N, NCG = NN / 16;
+  const size_t stride = (rdoq_wave_ws_bytes(LG) + 255) & ~(size_t)255;
+  // line[5] = last position, [6] = last position + 1 after phase B, [7] = sum of levels, [8] = highest group with a level
+  if (lane < SL) Ls[lane].line[5] = -1, Ls[lane].line[6] = 0, Ls[lane].line[7] = 0, Ls[lane].line[8] = -1;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int t = lane; t < SL * NN; t += 64) { // step 0
+    const int b = t / NN, sp = t - b * NN;
+    TuLds<N> &L = Ls[b];
+    if (!L.line[0]) continue;
+    const EstBitsDev *E;
+    const RdoqConst C = rdoq_chain_const<N>(L, RC, P, E);
+    const RdoqWs W = rdoq_ws_carve(ws + b * stride, NN);
+    const unsigned bp = rdoq_scan_pos(LG, C.scan_idx, sp);
+    int l;
+    double z;
+    rdoq_prep(L.tile[bp >> LG][bp & (N - 1)], C, l, z);
+    W.ld[sp] = l, W.cz[sp] = z;
+    if (rdoq_max_level(l, C.qbits) > 0) atomicMax(&L.line[5], sp);
+  }
+  rdoq_wave_fence();
+  for (int t = lane; t < SL * NCG * 8; t += 64) { // step 1
+    const int b = t / (NCG * 8), r = t - b * (NCG * 8), cg = r >> 3, v = r & 7;
+    TuLds<N> &L = Ls[b];
+    const int last_pos = L.line[5];
+    if (!L.line[0] || last_pos < 0 || cg > (last_pos >> 4)) continue;
+    const EstBitsDev *E;
+    const RdoqConst C = rdoq_chain_const<N>(L, RC, P, E);
+    const RdoqWs W = rdoq_ws_carve(ws + b * stride, NN);
+    const int scan_idx = C.scan_idx;
+    auto bp_of = [&](int sp) { return rdoq_scan_pos(LG, scan_idx, sp); };
+    RdoqSpecSink sink{&W.spec[r]};
+    W.spec[r].S = rdoq_walk_cg(C, *E, cg, bp_of, W.ld + cg * 16, W.cz + cg * 16, v & 3, v >> 2, last_pos, sink);
+  }
+  rdoq_wave_fence();
+  if (lane < SL && Ls[lane].line[0] && Ls[lane].line[5] >= 0) { // step 2
+    TuLds<N> &L = Ls[lane];
+    const EstBitsDev *E;
+    const RdoqConst C = rdoq_chain_const<N>(L, RC, P, E);
+    const RdoqWs W = rdoq_ws_carve(ws + lane * stride, NN);
+    const int scan_idx = C.scan_idx;
+    auto gpos_of = [&](int cg) {
+      const unsigned p0 = rdoq_scan_pos(LG, scan_idx, cg * 16);
+      return ((p0 & (unsigned)(N - 1)) >> 2) | (((p0 >> LG) >> 2) << 8);
+    };
+    RdoqRun R;
+    rdoq_resolve(C, *E, NCG, L.line[5] >> 4, gpos_of, W.cz, W.spec, W.sel, W.cgs, R);
+    *W.run = R;
+  }
+  rdoq_wave_fence();
+  for (int t = lane; t < SL * NCG; t += 64) { // step 3
+    const int b = t / NCG, cg = t - b * NCG;
+    TuLds<N> &L = Ls[b];
+    const int last_pos = L.line[5];
+    if (!L.line[0] || last_pos < 0) continue;
+    const RdoqWs W = rdoq_ws_carve(ws + b * stride, NN);
+    if (cg > (last_pos >> 4)) {
+      for (int k = 0; k < 16; k++) {
+        const int sp = cg * 16 + k;
+        W.lev[sp] = 0, W.cc[sp] = 0, W.cs[sp] = 0, W.ru[sp] = 0, W.rd[sp] = 0, W.sd[sp] = 0, W.du[sp] = 0;
+      }
+      continue;
+    }
+    const EstBitsDev *E;
+    const RdoqConst C = rdoq_chain_const<N>(L, RC, P, E);
+    const int scan_idx = C.scan_idx;
+    auto bp_of = [&](int sp) { return rdoq_scan_pos(LG, scan_idx, sp); };
+    RdoqFullSink sink{W.lev, W.cc, W.cs, W.ru, W.rd, W.sd, W.du, cg * 16};
+    const int v = W.sel[cg];
+    rdoq_walk_cg(C, *E, cg, bp_of, W.ld + cg * 16, W.cz + cg * 16, v & 3, v >> 2, last_pos, sink);
+    if ((W.run->zeroed >> cg) & 1) rdoq_apply_zeroed_cg(cg, W.cz, W.lev, W.cc, W.cs);
+  }
+  rdoq_wave_fence();
+  if (lane < SL && Ls[lane].line[0] && Ls[lane].line[5] >= 0) { // step 4a
+    TuLds<N> &L = Ls[lane];
+    const EstBitsDev *E;
+    const RdoqConst C = rdoq_chain_const<N>(L, RC, P, E);
+    const RdoqWs W = rdoq_ws_carve(ws + lane * stride, NN);
+    const int scan_idx = C.scan_idx;
+    auto bp_of = [&](int sp) { return rdoq_scan_pos(LG, scan_idx, sp); };
+    auto gpos_of = [&](int cg) {
+      const unsigned p0 = rdoq_scan_pos(LG, scan_idx, cg * 16);
+      return ((p0 & (unsigned)(N - 1)) >> 2) | (((p0 >> LG) >> 2) << 8);
+    };
+    L.line[6] = rdoq_phase_b(C, *E, L.line[5], L.line[5] >> 4, gpos_of, bp_of, *W.run, W.cz, W.lev, W.cc, W.cs, W.cgs);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int t = lane; t < SL * NN; t += 64) { // final levels (signed), their sum, the highest group that holds one
+    const int b = t / NN, sp = t - b * NN;
+    TuLds<N> &L = Ls[b];
+    if (!L.line[0] || L.line[5] < 0) continue;
+    const RdoqWs W = rdoq_ws_carve(ws + b * stride, NN);
+    const unsigned bp = rdoq_scan_pos(LG, L.line[3], sp);
+    const int l = sp < L.line[6] ? W.lev[sp] : 0;
+    if (l) {
+      atomicAdd(&L.line[7], l);
+      atomicMax(&L.line[8], sp >> 4);
+    }
+    W.lev[sp] = L.tile[bp >> LG][bp & (N - 1)] < 0 ? -l : l;
+  }
+  rdoq_wave_fence();
+  if (P.sign_hide) {
+    for (int t = lane; t < SL * NCG; t += 64) { // step 4c
+      const int b = t / NCG, cg = t - b * NCG;
+      TuLds<N> &L = Ls[b];
+      if (!L.line[0] || L.line[5] < 0 || L.line[7] < 2) continue;
+      const EstBitsDev *E;
+      const RdoqConst C = rdoq_chain_const<N>(L, RC, P, E);
+      const RdoqWs W = rdoq_ws_carve(ws + b * stride, NN);
+      int l16[16];
+      unsigned neg = 0;
+      bool any = false;
+      for (int k = 0; k < 16; k++) {
+        l16[k] = W.lev[cg * 16 + k];
+        any |= l16[k] != 0;
+        const unsigned bp = rdoq_scan_pos(LG, C.scan_idx, cg * 16 + k);
+        neg |= (L.tile[bp >> LG][bp & (N - 1)] < 0 ? 1u : 0u) << k;
+      }
+      if (!any) continue;
+      rdoq_phase_c_cg(C, cg == L.line[8], l16, neg, W.ru + cg * 16, W.rd + cg * 16, W.sd + cg * 16, W.du + cg * 16);
+      for (int k = 0; k < 16; k++) W.lev[cg * 16 + k] = l16[k];
+    }
+    rdoq_wave_fence();
+  }
+  for (int t = lane; t < SL * NN; t += 64) { // the levels take the coefficients' place in the tile
+    const int b = t / NN, sp = t - b * NN;
+    TuLds<N> &L = Ls[b];
+    if (!L.line[0]) continue;
+    const unsigned bp = rdoq_scan_pos(LG, L.line[3], sp);
+    L.tile[bp >> LG][bp & (N - 1)] = L.line[5] < 0 ? 0 : rdoq_ws_carve(ws + b * stride, NN).lev[sp];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One 4x4 block in ONE lane (the lane-per-block 4x4 chain): a single coefficient group, so no speculation -- walk, resolve,
+// last position, sign hiding in sequence with the core's functions, on private arrays.  coef / lev: raster order.
+__device__ __forceinline__ void rdoq_lane_4x4(const int *coef, int *lev_out, int pic, bool luma, int scan_idx, int cbf_ctx, const RdoqChain &RC,
+                                              const PicDev &P) {
+  const int pt = luma ? 0 : 1;
+  pic *= RC.pic_mul;
+  RdoqConst C;
+  C.lg = 2, C.scan_idx = scan_idx, C.is_luma = luma;
+  C.q = pt ? P.qd[1].q : P.qd[0].q;
+  C.qbits = 14 + (pt ? P.qd[1].per_qbits : P.qd[0].per_qbits) + (15 - P.bit_depth - 2);
+  C.root_cbf = 0, C.cbf_ctx = cbf_ctx, C.sign_hide = P.sign_hide;
+  C.lambda = RC.lambda[pic * 2 + pt], C.err_scale = RC.err_scale[pt][0], C.rd_factor = RC.rd_factor[pic * 2 + pt];
+  const EstBitsDev &E = RC.est[((size_t)pic * 2 + pt) * 4];
+  auto bp_of = [&](int sp) { return (unsigned)kScan4.t[scan_idx][sp]; };
+  auto gpos_of = [](int) { return 0u; };
+  int ld[16], lev[16], ru[16], rd[16], sd[16], du[16];
+  double cz[16], cc[16], cs[16], cgs[1];
+  int last_pos = -1;
+  for (int sp = 0; sp < 16; sp++) {
+    rdoq_prep(coef[bp_of(sp)], C, ld[sp], cz[sp]);
+    if (rdoq_max_level(ld[sp], C.qbits) > 0) last_pos = sp;
+  }
+  for (int k = 0; k < 16; k++) lev_out[k] = 0;
+  if (last_pos < 0) return;
+  RdoqSpec spec[1]; // the only variant a single group can take: no carry in, no neighbours
+  {
+    RdoqSpecSink sink{&spec[0]};
+    spec[0].S = rdoq_walk_cg(C, E, 0, bp_of, ld, cz, 0, 0, last_pos, sink);
+  }
+  unsigned char sel[1];
+  RdoqRun R;
+  rdoq_resolve(C, E, 1, 0, gpos_of, cz, spec, sel, cgs, R);
+  {
+    RdoqFullSink sink{lev, cc, cs, ru, rd, sd, du, 0};
+    rdoq_walk_cg(C, E, 0, bp_of, ld, cz, 0, 0, last_pos, sink);
+  }
+  const int blp1 = rdoq_phase_b(C, E, last_pos, 0, gpos_of, bp_of, R, cz, lev, cc, cs, cgs);
+  int sum = 0;
+  unsigned neg = 0;
+  for (int sp = 0; sp < 16; sp++) {
+    const int l = sp < blp1 ? lev[sp] : 0, c = coef[bp_of(sp)];
+    sum += l;
+    lev[sp] = c < 0 ? -l : l;
+    neg |= (c < 0 ? 1u : 0u) << sp;
+  }
+  if (C.sign_hide && sum >= 2) rdoq_phase_c_cg(C, true, lev, neg, ru, rd, sd, du);
+  for (int sp = 0; sp < 16; sp++) lev_out[bp_of(sp)] = lev[sp];
 }
 
 } // namespace hmx
