@@ -57,23 +57,38 @@ def algorithmic_bytes(tus, decode=False):
     return int(((n * n) * (6 if decode else 8) + (4 * n + 1) * 2).sum())
 
 
-def _cpu_fn():
+def rdoq_inputs(plan_seed, qp):
+    """--rdoq: what hmx_set_rdoq takes per picture -- eight bit-estimate tables [luma, chroma][4 sizes] (synthetic, a set per
+    decision structure) and the I-slice multipliers of the workload's QP."""
+    from thevc_amd import workload
+    return [workload.make_est_bits(7000 + 8 * plan_seed + k) for k in range(8)], workload.rdoq_lambdas(qp)
+
+
+def _cpu_fn(rdoq=None):
+    """the CPU side of cpu_baseline: HM's own functions (oracle/_ref) chained over the decisions, or the oracle; with RDOQ as
+    the quantiser (rdoq = (tables, multipliers)) the oracle's chain (the compiled reference exposes RDOQ per block only)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
+    if rdoq is not None:
+        ests, lams = rdoq
+        return "port", lambda tus, w, h, B, qp, org: ol.o_intra_frame_encode_rdoq(tus, w, h, B, qp, org, ests, lams)
     kind = "reference" if ol.have_ref() else "port"
     return kind, (ol.r_intra_frame_encode if kind == "reference" else ol.o_intra_frame_encode)
 
 
 def cpu_worker(argv):
-    """`bench.py --cpu-worker W H B QP TILING PLAN_SEED PIC_SEED SECONDS`: one host core codes one synthetic picture of the
+    """`bench.py --cpu-worker W H B QP TILING PLAN_SEED PIC_SEED SECONDS [rdoq]`: one host core codes one synthetic picture of the
     workload over and over for SECONDS and prints the pictures it finished and the time it took (a worker process of
     the all-cores leg of cpu_baseline; no GPU, no torch)."""
     from thevc_amd import workload
     w, h, B, qp = (int(v) for v in argv[:4])
     tiling = argv[4] if argv[4] == "mix" else int(argv[4])
     plan_seed, pic_seed, seconds = int(argv[5]), int(argv[6]), float(argv[7])
-    _kind, fn = _cpu_fn()
+    rdoq = len(argv) > 8 and argv[8] == "rdoq"
+    _kind, fn = _cpu_fn(rdoq_inputs(plan_seed, qp) if rdoq else None)
     tus = workload.make_tus(plan_seed, w, h, tiling)
+    if rdoq:
+        tus = workload.with_cbf_ctx(tus)
     org = workload.make_planes(pic_seed, w, h, B, "texture")
     fn(tus, w, h, B, qp, org)  # warm
     t0 = time.perf_counter()
@@ -87,13 +102,13 @@ def cpu_worker(argv):
     print(json.dumps({"pictures": n, "seconds": dt}), flush=True)
 
 
-def cpu_baseline(w, h, B, qp, tiling, checks, seconds_target=10.0, all_cores=True, max_cores=16):
+def cpu_baseline(w, h, B, qp, tiling, checks, seconds_target=10.0, all_cores=True, max_cores=16, rdoq=False):
     """checks = [(picture index, decisions (tus), plan seed, picture seed, original planes, (GPU reconstruction planes,
     GPU level planes))].  Leg 1: ONE core, in this process, codes the first entry over and over for seconds_target (what
     the CPU computes doubles as a check of what the GPU wrote; further entries -- --verify: a picture of every packing
     group -- are computed once).  Leg 2: every host core this process may run on, one worker process per core, each
     coding its own picture of the workload for the same time: the node's CPU throughput on independent pictures."""
-    kind, fn = _cpu_fn()
+    kind, fn = _cpu_fn(rdoq_inputs(checks[0][2], qp) if rdoq else None)
 
     def identical(result, gpu):
         return all(np.array_equal(gpu[0][p], result[0][p]) and np.array_equal(gpu[1][p], result[1][p]) for p in range(3))
@@ -111,12 +126,15 @@ def cpu_baseline(w, h, B, qp, tiling, checks, seconds_target=10.0, all_cores=Tru
             break
     one = n * w * h / dt / 1e6
     src = "HM's own functions from oracle/_ref" if kind == "reference" else "CPU oracle (oracle/hmx_oracle.c)"
+    if rdoq:
+        src += ", xRateDistOptQuant as the quantiser"
     out = {"value": round(one, 3), "unit": "Mpixels/s", "cores": 1, "kind": kind,
            "sample": f"{n} picture(s) {w}x{h} of the workload's block structure, single thread, {src}"}
     out["gpu_picture_0_identical"] = bool(same)  # levels and reconstruction of the batch's first picture
     if len(checks) > 1:
         for (_i, tus_i, _ps, _is, o, g) in checks[1:]:
-            same = same and identical(fn(tus_i, w, h, B, qp, o), g)
+            fn_i = _cpu_fn(rdoq_inputs(_ps, qp))[1] if rdoq else fn
+            same = same and identical(fn_i(tus_i, w, h, B, qp, o), g)
         out["gpu_pictures_checked"] = [c[0] for c in checks]
         out["gpu_pictures_identical"] = bool(same)
     if all_cores and seconds_target > 0:
@@ -125,7 +143,7 @@ def cpu_baseline(w, h, B, qp, tiling, checks, seconds_target=10.0, all_cores=Tru
         procs = []
         for k in range(cores):
             cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(w), str(h), str(B), str(qp), str(tiling),
-                   str(checks[0][2]), str(checks[0][3] + k), str(seconds_target)]
+                   str(checks[0][2]), str(checks[0][3] + k), str(seconds_target)] + (["rdoq"] if rdoq else [])
             procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True))
         rate, done = 0.0, 0
         for pr in procs:
@@ -310,6 +328,9 @@ def main():
     ap.add_argument("--decode", action="store_true",
                     help="time the decoder direction of the chain (levels -> reconstruction, DEC/TDecCu.cpp:469-687) instead of the "
                          "encoder direction; the levels come from one untimed encode")
+    ap.add_argument("--rdoq", action="store_true",
+                    help="quantise with xRateDistOptQuant inside the chain (hmx_set_rdoq; HM's encoder default) instead of the flat "
+                         "quantiser: per-picture bit-estimate tables (a set per decision structure) and multipliers")
     ap.add_argument("--planar", action="store_true",
                     help="hand the pictures over in the reference's plane geometry (TComPicYuv): every call converts them into and out "
                          "of the working layout; default: pictures resident in the working layout (hmx_tpool)")
@@ -367,6 +388,10 @@ def main():
     n_plans = max(1, args.plans)
     plan_seeds = [1 + j for j in range(n_plans)]
     tus_list = [workload.make_tus(sd, w, h_c, tiling) for sd in plan_seeds]
+    if args.rdoq:
+        if args.decode:
+            raise SystemExit("--rdoq is the encoder direction's quantiser")
+        tus_list = [workload.with_cbf_ctx(t) for t in tus_list]
     pp = capi.PicParam(w, h_c, qp, 0, capi.I_SLICE, 1)
     plans = [ctx.intra_plan(t, pp) for t in tus_list]
 
@@ -408,6 +433,10 @@ def main():
                 d.upload(src[i0 + k])
             p_org.import_planes(i0, part)
         ctx.sync()
+
+    if args.rdoq:
+        sets = [rdoq_inputs(sd, qp) for sd in plan_seeds[:n_plans]]
+        ctx.set_rdoq([(sets[i % n_plans][0], sets[i % n_plans][1][0], sets[i % n_plans][1][1]) for i in range(F)])
 
     def call(enc):
         if args.planar:
@@ -475,11 +504,13 @@ def main():
         n_launch = 1 if sched.value == 3 else n_levels * groups.value  # launches of the dominant kernel per step
         kernel = ["k_intra_wave<%s>", "k_intra_level<%s>", "k_intra_level_across<%s>", "k_intra_packed<%s>"][sched.value] % (
             "false" if args.decode else "true")
+        if args.rdoq:
+            kernel = "k_intra_packed<true, 64, false, true>"
         per_plan_bytes = [algorithmic_bytes(t, args.decode) for t in tus_list[:n_plans]]
         bytes_step = sum(per_plan_bytes[i % n_plans] for i in range(F))
         traffic = None
         tj = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if os.path.exists(tj) and args.workload == "ai2160p10" and args.tiling == "mix" and not args.decode:
+        if os.path.exists(tj) and args.workload == "ai2160p10" and args.tiling == "mix" and not args.decode and not args.rdoq:
             t = json.load(open(tj))
             if t.get("frames") == F and t.get("plans") == n_plans and t.get("kernel", "").startswith(kernel.split("<")[0]):
                 # PMC bytes per launch (tools/pmc.sh): gfx950 FETCH_SIZE counts 64 B per 128-B request
@@ -501,6 +532,7 @@ def main():
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {cfg_name}; all-intra chain " +
                                    ("DECODER direction (intra refs+pred, IQ, IT, recon from levels), " if args.decode else
+                                    "(intra refs+pred, T, RDOQ with per-picture bit-estimate tables, IQ, IT, recon), " if args.rdoq else
                                     "(intra refs+pred, T, flat Q+SBH, IQ, IT, recon), ") +
                                    f"{F} pictures {w}x{h_c} per GPU per step, QP {qp}, TU tiling '{args.tiling}', "
                                    f"{n_plans} distinct decision structures (picture i follows plan i mod {n_plans}: "
@@ -508,7 +540,7 @@ def main():
                                    f"{min(levels)}-{max(levels)} dependency levels per picture), "
                                    f"{len(cache)} distinct source pictures, frames sharded over ranks, no collective",
                        "pictures_per_gpu": F, "width": w, "height": h_c, "bit_depth": B, "qp": qp, "tiling": str(args.tiling),
-                       "distinct_plans": n_plans, "distinct_pictures": len(cache), "shared_decisions": n_plans == 1,
+                       "quantiser": "rdoq" if args.rdoq else "flat", "distinct_plans": n_plans, "distinct_pictures": len(cache), "shared_decisions": n_plans == 1,
                        "pictures": "plane geometry, converted per call" if args.planar else "resident in the working layout (hmx_tpool)"},
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -526,7 +558,7 @@ def main():
             checks = [(i, tus_list[i % n_plans], plan_seeds[i % n_plans], seeds[i], src[i],
                        (reconstruction(i), lev_slab.picture(i).to_planes(tus_list[i % n_plans]))) for i in idx]
             out["cpu_baseline"] = cpu_baseline(w, h_c, B, qp, args.tiling, checks, 0.0 if args.no_cpu_baseline else 10.0,
-                                               all_cores=not args.one_core_only, max_cores=args.cpu_cores)
+                                               all_cores=not args.one_core_only, max_cores=args.cpu_cores, rdoq=args.rdoq)
             if args.verify:
                 cb = out["cpu_baseline"]
                 out["verified_bit_exact_vs_oracle"] = cb.get("gpu_pictures_identical", cb["gpu_picture_0_identical"])

@@ -118,6 +118,122 @@ static void rdoq_block_lanes(const int *src, int *dst, int N, int B, const hmo_r
   for (int sp = 0; sp < nn; sp++) dst[scan[sp]] = lev[sp];
 }
 
+// The second decomposition (the one the whole-picture chain runs, rdoq_wave_tiles): nothing per coefficient is stored.
+// The variants of a few groups at a time (a "round" of 64 lanes) go through a small buffer and are resolved before the next
+// round; last position and sign hiding walk the chosen variant of a group AGAIN with a sink that does their arithmetic.
+struct LevelSink {
+  int *out;
+  void add(int, double) {}
+  void pos(int k, unsigned, int level, double, double, int, int, int, int, double) { out[k] = level; }
+};
+static long g_rewalk_last = 0, g_rewalk_hide = 0;
+static void rdoq_block_rewalk(const int *src, int *dst, int N, int B, const hmo_rdoq_cfg &cfg, const EstBitsDev &E, uint32_t *abs_sum) {
+  const int lg = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5, nn = N * N, n_cg = nn / 16, inc = B - 8, G = N >> 2;
+  const int tshift = 15 - B - lg;
+  const int groups_per_round = N == 32 ? 8 : N == 16 ? 2 : 1; // 64 lanes = blocks per wave x groups x 8 variants
+  RdoqConst C{};
+  C.lg = lg, C.scan_idx = cfg.scan_idx == 3 ? 0 : cfg.scan_idx, C.is_luma = cfg.is_luma;
+  C.q = kQuantScales[cfg.rem], C.qbits = 14 + cfg.per + tshift;
+  C.root_cbf = cfg.root_cbf, C.cbf_ctx = cfg.cbf_ctx, C.sign_hide = cfg.sign_hide;
+  C.lambda = cfg.lambda;
+  double e = (double)(1 << 15);
+  e = e * ldexp(1.0, -2 * tshift);
+  e = e / (double)C.q / (double)C.q / (double)(1 << (2 * inc));
+  C.err_scale = e;
+  const int iq = kInvQuantScales[cfg.rem];
+  C.rd_factor = (long long)((double)iq * (double)iq * (double)(1 << (2 * cfg.per)) / cfg.lambda / 16 / (double)(1 << (2 * inc)) + 0.5);
+  const std::vector<unsigned> scan = make_scan(N, C.scan_idx);
+  auto bp_of = [&](int sp) { return scan[sp]; };
+  auto gpos_of = [&](int cg) { const unsigned p0 = scan[cg * 16]; return ((p0 & (unsigned)(N - 1)) >> 2) | (((p0 >> lg) >> 2) << 8); };
+  auto cz_at = [&](int sp) {
+    int l;
+    double z;
+    rdoq_prep(src[scan[sp]], C, l, z);
+    return z;
+  };
+  memset(dst, 0, sizeof(int) * nn);
+  *abs_sum = 0;
+  int last_pos = -1;
+  for (int sp = 0; sp < nn; sp++) {
+    int l;
+    double z;
+    rdoq_prep(src[scan[sp]], C, l, z);
+    if (rdoq_max_level(l, C.qbits) > 0) last_pos = sp;
+  }
+  if (last_pos < 0) return;
+  const int last_cg = last_pos >> 4;
+  RdoqRun R;
+  rdoq_run_init(R);
+  for (int sp = nn - 1; sp >= (last_cg + 1) * 16; sp--) rdoq_resolve_above(R, cz_at(sp)); // the block's resolving lane
+  std::vector<unsigned char> sel(n_cg, 0xff);
+  std::vector<double> cgs(n_cg, 0.0);
+  int carry = 0;
+  for (int top = last_cg; top >= 0; top -= groups_per_round) { // a round
+    RdoqSpec buf[64];
+    for (int task = 0; task < groups_per_round * 8; task++) { // one lane each
+      const int cg = top - (task >> 3), v = task & 7;
+      if (cg < 0) continue;
+      RdoqSpecSink sink{&buf[task]};
+      auto in = [&](int, unsigned bp, int &ld, double &cz) { rdoq_prep(src[bp], C, ld, cz); };
+      buf[task].S = rdoq_walk_cg_in(C, E, cg, bp_of, in, v & 3, v >> 2, last_pos, sink);
+    }
+    for (int j = 0; j < groups_per_round; j++) { // the block's resolving lane
+      const int cg = top - j;
+      if (cg < 0) break;
+      sel[cg] = (unsigned char)rdoq_resolve_group(C, E, cg, last_cg, gpos_of(cg), buf + j * 8, [&](int k) { return cz_at(cg * 16 + k); }, R, carry, cgs[cg]);
+    }
+  }
+  // last position: the resolving lane again, coded groups walked once more
+  RdoqLast T;
+  rdoq_last_init(C, E, R, T);
+  for (int cg = last_cg; cg >= 0 && !T.found; cg--) {
+    const unsigned g = gpos_of(cg), gpos = (g >> 8) * (unsigned)G + (g & 255u);
+    rdoq_last_group(T, cgs[cg]);
+    if (!((R.cg_flag >> gpos) & 1)) continue;
+    RdoqLastSink sink{C, E, T, cg * 16, last_pos};
+    auto in = [&](int, unsigned bp, int &ld, double &cz) { rdoq_prep(src[bp], C, ld, cz); };
+    rdoq_walk_cg_in(C, E, cg, bp_of, in, sel[cg] & 3, sel[cg] >> 2, last_pos, sink);
+    g_rewalk_last++;
+  }
+  // levels: one lane per group
+  std::vector<int> lev(nn, 0);
+  uint32_t sum = 0;
+  int top_group = -1;
+  for (int cg = 0; cg <= last_cg; cg++) {
+    if ((R.zeroed >> cg) & 1) continue;
+    int l16[16];
+    LevelSink sink{l16};
+    auto in = [&](int, unsigned bp, int &ld, double &cz) { rdoq_prep(src[bp], C, ld, cz); };
+    rdoq_walk_cg_in(C, E, cg, bp_of, in, sel[cg] & 3, sel[cg] >> 2, last_pos, sink);
+    for (int k = 0; k < 16; k++) {
+      const int sp = cg * 16 + k, l = sp < T.best_last_p1 ? l16[k] : 0;
+      sum += (uint32_t)l;
+      if (l) top_group = cg > top_group ? cg : top_group;
+      lev[sp] = src[scan[sp]] < 0 ? -l : l;
+    }
+  }
+  *abs_sum = sum;
+  if (C.sign_hide && sum >= 2) {
+    for (int cg = 0; cg <= last_cg; cg++) { // one lane per group
+      unsigned neg = 0;
+      for (int k = 0; k < 16; k++) neg |= (src[scan[cg * 16 + k]] < 0 ? 1u : 0u) << k;
+      const int *l16 = &lev[cg * 16];
+      auto lev_of = [l16](int n) { return l16[n]; };
+      bool any = false;
+      for (int k = 0; k < 16; k++) any |= l16[k] != 0;
+      RdoqHide H;
+      if (!any || !rdoq_hide_begin(cg == top_group, lev_of, H)) continue;
+      // a group with levels is a coded group that was not zeroed: sel[cg] is its variant
+      RdoqHideSink<decltype(lev_of)> sink{C, H, lev_of, neg};
+      auto in = [&](int, unsigned bp, int &ld, double &cz) { rdoq_prep(src[bp], C, ld, cz); };
+      rdoq_walk_cg_in(C, E, cg, bp_of, in, sel[cg] & 3, sel[cg] >> 2, last_pos, sink);
+      g_rewalk_hide++;
+      if (H.min_pos >= 0) lev[cg * 16 + H.min_pos] += rdoq_hide_change(H, (neg >> H.min_pos) & 1u);
+    }
+  }
+  for (int sp = 0; sp < nn; sp++) dst[scan[sp]] = lev[sp];
+}
+
 int main(int argc, char **argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 400;
   std::mt19937_64 rng(20260101);
@@ -176,13 +292,27 @@ int main(int argc, char **argv) {
           }
         return 1;
       }
+      std::vector<int32_t> got2(N * N);
+      uint32_t s_got2 = 0;
+      rdoq_block_rewalk(src.data(), got2.data(), N, B, cfg, E, &s_got2);
+      if (s_want != s_got2 || memcmp(want.data(), got2.data(), sizeof(int32_t) * N * N)) {
+        printf("MISMATCH (re-walk decomposition) round %d N %d B %d luma %d scan %d root %d lambda %.3f style %d: abs sum %u vs %u\n", it, N, B,
+               cfg.is_luma, cfg.scan_idx, cfg.root_cbf, cfg.lambda, style, s_want, s_got2);
+        for (int i = 0; i < N * N; i++)
+          if (want[i] != got2[i]) {
+            printf("  first difference at (%d,%d): %d vs %d\n", i / N, i % N, want[i], got2[i]);
+            break;
+          }
+        return 1;
+      }
       checked++;
       nonzero += s_want > 0;
       (void)zeroed_like;
     }
   printf("rdoq_core_host: %ld blocks identical to the oracle (%ld with levels; %ld groups zeroed by the group decision, %ld entered with a carry, "
          "%ld changed by sign hiding)\n", checked, nonzero, g_zeroed_groups, g_carried_groups, g_sign_hidden);
-  if (!g_zeroed_groups || !g_carried_groups || !g_sign_hidden) {
+  printf("re-walk decomposition: identical too (%ld groups walked again for the last position, %ld for sign hiding)\n", g_rewalk_last, g_rewalk_hide);
+  if (!g_zeroed_groups || !g_carried_groups || !g_sign_hidden || !g_rewalk_last || !g_rewalk_hide) {
     printf("coverage hole\n");
     return 2;
   }

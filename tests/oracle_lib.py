@@ -256,7 +256,10 @@ def o_intra_frame_encode_rdoq(tus, w, h, B, qp, org, ests, lambdas, sign_hide=1)
     P3, I3 = C.c_void_p * 3, C.c_int * 3
     st = I3(w, w // 2, w // 2)
     t = np.ascontiguousarray(tus, TU_DTYPE)
-    est_arr = (EstBits * 8)(*ests)
+    est_arr = (EstBits * 8)()
+    for k in range(8):  # any structure with estBitsSbacStruct's layout (this module's EstBits, capi.EstBits)
+        assert C.sizeof(ests[k]) == C.sizeof(EstBits)
+        C.memmove(C.byref(est_arr[k]), C.byref(ests[k]), C.sizeof(EstBits))
     lam = (C.c_double * 2)(*lambdas)
     oracle().hmo_intra_frame_encode_rdoq(C.byref(cfg), t.ctypes.data, len(t), P3(*[p.ctypes.data for p in org]), st,
                                          P3(*[p.ctypes.data for p in rec]), st, P3(*[p.ctypes.data for p in lev]), est_arr, lam)

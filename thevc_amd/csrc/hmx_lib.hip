@@ -369,9 +369,10 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, cons
       if constexpr (SRC::kRdoq) { // xRateDistOptQuant in the quantiser's place (transform-skip blocks keep the flat one)
         static_assert(N >= 8, "4x4 blocks with RDOQ run in the lane-per-block chain");
         wave_sync(); // the prediction has read the reference line
-        if (gl == 0) L.line[0] = active && !ts, L.line[1] = src.picture(), L.line[2] = luma, L.line[3] = scan_idx, L.line[4] = src.cbf_ctx();
+        if (gl == 0)
+          L.line[0] = active && !ts, L.line[1] = src.picture(), L.line[2] = luma, L.line[3] = scan_idx, L.line[4] = src.cbf_ctx(), L.line[9] = src.group_slot();
         fwd_tq_block<N>(L, gl, active, row, ts, luma, luma, scan_idx, ts, P);
-        rdoq_wave_tiles<N, SL>(reinterpret_cast<TuLds<N> *>(smem), src.rdoq_ws(), src.rdoq(), P, lane);
+        rdoq_wave_tiles<N, SL>(reinterpret_cast<TuLds<N> *>(smem), src.rdoq_lds(), src.rdoq(), P, lane);
       } else {
         fwd_tq_block<N>(L, gl, active, row, ts, luma, luma, scan_idx, true, P);
       }
@@ -636,7 +637,18 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
         if (!ts) { // transform-skip blocks keep the flat quantiser
           int coef[16];
           lane4_coef(v, luma, false, P, coef);
-          rdoq_lane_4x4(coef, w, src.picture(), luma, coef_scan_idx(4, luma, true, mode), src.cbf_ctx(), src.rdoq(), P);
+          // the lane's coefficients in scan order and its levels go through its LDS rows (the reference line and the main
+          // reference are spent): no private array is indexed at run time
+          const int scan_idx = coef_scan_idx(4, luma, true, mode);
+          const bool hor = scan_idx == 1, ver = scan_idx == 2;
+          constexpr int dg[16] = {0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15}, inv_dg[16] = {0, 2, 5, 9, 1, 4, 8, 12, 3, 7, 11, 14, 6, 10, 13, 15};
+          int *c16 = LS.line[lane];
+          short *l16 = reinterpret_cast<short *>(LS.me[lane]);
+#pragma unroll
+          for (int k = 0; k < 16; k++) c16[k] = hor ? coef[k] : (ver ? coef[((k & 3) << 2) | (k >> 2)] : coef[dg[k]]);
+          rdoq_lane_4x4(c16, l16, src.picture(), src.group_slot() * 2 + (luma ? 0 : 1), luma, scan_idx, src.cbf_ctx(), src.rdoq(), src.rdoq_lds(), P);
+#pragma unroll
+          for (int q = 0; q < 16; q++) w[q] = l16[hor ? q : (ver ? (((q & 3) << 2) | (q >> 2)) : inv_dg[q])];
           flat = false;
         }
       }
@@ -740,11 +752,11 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const 
       fwd32_mfma(v, r, h, P.bit_depth, coef);
       if constexpr (SRC::kRdoq) {
         wave_sync();
-        if (lane == 0) L.line[0] = 1, L.line[1] = src.picture(), L.line[2] = luma, L.line[3] = 0, L.line[4] = src.cbf_ctx();
+        if (lane == 0) L.line[0] = 1, L.line[1] = src.picture(), L.line[2] = luma, L.line[3] = 0, L.line[4] = src.cbf_ctx(), L.line[9] = src.group_slot();
 #pragma unroll
         for (int g = 0; g < 16; g++) L.tile[mrow(g, h)][r] = coef[g];
         wave_sync();
-        rdoq_wave_tiles<32, 1>(&L, src.rdoq_ws(), src.rdoq(), P, lane);
+        rdoq_wave_tiles<32, 1>(&L, src.rdoq_lds(), src.rdoq(), P, lane);
       } else {
         quant_sbh_block<32, 64, 16, false>(
             L, lane, true, coef, [&](int k) { return mrow(k, h); }, [&](int) { return r; }, luma, 0, P);
@@ -1190,7 +1202,8 @@ struct PackedSrc {
   __device__ __forceinline__ int picture() const { return pic0 + (int)(ft.t.plane >> 2); }
   __device__ __forceinline__ int cbf_ctx() const { return (ft.t.flags >> 4) & 15; } // hmx_tu::flags bits 4..7
   __device__ __forceinline__ const RdoqChain &rdoq() const { return A->rq; }
-  __device__ __forceinline__ char *rdoq_ws() const { return A->rq.ws + (size_t)blockIdx.x * A->rq.ws_stride; }
+  __device__ __forceinline__ RdoqWaveLds &rdoq_lds() const { return *rq_lds; }
+  __device__ __forceinline__ int group_slot() const { return (int)(ft.t.plane >> 2); } // the picture's index in its group
   FTu ft;               // this lane's item, fetched during the previous wave-item
   const PackPic *gpics; // the group's pictures
   const short *org_g;   // the group's region of the pools
@@ -1205,6 +1218,7 @@ struct PackedSrc {
   PackNext *nx;
   const PackArgs *A;
   int pic0; // first picture of the group
+  RdoqWaveLds *rq_lds; // RDOQ variant: the wave's tables and buffers
 #ifdef HMX_PACK_PROFILE
   unsigned long long *pt; // [0] wait entry, [1] wait exit, [2] polls
 #endif
@@ -1276,6 +1290,12 @@ template <bool ENC, int SL4, bool SSE = false, bool RDOQ = false>
 __global__ __launch_bounds__(64, RDOQ ? 2 : 4) void k_intra_packed(PackArgs A) {
   static_assert(!RDOQ || (ENC && SL4 == 64), "RDOQ: encoder direction, 4x4 blocks one per lane");
   __shared__ __attribute__((aligned(16))) char smem[HMX_WAVE_SMEM];
+  __shared__ __attribute__((aligned(16))) char rq_raw[RDOQ ? sizeof(RdoqWaveLds) : 16];
+  RdoqWaveLds *rq_lds = reinterpret_cast<RdoqWaveLds *>(rq_raw);
+  if constexpr (RDOQ) {
+    if (lane_id() == 0) rq_lds->key = 0;
+    wave_sync();
+  }
   int xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   xcc &= 15;
@@ -1337,12 +1357,13 @@ __global__ __launch_bounds__(64, RDOQ ? 2 : 4) void k_intra_packed(PackArgs A) {
       const PackedSrc<SSE, RDOQ> src{ft, A.pics + (size_t)g * A.I, A.pool_org + greg, A.pool_rec + greg,
                           A.plane_off[1] * (uint32_t)A.I, A.plane_off[2] * (uint32_t)A.I, 64u * (uint32_t)A.I, A.ctu_w, A.clog,
                           d.dep_target ? A.done + (size_t)(d.row - (uint32_t)A.n_groups) * kDoneStride : nullptr, d.dep_target, &hdr->abort,
-                          A.sleep0, A.sleep1, &nx, &A, g * A.I
+                          A.sleep0, A.sleep1, &nx, &A, g * A.I, rq_lds
 #ifdef HMX_PACK_PROFILE
                           , pt
 #endif
       };
       wave_sync(); // the LDS scratch is re-interpreted per block size
+      if constexpr (RDOQ) rdoq_stage_tables(*rq_lds, A.rq, g, s, A.I, lane_id());
       PROF_T(p3);
       if (s == 0) {
         if constexpr (SL4 == 64) wave_chain_4_lane<ENC, true>(smem, src, A.P, n);
@@ -1604,8 +1625,6 @@ struct hmx_ctx {
     std::vector<double> lambda;   // [n][2]
     double *d_lambda = nullptr;   // [n][2], then the Int64 factors [n][2]
     size_t cap_lambda = 0;
-    char *ws = nullptr;
-    size_t cap_ws = 0;
     int max_waves = 0;            // resident waves of the RDOQ kernel variant
     uint64_t serial = 0;          // counts hmx_set_rdoq calls (part of the schedule key)
   } crq;
@@ -1790,7 +1809,6 @@ extern "C" void hmx_destroy(hmx_ctx *c) {
   hipFree(c->rdoq_ws);
   hipFree(c->crq.d_est);
   hipFree(c->crq.d_lambda);
-  hipFree(c->crq.ws);
   hipFree(c->pk.d_pics);
   hipFree(c->pk.d_rows);
   hipFree(c->pk.d_descs);
@@ -1823,6 +1841,17 @@ static int check_packed_abort(hmx_ctx *c) {
     fprintf(stderr, "[pack profile] last call: %llu wave-items, per item (us): ticket %.2f desc %.2f pre-wait %.2f wait %.2f (%.1f polls) chain %.2f drain %.2f count %.2f; "
                     "wave lifetime %.1f us avg over %d waves\n", pr[7], pr[0] / n / 100, pr[1] / n / 100, pr[2] / n / 100, pr[3] / n / 100, pr[8] / n, pr[4] / n / 100,
             pr[5] / n / 100, pr[6] / n / 100, c->pk.n_wg ? pr[9] / 100.0 / c->pk.n_wg : 0.0, c->pk.n_wg);
+    unsigned long long rq[40], zero[40] = {};
+    HIPCHK(c, hipMemcpyFromSymbol(rq, HIP_SYMBOL(g_rdoq_prof), sizeof(rq)));
+    HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_rdoq_prof), zero, sizeof(zero)));
+    if (rq[9]) fprintf(stderr, "[rdoq profile] 4x4 in a lane: %llu blocks, %.2f us each\n", rq[9], rq[0] / (double)rq[9] / 100);
+    for (int g = 1; g < 4; g++)
+      if (rq[g * 10 + 9]) {
+        const double m = (double)rq[g * 10 + 9] * 100;
+        fprintf(stderr, "[rdoq profile] %dx%d: %llu wave calls, us per call: prep %.2f walk8 %.2f resolve %.2f walk %.2f lastpos %.2f levels %.2f signhide %.2f store %.2f\n",
+                4 << g, 4 << g, rq[g * 10 + 9], rq[g * 10] / m, rq[g * 10 + 1] / m, rq[g * 10 + 2] / m, rq[g * 10 + 3] / m, rq[g * 10 + 4] / m, rq[g * 10 + 5] / m,
+                rq[g * 10 + 6] / m, rq[g * 10 + 7] / m);
+      }
   }
 #endif
   uint32_t ab = 0;
@@ -2427,6 +2456,7 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
   const bool rdoq = enc && c->crq.n > 0;
   if (rdoq) {
     if (c->crq.n != 1 && c->crq.n != n_pics) return fail(c, HMX_ERR_ARG, "frame_intra: hmx_set_rdoq described another number of pictures");
+    if (G.I > kRdoqMaxGroup) return fail(c, HMX_ERR_ARG, "frame_intra: RDOQ keeps the bit-estimate tables of a packing group in LDS: at most 4 pictures per group (HMX_PACK_GROUP)");
     G.slots4 = 64; // a 4x4 block's RDOQ runs inside one lane
   }
   const uint64_t n_rows = (uint64_t)G.max_levels * G.n_groups;
@@ -2528,9 +2558,6 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
   if (rdoq) {
 #pragma clang fp contract(off)
     auto &q = c->crq;
-    const size_t per_wave = rdoq_chain_ws_bytes();
-    int r = grow_dev(c, (void **)&q.ws, &q.cap_ws, per_wave * (size_t)pk.n_wg);
-    if (r) return r;
     // lambda and the factor of the sign-hiding cost per picture, the error scale per size: the quotients are formed here, in
     // the reference's operation order (setErrScaleCoeff TComTrQuant.cpp:2794-2818, :2205)
     const int B = A.P.bit_depth, inc = B - 8;
@@ -2556,9 +2583,8 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
     A.rq.est = q.d_est;
     A.rq.lambda = q.d_lambda;
     A.rq.rd_factor = reinterpret_cast<const long long *>(q.d_lambda + (size_t)q.n * 2);
-    A.rq.ws = q.ws;
-    A.rq.ws_stride = per_wave;
     A.rq.pic_mul = q.n == 1 ? 0 : 1;
+    A.rq.n_pics = n_pics;
   }
   const dim3 grid((unsigned)pk.n_wg), blk(64);
   if (rdoq) {

@@ -18,6 +18,7 @@
 // formed on the host.
 #pragma once
 #include "hmx_device.h"
+#include "hmx_kernels.h"
 #include "hmx_rdoq_core.h"
 
 #pragma clang fp contract(off)
@@ -505,9 +506,19 @@ __global__ __launch_bounds__(64) void k_rdoq_wave(RdoqArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// RDOQ as the quantiser of the whole-picture chain (k_intra_packed): the same lane decomposition over the SL blocks a chain
-// wave holds in LDS.  On entry Ls[b].tile[row][col] holds block b's Int coefficients (fwd_tq_block without the quantiser)
-// and Ls[b].line[0..4] = {active, picture, is_luma, scan_idx, cbf_ctx}; on exit the tile holds the levels.
+// RDOQ as the quantiser of the whole-picture chain (k_intra_packed): the second decomposition of hmx_rdoq_core.h over the
+// SL blocks a chain wave holds in LDS -- NOTHING per coefficient is stored, and nothing leaves the LDS:
+//   * the bit-estimate tables of the wave-item's pictures and size class and its scan tables are staged in LDS once per
+//     (picture group, size class) -- a walk is a chain of dependent table lookups, and from global memory every one of them
+//     was a round trip (measured: 70-210 us per round of walks);
+//   * |coef| * q and the cost of zero are recomputed from the coefficient in the tile wherever they are needed;
+//   * the variants of 64 / 8 groups at a time ("a round" = one lane per (block, group, carry, pattern)) go through a 64-entry
+//     buffer and are resolved by the block's resolving lane before the next round;
+//   * last position and sign hiding walk the chosen variant of a group AGAIN with a sink that does their arithmetic
+//     (RdoqLastSink, RdoqHideSink): a walk costs a few microseconds, an array per coefficient costs the LDS.
+// tests/native/rdoq_core_host.cpp runs exactly these steps on the CPU against the oracle.
+// On entry Ls[b].tile[row][col] holds block b's Int coefficients (fwd_tq_block without the quantiser) and Ls[b].line[0..4] =
+// {active, picture, is_luma, scan_idx, cbf_ctx}, line[9] = the picture's index in its group; on exit the tile holds the levels.
 // What the encoder takes from its live state is an input of the call (hmx_set_rdoq): per picture the bit estimates for
 // [luma, chroma][4 sizes] and lambda for luma / chroma blocks.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -515,18 +526,46 @@ struct RdoqChain {
   const EstBitsDev *est;      // [picture][luma, chroma][log2n - 2]
   const double *lambda;       // [picture][luma, chroma]
   const long long *rd_factor; // [picture][luma, chroma]
-  char *ws;                   // workspace: ws_stride bytes per persistent wave
-  size_t ws_stride;
   int pic_mul;                // 0: one set of tables for every picture of the call, 1: a set per picture
+  int n_pics;
   double err_scale[2][4];
 };
-__host__ __device__ inline size_t rdoq_chain_ws_bytes() { // the largest of 8 x 8x8, 4 x 16x16, 1 x 32x32 blocks
-  const size_t a = 8 * ((rdoq_wave_ws_bytes(3) + 255) & ~(size_t)255), b = 4 * ((rdoq_wave_ws_bytes(4) + 255) & ~(size_t)255),
-               c = (rdoq_wave_ws_bytes(5) + 255) & ~(size_t)255;
-  return a > b ? (a > c ? a : c) : (b > c ? b : c);
+constexpr int kRdoqMaxGroup = 4; // pictures per packing group with RDOQ: 2 x 4 tables of 1016 bytes in LDS
+struct RdoqWaveLds {
+  union {
+    RdoqSpec spec[64]; // the round's variants: [block][group of the round][carry * 4 + pattern]
+    double cz[1024];   // before the rounds: the costs of zero above the last position's group
+    short lev[1024];   // after them: the signed levels, scan order
+  } u;
+  double cgs[64];            // cost_cg_sig [block][group]
+  unsigned short scan[1024]; // the size class's scan tables: [scan_idx][position] (32x32: the diagonal scan only)
+  unsigned char sel[64];     // variant taken [block][group]
+  unsigned long long zeroed[8], cg_flag[8];
+  EstBitsDev est[2 * kRdoqMaxGroup]; // [picture of the group][luma, chroma], the wave-item's size class
+  int key;                           // ((group << 2) | size class) + 1 of what est / scan hold
+};
+// stage the tables of (picture group g, size class s = log2n - 2); I = pictures per group
+__device__ __forceinline__ void rdoq_stage_tables(RdoqWaveLds &W, const RdoqChain &RC, int g, int s, int I, int lane) {
+  const int key = ((g << 2) | s) + 1;
+  if (W.key == key) return; // wave-uniform
+  wave_sync();
+  constexpr int kWords = (int)(sizeof(EstBitsDev) / sizeof(int));
+  for (int i = lane; i < I * 2 * kWords; i += 64) {
+    const int tb = i / kWords, w = i - tb * kWords;
+    const int pic = min(g * I + (tb >> 1), RC.n_pics - 1) * RC.pic_mul;
+    reinterpret_cast<int *>(&W.est[tb])[w] = reinterpret_cast<const int *>(&RC.est[((size_t)pic * 2 + (tb & 1)) * 4 + s])[w];
+  }
+  if (s == 3) {
+    for (int i = lane; i < 1024; i += 64) W.scan[i] = (unsigned short)kScan32.t[0][i];
+  } else if (s > 0) {
+    const int nn = 16 << (2 * s);
+    for (int i = lane; i < 3 * nn; i += 64) W.scan[i] = (unsigned short)rdoq_scan_pos(s + 2, i / nn, i % nn);
+  }
+  if (lane == 0) W.key = key;
+  wave_sync();
 }
 template <int N>
-__device__ __forceinline__ RdoqConst rdoq_chain_const(const TuLds<N> &L, const RdoqChain &RC, const PicDev &P, const EstBitsDev *&E) {
+__device__ __forceinline__ RdoqConst rdoq_chain_const(const TuLds<N> &L, const RdoqChain &RC, const PicDev &P) {
   constexpr int LG = N == 8 ? 3 : N == 16 ? 4 : N == 32 ? 5 : 2;
   const int pic = L.line[1] * RC.pic_mul, luma = L.line[2], pt = luma ? 0 : 1;
   RdoqConst C;
@@ -535,153 +574,245 @@ __device__ __forceinline__ RdoqConst rdoq_chain_const(const TuLds<N> &L, const R
   C.qbits = 14 + (pt ? P.qd[1].per_qbits : P.qd[0].per_qbits) + (15 - P.bit_depth - LG);
   C.root_cbf = 0, C.cbf_ctx = L.line[4], C.sign_hide = P.sign_hide;
   C.lambda = RC.lambda[pic * 2 + pt], C.err_scale = RC.err_scale[pt][LG - 2], C.rd_factor = RC.rd_factor[pic * 2 + pt];
-  E = RC.est + ((size_t)pic * 2 + pt) * 4 + (LG - 2);
   return C;
 }
+template <int N>
+struct RdoqTileIn { // entry of a group from the block's coefficient tile
+  const TuLds<N> *L;
+  const RdoqConst *C;
+  __device__ __forceinline__ void operator()(int, unsigned bp, int &ld, double &cz) const {
+    constexpr int LG = N == 8 ? 3 : N == 16 ? 4 : 5;
+    rdoq_prep(L->tile[bp >> LG][bp & (N - 1)], *C, ld, cz);
+  }
+};
+template <int N>
+struct RdoqLevelSink { // the walked levels of a group, cut at the last position, signed, into LDS
+  short *out;          // the group's 16 entries
+  const TuLds<N> *L;
+  int base_sp, blp1;
+  int sum, any;
+  __device__ __forceinline__ void add(int, double) {}
+  __device__ __forceinline__ void pos(int k, unsigned bp, int level, double, double, int, int, int, int, double) {
+    constexpr int LG = N == 8 ? 3 : N == 16 ? 4 : 5;
+    const int l = base_sp + k < blp1 ? level : 0;
+    sum += l, any |= l;
+    out[k] = (short)(L->tile[bp >> LG][bp & (N - 1)] < 0 ? -l : l);
+  }
+};
+#ifdef HMX_PACK_PROFILE
+__device__ unsigned long long g_rdoq_prof[40]; // [log2n - 2][step 0..8, calls], 10 ns units
+#define RQ_T(i)                                                         \
+  if (lane == 0) {                                                      \
+    const unsigned long long now_ = wall_clock64();                     \
+    atomicAdd(&g_rdoq_prof[(LG - 2) * 10 + (i)], now_ - tprev_);        \
+    tprev_ = now_;                                                      \
+  }
+#define RQ_T0 unsigned long long tprev_ = wall_clock64()
+#define RQ_COUNT if (lane == 0) atomicAdd(&g_rdoq_prof[(LG - 2) * 10 + 9], 1ull)
+#else
+#define RQ_T(i)
+#define RQ_T0
+#define RQ_COUNT
+#endif
 template <int N, int SL>
-__device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, char *ws, const RdoqChain &RC, const PicDev &P, int lane) {
-  constexpr int LG = N == 8 ? 3 : N == 16 ? 4 : 5, NN = N * N, NCG = NN / 16;
-  const size_t stride = (rdoq_wave_ws_bytes(LG) + 255) & ~(size_t)255;
-  // line[5] = last position, [6] = last position + 1 after phase B, [7] = sum of levels, [8] = highest group with a level
+__device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, RdoqWaveLds &W, const RdoqChain &RC, const PicDev &P, int lane) {
+  constexpr int LG = N == 8 ? 3 : N == 16 ? 4 : 5, NN = N * N, NCG = NN / 16, G = N / 4;
+  constexpr int GPR = 8 / SL; // groups of a block per round: 64 lanes = SL blocks x GPR groups x 8 variants
+  static_assert(SL * NCG <= 64 && SL * NN <= 1024 && SL * GPR * 8 == 64, "one lane per group, one round per 64 variants");
+  RQ_T0;
+  // line[5] = last position, [6] = last position + 1 after the search, [7] = sum of levels, [8] = highest group with a level
   if (lane < SL) Ls[lane].line[5] = -1, Ls[lane].line[6] = 0, Ls[lane].line[7] = 0, Ls[lane].line[8] = -1;
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  for (int t = lane; t < SL * NN; t += 64) { // step 0
+  wave_sync();
+  auto scan_of = [&](int scan_idx, int sp) -> unsigned { return W.scan[(N == 32 ? 0 : scan_idx * NN) + sp]; };
+  for (int t = lane; t < SL * NN; t += 64) { // the last position with a non-zero candidate
     const int b = t / NN, sp = t - b * NN;
     TuLds<N> &L = Ls[b];
     if (!L.line[0]) continue;
-    const EstBitsDev *E;
-    const RdoqConst C = rdoq_chain_const<N>(L, RC, P, E);
-    const RdoqWs W = rdoq_ws_carve(ws + b * stride, NN);
-    const unsigned bp = rdoq_scan_pos(LG, C.scan_idx, sp);
+    const RdoqConst C = rdoq_chain_const<N>(L, RC, P);
+    const unsigned bp = scan_of(C.scan_idx, sp);
     int l;
     double z;
     rdoq_prep(L.tile[bp >> LG][bp & (N - 1)], C, l, z);
-    W.ld[sp] = l, W.cz[sp] = z;
     if (rdoq_max_level(l, C.qbits) > 0) atomicMax(&L.line[5], sp);
   }
-  rdoq_wave_fence();
-  for (int t = lane; t < SL * NCG * 8; t += 64) { // step 1
-    const int b = t / (NCG * 8), r = t - b * (NCG * 8), cg = r >> 3, v = r & 7;
-    TuLds<N> &L = Ls[b];
-    const int last_pos = L.line[5];
-    if (!L.line[0] || last_pos < 0 || cg > (last_pos >> 4)) continue;
-    const EstBitsDev *E;
-    const RdoqConst C = rdoq_chain_const<N>(L, RC, P, E);
-    const RdoqWs W = rdoq_ws_carve(ws + b * stride, NN);
-    const int scan_idx = C.scan_idx;
-    auto bp_of = [&](int sp) { return rdoq_scan_pos(LG, scan_idx, sp); };
-    RdoqSpecSink sink{&W.spec[r]};
-    W.spec[r].S = rdoq_walk_cg(C, *E, cg, bp_of, W.ld + cg * 16, W.cz + cg * 16, v & 3, v >> 2, last_pos, sink);
-  }
-  rdoq_wave_fence();
-  if (lane < SL && Ls[lane].line[0] && Ls[lane].line[5] >= 0) { // step 2
-    TuLds<N> &L = Ls[lane];
-    const EstBitsDev *E;
-    const RdoqConst C = rdoq_chain_const<N>(L, RC, P, E);
-    const RdoqWs W = rdoq_ws_carve(ws + lane * stride, NN);
-    const int scan_idx = C.scan_idx;
-    auto gpos_of = [&](int cg) {
-      const unsigned p0 = rdoq_scan_pos(LG, scan_idx, cg * 16);
-      return ((p0 & (unsigned)(N - 1)) >> 2) | (((p0 >> LG) >> 2) << 8);
-    };
-    RdoqRun R;
-    rdoq_resolve(C, *E, NCG, L.line[5] >> 4, gpos_of, W.cz, W.spec, W.sel, W.cgs, R);
-    *W.run = R;
-  }
-  rdoq_wave_fence();
-  for (int t = lane; t < SL * NCG; t += 64) { // step 3
-    const int b = t / NCG, cg = t - b * NCG;
-    TuLds<N> &L = Ls[b];
-    const int last_pos = L.line[5];
-    if (!L.line[0] || last_pos < 0) continue;
-    const RdoqWs W = rdoq_ws_carve(ws + b * stride, NN);
-    if (cg > (last_pos >> 4)) {
-      for (int k = 0; k < 16; k++) {
-        const int sp = cg * 16 + k;
-        W.lev[sp] = 0, W.cc[sp] = 0, W.cs[sp] = 0, W.ru[sp] = 0, W.rd[sp] = 0, W.sd[sp] = 0, W.du[sp] = 0;
-      }
-      continue;
-    }
-    const EstBitsDev *E;
-    const RdoqConst C = rdoq_chain_const<N>(L, RC, P, E);
-    const int scan_idx = C.scan_idx;
-    auto bp_of = [&](int sp) { return rdoq_scan_pos(LG, scan_idx, sp); };
-    RdoqFullSink sink{W.lev, W.cc, W.cs, W.ru, W.rd, W.sd, W.du, cg * 16};
-    const int v = W.sel[cg];
-    rdoq_walk_cg(C, *E, cg, bp_of, W.ld + cg * 16, W.cz + cg * 16, v & 3, v >> 2, last_pos, sink);
-    if ((W.run->zeroed >> cg) & 1) rdoq_apply_zeroed_cg(cg, W.cz, W.lev, W.cc, W.cs);
-  }
-  rdoq_wave_fence();
-  if (lane < SL && Ls[lane].line[0] && Ls[lane].line[5] >= 0) { // step 4a
-    TuLds<N> &L = Ls[lane];
-    const EstBitsDev *E;
-    const RdoqConst C = rdoq_chain_const<N>(L, RC, P, E);
-    const RdoqWs W = rdoq_ws_carve(ws + lane * stride, NN);
-    const int scan_idx = C.scan_idx;
-    auto bp_of = [&](int sp) { return rdoq_scan_pos(LG, scan_idx, sp); };
-    auto gpos_of = [&](int cg) {
-      const unsigned p0 = rdoq_scan_pos(LG, scan_idx, cg * 16);
-      return ((p0 & (unsigned)(N - 1)) >> 2) | (((p0 >> LG) >> 2) << 8);
-    };
-    L.line[6] = rdoq_phase_b(C, *E, L.line[5], L.line[5] >> 4, gpos_of, bp_of, *W.run, W.cz, W.lev, W.cc, W.cs, W.cgs);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  for (int t = lane; t < SL * NN; t += 64) { // final levels (signed), their sum, the highest group that holds one
+  wave_sync();
+  for (int t = lane; t < SL * NN; t += 64) { // the costs of zero above the last position's group, for the resolving lane
     const int b = t / NN, sp = t - b * NN;
     TuLds<N> &L = Ls[b];
-    if (!L.line[0] || L.line[5] < 0) continue;
-    const RdoqWs W = rdoq_ws_carve(ws + b * stride, NN);
-    const unsigned bp = rdoq_scan_pos(LG, L.line[3], sp);
-    const int l = sp < L.line[6] ? W.lev[sp] : 0;
-    if (l) {
-      atomicAdd(&L.line[7], l);
-      atomicMax(&L.line[8], sp >> 4);
-    }
-    W.lev[sp] = L.tile[bp >> LG][bp & (N - 1)] < 0 ? -l : l;
+    if (!L.line[0] || L.line[5] < 0 || sp < ((L.line[5] >> 4) + 1) * 16) continue;
+    const RdoqConst C = rdoq_chain_const<N>(L, RC, P);
+    const unsigned bp = scan_of(C.scan_idx, sp);
+    int l;
+    double z;
+    rdoq_prep(L.tile[bp >> LG][bp & (N - 1)], C, l, z);
+    W.u.cz[t] = z;
   }
-  rdoq_wave_fence();
-  if (P.sign_hide) {
-    for (int t = lane; t < SL * NCG; t += 64) { // step 4c
-      const int b = t / NCG, cg = t - b * NCG;
+  wave_sync();
+  RQ_T(0);
+  // ---- the resolving lane of block b is lane b: its running state stays in its registers
+  const bool resolver = lane < SL && Ls[lane < SL ? lane : 0].line[0] && Ls[lane < SL ? lane : 0].line[5] >= 0;
+  TuLds<N> &LR = Ls[lane < SL ? lane : 0];
+  RdoqConst CR;
+  RdoqRun R;
+  int carry = 0, rounds = 0;
+  const int my_last_pos = LR.line[5], my_last_cg = my_last_pos >> 4;
+  if (resolver) {
+    CR = rdoq_chain_const<N>(LR, RC, P);
+    rdoq_run_init(R);
+    for (int sp = NN - 1; sp >= (my_last_cg + 1) * 16; sp--) rdoq_resolve_above(R, W.u.cz[lane * NN + sp]);
+    rounds = (my_last_cg + GPR) / GPR;
+  }
+  for (int off = 32; off > 0; off >>= 1) rounds = max(rounds, __shfl_xor(rounds, off, 64));
+  wave_sync(); // the buffer changes hands
+  RQ_T(1);
+  const EstBitsDev &ER = W.est[LR.line[9] * 2 + (LR.line[2] ? 0 : 1)];
+  for (int r = 0; r < rounds; r++) {
+    { // one lane per (block, group of the round, carry, pattern)
+      const int b = lane / (GPR * 8), j = (lane >> 3) % GPR, v = lane & 7;
       TuLds<N> &L = Ls[b];
-      if (!L.line[0] || L.line[5] < 0 || L.line[7] < 2) continue;
-      const EstBitsDev *E;
-      const RdoqConst C = rdoq_chain_const<N>(L, RC, P, E);
-      const RdoqWs W = rdoq_ws_carve(ws + b * stride, NN);
-      int l16[16];
-      unsigned neg = 0;
-      bool any = false;
-      for (int k = 0; k < 16; k++) {
-        l16[k] = W.lev[cg * 16 + k];
-        any |= l16[k] != 0;
-        const unsigned bp = rdoq_scan_pos(LG, C.scan_idx, cg * 16 + k);
-        neg |= (L.tile[bp >> LG][bp & (N - 1)] < 0 ? 1u : 0u) << k;
+      const int last_pos = L.line[5], cg = (last_pos >> 4) - r * GPR - j;
+      if (L.line[0] && last_pos >= 0 && cg >= 0) {
+        const RdoqConst C = rdoq_chain_const<N>(L, RC, P);
+        const EstBitsDev &E = W.est[L.line[9] * 2 + (L.line[2] ? 0 : 1)];
+        const int scan_idx = C.scan_idx;
+        auto bp_of = [&](int sp) { return scan_of(scan_idx, sp); };
+        RdoqSpecSink sink{&W.u.spec[lane]};
+        const RdoqCgSums S = rdoq_walk_cg_in(C, E, cg, bp_of, RdoqTileIn<N>{&L, &C}, v & 3, v >> 2, last_pos, sink);
+        W.u.spec[lane].S = S;
       }
-      if (!any) continue;
-      rdoq_phase_c_cg(C, cg == L.line[8], l16, neg, W.ru + cg * 16, W.rd + cg * 16, W.sd + cg * 16, W.du + cg * 16);
-      for (int k = 0; k < 16; k++) W.lev[cg * 16 + k] = l16[k];
     }
-    rdoq_wave_fence();
+    wave_sync();
+    if (resolver) {
+      for (int j = 0; j < GPR; j++) {
+        const int cg = my_last_cg - r * GPR - j;
+        if (cg < 0) break;
+        const unsigned p0 = scan_of(CR.scan_idx, cg * 16), g = ((p0 & (unsigned)(N - 1)) >> 2) | (((p0 >> LG) >> 2) << 8);
+        const int scan_idx = CR.scan_idx;
+        auto cz_of = [&](int k) {
+          const unsigned bp = scan_of(scan_idx, cg * 16 + k);
+          int l;
+          double z;
+          rdoq_prep(LR.tile[bp >> LG][bp & (N - 1)], CR, l, z);
+          return z;
+        };
+        double cg_sig;
+        const int v = rdoq_resolve_group(CR, ER, cg, my_last_cg, g, &W.u.spec[(lane * GPR + j) * 8], cz_of, R, carry, cg_sig);
+        W.sel[lane * NCG + cg] = (unsigned char)v;
+        W.cgs[lane * NCG + cg] = cg_sig;
+      }
+    }
+    wave_sync();
   }
+  RQ_T(2);
+  if (resolver) { // the last position: coded groups walked once more, from the top, until a level above 1 ends the search
+    RdoqLast T;
+    rdoq_last_init(CR, ER, R, T);
+    const int scan_idx = CR.scan_idx;
+    auto bp_of = [&](int sp) { return scan_of(scan_idx, sp); };
+    for (int cg = my_last_cg; cg >= 0 && !T.found; cg--) {
+      const unsigned p0 = scan_of(scan_idx, cg * 16), gpos = ((p0 >> LG) >> 2) * (unsigned)G + ((p0 & (unsigned)(N - 1)) >> 2);
+      rdoq_last_group(T, W.cgs[lane * NCG + cg]);
+      if (!((R.cg_flag >> gpos) & 1)) continue;
+      RdoqLastSink sink{CR, ER, T, cg * 16, my_last_pos};
+      const int v = W.sel[lane * NCG + cg];
+      rdoq_walk_cg_in(CR, ER, cg, bp_of, RdoqTileIn<N>{&LR, &CR}, v & 3, v >> 2, my_last_pos, sink);
+    }
+    LR.line[6] = T.best_last_p1;
+    W.zeroed[lane] = R.zeroed;
+  }
+  wave_sync(); // and the buffer changes hands again: levels
+  RQ_T(3);
+  if (lane < SL * NCG) { // one lane per (block, group): the levels
+    const int b = lane / NCG, cg = lane - b * NCG;
+    TuLds<N> &L = Ls[b];
+    short *out = &W.u.lev[b * NN + cg * 16];
+    const int last_pos = L.line[5];
+    bool walked = false;
+    if (L.line[0] && last_pos >= 0 && cg <= (last_pos >> 4) && !((W.zeroed[b] >> cg) & 1) && cg * 16 < L.line[6]) {
+      const RdoqConst C = rdoq_chain_const<N>(L, RC, P);
+      const EstBitsDev &E = W.est[L.line[9] * 2 + (L.line[2] ? 0 : 1)];
+      const int scan_idx = C.scan_idx;
+      auto bp_of = [&](int sp) { return scan_of(scan_idx, sp); };
+      RdoqLevelSink<N> sink{out, &L, cg * 16, L.line[6], 0, 0};
+      const int v = W.sel[b * NCG + cg];
+      rdoq_walk_cg_in(C, E, cg, bp_of, RdoqTileIn<N>{&L, &C}, v & 3, v >> 2, last_pos, sink);
+      if (sink.any) {
+        atomicAdd(&L.line[7], sink.sum);
+        atomicMax(&L.line[8], cg);
+      }
+      walked = true;
+    }
+    if (!walked) {
+#pragma unroll
+      for (int k = 0; k < 16; k += 4) *reinterpret_cast<uint2 *>(out + k) = make_uint2(0u, 0u);
+    }
+  }
+  wave_sync();
+  RQ_T(4);
+  if (P.sign_hide && lane < SL * NCG) { // one lane per (block, group): rate-aware sign hiding, the group walked a third time
+    const int b = lane / NCG, cg = lane - b * NCG;
+    TuLds<N> &L = Ls[b];
+    short *l16 = &W.u.lev[b * NN + cg * 16];
+    if (L.line[0] && L.line[5] >= 0 && L.line[7] >= 2 && cg <= L.line[8]) {
+      auto lev_of = [l16](int n) { return (int)l16[n]; };
+      RdoqHide H;
+      if (rdoq_hide_begin(cg == L.line[8], lev_of, H)) { // implies the group holds a level: it was walked above
+        const RdoqConst C = rdoq_chain_const<N>(L, RC, P);
+        const EstBitsDev &E = W.est[L.line[9] * 2 + (L.line[2] ? 0 : 1)];
+        const int scan_idx = C.scan_idx;
+        auto bp_of = [&](int sp) { return scan_of(scan_idx, sp); };
+        unsigned neg = 0;
+        for (int k = 0; k < 16; k++) {
+          const unsigned bp = bp_of(cg * 16 + k);
+          neg |= (L.tile[bp >> LG][bp & (N - 1)] < 0 ? 1u : 0u) << k;
+        }
+        RdoqHideSink<decltype(lev_of)> sink{C, H, lev_of, neg};
+        const int v = W.sel[b * NCG + cg];
+        rdoq_walk_cg_in(C, E, cg, bp_of, RdoqTileIn<N>{&L, &C}, v & 3, v >> 2, L.line[5], sink);
+        if (H.min_pos >= 0) l16[H.min_pos] = (short)(l16[H.min_pos] + rdoq_hide_change(H, (neg >> H.min_pos) & 1u));
+      }
+    }
+  }
+  wave_sync();
+  RQ_T(5);
   for (int t = lane; t < SL * NN; t += 64) { // the levels take the coefficients' place in the tile
     const int b = t / NN, sp = t - b * NN;
     TuLds<N> &L = Ls[b];
     if (!L.line[0]) continue;
-    const unsigned bp = rdoq_scan_pos(LG, L.line[3], sp);
-    L.tile[bp >> LG][bp & (N - 1)] = L.line[5] < 0 ? 0 : rdoq_ws_carve(ws + b * stride, NN).lev[sp];
+    const unsigned bp = scan_of(L.line[3], sp);
+    L.tile[bp >> LG][bp & (N - 1)] = L.line[5] < 0 ? 0 : (int)W.u.lev[t];
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  wave_sync();
+  RQ_T(6);
+  RQ_COUNT;
 }
 
-// One 4x4 block in ONE lane (the lane-per-block 4x4 chain): a single coefficient group, so no speculation -- walk, resolve,
-// last position, sign hiding in sequence with the core's functions, on private arrays.  coef / lev: raster order.
-__device__ __forceinline__ void rdoq_lane_4x4(const int *coef, int *lev_out, int pic, bool luma, int scan_idx, int cbf_ctx, const RdoqChain &RC,
-                                              const PicDev &P) {
+// One 4x4 block in ONE lane (the lane-per-block 4x4 chain): a single coefficient group, so no variants -- the walk with a
+// sink that keeps the two running sums, then the same re-walks as above.  The lane's coefficients (scan order) and levels
+// live in its LDS rows (c16: 16 ints; l16: 16 shorts), nothing in private arrays.  Returns the levels in l16, scan order.
+struct RdoqSumSink { // resolve of a single group: the terms arrive in the order the reference adds them
+  RdoqRun &R;
+  HMX_HD void add(int, double v) { R.base += v; }
+  HMX_HD void pos(int, unsigned, int, double, double, int, int, int, int, double cz) { R.uncoded += cz; }
+};
+struct RdoqLaneIn {
+  const int *c16;
+  const RdoqConst *C;
+  __device__ __forceinline__ void operator()(int k, unsigned, int &ld, double &cz) const { rdoq_prep(c16[k], *C, ld, cz); }
+};
+struct RdoqLaneLevelSink {
+  short *out;
+  const int *c16;
+  int blp1, sum;
+  __device__ __forceinline__ void add(int, double) {}
+  __device__ __forceinline__ void pos(int k, unsigned, int level, double, double, int, int, int, int, double) {
+    const int l = k < blp1 ? level : 0;
+    sum += l;
+    out[k] = (short)(c16[k] < 0 ? -l : l);
+  }
+};
+__device__ __forceinline__ void rdoq_lane_4x4(const int *c16, short *l16, int pic, int est_slot, bool luma, int scan_idx, int cbf_ctx,
+                                              const RdoqChain &RC, const RdoqWaveLds &W, const PicDev &P) {
   const int pt = luma ? 0 : 1;
   pic *= RC.pic_mul;
   RdoqConst C;
@@ -690,41 +821,49 @@ __device__ __forceinline__ void rdoq_lane_4x4(const int *coef, int *lev_out, int
   C.qbits = 14 + (pt ? P.qd[1].per_qbits : P.qd[0].per_qbits) + (15 - P.bit_depth - 2);
   C.root_cbf = 0, C.cbf_ctx = cbf_ctx, C.sign_hide = P.sign_hide;
   C.lambda = RC.lambda[pic * 2 + pt], C.err_scale = RC.err_scale[pt][0], C.rd_factor = RC.rd_factor[pic * 2 + pt];
-  const EstBitsDev &E = RC.est[((size_t)pic * 2 + pt) * 4];
-  auto bp_of = [&](int sp) { return (unsigned)kScan4.t[scan_idx][sp]; };
-  auto gpos_of = [](int) { return 0u; };
-  int ld[16], lev[16], ru[16], rd[16], sd[16], du[16];
-  double cz[16], cc[16], cs[16], cgs[1];
+  const EstBitsDev &E = W.est[est_slot];
+  auto bp_of = [scan_idx](int sp) { // raster position of scan entry sp of a 4x4 block
+    const unsigned dg = (unsigned)((0xfbe7ad369c258140ull >> (4 * sp)) & 15), ver = (unsigned)(((sp & 3) << 2) | (sp >> 2));
+    return scan_idx == 1 ? (unsigned)sp : (scan_idx == 2 ? ver : dg);
+  };
+  const RdoqLaneIn in{c16, &C};
   int last_pos = -1;
   for (int sp = 0; sp < 16; sp++) {
-    rdoq_prep(coef[bp_of(sp)], C, ld[sp], cz[sp]);
-    if (rdoq_max_level(ld[sp], C.qbits) > 0) last_pos = sp;
+    int l;
+    double z;
+    rdoq_prep(c16[sp], C, l, z);
+    if (rdoq_max_level(l, C.qbits) > 0) last_pos = sp;
   }
-  for (int k = 0; k < 16; k++) lev_out[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) reinterpret_cast<int *>(l16)[k] = 0; // (rows of 13 ints: 4-byte aligned)
   if (last_pos < 0) return;
-  RdoqSpec spec[1]; // the only variant a single group can take: no carry in, no neighbours
-  {
-    RdoqSpecSink sink{&spec[0]};
-    spec[0].S = rdoq_walk_cg(C, E, 0, bp_of, ld, cz, 0, 0, last_pos, sink);
-  }
-  unsigned char sel[1];
   RdoqRun R;
-  rdoq_resolve(C, E, 1, 0, gpos_of, cz, spec, sel, cgs, R);
+  rdoq_run_init(R);
   {
-    RdoqFullSink sink{lev, cc, cs, ru, rd, sd, du, 0};
-    rdoq_walk_cg(C, E, 0, bp_of, ld, cz, 0, 0, last_pos, sink);
+    RdoqSumSink sink{R};
+    rdoq_walk_cg_in(C, E, 0, bp_of, in, 0, 0, last_pos, sink);
   }
-  const int blp1 = rdoq_phase_b(C, E, last_pos, 0, gpos_of, bp_of, R, cz, lev, cc, cs, cgs);
-  int sum = 0;
-  unsigned neg = 0;
-  for (int sp = 0; sp < 16; sp++) {
-    const int l = sp < blp1 ? lev[sp] : 0, c = coef[bp_of(sp)];
-    sum += l;
-    lev[sp] = c < 0 ? -l : l;
-    neg |= (c < 0 ? 1u : 0u) << sp;
+  R.cg_flag = 1; // group 0 always counts as coded (:2088)
+  RdoqLast T;
+  rdoq_last_init(C, E, R, T);
+  rdoq_last_group(T, 0.0);
+  {
+    RdoqLastSink sink{C, E, T, 0, last_pos};
+    rdoq_walk_cg_in(C, E, 0, bp_of, in, 0, 0, last_pos, sink);
   }
-  if (C.sign_hide && sum >= 2) rdoq_phase_c_cg(C, true, lev, neg, ru, rd, sd, du);
-  for (int sp = 0; sp < 16; sp++) lev_out[bp_of(sp)] = lev[sp];
+  RdoqLaneLevelSink lsink{l16, c16, T.best_last_p1, 0};
+  rdoq_walk_cg_in(C, E, 0, bp_of, in, 0, 0, last_pos, lsink);
+  if (C.sign_hide && lsink.sum >= 2) {
+    auto lev_of = [l16](int n) { return (int)l16[n]; };
+    RdoqHide H;
+    if (rdoq_hide_begin(true, lev_of, H)) {
+      unsigned neg = 0;
+      for (int k = 0; k < 16; k++) neg |= (c16[k] < 0 ? 1u : 0u) << k;
+      RdoqHideSink<decltype(lev_of)> sink{C, H, lev_of, neg};
+      rdoq_walk_cg_in(C, E, 0, bp_of, in, 0, 0, last_pos, sink);
+      if (H.min_pos >= 0) l16[H.min_pos] = (short)(l16[H.min_pos] + rdoq_hide_change(H, (neg >> H.min_pos) & 1u));
+    }
+  }
 }
 
 } // namespace hmx

@@ -169,9 +169,12 @@ struct RdoqCgSums { // what the group-level decision needs of a walked group
 // ignored for 4x4 blocks; carry_in: the previous group's carry (ignored in the group of the last position, whose state starts
 // there).  Sink: add(k, term) the term the running cost receives for entry k; pos(k, level, cc, cs, rate_up, rate_down,
 // sig_delta, delta_u) everything else about it.
-template <typename BpFn, typename Sink>
-HMX_HD RdoqCgSums rdoq_walk_cg(const RdoqConst &C, const EstBitsDev &E, int cg, BpFn bp_of, const int *ld16, const double *cz16, int pattern,
-                               int carry_in, int last_pos, Sink &sink) {
+// in(k, bp, ld, cz): entry k of the group (block position bp) as rdoq_prep leaves it (from arrays, or computed on the spot
+// from the coefficient).  Sink: add(k, term) the term the running cost receives for entry k; pos(k, bp, level, cc, cs, rate_up,
+// rate_down, sig_delta, delta_u, cz) everything else about it.
+template <typename BpFn, typename InFn, typename Sink>
+HMX_HD RdoqCgSums rdoq_walk_cg_in(const RdoqConst &C, const EstBitsDev &E, int cg, BpFn bp_of, InFn in, int pattern, int carry_in, int last_pos,
+                                  Sink &sink) {
   const int lg = C.lg, N = 1 << lg, qbits = C.qbits;
   const bool is_luma = C.is_luma != 0;
   const double lambda = C.lambda, err_scale = C.err_scale;
@@ -182,8 +185,11 @@ HMX_HD RdoqCgSums rdoq_walk_cg(const RdoqConst &C, const EstBitsDev &E, int cg, 
   S.s_sig = 0, S.s_sig0 = 0, S.s_coded = 0, S.s_uncoded = 0;
   S.nz_mask = 0, S.nnz_before0 = 0;
   for (int k = 15; k >= 0; k--) {
-    const int sp = cg * 16 + k, ld = ld16[k];
-    const double cz = cz16[k];
+    const int sp = cg * 16 + k;
+    const unsigned bp = bp_of(sp);
+    int ld;
+    double cz;
+    in(k, bp, ld, cz);
     const unsigned max_lvl = rdoq_max_level(ld, qbits);
     int out_level = (int)max_lvl;
     double cc = 0, cs = 0;
@@ -192,7 +198,6 @@ HMX_HD RdoqCgSums rdoq_walk_cg(const RdoqConst &C, const EstBitsDev &E, int cg, 
       sink.add(k, cz);
     } else {
       if (sp == last_pos) ctx_set = (sp < 16 || !is_luma) ? 0u : 2u; // the state starts here: c1 = 1, c2 = 0, no carry
-      const unsigned bp = bp_of(sp);
       const unsigned ctx1 = 4 * ctx_set + (unsigned)c1, ctx2 = ctx_set + (unsigned)c2;
       const bool is_last = sp == last_pos;
       unsigned ctx_sig = 0;
@@ -242,7 +247,7 @@ HMX_HD RdoqCgSums rdoq_walk_cg(const RdoqConst &C, const EstBitsDev &E, int cg, 
         c1++;
       }
     }
-    sink.pos(k, out_level, cc, cs, r_up, r_down, sdel, du);
+    sink.pos(k, bp, out_level, cc, cs, r_up, r_down, sdel, du, cz);
     S.s_sig += cs;
     if (k == 0) S.s_sig0 = cs;
     if (out_level) {
@@ -255,6 +260,16 @@ HMX_HD RdoqCgSums rdoq_walk_cg(const RdoqConst &C, const EstBitsDev &E, int cg, 
   S.carry_out = c1 == 0;
   return S;
 }
+struct RdoqArrayIn { // the group's entries from arrays in scan order
+  const int *ld16;
+  const double *cz16;
+  HMX_HD void operator()(int k, unsigned, int &ld, double &cz) const { ld = ld16[k], cz = cz16[k]; }
+};
+template <typename BpFn, typename Sink>
+HMX_HD RdoqCgSums rdoq_walk_cg(const RdoqConst &C, const EstBitsDev &E, int cg, BpFn bp_of, const int *ld16, const double *cz16, int pattern,
+                               int carry_in, int last_pos, Sink &sink) {
+  return rdoq_walk_cg_in(C, E, cg, bp_of, RdoqArrayIn{ld16, cz16}, pattern, carry_in, last_pos, sink);
+}
 
 struct RdoqSpec { // one (group, carry, pattern) variant of step 1
   double add[16];
@@ -263,7 +278,7 @@ struct RdoqSpec { // one (group, carry, pattern) variant of step 1
 struct RdoqSpecSink {
   RdoqSpec *o;
   HMX_HD void add(int k, double v) { o->add[k] = v; }
-  HMX_HD void pos(int, int, double, double, int, int, int, int) {}
+  HMX_HD void pos(int, unsigned, int, double, double, int, int, int, int, double) {}
 };
 struct RdoqFullSink { // step 3: everything about the chosen variant, scan order
   int *lev;
@@ -271,7 +286,7 @@ struct RdoqFullSink { // step 3: everything about the chosen variant, scan order
   int *rate_up, *rate_down, *sig_delta, *delta_u;
   int base; // cg * 16
   HMX_HD void add(int, double) {}
-  HMX_HD void pos(int k, int level, double cc, double cs, int ru, int rd, int sd, int du) {
+  HMX_HD void pos(int k, unsigned, int level, double cc, double cs, int ru, int rd, int sd, int du, double) {
     const int sp = base + k;
     lev[sp] = level, cost_coded[sp] = cc, cost_sig[sp] = cs;
     rate_up[sp] = ru, rate_down[sp] = rd, sig_delta[sp] = sd, delta_u[sp] = du;
@@ -284,66 +299,80 @@ struct RdoqRun { // the running quantities of the serial pass
   unsigned long long zeroed;  // by group index in scan order: the group-level decision zeroed it
 };
 
-// Step 2, ONE lane: groups n_cg-1 .. 0 in the reference's order.  gpos_of(cg) -> gx | gy << 8.  spec[cg * 8 + carry * 4 + pattern].
-// sel[cg] = the variant taken (0xff above the last position's group); cost_cg_sig[cg] as the reference keeps it.
+// Step 2, ONE lane: groups n_cg-1 .. 0 in the reference's order, in pieces so that the caller decides where the 8 variants
+// of a group and the costs of zero come from.
+HMX_HD void rdoq_run_init(RdoqRun &R) { R.base = 0, R.uncoded = 0, R.cg_flag = 0, R.zeroed = 0; }
+// a coefficient above the last position's group: it stays zero and costs its distortion
+HMX_HD void rdoq_resolve_above(RdoqRun &R, double cz) {
+  R.uncoded += cz;
+  R.base += cz;
+}
+// group cg <= last_cg.  gpos = gx | gy << 8; spec8 = the group's variants [carry * 4 + pattern]; cz_of(k) the cost of zero of
+// entry k; carry: the previous group's (in/out).  Returns the variant taken; cg_sig = cost_cg_sig[cg] as the reference keeps it.
+template <typename CzFn>
+HMX_HD int rdoq_resolve_group(const RdoqConst &C, const EstBitsDev &E, int cg, int last_cg, unsigned g, const RdoqSpec *spec8, CzFn cz_of, RdoqRun &R,
+                              int &carry, double &cg_sig) {
+  const int N = 1 << C.lg, G = N >> 2;
+  const double lambda = C.lambda;
+  cg_sig = 0;
+  const unsigned gx = g & 255u, gy = g >> 8, gpos = gy * (unsigned)G + gx;
+  const unsigned right = gx < (unsigned)G - 1 ? (unsigned)((R.cg_flag >> (gy * G + gx + 1)) & 1) : 0u;
+  const unsigned lower = gy < (unsigned)G - 1 ? (unsigned)((R.cg_flag >> ((gy + 1) * G + gx)) & 1) : 0u;
+  const int v = (cg == last_cg ? 0 : carry * 4) + (int)(right + (lower << 1));
+  const RdoqSpec &S = spec8[v];
+  for (int k = 15; k >= 0; k--) {
+    R.uncoded += cz_of(k);
+    R.base += S.add[k];
+  }
+  double s_sig = S.S.s_sig;
+  if (S.S.nz_mask) R.cg_flag |= 1ull << gpos;
+  // the group-level decision (:1992-2089); last_cg >= 0 here
+  if (cg) {
+    const unsigned cctx = (right || lower) ? 1u : 0u; // the neighbours' flags have not changed since the pattern was formed
+    if (!((R.cg_flag >> gpos) & 1)) {
+      R.base += lambda * E.sig_cg[cctx][0] - s_sig;
+      cg_sig = lambda * E.sig_cg[cctx][0];
+    } else if (cg < last_cg) {
+      if (S.S.nnz_before0 == 0) {
+        R.base -= S.S.s_sig0;
+        s_sig -= S.S.s_sig0;
+      }
+      double zero_cost = R.base;
+      R.base += lambda * E.sig_cg[cctx][1];
+      zero_cost += lambda * E.sig_cg[cctx][0];
+      cg_sig = lambda * E.sig_cg[cctx][1];
+      zero_cost += S.S.s_uncoded;
+      zero_cost -= S.S.s_coded;
+      zero_cost -= s_sig;
+      if (zero_cost < R.base) {
+        R.cg_flag &= ~(1ull << gpos);
+        R.base = zero_cost;
+        cg_sig = lambda * E.sig_cg[cctx][0];
+        R.zeroed |= 1ull << cg;
+      }
+    }
+  } else {
+    R.cg_flag |= 1ull << gpos;
+  }
+  carry = S.S.carry_out;
+  return v;
+}
+// the whole pass over arrays: spec[cg * 8 + carry * 4 + pattern], cz in scan order.  gpos_of(cg) -> gx | gy << 8.
+// sel[cg] = the variant taken (0xff above the last position's group).
 template <typename GposFn>
 HMX_HD void rdoq_resolve(const RdoqConst &C, const EstBitsDev &E, int n_cg, int last_cg, GposFn gpos_of, const double *cz, const RdoqSpec *spec,
                          unsigned char *sel, double *cost_cg_sig, RdoqRun &R) {
-  const int N = 1 << C.lg, G = N >> 2;
-  const double lambda = C.lambda;
-  R.base = 0, R.uncoded = 0, R.cg_flag = 0, R.zeroed = 0;
+  rdoq_run_init(R);
   int carry = 0;
   for (int cg = n_cg - 1; cg >= 0; cg--) {
-    cost_cg_sig[cg] = 0;
     if (cg > last_cg) {
-      for (int k = 15; k >= 0; k--) {
-        R.uncoded += cz[cg * 16 + k];
-        R.base += cz[cg * 16 + k];
-      }
+      cost_cg_sig[cg] = 0;
+      for (int k = 15; k >= 0; k--) rdoq_resolve_above(R, cz[cg * 16 + k]);
       sel[cg] = 0xff;
       continue;
     }
-    const unsigned g = gpos_of(cg), gx = g & 255u, gy = g >> 8, gpos = gy * (unsigned)G + gx;
-    const unsigned right = gx < (unsigned)G - 1 ? (unsigned)((R.cg_flag >> (gy * G + gx + 1)) & 1) : 0u;
-    const unsigned lower = gy < (unsigned)G - 1 ? (unsigned)((R.cg_flag >> ((gy + 1) * G + gx)) & 1) : 0u;
-    const int v = (cg == last_cg ? 0 : carry * 4) + (int)(right + (lower << 1));
-    sel[cg] = (unsigned char)v;
-    const RdoqSpec &S = spec[cg * 8 + v];
-    for (int k = 15; k >= 0; k--) {
-      R.uncoded += cz[cg * 16 + k];
-      R.base += S.add[k];
-    }
-    double s_sig = S.S.s_sig;
-    if (S.S.nz_mask) R.cg_flag |= 1ull << gpos;
-    // the group-level decision (:1992-2089); last_cg >= 0 here
-    if (cg) {
-      const unsigned cctx = (right || lower) ? 1u : 0u; // the neighbours' flags have not changed since the pattern was formed
-      if (!((R.cg_flag >> gpos) & 1)) {
-        R.base += lambda * E.sig_cg[cctx][0] - s_sig;
-        cost_cg_sig[cg] = lambda * E.sig_cg[cctx][0];
-      } else if (cg < last_cg) {
-        if (S.S.nnz_before0 == 0) {
-          R.base -= S.S.s_sig0;
-          s_sig -= S.S.s_sig0;
-        }
-        double zero_cost = R.base;
-        R.base += lambda * E.sig_cg[cctx][1];
-        zero_cost += lambda * E.sig_cg[cctx][0];
-        cost_cg_sig[cg] = lambda * E.sig_cg[cctx][1];
-        zero_cost += S.S.s_uncoded;
-        zero_cost -= S.S.s_coded;
-        zero_cost -= s_sig;
-        if (zero_cost < R.base) {
-          R.cg_flag &= ~(1ull << gpos);
-          R.base = zero_cost;
-          cost_cg_sig[cg] = lambda * E.sig_cg[cctx][0];
-          R.zeroed |= 1ull << cg;
-        }
-      }
-    } else {
-      R.cg_flag |= 1ull << gpos;
-    }
-    carry = S.S.carry_out;
+    const double *cz16 = cz + cg * 16;
+    sel[cg] = (unsigned char)rdoq_resolve_group(C, E, cg, last_cg, gpos_of(cg), spec + cg * 8, [cz16](int k) { return cz16[k]; }, R, carry, cost_cg_sig[cg]);
   }
 }
 
@@ -359,109 +388,161 @@ HMX_HD void rdoq_apply_zeroed_cg(int cg, const double *cz, int *lev, double *cos
   }
 }
 
-// Step 4a, one lane: the last significant position (:2132-2200).  Returns best_last_p1; R.base / R.uncoded as rdoq_resolve left them.
+// Step 4a, one lane: the last significant position (:2132-2200), in pieces: the running state, the entry of a group, one
+// position of a coded group (k = 15..0, only sp <= last_pos).
+struct RdoqLast {
+  double base, best_cost;
+  int best_last_p1;
+  int found;
+};
+HMX_HD void rdoq_last_init(const RdoqConst &C, const EstBitsDev &E, const RdoqRun &R, RdoqLast &T) {
+  const double lambda = C.lambda;
+  T.base = R.base;
+  if (C.root_cbf) {
+    T.best_cost = R.uncoded + lambda * E.root_cbf[0][0];
+    T.base += lambda * E.root_cbf[0][1];
+  } else {
+    T.best_cost = R.uncoded + lambda * E.cbf[C.cbf_ctx][0];
+    T.base += lambda * E.cbf[C.cbf_ctx][1];
+  }
+  T.best_last_p1 = 0, T.found = 0;
+}
+HMX_HD void rdoq_last_group(RdoqLast &T, double cost_cg_sig) { T.base -= cost_cg_sig; } // every group visited before the search ends
+HMX_HD void rdoq_last_pos(const RdoqConst &C, const EstBitsDev &E, RdoqLast &T, int sp, unsigned bp, int lv, double cost_coded, double cost_sig,
+                          double cz) {
+  if (lv) {
+    const unsigned py = bp >> C.lg, px = bp & (unsigned)((1 << C.lg) - 1);
+    const double lc = C.scan_idx == 2 ? rdoq_last_cost(E, C.lambda, py, px) : rdoq_last_cost(E, C.lambda, px, py);
+    const double total = T.base + lc - cost_sig;
+    if (total < T.best_cost) {
+      T.best_last_p1 = sp + 1;
+      T.best_cost = total;
+    }
+    if (lv > 1) {
+      T.found = 1;
+      return;
+    }
+    T.base -= cost_coded;
+    T.base += cz;
+  } else {
+    T.base -= cost_sig;
+  }
+}
+// the search as a sink of the walk: the chosen variant of a coded group walked again, nothing stored
+struct RdoqLastSink {
+  const RdoqConst &C;
+  const EstBitsDev &E;
+  RdoqLast &T;
+  int base_sp, last_pos;
+  HMX_HD void add(int, double) {}
+  HMX_HD void pos(int k, unsigned bp, int level, double cc, double cs, int, int, int, int, double cz) {
+    const int sp = base_sp + k;
+    if (T.found || sp > last_pos) return;
+    rdoq_last_pos(C, E, T, sp, bp, level, cc, cs, cz);
+  }
+};
+// the search over arrays.  Returns best_last_p1; R.base / R.uncoded as rdoq_resolve left them.
 template <typename GposFn, typename BpFn>
 HMX_HD int rdoq_phase_b(const RdoqConst &C, const EstBitsDev &E, int last_pos, int last_cg, GposFn gpos_of, BpFn bp_of, const RdoqRun &Rin,
                         const double *cz, const int *lev, const double *cost_coded, const double *cost_sig, const double *cost_cg_sig) {
-  const int lg = C.lg, N = 1 << lg, G = N >> 2;
-  const double lambda = C.lambda;
-  double base = Rin.base, best_cost;
-  if (C.root_cbf) {
-    best_cost = Rin.uncoded + lambda * E.root_cbf[0][0];
-    base += lambda * E.root_cbf[0][1];
-  } else {
-    best_cost = Rin.uncoded + lambda * E.cbf[C.cbf_ctx][0];
-    base += lambda * E.cbf[C.cbf_ctx][1];
-  }
-  int best_last_p1 = 0;
-  bool found = false;
-  for (int cg = last_cg; cg >= 0 && !found; cg--) {
+  const int G = (1 << C.lg) >> 2;
+  RdoqLast T;
+  rdoq_last_init(C, E, Rin, T);
+  for (int cg = last_cg; cg >= 0 && !T.found; cg--) {
     const unsigned g = gpos_of(cg), gpos = (g >> 8) * (unsigned)G + (g & 255u);
-    base -= cost_cg_sig[cg];
+    rdoq_last_group(T, cost_cg_sig[cg]);
     if (!((Rin.cg_flag >> gpos) & 1)) continue;
-    for (int k = 15; k >= 0; k--) {
+    for (int k = 15; k >= 0 && !T.found; k--) {
       const int sp = cg * 16 + k;
       if (sp > last_pos) continue;
-      const int lv = lev[sp];
-      if (lv) {
-        const unsigned bp = bp_of(sp), py = bp >> lg, px = bp & (unsigned)(N - 1);
-        const double lc = C.scan_idx == 2 ? rdoq_last_cost(E, lambda, py, px) : rdoq_last_cost(E, lambda, px, py);
-        const double total = base + lc - cost_sig[sp];
-        if (total < best_cost) {
-          best_last_p1 = sp + 1;
-          best_cost = total;
-        }
-        if (lv > 1) {
-          found = true;
-          break;
-        }
-        base -= cost_coded[sp];
-        base += cz[sp];
-      } else {
-        base -= cost_sig[sp];
-      }
+      rdoq_last_pos(C, E, T, sp, bp_of(sp), lev[sp], cost_coded[sp], cost_sig[sp], cz[sp]);
     }
   }
-  return best_last_p1;
+  return T.best_last_p1;
 }
 
-// Step 4c, one group `sub` of the FINAL signed levels (scan order, lev16 = the group's 16 entries): rate-aware sign-bit hiding
-// (:2203-2304).  first_nz_group: no group above this one holds a level.  neg16 bit k: the unquantised coefficient is negative.
-HMX_HD void rdoq_phase_c_cg(const RdoqConst &C, bool first_nz_group, int *lev16, unsigned neg16, const int *rate_up, const int *rate_down,
-                            const int *sig_delta, const int *delta_u) {
-  const long long rd_factor = C.rd_factor, kMax = 0x7fffffffffffffffll;
+// Step 4c, one group of the FINAL signed levels (scan order): rate-aware sign-bit hiding (:2203-2304), in pieces: what the
+// levels alone decide, the cost of changing one position (n from the start position down to 0), the change.
+struct RdoqHide {
+  long long min_cost;
+  int min_pos, final_change;
+  int first, lastnz, start; // start: the first position the search looks at (lastnz in the block's top group, else 15)
+  unsigned signbit;
+  int top;                  // first_nz_group
+};
+// lev_of(n): final signed level of entry n.  false: nothing to hide in this group.
+template <typename LevFn>
+HMX_HD bool rdoq_hide_begin(bool first_nz_group, LevFn lev_of, RdoqHide &H) {
   int first = 16, lastnz = -1, sum = 0;
   for (int n = 15; n >= 0; n--)
-    if (lev16[n]) {
+    if (lev_of(n)) {
       lastnz = n;
       break;
     }
   for (int n = 0; n < 16; n++)
-    if (lev16[n]) {
+    if (lev_of(n)) {
       first = n;
       break;
     }
-  for (int n = first; n <= lastnz; n++) sum += lev16[n];
-  if (lastnz - first < 4) return;
-  const unsigned signbit = lev16[first] > 0 ? 0u : 1u;
-  if (signbit == (unsigned)(sum & 1)) return;
-  long long min_cost = kMax, cur = kMax;
-  int min_pos = -1, final_change = 0, change = 0;
-  for (int n = (first_nz_group ? lastnz : 15); n >= 0; n--) {
-    const int lv = lev16[n], du = delta_u[n], ru = rate_up[n];
-    const int alv = lv < 0 ? -lv : lv;
-    if (lv != 0) {
-      const long long up = rd_factor * (-du) + ru;
-      long long down = rd_factor * (du) + rate_down[n] - (alv == 1 ? ((1 << 15) + sig_delta[n]) : 0);
-      if (first_nz_group && lastnz == n && alv == 1) down -= (4 << 15);
-      if (up < down) {
-        cur = up;
-        change = 1;
-      } else {
-        change = -1;
-        cur = (n == first && alv == 1) ? kMax : down;
-      }
-    } else {
-      const int adu = du < 0 ? -du : du;
-      cur = rd_factor * (-(long long)adu) + (1 << 15) + ru + sig_delta[n];
+  for (int n = first; n <= lastnz; n++) sum += lev_of(n);
+  if (lastnz - first < 4) return false;
+  H.signbit = lev_of(first) > 0 ? 0u : 1u;
+  if (H.signbit == (unsigned)(sum & 1)) return false;
+  H.min_cost = 0x7fffffffffffffffll, H.min_pos = -1, H.final_change = 0;
+  H.first = first, H.lastnz = lastnz, H.top = first_nz_group, H.start = first_nz_group ? lastnz : 15;
+  return true;
+}
+// entry n <= H.start, in the order start..0.  neg_n: the unquantised coefficient is negative.
+HMX_HD void rdoq_hide_pos(const RdoqConst &C, RdoqHide &H, int n, int lv, unsigned neg_n, int ru, int rate_down, int sig_delta, int du) {
+  const long long rd_factor = C.rd_factor, kMax = 0x7fffffffffffffffll;
+  long long cur;
+  int change;
+  const int alv = lv < 0 ? -lv : lv;
+  if (lv != 0) {
+    const long long up = rd_factor * (-du) + ru;
+    long long down = rd_factor * (du) + rate_down - (alv == 1 ? ((1 << 15) + sig_delta) : 0);
+    if (H.top && H.lastnz == n && alv == 1) down -= (4 << 15);
+    if (up < down) {
+      cur = up;
       change = 1;
-      if (n < first) {
-        const unsigned s = (neg16 >> n) & 1u;
-        if (s != signbit) cur = kMax;
-      }
+    } else {
+      change = -1;
+      cur = (n == H.first && alv == 1) ? kMax : down;
     }
-    if (cur < min_cost) {
-      min_cost = cur;
-      final_change = change;
-      min_pos = n;
-    }
+  } else {
+    const int adu = du < 0 ? -du : du;
+    cur = rd_factor * (-(long long)adu) + (1 << 15) + ru + sig_delta;
+    change = 1;
+    if (n < H.first && neg_n != H.signbit) cur = kMax;
   }
-  if (min_pos >= 0) {
-    if (!((neg16 >> min_pos) & 1u))
-      lev16[min_pos] += final_change;
-    else
-      lev16[min_pos] -= final_change;
+  if (cur < H.min_cost) {
+    H.min_cost = cur;
+    H.final_change = change;
+    H.min_pos = n;
   }
+}
+// the change to apply at H.min_pos (0: none): added to the signed level
+HMX_HD int rdoq_hide_change(const RdoqHide &H, unsigned neg_min_pos) { return H.min_pos < 0 ? 0 : (neg_min_pos ? -H.final_change : H.final_change); }
+// the search as a sink of the walk; lev_of(n) / neg16 as above
+template <typename LevFn>
+struct RdoqHideSink {
+  const RdoqConst &C;
+  RdoqHide &H;
+  LevFn lev_of;
+  unsigned neg16;
+  HMX_HD void add(int, double) {}
+  HMX_HD void pos(int k, unsigned, int, double, double, int ru, int rd, int sd, int du, double) {
+    if (k <= H.start) rdoq_hide_pos(C, H, k, lev_of(k), (neg16 >> k) & 1u, ru, rd, sd, du);
+  }
+};
+// over arrays: lev16 = the group's 16 entries.  first_nz_group: no group above this one holds a level.  neg16 bit k: the
+// unquantised coefficient is negative.
+HMX_HD void rdoq_phase_c_cg(const RdoqConst &C, bool first_nz_group, int *lev16, unsigned neg16, const int *rate_up, const int *rate_down,
+                            const int *sig_delta, const int *delta_u) {
+  RdoqHide H;
+  if (!rdoq_hide_begin(first_nz_group, [lev16](int n) { return lev16[n]; }, H)) return;
+  for (int n = H.start; n >= 0; n--) rdoq_hide_pos(C, H, n, lev16[n], (neg16 >> n) & 1u, rate_up[n], rate_down[n], sig_delta[n], delta_u[n]);
+  if (H.min_pos >= 0) lev16[H.min_pos] += rdoq_hide_change(H, (neg16 >> H.min_pos) & 1u);
 }
 
 } // namespace hmx

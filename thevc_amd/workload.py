@@ -7,7 +7,7 @@ the Cb TUs, then the Cr TUs (ENC/TEncSearch.cpp:1394-1700, 2160-2400); an 8x8 CU
 TUs carries one 4x4 TU per chroma plane (TComTrQuant.cpp:1467-1476)."""
 import numpy as np
 
-from .capi import PU_DTYPE, TU_DTYPE, TU_TRANSFORM_SKIP
+from .capi import PU_DTYPE, TU_DTYPE, TU_TRANSFORM_SKIP, EstBits
 
 CHROMA_MODES = (0, 26, 10, 1)  # planar, vertical, horizontal, DC (+ DM = luma mode)
 
@@ -157,3 +157,50 @@ def make_pus(seed, pic_w, pic_h, n_refs=1, bi_frac=0.0, mv_range=64, ctu=64):
         pus[k + "x"] = np.clip(mvx, (-ctu - 8 - a[:, 0] + 1) * 4, (pic_w + 8 - a[:, 0] - 1) * 4)
         pus[k + "y"] = np.clip(mvy, (-ctu - 8 - a[:, 1] + 1) * 4, (pic_h + 8 - a[:, 1] - 1) * 4)
     return pus
+
+
+# --- what RDOQ takes from the encoder's live state (hmx_set_rdoq), synthesised --------------------------------------
+def make_est_bits(seed):
+    """A plausible bit-estimate table (estBitsSbacStruct): every context holds a probability p of the bin being 1,
+    bits[0] = -log2(1 - p), bits[1] = -log2(p) in 1/32768 bit (the scale of TEncBinCABAC's entropy bits); the last-position
+    prefixes cost more the further out they reach."""
+    rng = np.random.default_rng(seed)
+    e = EstBits()
+
+    def pair(dst):
+        p = float(rng.uniform(0.03, 0.97))
+        dst[0] = int(round(-np.log2(1 - p) * 32768))
+        dst[1] = int(round(-np.log2(p) * 32768))
+
+    for name, n in (("significantCoeffGroupBits", 2), ("significantBits", 42), ("greaterOneBits", 24), ("levelAbsBits", 6),
+                    ("blockCbpBits", 15), ("blockRootCbpBits", 4)):
+        arr = getattr(e, name)
+        for i in range(n):
+            pair(arr[i])
+    for i in range(32):
+        e.lastXBits[i] = int(rng.integers(8000, 60000) * (1 + i // 4))
+        e.lastYBits[i] = int(rng.integers(8000, 60000) * (1 + i // 4))
+    pair(e.scanZigzag)
+    pair(e.scanNonZigzag)
+    return e
+
+
+def rdoq_lambdas(qp):
+    """m_dLambda of an I slice as TEncSlice::initEncSlice forms it for the all-intra cfgs (TEncSlice.cpp:260-330: QP factor
+    0.57, no B pictures), luma; the chroma blocks' multiplier is the luma one divided by the chroma weight
+    2^((qp - qp_chroma) / 3) (TEncSlice.cpp:380-395)."""
+    lam = 0.57 * 2.0 ** ((qp - 12) / 3.0)
+    mid = (29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37)
+    qpc = qp if qp < 30 else (qp - 6 if qp >= 43 else mid[qp - 30])
+    return lam, lam / 2.0 ** ((qp - qpc) / 3.0)
+
+
+def with_cbf_ctx(tus):
+    """The context of every block's coded-block flag in hmx_tu::flags bits 4..7 (TComDataCU::getCtxQtCbf: luma 1 at
+    transform depth 0 else 0; chroma = the transform depth, behind the five luma contexts).  The synthetic decisions do
+    not carry CU sizes: blocks of 16 and more count as depth 0, 8 as depth 1, 4 as depth 2."""
+    t = tus.copy()
+    depth = np.where(t["log2n"] >= 4, 0, np.where(t["log2n"] == 3, 1, 2))
+    ctx = np.where(t["plane"] == 0, (depth == 0).astype(np.int64), 5 + depth)
+    t["flags"] = (t["flags"] & 15) | (ctx.astype(np.uint8) << 4)
+    return t
