@@ -409,6 +409,9 @@ def main():
     with ThreadPoolExecutor(max_workers=min(16, len(uniq), os.cpu_count() or 1)) as ex:  # numpy releases the GIL in the large array ops
         cache = dict(zip(uniq, ex.map(lambda sd: workload.make_planes(sd, w, h_c, B, "texture"), uniq)))
     src = [cache[sd] for sd in seeds]
+    if args.rdoq:  # before the pools are laid out: RDOQ keeps the packing groups small
+        sets = [rdoq_inputs(sd, qp) for sd in plan_seeds[:n_plans]]
+        ctx.set_rdoq([(sets[i % n_plans][0], sets[i % n_plans][1][0], sets[i % n_plans][1][1]) for i in range(F)])
     lev_slab = capi.DevLevelsZSlab(ctx, w, h_c, F).zero()  # the reference's own coefficient layout, one slab per plane
     lev_arr = (capi.Levels * F)(*[lev_slab.as_pic(i) for i in range(F)])
     plan_arr = (C.c_void_p * F)(*[plans[i % n_plans].value for i in range(F)])
@@ -433,10 +436,6 @@ def main():
                 d.upload(src[i0 + k])
             p_org.import_planes(i0, part)
         ctx.sync()
-
-    if args.rdoq:
-        sets = [rdoq_inputs(sd, qp) for sd in plan_seeds[:n_plans]]
-        ctx.set_rdoq([(sets[i % n_plans][0], sets[i % n_plans][1][0], sets[i % n_plans][1][1]) for i in range(F)])
 
     def call(enc):
         if args.planar:

@@ -349,8 +349,8 @@ int hmx_frame_intra_decode_multi(hmx_ctx *ctx, const hmx_intra_plan *const *plan
  * hmx_tu::flags, bits 4..7 (= getCtxQtCbf: the transform depth for luma, + NUM_QT_CBF_CTX for chroma).
  * n_pics = the pictures of the following calls, or 1 = one set for every picture.  pics = NULL turns RDOQ off again.
  * Transform-skip blocks keep the flat quantiser (TComTrQuant.cpp:1121-1122 with TransformSkipFast, which every shipped
- * cfg that enables transform skip sets); packed schedule only, packing groups of at most 4 pictures (the tables of a group
- * wait in LDS). */
+ * cfg that enables transform skip sets); packed schedule only, packing groups of at most 2 pictures (HMX_PACK_GROUP; the
+ * tables of a group wait in LDS). */
 typedef struct hmx_rdoq_pic {
   hmx_est_bits est[8]; /* [luma, chroma][log2(size) - 2] */
   double lambda_luma, lambda_chroma;

@@ -78,7 +78,7 @@ static void rdoq_block_lanes(const int *src, int *dst, int N, int B, const hmo_r
   for (int task = 0; task < (last_cg + 1) * 8; task++) { // step 1: one lane per (group, carry, pattern)
     const int cg = task >> 3, v = task & 7;
     RdoqSpecSink sink{&spec[task]};
-    spec[task].S = rdoq_walk_cg(C, E, cg, bp_of, &ld[cg * 16], &cz[cg * 16], v & 3, v >> 2, last_pos, sink);
+    spec[task].S = rdoq_walk_cg(C, E, cg, bp_of, src, N, v & 3, v >> 2, last_pos, sink);
   }
   std::vector<unsigned char> sel(n_cg);
   RdoqRun R;
@@ -90,7 +90,7 @@ static void rdoq_block_lanes(const int *src, int *dst, int N, int B, const hmo_r
       continue;
     }
     RdoqFullSink sink{lev.data(), cc.data(), cs.data(), ru.data(), rd.data(), sd.data(), du.data(), cg * 16};
-    rdoq_walk_cg(C, E, cg, bp_of, &ld[cg * 16], &cz[cg * 16], sel[cg] & 3, sel[cg] >> 2, last_pos, sink);
+    rdoq_walk_cg(C, E, cg, bp_of, src, N, sel[cg] & 3, sel[cg] >> 2, last_pos, sink);
     if ((R.zeroed >> cg) & 1) rdoq_apply_zeroed_cg(cg, cz.data(), lev.data(), cc.data(), cs.data());
   }
   const int best_last_p1 = rdoq_phase_b(C, E, last_pos, last_cg, gpos_of, bp_of, R, cz.data(), lev.data(), cc.data(), cs.data(), cgs.data()); // one lane
@@ -174,7 +174,7 @@ static void rdoq_block_rewalk(const int *src, int *dst, int N, int B, const hmo_
       const int cg = top - (task >> 3), v = task & 7;
       if (cg < 0) continue;
       RdoqSpecSink sink{&buf[task]};
-      auto in = [&](int, unsigned bp, int &ld, double &cz) { rdoq_prep(src[bp], C, ld, cz); };
+      auto in = [&](int, unsigned bp) { return src[bp]; };
       buf[task].S = rdoq_walk_cg_in(C, E, cg, bp_of, in, v & 3, v >> 2, last_pos, sink);
     }
     for (int j = 0; j < groups_per_round; j++) { // the block's resolving lane
@@ -191,7 +191,7 @@ static void rdoq_block_rewalk(const int *src, int *dst, int N, int B, const hmo_
     rdoq_last_group(T, cgs[cg]);
     if (!((R.cg_flag >> gpos) & 1)) continue;
     RdoqLastSink sink{C, E, T, cg * 16, last_pos};
-    auto in = [&](int, unsigned bp, int &ld, double &cz) { rdoq_prep(src[bp], C, ld, cz); };
+    auto in = [&](int, unsigned bp) { return src[bp]; };
     rdoq_walk_cg_in(C, E, cg, bp_of, in, sel[cg] & 3, sel[cg] >> 2, last_pos, sink);
     g_rewalk_last++;
   }
@@ -203,7 +203,7 @@ static void rdoq_block_rewalk(const int *src, int *dst, int N, int B, const hmo_
     if ((R.zeroed >> cg) & 1) continue;
     int l16[16];
     LevelSink sink{l16};
-    auto in = [&](int, unsigned bp, int &ld, double &cz) { rdoq_prep(src[bp], C, ld, cz); };
+    auto in = [&](int, unsigned bp) { return src[bp]; };
     rdoq_walk_cg_in(C, E, cg, bp_of, in, sel[cg] & 3, sel[cg] >> 2, last_pos, sink);
     for (int k = 0; k < 16; k++) {
       const int sp = cg * 16 + k, l = sp < T.best_last_p1 ? l16[k] : 0;
@@ -225,7 +225,7 @@ static void rdoq_block_rewalk(const int *src, int *dst, int N, int B, const hmo_
       if (!any || !rdoq_hide_begin(cg == top_group, lev_of, H)) continue;
       // a group with levels is a coded group that was not zeroed: sel[cg] is its variant
       RdoqHideSink<decltype(lev_of)> sink{C, H, lev_of, neg};
-      auto in = [&](int, unsigned bp, int &ld, double &cz) { rdoq_prep(src[bp], C, ld, cz); };
+      auto in = [&](int, unsigned bp) { return src[bp]; };
       rdoq_walk_cg_in(C, E, cg, bp_of, in, sel[cg] & 3, sel[cg] >> 2, last_pos, sink);
       g_rewalk_hide++;
       if (H.min_pos >= 0) lev[cg * 16 + H.min_pos] += rdoq_hide_change(H, (neg >> H.min_pos) & 1u);

@@ -1289,9 +1289,14 @@ __device__ __forceinline__ int pack_lane_item(int lane, int s) {
 template <bool ENC, int SL4, bool SSE = false, bool RDOQ = false>
 __global__ __launch_bounds__(64, RDOQ ? 2 : 4) void k_intra_packed(PackArgs A) {
   static_assert(!RDOQ || (ENC && SL4 == 64), "RDOQ: encoder direction, 4x4 blocks one per lane");
-  __shared__ __attribute__((aligned(16))) char smem[HMX_WAVE_SMEM];
+  // RDOQ variant: every byte of LDS decides how many waves a CU holds (the walks are latency chains); the lane-per-block 4x4
+  // chain, the largest user of the common scratch, borrows the round buffer its RDOQ does not need
+  constexpr int kSmem = RDOQ ? (int)(4 * sizeof(TuLds<16>)) : HMX_WAVE_SMEM;
+  static_assert(!RDOQ || (8 * sizeof(TuLds<8>) <= kSmem && sizeof(TuLds<32>) <= kSmem && sizeof(Lane4Lds) <= sizeof(RdoqWaveLds::u)), "RDOQ variant: LDS scratch");
+  __shared__ __attribute__((aligned(16))) char smem[kSmem];
   __shared__ __attribute__((aligned(16))) char rq_raw[RDOQ ? sizeof(RdoqWaveLds) : 16];
   RdoqWaveLds *rq_lds = reinterpret_cast<RdoqWaveLds *>(rq_raw);
+  char *const smem4 = RDOQ ? rq_lds->u.lane4 : smem;
   if constexpr (RDOQ) {
     if (lane_id() == 0) rq_lds->key = 0;
     wave_sync();
@@ -1366,7 +1371,7 @@ __global__ __launch_bounds__(64, RDOQ ? 2 : 4) void k_intra_packed(PackArgs A) {
       if constexpr (RDOQ) rdoq_stage_tables(*rq_lds, A.rq, g, s, A.I, lane_id());
       PROF_T(p3);
       if (s == 0) {
-        if constexpr (SL4 == 64) wave_chain_4_lane<ENC, true>(smem, src, A.P, n);
+        if constexpr (SL4 == 64) wave_chain_4_lane<ENC, true>(smem4, src, A.P, n);
         else wave_chain_valu<4, ENC, true>(smem, src, A.P, n);
       } else if (s == 1) wave_chain_valu<8, ENC, true>(smem, src, A.P, n);
       else if (s == 2) wave_chain_valu<16, ENC, true>(smem, src, A.P, n);
@@ -2456,7 +2461,7 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
   const bool rdoq = enc && c->crq.n > 0;
   if (rdoq) {
     if (c->crq.n != 1 && c->crq.n != n_pics) return fail(c, HMX_ERR_ARG, "frame_intra: hmx_set_rdoq described another number of pictures");
-    if (G.I > kRdoqMaxGroup) return fail(c, HMX_ERR_ARG, "frame_intra: RDOQ keeps the bit-estimate tables of a packing group in LDS: at most 4 pictures per group (HMX_PACK_GROUP)");
+    if (G.I > kRdoqMaxGroup) return fail(c, HMX_ERR_ARG, "frame_intra: RDOQ keeps the bit-estimate tables of a packing group in LDS: at most 2 pictures per group (HMX_PACK_GROUP)");
     G.slots4 = 64; // a 4x4 block's RDOQ runs inside one lane
   }
   const uint64_t n_rows = (uint64_t)G.max_levels * G.n_groups;
@@ -2865,6 +2870,7 @@ static int issue_chain_launches(hmx_ctx *c, const hmx_intra_plan *const *plans, 
 // pictures: 9.5 / 9.9 with 2 / 1).  Groups are dealt to the 8 XCDs round-robin.
 static int pack_group_size(const hmx_ctx *c, int n_pics) {
   if (c && c->knob.pack_group > 0) return std::min(c->knob.pack_group, n_pics);
+  if (c && c->crq.n > 0) return n_pics >= 512 ? kRdoqMaxGroup : 1; // RDOQ on (hmx_set_rdoq): the tables of a group wait in LDS
   return n_pics >= 1536 ? 4 : n_pics >= 512 ? 2 : 1;
 }
 // ---- pictures resident in the working layout (include/hmx.h: hmx_tpool) ----

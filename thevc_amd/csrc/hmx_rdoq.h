@@ -437,7 +437,7 @@ __global__ __launch_bounds__(64) void k_rdoq_wave(RdoqArgs A) {
   for (int task = lane; task < (last_cg + 1) * 8; task += 64) {
     const int cg = task >> 3, v = task & 7;
     RdoqSpecSink sink{&spec[task]};
-    spec[task].S = rdoq_walk_cg(C, E, cg, bp_of, ld + cg * 16, cz + cg * 16, v & 3, v >> 2, last_pos, sink);
+    spec[task].S = rdoq_walk_cg(C, E, cg, bp_of, src, ss, v & 3, v >> 2, last_pos, sink);
   }
   rdoq_wave_fence();
   // step 2
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(64) void k_rdoq_wave(RdoqArgs A) {
     } else {
       RdoqFullSink sink{lev, cc, cs, ru, rd, sd, du, cg * 16};
       const int v = sel[cg];
-      rdoq_walk_cg(C, E, cg, bp_of, ld + cg * 16, cz + cg * 16, v & 3, v >> 2, last_pos, sink);
+      rdoq_walk_cg(C, E, cg, bp_of, src, ss, v & 3, v >> 2, last_pos, sink);
       if ((run->zeroed >> cg) & 1) rdoq_apply_zeroed_cg(cg, cz, lev, cc, cs);
     }
   }
@@ -530,17 +530,18 @@ struct RdoqChain {
   int n_pics;
   double err_scale[2][4];
 };
-constexpr int kRdoqMaxGroup = 4; // pictures per packing group with RDOQ: 2 x 4 tables of 1016 bytes in LDS
+constexpr int kRdoqMaxGroup = 2; // pictures per packing group with RDOQ: 2 x 2 tables of 1016 bytes in LDS
 struct RdoqWaveLds {
   union {
     RdoqSpec spec[64]; // the round's variants: [block][group of the round][carry * 4 + pattern]
     double cz[1024];   // before the rounds: the costs of zero above the last position's group
     short lev[1024];   // after them: the signed levels, scan order
+    char lane4[7680];  // 4x4 blocks, one per lane: the chain's Lane4Lds (its RDOQ needs no buffer)
   } u;
   double cgs[64];            // cost_cg_sig [block][group]
   unsigned short scan[1024]; // the size class's scan tables: [scan_idx][position] (32x32: the diagonal scan only)
   unsigned char sel[64];     // variant taken [block][group]
-  unsigned long long zeroed[8], cg_flag[8];
+  unsigned long long zeroed[8];
   EstBitsDev est[2 * kRdoqMaxGroup]; // [picture of the group][luma, chroma], the wave-item's size class
   int key;                           // ((group << 2) | size class) + 1 of what est / scan hold
 };
@@ -555,6 +556,7 @@ __device__ __forceinline__ void rdoq_stage_tables(RdoqWaveLds &W, const RdoqChai
     const int pic = min(g * I + (tb >> 1), RC.n_pics - 1) * RC.pic_mul;
     reinterpret_cast<int *>(&W.est[tb])[w] = reinterpret_cast<const int *>(&RC.est[((size_t)pic * 2 + (tb & 1)) * 4 + s])[w];
   }
+  // the walks are bound by the instructions they issue: a table lookup, not the arithmetic of the scan (2 KB of LDS)
   if (s == 3) {
     for (int i = lane; i < 1024; i += 64) W.scan[i] = (unsigned short)kScan32.t[0][i];
   } else if (s > 0) {
@@ -580,9 +582,9 @@ template <int N>
 struct RdoqTileIn { // entry of a group from the block's coefficient tile
   const TuLds<N> *L;
   const RdoqConst *C;
-  __device__ __forceinline__ void operator()(int, unsigned bp, int &ld, double &cz) const {
+  __device__ __forceinline__ int operator()(int, unsigned bp) const {
     constexpr int LG = N == 8 ? 3 : N == 16 ? 4 : 5;
-    rdoq_prep(L->tile[bp >> LG][bp & (N - 1)], *C, ld, cz);
+    return L->tile[bp >> LG][bp & (N - 1)];
   }
 };
 template <int N>
@@ -798,7 +800,7 @@ struct RdoqSumSink { // resolve of a single group: the terms arrive in the order
 struct RdoqLaneIn {
   const int *c16;
   const RdoqConst *C;
-  __device__ __forceinline__ void operator()(int k, unsigned, int &ld, double &cz) const { rdoq_prep(c16[k], *C, ld, cz); }
+  __device__ __forceinline__ int operator()(int k, unsigned) const { return c16[k]; }
 };
 struct RdoqLaneLevelSink {
   short *out;

@@ -43,9 +43,21 @@ struct EstBitsDev { // estBitsSbacStruct (TComTrQuant.h:59-72), 1/32768 bit
 
 HMX_HD int rdoq_base_level(unsigned c1i, unsigned c2i) { return c1i < 8 ? (2 + (c2i < 1)) : 1; }
 
+// The bits of the three contexts a coefficient can touch, fetched together at its start: a walk is a chain of decisions, and
+// every table entry fetched where it is used would be a round trip of its own (the tables wait in LDS on the device).
+struct RdoqCtxBits {
+  int sig[2], g1[2], g2[2]; // significantBits[ctx_sig], greaterOneBits[ctx1], levelAbsBits[ctx2]
+};
+HMX_HD RdoqCtxBits rdoq_ctx_bits(const EstBitsDev &e, unsigned ctx_sig, unsigned ctx1, unsigned ctx2) {
+  RdoqCtxBits b;
+  b.sig[0] = e.sig[ctx_sig][0], b.sig[1] = e.sig[ctx_sig][1];
+  b.g1[0] = e.greater1[ctx1][0], b.g1[1] = e.greater1[ctx1][1];
+  b.g2[0] = e.greater2[ctx2][0], b.g2[1] = e.greater2[ctx2][1];
+  return b;
+}
+
 // rate of |level| beyond the significance flag as a COST (xGetICRateCost :2508)
-HMX_HD double rdoq_level_cost(const EstBitsDev &e, double lambda, unsigned lvl, unsigned ctx1, unsigned ctx2, unsigned rice, unsigned c1i,
-                              unsigned c2i) {
+HMX_HD double rdoq_level_cost(const RdoqCtxBits &e, double lambda, unsigned lvl, unsigned rice, unsigned c1i, unsigned c2i) {
   double rate = 32768;
   const unsigned base = (unsigned)rdoq_base_level(c1i, c2i);
   if (lvl >= base) {
@@ -60,20 +72,24 @@ HMX_HD double rdoq_level_cost(const EstBitsDev &e, double lambda, unsigned lvl, 
       rate += (double)((3 + len + 1 - rice + len) << 15);
     }
     if (c1i < 8) {
-      rate += e.greater1[ctx1][1];
-      if (c2i < 1) rate += e.greater2[ctx2][1];
+      rate += e.g1[1];
+      if (c2i < 1) rate += e.g2[1];
     }
   } else if (lvl == 1) {
-    rate += e.greater1[ctx1][0];
+    rate += e.g1[0];
   } else {
-    rate += e.greater1[ctx1][1];
-    rate += e.greater2[ctx2][0];
+    rate += e.g1[1];
+    rate += e.g2[0];
   }
   return lambda * rate;
 }
+HMX_HD double rdoq_level_cost(const EstBitsDev &e, double lambda, unsigned lvl, unsigned ctx1, unsigned ctx2, unsigned rice, unsigned c1i,
+                              unsigned c2i) {
+  return rdoq_level_cost(rdoq_ctx_bits(e, 0, ctx1, ctx2), lambda, lvl, rice, c1i, c2i);
+}
 
 // integer rate of |level| (xGetICRate :2577): only for the sign-hiding deltas
-HMX_HD int rdoq_level_rate(const EstBitsDev &e, unsigned lvl, unsigned ctx1, unsigned ctx2, unsigned rice, unsigned c1i, unsigned c2i) {
+HMX_HD int rdoq_level_rate(const RdoqCtxBits &e, unsigned lvl, unsigned rice, unsigned c1i, unsigned c2i) {
   int rate = 0;
   const unsigned base = (unsigned)rdoq_base_level(c1i, c2i);
   if (lvl >= base) {
@@ -91,18 +107,21 @@ HMX_HD int rdoq_level_rate(const EstBitsDev &e, unsigned lvl, unsigned ctx1, uns
     const unsigned bins = (pre < pre_max ? pre : pre_max) + rice;
     rate += (int)((bins & 0xffffu) << 15);
     if (c1i < 8) {
-      rate += e.greater1[ctx1][1];
-      if (c2i < 1) rate += e.greater2[ctx2][1];
+      rate += e.g1[1];
+      if (c2i < 1) rate += e.g2[1];
     }
   } else if (lvl == 0) {
     return 0;
   } else if (lvl == 1) {
-    rate += e.greater1[ctx1][0];
+    rate += e.g1[0];
   } else {
-    rate += e.greater1[ctx1][1];
-    rate += e.greater2[ctx2][0];
+    rate += e.g1[1];
+    rate += e.g2[0];
   }
   return rate;
+}
+HMX_HD int rdoq_level_rate(const EstBitsDev &e, unsigned lvl, unsigned ctx1, unsigned ctx2, unsigned rice, unsigned c1i, unsigned c2i) {
+  return rdoq_level_rate(rdoq_ctx_bits(e, 0, ctx1, ctx2), lvl, rice, c1i, c2i);
 }
 
 // significance context (getSigCtxInc :2349, REMOVAL_8x2_2x8_CG branch); scan_idx 0 = diagonal
@@ -159,19 +178,18 @@ HMX_HD unsigned rdoq_max_level(int ld, int qbits) { return (unsigned)((ld + (1 <
 
 struct RdoqCgSums { // what the group-level decision needs of a walked group
   double s_sig, s_sig0, s_coded, s_uncoded;
-  unsigned nz_mask;   // bit k: scan entry k of the group got a non-zero level
-  int nnz_before0;    // non-zero levels at k = 1..15
-  int carry_out;      // c1 == 0 at the end of the group: the next group's context set moves up by one
+  unsigned short nz_mask;    // bit k: scan entry k of the group got a non-zero level
+  unsigned char nnz_before0; // non-zero levels at k = 1..15
+  unsigned char carry_out;   // c1 == 0 at the end of the group: the next group's context set moves up by one
 };
 
-// Walk scan entries 15..0 of coefficient group cg (TComTrQuant.cpp:1786-1990 for one group).  ld16 / cz16: the group's 16
-// entries of rdoq_prep in scan order; bp(sp): block position (raster) of scan position sp; pattern: 0..3 (right | lower << 1),
-// ignored for 4x4 blocks; carry_in: the previous group's carry (ignored in the group of the last position, whose state starts
-// there).  Sink: add(k, term) the term the running cost receives for entry k; pos(k, level, cc, cs, rate_up, rate_down,
-// sig_delta, delta_u) everything else about it.
-// in(k, bp, ld, cz): entry k of the group (block position bp) as rdoq_prep leaves it (from arrays, or computed on the spot
-// from the coefficient).  Sink: add(k, term) the term the running cost receives for entry k; pos(k, bp, level, cc, cs, rate_up,
-// rate_down, sig_delta, delta_u, cz) everything else about it.
+// Walk scan entries 15..0 of coefficient group cg (TComTrQuant.cpp:1786-1990 for one group).  bp(sp): block position (raster)
+// of scan position sp; pattern: 0..3 (right | lower << 1), ignored for 4x4 blocks; carry_in: the previous group's carry
+// (ignored in the group of the last position, whose state starts there).
+// in(k, bp): the coefficient of entry k of the group (block position bp).  Sink: add(k, term) the term the running cost receives
+// for entry k; pos(k, bp, level, cc, cs, rate_up, rate_down, sig_delta, delta_u, cz) everything else about it.
+// Per entry the loads come first, all together -- the next entry's coefficient and the bits of this entry's three contexts --
+// then nothing but arithmetic.
 template <typename BpFn, typename InFn, typename Sink>
 HMX_HD RdoqCgSums rdoq_walk_cg_in(const RdoqConst &C, const EstBitsDev &E, int cg, BpFn bp_of, InFn in, int pattern, int carry_in, int last_pos,
                                   Sink &sink) {
@@ -184,12 +202,25 @@ HMX_HD RdoqCgSums rdoq_walk_cg_in(const RdoqConst &C, const EstBitsDev &E, int c
   RdoqCgSums S;
   S.s_sig = 0, S.s_sig0 = 0, S.s_coded = 0, S.s_uncoded = 0;
   S.nz_mask = 0, S.nnz_before0 = 0;
+  unsigned bp = bp_of(cg * 16 + 15);
+  int coef = in(15, bp);
   for (int k = 15; k >= 0; k--) {
     const int sp = cg * 16 + k;
-    const unsigned bp = bp_of(sp);
+    const unsigned bp_k = bp;
+    const int coef_k = coef;
+    if (k > 0) { // the next entry, under way while this one is decided
+      bp = bp_of(sp - 1);
+      coef = in(k - 1, bp);
+    }
+    if (sp == last_pos) ctx_set = (sp < 16 || !is_luma) ? 0u : 2u; // the state starts here: c1 = 1, c2 = 0, no carry
+    const bool is_last = sp == last_pos;
+    const unsigned ctx1 = 4 * ctx_set + (unsigned)c1, ctx2 = ctx_set + (unsigned)c2;
+    unsigned ctx_sig = 0;
+    if (!is_last) ctx_sig = (unsigned)rdoq_sig_ctx(pattern, C.scan_idx, (int)(bp_k & (unsigned)(N - 1)), (int)(bp_k >> lg), lg, is_luma);
+    const RdoqCtxBits B = rdoq_ctx_bits(E, ctx_sig, ctx1, ctx2);
     int ld;
     double cz;
-    in(k, bp, ld, cz);
+    rdoq_prep(coef_k, C, ld, cz);
     const unsigned max_lvl = rdoq_max_level(ld, qbits);
     int out_level = (int)max_lvl;
     double cc = 0, cs = 0;
@@ -197,27 +228,22 @@ HMX_HD RdoqCgSums rdoq_walk_cg_in(const RdoqConst &C, const EstBitsDev &E, int c
     if (sp > last_pos) { // above the last position: the coefficient is zero and costs its distortion
       sink.add(k, cz);
     } else {
-      if (sp == last_pos) ctx_set = (sp < 16 || !is_luma) ? 0u : 2u; // the state starts here: c1 = 1, c2 = 0, no carry
-      const unsigned ctx1 = 4 * ctx_set + (unsigned)c1, ctx2 = ctx_set + (unsigned)c2;
-      const bool is_last = sp == last_pos;
-      unsigned ctx_sig = 0;
-      if (!is_last) ctx_sig = (unsigned)rdoq_sig_ctx(pattern, C.scan_idx, (int)(bp & (unsigned)(N - 1)), (int)(bp >> lg), lg, is_luma);
       unsigned best = 0;
       double sig1 = 0;
       bool decided = false;
       if (!is_last && max_lvl < 3) {
-        cs = lambda * E.sig[ctx_sig][0];
+        cs = lambda * B.sig[0];
         cc = cz + cs;
         if (max_lvl == 0) decided = true;
       } else {
         cc = 1.7e+308;
       }
       if (!decided) {
-        if (!is_last) sig1 = lambda * E.sig[ctx_sig][1];
+        if (!is_last) sig1 = lambda * B.sig[1];
         const unsigned lo = max_lvl > 1 ? max_lvl - 1 : 1;
         for (int l = (int)max_lvl; l >= (int)lo; l--) {
           const double d = (double)(ld - (l << qbits));
-          double cst = d * d * err_scale + rdoq_level_cost(E, lambda, (unsigned)l, ctx1, ctx2, rice, c1i, c2i);
+          double cst = d * d * err_scale + rdoq_level_cost(B, lambda, (unsigned)l, rice, c1i, c2i);
           cst += sig1;
           if (cst < cc) {
             best = (unsigned)l;
@@ -226,14 +252,14 @@ HMX_HD RdoqCgSums rdoq_walk_cg_in(const RdoqConst &C, const EstBitsDev &E, int c
           }
         }
       }
-      if (!is_last) sdel = E.sig[ctx_sig][1] - E.sig[ctx_sig][0];
+      if (!is_last) sdel = B.sig[1] - B.sig[0];
       du = (ld - ((int)best << qbits)) >> (qbits - 8);
       if (best > 0) {
-        const int now = rdoq_level_rate(E, best, ctx1, ctx2, rice, c1i, c2i);
-        r_up = rdoq_level_rate(E, best + 1, ctx1, ctx2, rice, c1i, c2i) - now;
-        r_down = rdoq_level_rate(E, best - 1, ctx1, ctx2, rice, c1i, c2i) - now;
+        const int now = rdoq_level_rate(B, best, rice, c1i, c2i);
+        r_up = rdoq_level_rate(B, best + 1, rice, c1i, c2i) - now;
+        r_down = rdoq_level_rate(B, best - 1, rice, c1i, c2i) - now;
       } else {
-        r_up = E.greater1[ctx1][0];
+        r_up = B.g1[0];
       }
       out_level = (int)best;
       sink.add(k, cc);
@@ -247,28 +273,28 @@ HMX_HD RdoqCgSums rdoq_walk_cg_in(const RdoqConst &C, const EstBitsDev &E, int c
         c1++;
       }
     }
-    sink.pos(k, bp, out_level, cc, cs, r_up, r_down, sdel, du, cz);
+    sink.pos(k, bp_k, out_level, cc, cs, r_up, r_down, sdel, du, cz);
     S.s_sig += cs;
     if (k == 0) S.s_sig0 = cs;
     if (out_level) {
-      S.nz_mask |= 1u << k;
+      S.nz_mask = (unsigned short)(S.nz_mask | (1u << k));
       S.s_coded += cc - cs;
       S.s_uncoded += cz;
       if (k != 0) S.nnz_before0++;
     }
   }
-  S.carry_out = c1 == 0;
+  S.carry_out = (unsigned char)(c1 == 0);
   return S;
 }
-struct RdoqArrayIn { // the group's entries from arrays in scan order
-  const int *ld16;
-  const double *cz16;
-  HMX_HD void operator()(int k, unsigned, int &ld, double &cz) const { ld = ld16[k], cz = cz16[k]; }
+struct RdoqBlockIn { // the coefficients from a block in memory: src[row * stride + col]
+  const int *src;
+  int stride, lg;
+  HMX_HD int operator()(int, unsigned bp) const { return src[(bp >> lg) * (unsigned)stride + (bp & ((1u << lg) - 1u))]; }
 };
 template <typename BpFn, typename Sink>
-HMX_HD RdoqCgSums rdoq_walk_cg(const RdoqConst &C, const EstBitsDev &E, int cg, BpFn bp_of, const int *ld16, const double *cz16, int pattern,
-                               int carry_in, int last_pos, Sink &sink) {
-  return rdoq_walk_cg_in(C, E, cg, bp_of, RdoqArrayIn{ld16, cz16}, pattern, carry_in, last_pos, sink);
+HMX_HD RdoqCgSums rdoq_walk_cg(const RdoqConst &C, const EstBitsDev &E, int cg, BpFn bp_of, const int *src, int stride, int pattern, int carry_in,
+                               int last_pos, Sink &sink) {
+  return rdoq_walk_cg_in(C, E, cg, bp_of, RdoqBlockIn{src, stride, C.lg}, pattern, carry_in, last_pos, sink);
 }
 
 struct RdoqSpec { // one (group, carry, pattern) variant of step 1
