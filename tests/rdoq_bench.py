@@ -53,7 +53,6 @@ K = 1 if len(sys.argv) < 4 else int(sys.argv[3])
 if K > 1:
     t_k = np.ascontiguousarray(np.tile(tus, K), capi.TU_DTYPE)
     side_k = (capi.RdoqSide * (n * K))()
-    C.memmove(side_k, (capi.RdoqSide * n * K)(*([side] * K)), C.sizeof(side) * K) if False else None
     for r in range(K):
         C.memmove(C.addressof(side_k) + r * C.sizeof(side), side, C.sizeof(side))
 

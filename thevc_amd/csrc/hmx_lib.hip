@@ -370,7 +370,7 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, cons
         static_assert(N >= 8, "4x4 blocks with RDOQ run in the lane-per-block chain");
         wave_sync(); // the prediction has read the reference line
         if (gl == 0)
-          L.line[0] = active && !ts, L.line[1] = src.picture(), L.line[2] = luma, L.line[3] = scan_idx, L.line[4] = src.cbf_ctx(), L.line[9] = src.group_slot();
+          L.line[0] = active && !ts, L.line[1] = src.picture(), L.line[2] = luma, L.line[3] = scan_idx, L.line[4] = src.cbf_ctx(), L.line[9] = src.group_slot() * 2 + (luma ? 0 : 1), L.line[10] = 0;
         fwd_tq_block<N>(L, gl, active, row, ts, luma, luma, scan_idx, ts, P);
         rdoq_wave_tiles<N, SL>(reinterpret_cast<TuLds<N> *>(smem), src.rdoq_lds(), src.rdoq(), P, lane);
       } else {
@@ -752,7 +752,7 @@ __device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const 
       fwd32_mfma(v, r, h, P.bit_depth, coef);
       if constexpr (SRC::kRdoq) {
         wave_sync();
-        if (lane == 0) L.line[0] = 1, L.line[1] = src.picture(), L.line[2] = luma, L.line[3] = 0, L.line[4] = src.cbf_ctx(), L.line[9] = src.group_slot();
+        if (lane == 0) L.line[0] = 1, L.line[1] = src.picture(), L.line[2] = luma, L.line[3] = 0, L.line[4] = src.cbf_ctx(), L.line[9] = src.group_slot() * 2 + (luma ? 0 : 1), L.line[10] = 0;
 #pragma unroll
         for (int g = 0; g < 16; g++) L.tile[mrow(g, h)][r] = coef[g];
         wave_sync();
@@ -1597,8 +1597,12 @@ struct hmx_ctx {
   int rdoq_T = 0, rdoq_est_cap = 0, rdoq_blocks_cap = 0;
   uint64_t rdoq_key = 0;      // of the block list and tables resident on the device
   bool rdoq_resident = false;
-  char *rdoq_ws = nullptr; // k_rdoq_wave: per-block workspace of a launch chunk
-  size_t rdoq_ws_bytes = 0;
+  size_t rdoq_class_n[4] = {0, 0, 0, 0}; // blocks of 32, 16, 8, 4 in the resident list
+  uint64_t rdoq_in_key = 0;              // of the caller's arguments that produced the resident list (hmx_batch_xRateDistOptQuant)
+  bool rdoq_join[2] = {false, false}; // side streams of the current RDOQ call still to be joined
+  double rdoq_consts_h[4] = {};
+  bool rdoq_consts_valid = false;
+  double *rdoq_consts = nullptr; // k_rdoq_tiles: lambda [luma, chroma], then the Int64 factors of sign hiding
   int *d_mcmap = nullptr; // cell -> PU maps of the last motion-compensation call
   size_t mcmap_cap = 0;
   char *arena_h = nullptr, *arena_d = nullptr;
@@ -1811,7 +1815,7 @@ extern "C" void hmx_destroy(hmx_ctx *c) {
   hipFree(c->rdoq_wi);
   hipFree(c->rdoq_blocks);
   hipFree(c->rdoq_est);
-  hipFree(c->rdoq_ws);
+  hipFree(c->rdoq_consts);
   hipFree(c->crq.d_est);
   hipFree(c->crq.d_lambda);
   hipFree(c->pk.d_pics);
@@ -3418,6 +3422,14 @@ static void rdoq_constants(RdoqArgs &A, int B, const hmx_qp qp[2], const double 
   A.bit_depth = B;
 }
 
+static int rdoq_issue(hmx_ctx *c, RdoqArgs A);
+static uint64_t hash_words(uint64_t h, const void *p, size_t bytes) {
+  const uint64_t *w = static_cast<const uint64_t *>(p);
+  for (size_t i = 0; i < bytes / 8; i++) h = (h ^ w[i]) * 0x9e3779b97f4a7c15ull, h ^= h >> 29;
+  const unsigned char *t = static_cast<const unsigned char *>(p) + (bytes & ~(size_t)7);
+  for (size_t i = 0; i < (bytes & 7); i++) h = (h ^ t[i]) * 0x100000001b3ull;
+  return h;
+}
 static int rdoq_launch(hmx_ctx *c, RdoqArgs A, const std::vector<RdoqBlock> &blocks, const hmx_est_bits *est, int n_est) {
   if (n_est > c->rdoq_est_cap) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -3447,13 +3459,6 @@ static int rdoq_launch(hmx_ctx *c, RdoqArgs A, const std::vector<RdoqBlock> &blo
   }
   // a pipeline quantises the same block structure picture after picture: when the list and the tables are the ones already
   // resident (64-bit hash over both), nothing is uploaded and nothing synchronises
-  auto hash_words = [](uint64_t h, const void *p, size_t bytes) {
-    const uint64_t *w = static_cast<const uint64_t *>(p);
-    for (size_t i = 0; i < bytes / 8; i++) h = (h ^ w[i]) * 0x9e3779b97f4a7c15ull, h ^= h >> 29;
-    const unsigned char *t = static_cast<const unsigned char *>(p) + (bytes & ~(size_t)7);
-    for (size_t i = 0; i < (bytes & 7); i++) h = (h ^ t[i]) * 0x100000001b3ull;
-    return h;
-  };
   uint64_t key = hash_words(0x243f6a8885a308d3ull ^ blocks.size(), blocks.data(), sizeof(RdoqBlock) * blocks.size());
   key = hash_words(key ^ (uint64_t)n_est, est, sizeof(EstBitsDev) * n_est);
   if (!c->rdoq_resident || c->rdoq_key != key) {
@@ -3462,37 +3467,92 @@ static int rdoq_launch(hmx_ctx *c, RdoqArgs A, const std::vector<RdoqBlock> &blo
     HIPCHK(c, hipStreamSynchronize(c->stream)); // pageable sources
     c->rdoq_key = key;
     c->rdoq_resident = true;
+    c->rdoq_in_key = 0; // whoever built this list names its arguments afterwards
   }
+  for (int k = 0; k < 4; k++) c->rdoq_class_n[k] = 0; // blocks per size, the list is sorted largest first
+  for (const RdoqBlock &b : blocks) c->rdoq_class_n[5 - b.log2n]++;
+  return rdoq_issue(c, A);
+}
+// the launches over the block list resident on the device
+static int rdoq_issue(hmx_ctx *c, RdoqArgs A) {
   A.est = c->rdoq_est;
   A.wd = c->rdoq_wd;
   A.wi = c->rdoq_wi;
   A.T = c->rdoq_T;
-  // blocks arrive sorted by size, largest first: 8x8 and larger go one WAVE per block (k_rdoq_wave, the lane decomposition
+  // blocks arrive sorted by size, largest first: 8x8 and larger go through the wave-cooperative routine (the decomposition
   // of hmx_rdoq_core.h), 4x4 blocks -- a single coefficient group, nothing to decompose -- one LANE per block (k_rdoq)
-  size_t n_wave = 0;
-  while (n_wave < blocks.size() && blocks[n_wave].log2n > 2) n_wave++;
+  const size_t n_wave = c->rdoq_class_n[0] + c->rdoq_class_n[1] + c->rdoq_class_n[2], n_all = n_wave + c->rdoq_class_n[3];
   const bool lane_only = c->knob.rdoq_lane_only;
-  if (n_wave && !lane_only && !c->rdoq_ws) {
-    c->rdoq_ws_bytes = (size_t)2048 * ((rdoq_wave_ws_bytes(5) + 255) & ~(size_t)255);
-    if (hipMalloc((void **)&c->rdoq_ws, c->rdoq_ws_bytes) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc RDOQ wave workspace");
-  }
-  for (size_t o = 0; o < blocks.size();) { // chunks share the workspaces: launches of one stream run one after the other
-    const bool wave = o < n_wave && !lane_only;
-    size_t n = std::min(blocks.size() - o, (size_t)kRdoqChunk);
-    if (wave) {
-      A.ws = c->rdoq_ws;
-      A.ws_stride = (rdoq_wave_ws_bytes(blocks[o].log2n) + 255) & ~(size_t)255; // the largest block of the chunk comes first
-      n = std::min({blocks.size() - o, n_wave - o, c->rdoq_ws_bytes / A.ws_stride});
-    } else if (!lane_only && o < n_wave) {
-      n = std::min(n, n_wave - o);
+  if (n_wave && !lane_only) {
+    // 8x8 and larger: the wave-cooperative routine of the whole-picture chain (rdoq_wave_tiles), a wave per 8 / 4 / 1 blocks
+    if (!c->rdoq_consts && hipMalloc((void **)&c->rdoq_consts, 4 * sizeof(double)) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc RDOQ constants");
+    double up[4];
+    up[0] = A.lambda[0], up[1] = A.lambda[1];
+    memcpy(&up[2], A.rd_factor, 2 * sizeof(long long));
+    if (!c->rdoq_consts_valid || memcmp(up, c->rdoq_consts_h, sizeof(up))) { // a pipeline calls with the same multipliers
+      HIPCHK(c, hipStreamSynchronize(c->stream)); // an earlier call may still read them
+      memcpy(c->rdoq_consts_h, up, sizeof(up));
+      HIPCHK(c, hipMemcpyAsync(c->rdoq_consts, c->rdoq_consts_h, sizeof(up), hipMemcpyHostToDevice, c->stream));
+      c->rdoq_consts_valid = true;
     }
+    RdoqChain RC{};
+    RC.est = nullptr, RC.lambda = c->rdoq_consts, RC.rd_factor = reinterpret_cast<const long long *>(c->rdoq_consts + 2);
+    RC.pic_mul = 0, RC.n_pics = 1;
+    memcpy(RC.err_scale, A.err_scale, sizeof(RC.err_scale));
+    PicDev P{};
+    P.bit_depth = A.bit_depth, P.sign_hide = A.sign_hide;
+    for (int t = 0; t < 2; t++) P.qd[t].q = A.q[t], P.qd[t].per_qbits = A.per[t];
+    // the size classes are independent, and a picture's worth of one class does not fill the chip (a launch lasts about as
+    // long as one block): they run side by side, 16x16 and 8x8 on side streams that fork from and join the caller's
+    if (c->n_side < 2) {
+      if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+      for (int g = c->n_side; g < 2; g++) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->side[g], hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming));
+      }
+      c->n_side = 2;
+    }
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    size_t o = 0;
+    bool used[2] = {false, false};
+    for (int lg = 5; lg >= 3; lg--) {
+      const size_t e = o + c->rdoq_class_n[5 - lg];
+      if (e > o) {
+        A.blocks = c->rdoq_blocks + o;
+        A.n = (int)(e - o);
+        hipStream_t st = c->stream;
+        if (lg < 5) {
+          st = c->side[4 - lg];
+          used[4 - lg] = true;
+          HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0));
+        }
+        if (lg == 5) hipLaunchKernelGGL((k_rdoq_tiles<32, 1>), dim3((unsigned)A.n), dim3(64), 0, st, A, RC, P);
+        else if (lg == 4) hipLaunchKernelGGL((k_rdoq_tiles<16, 4>), dim3((unsigned)((A.n + 3) / 4)), dim3(64), 0, st, A, RC, P);
+        else hipLaunchKernelGGL((k_rdoq_tiles<8, 8>), dim3((unsigned)((A.n + 7) / 8)), dim3(64), 0, st, A, RC, P);
+        HIPCHK(c, hipGetLastError());
+      }
+      o = e;
+    }
+    for (int g = 0; g < 2; g++) // the 4x4 launches that follow on the caller's stream overlap too; the call ends joined
+      if (used[g]) {
+        HIPCHK(c, hipEventRecord(c->ev_join[g], c->side[g]));
+      }
+    c->rdoq_join[0] = used[0], c->rdoq_join[1] = used[1];
+  }
+  // 4x4 blocks -- a single coefficient group, nothing to decompose -- one LANE per block (k_rdoq); HMX_RDOQ_LANE: every block
+  for (size_t o = lane_only ? 0 : n_wave; o < n_all;) { // chunks share the workspace: launches of one stream run one after the other
+    const size_t n = std::min(n_all - o, (size_t)kRdoqChunk);
     A.blocks = c->rdoq_blocks + o;
     A.n = (int)n;
-    if (wave) hipLaunchKernelGGL(k_rdoq_wave, dim3((unsigned)n), dim3(64), 0, c->stream, A);
-    else hipLaunchKernelGGL(k_rdoq, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, A);
+    hipLaunchKernelGGL(k_rdoq, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, A);
     HIPCHK(c, hipGetLastError());
     o += n;
   }
+  for (int g = 0; g < 2; g++)
+    if (c->rdoq_join[g]) {
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[g], 0));
+      c->rdoq_join[g] = false;
+    }
   return HMX_OK;
 }
 
@@ -3534,6 +3594,18 @@ extern "C" int hmx_batch_xRateDistOptQuant(hmx_ctx *c, const hmx_tu *tus, const 
   const double lam[2] = {lambda_luma, lambda_chroma};
   rdoq_constants(A, c->cfg.bit_depth, qps, lam);
   A.sign_hide = pp->sign_hide;
+  // a pipeline quantises the same block structure picture after picture: when the arguments are the ones that produced the
+  // list resident on the device (64-bit hash), the list is neither rebuilt nor sorted nor uploaded
+  uint64_t in_key = hash_words(0x13198a2e03707344ull ^ (uint64_t)n, tus, sizeof(hmx_tu) * (size_t)n);
+  in_key = hash_words(in_key, side, sizeof(hmx_rdoq_side) * (size_t)n);
+  in_key = hash_words(in_key, coef, sizeof(*coef));
+  in_key = hash_words(in_key, lev, sizeof(*lev));
+  in_key = hash_words(in_key ^ (uint64_t)(uintptr_t)d_abs_sum ^ (uint64_t)n_est, est, sizeof(hmx_est_bits) * (size_t)n_est);
+  if (c->rdoq_resident && c->rdoq_in_key == in_key && in_key) {
+    // the multipliers and the QP may differ from call to call: they travel with the launch, not with the list
+    const int r = rdoq_issue(c, A);
+    return r;
+  }
   std::vector<RdoqBlock> b(n);
   for (int i = 0; i < n; i++) {
     const hmx_tu &t = tus[i];
@@ -3550,7 +3622,9 @@ extern "C" int hmx_batch_xRateDistOptQuant(hmx_ctx *c, const hmx_tu *tus, const 
   // a block is one lane and its cost grows with its size: lanes of a wave should hold blocks of one size,
   // the long ones first
   std::stable_sort(b.begin(), b.end(), [](const RdoqBlock &x, const RdoqBlock &y) { return x.log2n > y.log2n; });
-  return rdoq_launch(c, A, b, est, n_est);
+  const int r = rdoq_launch(c, A, b, est, n_est);
+  c->rdoq_in_key = r ? 0 : in_key;
+  return r;
 }
 
 extern "C" int hmx_xDeQuant(hmx_ctx *c, const hmx_coeff *src, int32_t *dst, int w, int h, const hmx_qp *qp) {

@@ -9,9 +9,11 @@
 //      the running c1/c2/Rice context state; per coefficient group the decision to zero the whole group;
 //   B. the last significant position;
 //   C. sign-bit hiding with rate-aware costs.
-// The running context state makes a block sequential, so the work item is ONE LANE PER BLOCK; blocks are
-// independent.  Per-position records live in a global workspace interleaved by lane (record i of lane t at
-// i * T + t): lanes of a wave walk the same positions, so the accesses coalesce.
+// Two forms.  k_rdoq: ONE LANE PER BLOCK, the reference's sequential walk with its per-position records in a global
+// workspace interleaved by lane (4x4 blocks of the batch entry points, and the cross-check of the other form).
+// rdoq_wave_tiles: the lanes of a wave SHARE the blocks it holds in LDS (hmx_rdoq_core.h's decomposition), nothing per
+// coefficient stored, nothing outside the LDS -- the quantiser of the whole-picture chain and of 8x8 and larger blocks of
+// the batch entry points.
 //
 // Costs are IEEE doubles evaluated in the reference's order.  Fused multiply-add would round differently:
 // contraction is switched off for this file, and the two quotients (error scale, sign-hiding factor) are
@@ -42,9 +44,6 @@ struct RdoqArgs {
   double *wd;
   int *wi;
   int T;
-  // workspace of k_rdoq_wave (one wave per block): ws_stride bytes per block of the launch
-  char *ws;
-  size_t ws_stride;
   int bit_depth, sign_hide;
   int per[2], rem[2], q[2];
   double lambda[2];
@@ -355,157 +354,6 @@ __global__ __launch_bounds__(64) void k_rdoq(RdoqArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// ONE WAVE PER BLOCK (8x8, 16x16, 32x32): the lane decomposition of hmx_rdoq_core.h.
-//   step 0  a lane per scan position: |coef| * q, cost of zero; the last position with a non-zero candidate (wave max)
-//   step 1  a lane per (coefficient group, carry, neighbour pattern): the group walked under that assumption
-//   step 2  lane 0: the groups in the reference's order -- variant picked, its 16 cost terms added one by one, group decision
-//   step 3  a lane per group: the chosen variant walked again for levels, per-coefficient costs and rate deltas
-//   step 4  lane 0: last position; a lane per position: final levels; a lane per group: rate-aware sign hiding
-// The steps hand their results on through the block's workspace in global memory (the lanes of one wave: a drained store is
-// visible to the wave's own later loads).  Workspace per block: rdoq_wave_ws_bytes(log2n).
-// ---------------------------------------------------------------------------------------------------------------------
-__host__ __device__ inline size_t rdoq_wave_ws_bytes(int lg) {
-  const size_t nn = (size_t)1 << (2 * lg), n_cg = nn >> 4;
-  return nn * (6 * sizeof(int) + 3 * sizeof(double)) + n_cg * 8 * sizeof(RdoqSpec) + 64 * sizeof(double) + 64 + sizeof(RdoqRun) + 64;
-}
-struct RdoqWs { // a block's workspace, carved
-  double *cz, *cc, *cs, *cgs;
-  RdoqSpec *spec;
-  RdoqRun *run;
-  int *ld, *lev, *ru, *rd, *sd, *du;
-  unsigned char *sel;
-};
-__device__ __forceinline__ RdoqWs rdoq_ws_carve(char *w, int nn) {
-  RdoqWs W;
-  W.cz = reinterpret_cast<double *>(w), W.cc = W.cz + nn, W.cs = W.cc + nn, W.cgs = W.cs + nn;
-  W.spec = reinterpret_cast<RdoqSpec *>(W.cgs + 64);
-  W.run = reinterpret_cast<RdoqRun *>(W.spec + (size_t)(nn >> 4) * 8);
-  W.ld = reinterpret_cast<int *>(W.run + 1), W.lev = W.ld + nn, W.ru = W.lev + nn, W.rd = W.ru + nn, W.sd = W.rd + nn, W.du = W.sd + nn;
-  W.sel = reinterpret_cast<unsigned char *>(W.du + nn);
-  return W;
-}
-__device__ __forceinline__ void rdoq_wave_fence() { // this wave's global stores before its later loads by other lanes
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-__global__ __launch_bounds__(64) void k_rdoq_wave(RdoqArgs A) {
-  const int lane = threadIdx.x;
-  const RdoqBlock K = A.blocks[blockIdx.x];
-  const EstBitsDev &E = A.est[K.est_idx];
-  const int lg = K.log2n, N = 1 << lg, nn = N * N, n_cg = nn >> 4;
-  const int pt = K.plane_type, B = A.bit_depth, scan_idx = K.scan_idx;
-  RdoqConst C;
-  C.lg = lg, C.scan_idx = scan_idx, C.is_luma = K.is_luma;
-  C.q = A.q[pt], C.qbits = 14 + A.per[pt] + (15 - B - lg);
-  C.root_cbf = K.root_cbf, C.cbf_ctx = K.cbf_ctx, C.sign_hide = A.sign_hide;
-  C.lambda = A.lambda[pt], C.err_scale = A.err_scale[pt][lg - 2], C.rd_factor = A.rd_factor[pt];
-  // carve the workspace
-  char *w = A.ws + (size_t)blockIdx.x * A.ws_stride;
-  double *cz = reinterpret_cast<double *>(w), *cc = cz + nn, *cs = cc + nn, *cgs = cs + nn;
-  RdoqSpec *spec = reinterpret_cast<RdoqSpec *>(cgs + 64);
-  RdoqRun *run = reinterpret_cast<RdoqRun *>(spec + (size_t)n_cg * 8);
-  int *ld = reinterpret_cast<int *>(run + 1), *lev = ld + nn, *ru = lev + nn, *rd = ru + nn, *sd = rd + nn, *du = sd + nn;
-  unsigned char *sel = reinterpret_cast<unsigned char *>(du + nn);
-  const int *src = K.src;
-  int *dst = K.dst;
-  const int ss = K.src_stride, ds = K.dst_stride;
-  auto bp_of = [&](int sp) { return rdoq_scan_pos(lg, scan_idx, sp); };
-  auto gpos_of = [&](int cg) {
-    const unsigned p0 = rdoq_scan_pos(lg, scan_idx, cg * 16);
-    return ((p0 & (unsigned)(N - 1)) >> 2) | (((p0 >> lg) >> 2) << 8);
-  };
-  // step 0
-  int last_pos = -1;
-  for (int sp = lane; sp < nn; sp += 64) {
-    const unsigned bp = bp_of(sp);
-    int l;
-    double z;
-    rdoq_prep(src[(bp >> lg) * ss + (bp & (unsigned)(N - 1))], C, l, z);
-    ld[sp] = l, cz[sp] = z;
-    if (rdoq_max_level(l, C.qbits) > 0) last_pos = sp;
-  }
-  for (int off = 32; off > 0; off >>= 1) last_pos = max(last_pos, __shfl_xor(last_pos, off, 64));
-  if (last_pos < 0) { // nothing survives quantisation
-    for (int sp = lane; sp < nn; sp += 64) dst[(sp >> lg) * ds + (sp & (N - 1))] = 0;
-    if (lane == 0 && K.abs_sum) *K.abs_sum = 0;
-    return;
-  }
-  const int last_cg = last_pos >> 4;
-  rdoq_wave_fence();
-  // step 1
-  for (int task = lane; task < (last_cg + 1) * 8; task += 64) {
-    const int cg = task >> 3, v = task & 7;
-    RdoqSpecSink sink{&spec[task]};
-    spec[task].S = rdoq_walk_cg(C, E, cg, bp_of, src, ss, v & 3, v >> 2, last_pos, sink);
-  }
-  rdoq_wave_fence();
-  // step 2
-  if (lane == 0) {
-    RdoqRun R;
-    rdoq_resolve(C, E, n_cg, last_cg, gpos_of, cz, spec, sel, cgs, R);
-    *run = R;
-  }
-  rdoq_wave_fence();
-  // step 3
-  if (lane < n_cg) {
-    const int cg = lane;
-    if (cg > last_cg) {
-      for (int k = 0; k < 16; k++) {
-        const int sp = cg * 16 + k;
-        lev[sp] = 0, cc[sp] = 0, cs[sp] = 0, ru[sp] = 0, rd[sp] = 0, sd[sp] = 0, du[sp] = 0;
-      }
-    } else {
-      RdoqFullSink sink{lev, cc, cs, ru, rd, sd, du, cg * 16};
-      const int v = sel[cg];
-      rdoq_walk_cg(C, E, cg, bp_of, src, ss, v & 3, v >> 2, last_pos, sink);
-      if ((run->zeroed >> cg) & 1) rdoq_apply_zeroed_cg(cg, cz, lev, cc, cs);
-    }
-  }
-  rdoq_wave_fence();
-  // step 4a
-  int blp1 = 0;
-  if (lane == 0) blp1 = rdoq_phase_b(C, E, last_pos, last_cg, gpos_of, bp_of, *run, cz, lev, cc, cs, cgs);
-  blp1 = __shfl(blp1, 0, 64);
-  // final levels
-  uint32_t sum = 0;
-  unsigned neg = 0; // for lanes that are a group: the signs of the group's unquantised coefficients
-  for (int sp = lane; sp < nn; sp += 64) {
-    const unsigned bp = bp_of(sp);
-    const int l = sp < blp1 ? lev[sp] : 0;
-    sum += (uint32_t)l;
-    lev[sp] = src[(bp >> lg) * ss + (bp & (unsigned)(N - 1))] < 0 ? -l : l;
-  }
-  for (int off = 32; off > 0; off >>= 1) sum += (uint32_t)__shfl_xor((int)sum, off, 64);
-  if (lane == 0 && K.abs_sum) *K.abs_sum = sum;
-  rdoq_wave_fence();
-  // step 4c
-  if (A.sign_hide && sum >= 2) {
-    bool any = false;
-    int l16[16];
-    if (lane < n_cg) {
-      for (int k = 0; k < 16; k++) {
-        l16[k] = lev[lane * 16 + k];
-        any |= l16[k] != 0;
-        const unsigned bp = bp_of(lane * 16 + k);
-        neg |= (src[(bp >> lg) * ss + (bp & (unsigned)(N - 1))] < 0 ? 1u : 0u) << k;
-      }
-    }
-    const unsigned long long mask = __ballot(any);
-    const int top = mask ? 63 - __clzll((long long)mask) : -1;
-    if (lane < n_cg && any) {
-      rdoq_phase_c_cg(C, lane == top, l16, neg, ru + lane * 16, rd + lane * 16, sd + lane * 16, du + lane * 16);
-      for (int k = 0; k < 16; k++) lev[lane * 16 + k] = l16[k];
-    }
-    rdoq_wave_fence();
-  }
-  for (int sp = lane; sp < nn; sp += 64) {
-    const unsigned bp = bp_of(sp);
-    dst[(bp >> lg) * ds + (bp & (unsigned)(N - 1))] = lev[sp];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // RDOQ as the quantiser of the whole-picture chain (k_intra_packed): the second decomposition of hmx_rdoq_core.h over the
 // SL blocks a chain wave holds in LDS -- NOTHING per coefficient is stored, and nothing leaves the LDS:
 //   * the bit-estimate tables of the wave-item's pictures and size class and its scan tables are staged in LDS once per
@@ -518,7 +366,7 @@ __global__ __launch_bounds__(64) void k_rdoq_wave(RdoqArgs A) {
 //     (RdoqLastSink, RdoqHideSink): a walk costs a few microseconds, an array per coefficient costs the LDS.
 // tests/native/rdoq_core_host.cpp runs exactly these steps on the CPU against the oracle.
 // On entry Ls[b].tile[row][col] holds block b's Int coefficients (fwd_tq_block without the quantiser) and Ls[b].line[0..4] =
-// {active, picture, is_luma, scan_idx, cbf_ctx}, line[9] = the picture's index in its group; on exit the tile holds the levels.
+// {active, picture, is_luma, scan_idx, cbf_ctx}, line[9] = its table in W.est, line[10] = root_cbf; on exit the tile holds the levels.
 // What the encoder takes from its live state is an input of the call (hmx_set_rdoq): per picture the bit estimates for
 // [luma, chroma][4 sizes] and lambda for luma / chroma blocks.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -531,7 +379,8 @@ struct RdoqChain {
   double err_scale[2][4];
 };
 constexpr int kRdoqMaxGroup = 2; // pictures per packing group with RDOQ: 2 x 2 tables of 1016 bytes in LDS
-struct RdoqWaveLds {
+template <int NEST>
+struct RdoqWaveLdsT {
   union {
     RdoqSpec spec[64]; // the round's variants: [block][group of the round][carry * 4 + pattern]
     double cz[1024];   // before the rounds: the costs of zero above the last position's group
@@ -542,9 +391,20 @@ struct RdoqWaveLds {
   unsigned short scan[1024]; // the size class's scan tables: [scan_idx][position] (32x32: the diagonal scan only)
   unsigned char sel[64];     // variant taken [block][group]
   unsigned long long zeroed[8];
-  EstBitsDev est[2 * kRdoqMaxGroup]; // [picture of the group][luma, chroma], the wave-item's size class
-  int key;                           // ((group << 2) | size class) + 1 of what est / scan hold
+  EstBitsDev est[NEST]; // the chain: [picture of the group][luma, chroma] for the wave-item's size class; line[9] of a block selects
+  int key;              // ((group << 2) | size class) + 1 of what est / scan hold
 };
+typedef RdoqWaveLdsT<2 * kRdoqMaxGroup> RdoqWaveLds; // of the whole-picture chain
+template <typename WL>
+__device__ __forceinline__ void rdoq_stage_scan(WL &W, int s, int lane) { // the scan tables of size class s = log2n - 2
+  // the walks are bound by the instructions they issue: a table lookup, not the arithmetic of the scan (2 KB of LDS)
+  if (s == 3) {
+    for (int i = lane; i < 1024; i += 64) W.scan[i] = (unsigned short)kScan32.t[0][i];
+  } else if (s > 0) {
+    const int nn = 16 << (2 * s);
+    for (int i = lane; i < 3 * nn; i += 64) W.scan[i] = (unsigned short)rdoq_scan_pos(s + 2, i / nn, i % nn);
+  }
+}
 // stage the tables of (picture group g, size class s = log2n - 2); I = pictures per group
 __device__ __forceinline__ void rdoq_stage_tables(RdoqWaveLds &W, const RdoqChain &RC, int g, int s, int I, int lane) {
   const int key = ((g << 2) | s) + 1;
@@ -556,13 +416,7 @@ __device__ __forceinline__ void rdoq_stage_tables(RdoqWaveLds &W, const RdoqChai
     const int pic = min(g * I + (tb >> 1), RC.n_pics - 1) * RC.pic_mul;
     reinterpret_cast<int *>(&W.est[tb])[w] = reinterpret_cast<const int *>(&RC.est[((size_t)pic * 2 + (tb & 1)) * 4 + s])[w];
   }
-  // the walks are bound by the instructions they issue: a table lookup, not the arithmetic of the scan (2 KB of LDS)
-  if (s == 3) {
-    for (int i = lane; i < 1024; i += 64) W.scan[i] = (unsigned short)kScan32.t[0][i];
-  } else if (s > 0) {
-    const int nn = 16 << (2 * s);
-    for (int i = lane; i < 3 * nn; i += 64) W.scan[i] = (unsigned short)rdoq_scan_pos(s + 2, i / nn, i % nn);
-  }
+  rdoq_stage_scan(W, s, lane);
   if (lane == 0) W.key = key;
   wave_sync();
 }
@@ -574,7 +428,7 @@ __device__ __forceinline__ RdoqConst rdoq_chain_const(const TuLds<N> &L, const R
   C.lg = LG, C.scan_idx = L.line[3], C.is_luma = luma;
   C.q = pt ? P.qd[1].q : P.qd[0].q;
   C.qbits = 14 + (pt ? P.qd[1].per_qbits : P.qd[0].per_qbits) + (15 - P.bit_depth - LG);
-  C.root_cbf = 0, C.cbf_ctx = L.line[4], C.sign_hide = P.sign_hide;
+  C.root_cbf = L.line[10], C.cbf_ctx = L.line[4], C.sign_hide = P.sign_hide;
   C.lambda = RC.lambda[pic * 2 + pt], C.err_scale = RC.err_scale[pt][LG - 2], C.rd_factor = RC.rd_factor[pic * 2 + pt];
   return C;
 }
@@ -616,8 +470,8 @@ __device__ unsigned long long g_rdoq_prof[40]; // [log2n - 2][step 0..8, calls],
 #define RQ_T0
 #define RQ_COUNT
 #endif
-template <int N, int SL>
-__device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, RdoqWaveLds &W, const RdoqChain &RC, const PicDev &P, int lane) {
+template <int N, int SL, typename WL>
+__device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqChain &RC, const PicDev &P, int lane) {
   constexpr int LG = N == 8 ? 3 : N == 16 ? 4 : 5, NN = N * N, NCG = NN / 16, G = N / 4;
   constexpr int GPR = 8 / SL; // groups of a block per round: 64 lanes = SL blocks x GPR groups x 8 variants
   static_assert(SL * NCG <= 64 && SL * NN <= 1024 && SL * GPR * 8 == 64, "one lane per group, one round per 64 variants");
@@ -667,7 +521,7 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, RdoqWaveLds &W, co
   for (int off = 32; off > 0; off >>= 1) rounds = max(rounds, __shfl_xor(rounds, off, 64));
   wave_sync(); // the buffer changes hands
   RQ_T(1);
-  const EstBitsDev &ER = W.est[LR.line[9] * 2 + (LR.line[2] ? 0 : 1)];
+  const EstBitsDev &ER = W.est[LR.line[9]];
   for (int r = 0; r < rounds; r++) {
     { // one lane per (block, group of the round, carry, pattern)
       const int b = lane / (GPR * 8), j = (lane >> 3) % GPR, v = lane & 7;
@@ -675,7 +529,7 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, RdoqWaveLds &W, co
       const int last_pos = L.line[5], cg = (last_pos >> 4) - r * GPR - j;
       if (L.line[0] && last_pos >= 0 && cg >= 0) {
         const RdoqConst C = rdoq_chain_const<N>(L, RC, P);
-        const EstBitsDev &E = W.est[L.line[9] * 2 + (L.line[2] ? 0 : 1)];
+        const EstBitsDev &E = W.est[L.line[9]];
         const int scan_idx = C.scan_idx;
         auto bp_of = [&](int sp) { return scan_of(scan_idx, sp); };
         RdoqSpecSink sink{&W.u.spec[lane]};
@@ -732,7 +586,7 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, RdoqWaveLds &W, co
     bool walked = false;
     if (L.line[0] && last_pos >= 0 && cg <= (last_pos >> 4) && !((W.zeroed[b] >> cg) & 1) && cg * 16 < L.line[6]) {
       const RdoqConst C = rdoq_chain_const<N>(L, RC, P);
-      const EstBitsDev &E = W.est[L.line[9] * 2 + (L.line[2] ? 0 : 1)];
+      const EstBitsDev &E = W.est[L.line[9]];
       const int scan_idx = C.scan_idx;
       auto bp_of = [&](int sp) { return scan_of(scan_idx, sp); };
       RdoqLevelSink<N> sink{out, &L, cg * 16, L.line[6], 0, 0};
@@ -760,7 +614,7 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, RdoqWaveLds &W, co
       RdoqHide H;
       if (rdoq_hide_begin(cg == L.line[8], lev_of, H)) { // implies the group holds a level: it was walked above
         const RdoqConst C = rdoq_chain_const<N>(L, RC, P);
-        const EstBitsDev &E = W.est[L.line[9] * 2 + (L.line[2] ? 0 : 1)];
+        const EstBitsDev &E = W.est[L.line[9]];
         const int scan_idx = C.scan_idx;
         auto bp_of = [&](int sp) { return scan_of(scan_idx, sp); };
         unsigned neg = 0;
@@ -789,6 +643,37 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, RdoqWaveLds &W, co
   RQ_COUNT;
 }
 
+// The same routine behind hmx_batch_xRateDistOptQuant: a wave takes SL consecutive blocks of one size from the (sorted) list,
+// brings their coefficients and tables into LDS, and writes levels and sums back.  RC.lambda / RC.rd_factor: [luma, chroma].
+template <int N, int SL>
+__global__ __launch_bounds__(64) void k_rdoq_tiles(RdoqArgs A, RdoqChain RC, PicDev P) {
+  constexpr int LG = N == 8 ? 3 : N == 16 ? 4 : 5, NN = N * N;
+  __shared__ TuLds<N> tiles[SL];
+  __shared__ RdoqWaveLdsT<SL> W;
+  const int lane = threadIdx.x, first = blockIdx.x * SL;
+  rdoq_stage_scan(W, LG - 2, lane);
+  constexpr int kWords = (int)(sizeof(EstBitsDev) / sizeof(int));
+  for (int b = 0; b < SL; b++) {
+    const bool active = first + b < A.n;
+    const RdoqBlock K = A.blocks[active ? first + b : first];
+    TuLds<N> &L = tiles[b];
+    if (lane == 0)
+      L.line[0] = active, L.line[1] = 0, L.line[2] = K.is_luma, L.line[3] = K.scan_idx, L.line[4] = K.cbf_ctx, L.line[9] = b, L.line[10] = K.root_cbf;
+    if (!active) continue;
+    for (int i = lane; i < kWords; i += 64) reinterpret_cast<int *>(&W.est[b])[i] = reinterpret_cast<const int *>(&A.est[K.est_idx])[i];
+    for (int i = lane; i < NN; i += 64) L.tile[i >> LG][i & (N - 1)] = K.src[(i >> LG) * K.src_stride + (i & (N - 1))];
+  }
+  wave_sync();
+  rdoq_wave_tiles<N, SL>(tiles, W, RC, P, lane);
+  for (int b = 0; b < SL; b++) {
+    if (first + b >= A.n) break;
+    const RdoqBlock K = A.blocks[first + b];
+    TuLds<N> &L = tiles[b];
+    for (int i = lane; i < NN; i += 64) K.dst[(i >> LG) * K.dst_stride + (i & (N - 1))] = L.tile[i >> LG][i & (N - 1)];
+    if (lane == 0 && K.abs_sum) *K.abs_sum = (uint32_t)L.line[7];
+  }
+}
+
 // One 4x4 block in ONE lane (the lane-per-block 4x4 chain): a single coefficient group, so no variants -- the walk with a
 // sink that keeps the two running sums, then the same re-walks as above.  The lane's coefficients (scan order) and levels
 // live in its LDS rows (c16: 16 ints; l16: 16 shorts), nothing in private arrays.  Returns the levels in l16, scan order.
@@ -813,8 +698,9 @@ struct RdoqLaneLevelSink {
     out[k] = (short)(c16[k] < 0 ? -l : l);
   }
 };
+template <typename WL>
 __device__ __forceinline__ void rdoq_lane_4x4(const int *c16, short *l16, int pic, int est_slot, bool luma, int scan_idx, int cbf_ctx,
-                                              const RdoqChain &RC, const RdoqWaveLds &W, const PicDev &P) {
+                                              const RdoqChain &RC, const WL &W, const PicDev &P) {
   const int pt = luma ? 0 : 1;
   pic *= RC.pic_mul;
   RdoqConst C;
