@@ -1379,3 +1379,65 @@ def test_frame_intra_rdoq_in_chain(ctx, shared):
         L.hmx_intra_plan_destroy(ctx.h, pl)
     for d in d_org + d_rec + d_lev:
         d.free()
+
+
+def test_frame_intra_rdoq_resident_with_sse(ctx, hmx_opts):
+    """RDOQ inside the chain together with the distortion output (the kernel variant of its own), on pictures RESIDENT in the
+    working layout, packing groups of two pictures with a ragged last group (the tables of a group wait in LDS: slot =
+    picture within the group), per-picture tables and multipliers; levels, reconstruction and xGetSSE vs the oracle.  A
+    packing group the tables do not fit is refused."""
+    hmx_opts(ctx, HMX_PACK_GROUP="2")
+    O, B, L = ol.oracle(), ctx.bit_depth, capi.lib()
+    O.hmo_getSSE.restype = C.c_uint32
+    w, h, n, qp = 320, 192, 5, 30
+    rng = np.random.default_rng(99)
+    pp = capi.PicParam(w, h, qp, 0, capi.I_SLICE, 1)
+    tus = [workload.with_cbf_ctx(workload.make_tus(3300 + i, w, h, "mix")) for i in range(n)]
+    plans = [ctx.intra_plan(t, pp) for t in tus]
+    orgs = [workload.make_planes(3400 + i, w, h, B, "texture" if i % 2 else "noise") for i in range(n)]
+    ests = [[workload.make_est_bits(4000 + 8 * i + k) for k in range(8)] for i in range(n)]
+    lams = [(float(rng.uniform(20, 120)), float(rng.uniform(15, 90))) for _ in range(n)]
+    ctx.set_rdoq([(ests[i], lams[i][0], lams[i][1]) for i in range(n)])  # before the pools: it bounds the packing group
+    d_org = [capi.DevPicture(ctx, w, h).upload(o) for o in orgs]
+    d_out = [capi.DevPicture(ctx, w, h).zero() for _ in range(n)]
+    p_org, p_rec = capi.ResidentPool(ctx, w, h, n), capi.ResidentPool(ctx, w, h, n)
+    p_org.import_planes(0, d_org)
+    d_lev = [capi.DevLevelsZ(ctx, w, h) for _ in range(n)]
+    lev_arr = (capi.Levels * n)(*[d.as_pic() for d in d_lev])
+    parr = (C.c_void_p * n)(*[p.value for p in plans])
+    cw, ch = -(-w // 64), -(-h // 64)
+    units = [cw * ch * 256, cw * ch * 64, cw * ch * 64]
+    d_sse = [[ctx.alloc(4 * u).zero() for u in units] for _ in range(n)]
+    sse_arr = (capi.Sse * n)()
+    for i in range(n):
+        for p in range(3):
+            sse_arr[i].plane[p] = d_sse[i][p].ptr
+    ctx._chk(L.hmx_set_sse_output(ctx.h, sse_arr, n))
+    ctx._chk(L.hmx_frame_intra_encode_resident(ctx.h, parr, 1, n, p_org.h_, p_rec.h_, lev_arr))
+    p_rec.export_planes(0, d_out)
+    ctx.sync()
+    for i in range(n):
+        rr, lr = ol.o_intra_frame_encode_rdoq(tus[i], w, h, B, qp, orgs[i], ests[i], lams[i])
+        rec, lev = d_out[i].download(), d_lev[i].to_planes(tus[i])
+        got = [d_sse[i][p].download(np.uint32) for p in range(3)]
+        for p in range(3):
+            assert np.array_equal(lev[p], lr[p]), ("levels", i, p)
+            assert np.array_equal(rec[p], rr[p]), ("recon", i, p)
+        for t in tus[i][:: 7]:
+            N, p, x, y = 1 << int(t["log2n"]), int(t["plane"]), int(t["x"]), int(t["y"])
+            o = np.ascontiguousarray(orgs[i][p][y:y + N, x:x + N])
+            r = np.ascontiguousarray(rr[p][y:y + N, x:x + N])
+            want = O.hmo_getSSE(o.ctypes.data_as(C.c_void_p), N, r.ctypes.data_as(C.c_void_p), N, N, N, B)
+            assert int(got[p][d_lev[i].block_offset(p, x, y) // 16]) == want, ("sse", i, p, x, y, N)
+    ctx._chk(L.hmx_set_sse_output(ctx.h, None, 0))
+    # groups of four: the tables of a group would not fit
+    hmx_opts(ctx, HMX_PACK_GROUP="4")
+    p4_org, p4_rec = capi.ResidentPool(ctx, w, h, n), capi.ResidentPool(ctx, w, h, n)
+    assert L.hmx_frame_intra_encode_resident(ctx.h, parr, 1, n, p4_org.h_, p4_rec.h_, lev_arr) != 0
+    ctx.set_rdoq(None)
+    for x in (p_org, p_rec, p4_org, p4_rec):
+        x.free()
+    for pl in plans:
+        L.hmx_intra_plan_destroy(ctx.h, pl)
+    for d in d_org + d_out + d_lev + [b for row in d_sse for b in row]:
+        d.free()
