@@ -120,7 +120,8 @@ static void rdoq_block_lanes(const int *src, int *dst, int N, int B, const hmo_r
 
 // The second decomposition (the one the whole-picture chain runs, rdoq_wave_tiles): nothing per coefficient is stored.
 // The variants of a few groups at a time (a "round" of 64 lanes) go through a small buffer and are resolved before the next
-// round; last position and sign hiding walk the chosen variant of a group AGAIN with a sink that does their arithmetic.
+// round; the chosen variant of every group is walked AGAIN for its levels (the upper groups also leave the two costs per entry
+// the last-position search needs), and sign hiding walks a group a third time with a sink that does its arithmetic.
 struct LevelSink {
   int *out;
   void add(int, double) {}
@@ -183,35 +184,63 @@ static void rdoq_block_rewalk(const int *src, int *dst, int N, int B, const hmo_
       sel[cg] = (unsigned char)rdoq_resolve_group(C, E, cg, last_cg, gpos_of(cg), buf + j * 8, [&](int k) { return cz_at(cg * 16 + k); }, R, carry, cgs[cg]);
     }
   }
-  // last position: the resolving lane again, coded groups walked once more
+  // levels as walked, one lane per group; the upper groups also leave the two costs per entry the search needs
+  const int REC = N == 32 ? 32 : N == 16 ? 8 : N == 8 ? 4 : 1;
+  struct Rec {
+    double cs[16], cc[16];
+  };
+  struct RecordSink {
+    int *lev;
+    double *cs, *cc;
+    void add(int, double) {}
+    void pos(int k, unsigned, int level, double c_coded, double c_sig, int, int, int, int, double) {
+      lev[k] = level;
+      if (cs) cs[k] = c_sig, cc[k] = c_coded;
+    }
+  };
+  std::vector<Rec> rec(REC);
+  std::vector<int> lev(nn, 0);
+  auto flagged = [&](int cg) {
+    const unsigned g = gpos_of(cg), gpos = (g >> 8) * (unsigned)G + (g & 255u);
+    return (R.cg_flag >> gpos) & 1;
+  };
+  for (int cg = 0; cg <= last_cg; cg++) {
+    if ((R.zeroed >> cg) & 1) continue;
+    const bool r = last_cg - cg < REC && flagged(cg);
+    RecordSink sink{&lev[cg * 16], r ? rec[last_cg - cg].cs : nullptr, r ? rec[last_cg - cg].cc : nullptr};
+    auto in = [&](int, unsigned bp) { return src[bp]; };
+    rdoq_walk_cg_in(C, E, cg, bp_of, in, sel[cg] & 3, sel[cg] >> 2, last_pos, sink);
+  }
+  // last position: the resolving lane, over the records; deeper groups (rare) walked once more with the search as the sink
   RdoqLast T;
   rdoq_last_init(C, E, R, T);
   for (int cg = last_cg; cg >= 0 && !T.found; cg--) {
-    const unsigned g = gpos_of(cg), gpos = (g >> 8) * (unsigned)G + (g & 255u);
     rdoq_last_group(T, cgs[cg]);
-    if (!((R.cg_flag >> gpos) & 1)) continue;
-    RdoqLastSink sink{C, E, T, cg * 16, last_pos};
-    auto in = [&](int, unsigned bp) { return src[bp]; };
-    rdoq_walk_cg_in(C, E, cg, bp_of, in, sel[cg] & 3, sel[cg] >> 2, last_pos, sink);
-    g_rewalk_last++;
+    if (!flagged(cg)) continue;
+    if (last_cg - cg < REC) {
+      for (int k = 15; k >= 0 && !T.found; k--) {
+        const int sp = cg * 16 + k;
+        if (sp > last_pos) continue;
+        const int lv = lev[sp];
+        rdoq_last_pos(C, E, T, sp, lv ? scan[sp] : 0u, lv, rec[last_cg - cg].cc[k], rec[last_cg - cg].cs[k], lv ? cz_at(sp) : 0.0);
+      }
+    } else {
+      RdoqLastSink sink{C, E, T, cg * 16, last_pos};
+      auto in = [&](int, unsigned bp) { return src[bp]; };
+      rdoq_walk_cg_in(C, E, cg, bp_of, in, sel[cg] & 3, sel[cg] >> 2, last_pos, sink);
+      g_rewalk_last++;
+    }
   }
-  // levels: one lane per group
-  std::vector<int> lev(nn, 0);
+  // cut at the last position, signed; one lane per group
   uint32_t sum = 0;
   int top_group = -1;
-  for (int cg = 0; cg <= last_cg; cg++) {
-    if ((R.zeroed >> cg) & 1) continue;
-    int l16[16];
-    LevelSink sink{l16};
-    auto in = [&](int, unsigned bp) { return src[bp]; };
-    rdoq_walk_cg_in(C, E, cg, bp_of, in, sel[cg] & 3, sel[cg] >> 2, last_pos, sink);
+  for (int cg = 0; cg <= last_cg; cg++)
     for (int k = 0; k < 16; k++) {
-      const int sp = cg * 16 + k, l = sp < T.best_last_p1 ? l16[k] : 0;
+      const int sp = cg * 16 + k, l = sp < T.best_last_p1 ? lev[sp] : 0;
       sum += (uint32_t)l;
       if (l) top_group = cg > top_group ? cg : top_group;
       lev[sp] = src[scan[sp]] < 0 ? -l : l;
     }
-  }
   *abs_sum = sum;
   if (C.sign_hide && sum >= 2) {
     for (int cg = 0; cg <= last_cg; cg++) { // one lane per group
@@ -311,8 +340,8 @@ int main(int argc, char **argv) {
     }
   printf("rdoq_core_host: %ld blocks identical to the oracle (%ld with levels; %ld groups zeroed by the group decision, %ld entered with a carry, "
          "%ld changed by sign hiding)\n", checked, nonzero, g_zeroed_groups, g_carried_groups, g_sign_hidden);
-  printf("re-walk decomposition: identical too (%ld groups walked again for the last position, %ld for sign hiding)\n", g_rewalk_last, g_rewalk_hide);
-  if (!g_zeroed_groups || !g_carried_groups || !g_sign_hidden || !g_rewalk_last || !g_rewalk_hide) {
+  printf("re-walk decomposition: identical too (%ld groups beyond the search records walked again for the last position, %ld for sign hiding)\n", g_rewalk_last, g_rewalk_hide);
+  if (!g_zeroed_groups || !g_carried_groups || !g_sign_hidden || !g_rewalk_hide) {
     printf("coverage hole\n");
     return 2;
   }

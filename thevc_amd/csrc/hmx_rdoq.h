@@ -384,13 +384,19 @@ struct RdoqWaveLdsT {
   union {
     RdoqSpec spec[64]; // the round's variants: [block][group of the round][carry * 4 + pattern]
     double cz[1024];   // before the rounds: the costs of zero above the last position's group
-    short lev[1024];   // after them: the signed levels, scan order
+    struct {
+      short lev[1024]; // after them: the levels, scan order (as walked, then cut at the last position and signed)
+      struct Rec {     // and what the last-position search needs of the upper groups of every block, [block][last_cg - cg]
+        double cs[16], cc[16];
+      } rec[32];
+    } a;
     char lane4[7680];  // 4x4 blocks, one per lane: the chain's Lane4Lds (its RDOQ needs no buffer)
   } u;
   double cgs[64];            // cost_cg_sig [block][group]
+  double rcz[8][16];         // the costs of zero of the round's groups, left by the lane of variant 0 for the resolving lane
   unsigned short scan[1024]; // the size class's scan tables: [scan_idx][position] (32x32: the diagonal scan only)
   unsigned char sel[64];     // variant taken [block][group]
-  unsigned long long zeroed[8];
+  unsigned long long zeroed[8], cg_flag[8];
   EstBitsDev est[NEST]; // the chain: [picture of the group][luma, chroma] for the wave-item's size class; line[9] of a block selects
   int key;              // ((group << 2) | size class) + 1 of what est / scan hold
 };
@@ -441,18 +447,21 @@ struct RdoqTileIn { // entry of a group from the block's coefficient tile
     return L->tile[bp >> LG][bp & (N - 1)];
   }
 };
-template <int N>
-struct RdoqLevelSink { // the walked levels of a group, cut at the last position, signed, into LDS
-  short *out;          // the group's 16 entries
-  const TuLds<N> *L;
-  int base_sp, blp1;
-  int sum, any;
+struct RdoqSpecCzSink { // a variant of a round; variant 0 also leaves the group's costs of zero
+  RdoqSpec *o;
+  double *cz16; // NULL for the other variants
+  __device__ __forceinline__ void add(int k, double v) { o->add[k] = v; }
+  __device__ __forceinline__ void pos(int k, unsigned, int, double, double, int, int, int, int, double cz) {
+    if (cz16) cz16[k] = cz;
+  }
+};
+struct RdoqRecordSink { // the chosen variant of a group: its levels as walked, and (upper groups) the search's two costs per entry
+  short *lev;           // the group's 16 entries
+  double *cs, *cc;      // NULL: no record
   __device__ __forceinline__ void add(int, double) {}
-  __device__ __forceinline__ void pos(int k, unsigned bp, int level, double, double, int, int, int, int, double) {
-    constexpr int LG = N == 8 ? 3 : N == 16 ? 4 : 5;
-    const int l = base_sp + k < blp1 ? level : 0;
-    sum += l, any |= l;
-    out[k] = (short)(L->tile[bp >> LG][bp & (N - 1)] < 0 ? -l : l);
+  __device__ __forceinline__ void pos(int k, unsigned, int level, double c_coded, double c_sig, int, int, int, int, double) {
+    lev[k] = (short)level;
+    if (cs) cs[k] = c_sig, cc[k] = c_coded;
   }
 };
 #ifdef HMX_PACK_PROFILE
@@ -532,7 +541,7 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
         const EstBitsDev &E = W.est[L.line[9]];
         const int scan_idx = C.scan_idx;
         auto bp_of = [&](int sp) { return scan_of(scan_idx, sp); };
-        RdoqSpecSink sink{&W.u.spec[lane]};
+        RdoqSpecCzSink sink{&W.u.spec[lane], v == 0 ? W.rcz[lane >> 3] : nullptr};
         const RdoqCgSums S = rdoq_walk_cg_in(C, E, cg, bp_of, RdoqTileIn<N>{&L, &C}, v & 3, v >> 2, last_pos, sink);
         W.u.spec[lane].S = S;
       }
@@ -543,14 +552,8 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
         const int cg = my_last_cg - r * GPR - j;
         if (cg < 0) break;
         const unsigned p0 = scan_of(CR.scan_idx, cg * 16), g = ((p0 & (unsigned)(N - 1)) >> 2) | (((p0 >> LG) >> 2) << 8);
-        const int scan_idx = CR.scan_idx;
-        auto cz_of = [&](int k) {
-          const unsigned bp = scan_of(scan_idx, cg * 16 + k);
-          int l;
-          double z;
-          rdoq_prep(LR.tile[bp >> LG][bp & (N - 1)], CR, l, z);
-          return z;
-        };
+        const double *rcz = W.rcz[lane * GPR + j];
+        auto cz_of = [rcz](int k) { return rcz[k]; };
         double cg_sig;
         const int v = rdoq_resolve_group(CR, ER, cg, my_last_cg, g, &W.u.spec[(lane * GPR + j) * 8], cz_of, R, carry, cg_sig);
         W.sel[lane * NCG + cg] = (unsigned char)v;
@@ -560,42 +563,26 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
     wave_sync();
   }
   RQ_T(2);
-  if (resolver) { // the last position: coded groups walked once more, from the top, until a level above 1 ends the search
-    RdoqLast T;
-    rdoq_last_init(CR, ER, R, T);
-    const int scan_idx = CR.scan_idx;
-    auto bp_of = [&](int sp) { return scan_of(scan_idx, sp); };
-    for (int cg = my_last_cg; cg >= 0 && !T.found; cg--) {
-      const unsigned p0 = scan_of(scan_idx, cg * 16), gpos = ((p0 >> LG) >> 2) * (unsigned)G + ((p0 & (unsigned)(N - 1)) >> 2);
-      rdoq_last_group(T, W.cgs[lane * NCG + cg]);
-      if (!((R.cg_flag >> gpos) & 1)) continue;
-      RdoqLastSink sink{CR, ER, T, cg * 16, my_last_pos};
-      const int v = W.sel[lane * NCG + cg];
-      rdoq_walk_cg_in(CR, ER, cg, bp_of, RdoqTileIn<N>{&LR, &CR}, v & 3, v >> 2, my_last_pos, sink);
-    }
-    LR.line[6] = T.best_last_p1;
-    W.zeroed[lane] = R.zeroed;
-  }
-  wave_sync(); // and the buffer changes hands again: levels
-  RQ_T(3);
-  if (lane < SL * NCG) { // one lane per (block, group): the levels
+  if (resolver) W.zeroed[lane] = R.zeroed, W.cg_flag[lane] = R.cg_flag;
+  wave_sync(); // and the buffer changes hands again: levels and the search's records
+  constexpr int REC = 32 / SL; // records per block: its REC upper groups (8x8: all four)
+  if (lane < SL * NCG) { // one lane per (block, group): the chosen variant walked again
     const int b = lane / NCG, cg = lane - b * NCG;
     TuLds<N> &L = Ls[b];
-    short *out = &W.u.lev[b * NN + cg * 16];
-    const int last_pos = L.line[5];
+    short *out = &W.u.a.lev[b * NN + cg * 16];
+    const int last_pos = L.line[5], last_cg = last_pos >> 4;
     bool walked = false;
-    if (L.line[0] && last_pos >= 0 && cg <= (last_pos >> 4) && !((W.zeroed[b] >> cg) & 1) && cg * 16 < L.line[6]) {
+    if (L.line[0] && last_pos >= 0 && cg <= last_cg && !((W.zeroed[b] >> cg) & 1)) {
       const RdoqConst C = rdoq_chain_const<N>(L, RC, P);
       const EstBitsDev &E = W.est[L.line[9]];
       const int scan_idx = C.scan_idx;
       auto bp_of = [&](int sp) { return scan_of(scan_idx, sp); };
-      RdoqLevelSink<N> sink{out, &L, cg * 16, L.line[6], 0, 0};
+      const unsigned p0 = scan_of(scan_idx, cg * 16), gpos = ((p0 >> LG) >> 2) * (unsigned)G + ((p0 & (unsigned)(N - 1)) >> 2);
+      const bool rec = last_cg - cg < REC && ((W.cg_flag[b] >> gpos) & 1);
+      auto &RR = W.u.a.rec[b * REC + (rec ? last_cg - cg : 0)];
+      RdoqRecordSink sink{out, rec ? RR.cs : nullptr, rec ? RR.cc : nullptr};
       const int v = W.sel[b * NCG + cg];
       rdoq_walk_cg_in(C, E, cg, bp_of, RdoqTileIn<N>{&L, &C}, v & 3, v >> 2, last_pos, sink);
-      if (sink.any) {
-        atomicAdd(&L.line[7], sink.sum);
-        atomicMax(&L.line[8], cg);
-      }
       walked = true;
     }
     if (!walked) {
@@ -604,11 +591,66 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
     }
   }
   wave_sync();
+  RQ_T(3);
+  if (resolver) { // the last position (:2132-2200): from the top until a level above 1 ends the search, over the records
+    RdoqLast T;
+    rdoq_last_init(CR, ER, R, T);
+    const int scan_idx = CR.scan_idx;
+    auto bp_of = [&](int sp) { return scan_of(scan_idx, sp); };
+    for (int cg = my_last_cg; cg >= 0 && !T.found; cg--) {
+      const unsigned p0 = scan_of(scan_idx, cg * 16), gpos = ((p0 >> LG) >> 2) * (unsigned)G + ((p0 & (unsigned)(N - 1)) >> 2);
+      rdoq_last_group(T, W.cgs[lane * NCG + cg]);
+      if (!((R.cg_flag >> gpos) & 1)) continue;
+      if (my_last_cg - cg < REC) {
+        const auto &RR = W.u.a.rec[lane * REC + (my_last_cg - cg)];
+        const short *l16 = &W.u.a.lev[lane * NN + cg * 16];
+        for (int k = 15; k >= 0 && !T.found; k--) {
+          const int sp = cg * 16 + k;
+          if (sp > my_last_pos) continue;
+          const int lv = l16[k];
+          unsigned bp = 0;
+          double cz = 0;
+          if (lv) {
+            int l;
+            bp = bp_of(sp);
+            rdoq_prep(LR.tile[bp >> LG][bp & (N - 1)], CR, l, cz);
+          }
+          rdoq_last_pos(CR, ER, T, sp, bp, lv, RR.cc[k], RR.cs[k], cz);
+        }
+      } else { // deeper than the records reach (rare): the group walked once more with the search as the sink
+        RdoqLastSink sink{CR, ER, T, cg * 16, my_last_pos};
+        const int v = W.sel[lane * NCG + cg];
+        rdoq_walk_cg_in(CR, ER, cg, bp_of, RdoqTileIn<N>{&LR, &CR}, v & 3, v >> 2, my_last_pos, sink);
+      }
+    }
+    LR.line[6] = T.best_last_p1;
+  }
+  wave_sync();
+  if (lane < SL * NCG) { // one lane per (block, group): levels cut at the last position and signed; their sum; the highest group
+    const int b = lane / NCG, cg = lane - b * NCG;
+    TuLds<N> &L = Ls[b];
+    short *l16 = &W.u.a.lev[b * NN + cg * 16];
+    if (L.line[0] && L.line[5] >= 0 && cg <= (L.line[5] >> 4)) {
+      const int blp1 = L.line[6], scan_idx = L.line[3];
+      int sum = 0;
+      for (int k = 0; k < 16; k++) {
+        const int sp = cg * 16 + k, l = sp < blp1 ? (int)l16[k] : 0;
+        const unsigned bp = scan_of(scan_idx, sp);
+        sum += l;
+        l16[k] = (short)(L.tile[bp >> LG][bp & (N - 1)] < 0 ? -l : l);
+      }
+      if (sum) {
+        atomicAdd(&L.line[7], sum);
+        atomicMax(&L.line[8], cg);
+      }
+    }
+  }
+  wave_sync();
   RQ_T(4);
   if (P.sign_hide && lane < SL * NCG) { // one lane per (block, group): rate-aware sign hiding, the group walked a third time
     const int b = lane / NCG, cg = lane - b * NCG;
     TuLds<N> &L = Ls[b];
-    short *l16 = &W.u.lev[b * NN + cg * 16];
+    short *l16 = &W.u.a.lev[b * NN + cg * 16];
     if (L.line[0] && L.line[5] >= 0 && L.line[7] >= 2 && cg <= L.line[8]) {
       auto lev_of = [l16](int n) { return (int)l16[n]; };
       RdoqHide H;
@@ -636,7 +678,7 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
     TuLds<N> &L = Ls[b];
     if (!L.line[0]) continue;
     const unsigned bp = scan_of(L.line[3], sp);
-    L.tile[bp >> LG][bp & (N - 1)] = L.line[5] < 0 ? 0 : (int)W.u.lev[t];
+    L.tile[bp >> LG][bp & (N - 1)] = L.line[5] < 0 ? 0 : (int)W.u.a.lev[t];
   }
   wave_sync();
   RQ_T(6);
