@@ -393,6 +393,8 @@ struct RdoqWaveLdsT {
     char lane4[7680];  // 4x4 blocks, one per lane: the chain's Lane4Lds (its RDOQ needs no buffer)
   } u;
   double cgs[64];            // cost_cg_sig [block][group]
+  double lam[8];             // per block of the wave-item: lambda and the sign-hiding factor of its picture and plane type
+  long long rdf[8];          // (fetched once per block: a load from global memory per phase otherwise)
   double rcz[8][16];         // the costs of zero of the round's groups, left by the lane of variant 0 for the resolving lane
   unsigned short scan[1024]; // the size class's scan tables: [scan_idx][position] (32x32: the diagonal scan only)
   unsigned char sel[64];     // variant taken [block][group]
@@ -426,16 +428,16 @@ __device__ __forceinline__ void rdoq_stage_tables(RdoqWaveLds &W, const RdoqChai
   if (lane == 0) W.key = key;
   wave_sync();
 }
-template <int N>
-__device__ __forceinline__ RdoqConst rdoq_chain_const(const TuLds<N> &L, const RdoqChain &RC, const PicDev &P) {
+template <int N, typename WL>
+__device__ __forceinline__ RdoqConst rdoq_chain_const(const TuLds<N> &L, const RdoqChain &RC, const PicDev &P, const WL &W, int b) {
   constexpr int LG = N == 8 ? 3 : N == 16 ? 4 : N == 32 ? 5 : 2;
-  const int pic = L.line[1] * RC.pic_mul, luma = L.line[2], pt = luma ? 0 : 1;
+  const int luma = L.line[2], pt = luma ? 0 : 1;
   RdoqConst C;
   C.lg = LG, C.scan_idx = L.line[3], C.is_luma = luma;
   C.q = pt ? P.qd[1].q : P.qd[0].q;
   C.qbits = 14 + (pt ? P.qd[1].per_qbits : P.qd[0].per_qbits) + (15 - P.bit_depth - LG);
   C.root_cbf = L.line[10], C.cbf_ctx = L.line[4], C.sign_hide = P.sign_hide;
-  C.lambda = RC.lambda[pic * 2 + pt], C.err_scale = RC.err_scale[pt][LG - 2], C.rd_factor = RC.rd_factor[pic * 2 + pt];
+  C.lambda = W.lam[b], C.err_scale = RC.err_scale[pt][LG - 2], C.rd_factor = W.rdf[b];
   return C;
 }
 template <int N>
@@ -486,14 +488,19 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
   static_assert(SL * NCG <= 64 && SL * NN <= 1024 && SL * GPR * 8 == 64, "one lane per group, one round per 64 variants");
   RQ_T0;
   // line[5] = last position, [6] = last position + 1 after the search, [7] = sum of levels, [8] = highest group with a level
-  if (lane < SL) Ls[lane].line[5] = -1, Ls[lane].line[6] = 0, Ls[lane].line[7] = 0, Ls[lane].line[8] = -1;
+  if (lane < SL) {
+    TuLds<N> &L = Ls[lane];
+    L.line[5] = -1, L.line[6] = 0, L.line[7] = 0, L.line[8] = -1;
+    const int idx = L.line[1] * RC.pic_mul * 2 + (L.line[2] ? 0 : 1);
+    W.lam[lane] = RC.lambda[idx], W.rdf[lane] = RC.rd_factor[idx];
+  }
   wave_sync();
   auto scan_of = [&](int scan_idx, int sp) -> unsigned { return W.scan[(N == 32 ? 0 : scan_idx * NN) + sp]; };
   for (int t = lane; t < SL * NN; t += 64) { // the last position with a non-zero candidate
     const int b = t / NN, sp = t - b * NN;
     TuLds<N> &L = Ls[b];
     if (!L.line[0]) continue;
-    const RdoqConst C = rdoq_chain_const<N>(L, RC, P);
+    const RdoqConst C = rdoq_chain_const<N>(L, RC, P, W, b);
     const unsigned bp = scan_of(C.scan_idx, sp);
     int l;
     double z;
@@ -505,7 +512,7 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
     const int b = t / NN, sp = t - b * NN;
     TuLds<N> &L = Ls[b];
     if (!L.line[0] || L.line[5] < 0 || sp < ((L.line[5] >> 4) + 1) * 16) continue;
-    const RdoqConst C = rdoq_chain_const<N>(L, RC, P);
+    const RdoqConst C = rdoq_chain_const<N>(L, RC, P, W, b);
     const unsigned bp = scan_of(C.scan_idx, sp);
     int l;
     double z;
@@ -522,7 +529,7 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
   int carry = 0, rounds = 0;
   const int my_last_pos = LR.line[5], my_last_cg = my_last_pos >> 4;
   if (resolver) {
-    CR = rdoq_chain_const<N>(LR, RC, P);
+    CR = rdoq_chain_const<N>(LR, RC, P, W, lane);
     rdoq_run_init(R);
     for (int sp = NN - 1; sp >= (my_last_cg + 1) * 16; sp--) rdoq_resolve_above(R, W.u.cz[lane * NN + sp]);
     rounds = (my_last_cg + GPR) / GPR;
@@ -537,7 +544,7 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
       TuLds<N> &L = Ls[b];
       const int last_pos = L.line[5], cg = (last_pos >> 4) - r * GPR - j;
       if (L.line[0] && last_pos >= 0 && cg >= 0) {
-        const RdoqConst C = rdoq_chain_const<N>(L, RC, P);
+        const RdoqConst C = rdoq_chain_const<N>(L, RC, P, W, b);
         const EstBitsDev &E = W.est[L.line[9]];
         const int scan_idx = C.scan_idx;
         auto bp_of = [&](int sp) { return scan_of(scan_idx, sp); };
@@ -573,7 +580,7 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
     const int last_pos = L.line[5], last_cg = last_pos >> 4;
     bool walked = false;
     if (L.line[0] && last_pos >= 0 && cg <= last_cg && !((W.zeroed[b] >> cg) & 1)) {
-      const RdoqConst C = rdoq_chain_const<N>(L, RC, P);
+      const RdoqConst C = rdoq_chain_const<N>(L, RC, P, W, b);
       const EstBitsDev &E = W.est[L.line[9]];
       const int scan_idx = C.scan_idx;
       auto bp_of = [&](int sp) { return scan_of(scan_idx, sp); };
@@ -655,7 +662,7 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
       auto lev_of = [l16](int n) { return (int)l16[n]; };
       RdoqHide H;
       if (rdoq_hide_begin(cg == L.line[8], lev_of, H)) { // implies the group holds a level: it was walked above
-        const RdoqConst C = rdoq_chain_const<N>(L, RC, P);
+        const RdoqConst C = rdoq_chain_const<N>(L, RC, P, W, b);
         const EstBitsDev &E = W.est[L.line[9]];
         const int scan_idx = C.scan_idx;
         auto bp_of = [&](int sp) { return scan_of(scan_idx, sp); };
