@@ -1040,18 +1040,29 @@ struct PackGeom {
 __host__ __device__ __forceinline__ uint32_t pack_slots(int s, int slots4) { return s == 0 ? (uint32_t)slots4 : s == 1 ? 8u : s == 2 ? 4u : 1u; }
 
 // prep 1: blocks per size class of every row (one wave per row, lane = picture of the group)
-__global__ __launch_bounds__(64) void k_pack_count(const PackPic *pics, PackRow *rows, PackGeom G) {
-  const int row = blockIdx.x, L = row / G.n_groups, g = row - L * G.n_groups, k = threadIdx.x;
+// (a wave covers 64 / I rows: lane = (row of the wave, picture of the group); the first cut spent one wave per row with
+// I <= 4 lanes at work -- 9 M workgroups for 2048 pictures of 2160p, 115 ms of launch overhead for the fill alone)
+__device__ __forceinline__ int seg_sum(int v, int I, int k) { // sum over the I lanes of a segment (k = lane in segment), any I <= 64
+  const int lane = threadIdx.x, base = lane - k;
+  int t = 0;
+  for (int q = 0; q < I; q++) t += __shfl(v, base + q, 64);
+  return t;
+}
+__global__ __launch_bounds__(64) void k_pack_count(const PackPic *pics, PackRow *rows, PackGeom G, int n_rows) {
+  const int rpw = 64 / G.I, sub = threadIdx.x / G.I, k = threadIdx.x - sub * G.I;
+  const int row = blockIdx.x * rpw + sub;
+  const bool live = sub < rpw && row < n_rows;
+  const int L = live ? row / G.n_groups : 0, g = live ? row - L * G.n_groups : 0;
   const int pic = g * G.I + k;
   uint32_t c[4] = {0, 0, 0, 0};
-  if (k < G.I && pic < G.n_pics && L < pics[pic].n_levels) {
+  if (live && pic < G.n_pics && L < pics[pic].n_levels) {
     const LevelRow r = pics[pic].ltab[L];
 #pragma unroll
     for (int s = 0; s < 4; s++) c[s] = r.count[s];
   }
 #pragma unroll
-  for (int s = 0; s < 4; s++) c[s] = (uint32_t)group_sum((int)c[s], 64);
-  if (k == 0) {
+  for (int s = 0; s < 4; s++) c[s] = (uint32_t)seg_sum((int)c[s], G.I, k);
+  if (live && k == 0) {
     PackRow R{};
     uint32_t nw = 0;
 #pragma unroll
@@ -1123,36 +1134,44 @@ __global__ __launch_bounds__(1024) void k_pack_scan(PackRow *rows, PackHdr *hdr,
 // by rank inside their picture's bucket, then by picture: pictures that share a plan put the SAME block of consecutive
 // pictures on consecutive lanes (consecutive lines of the interleaved pool, uniform control flow); pictures with their
 // own plans put blocks of similar code path (the plan sorts a bucket by plane, transform skip, mode) next to each other.
-__global__ __launch_bounds__(64) void k_pack_fill(const PackPic *pics, const PackRow *rows, PackDesc *descs, FTu *items, PackGeom G) {
-  const int row = blockIdx.x >> 2, s = blockIdx.x & 3, L = row / G.n_groups, g = row - L * G.n_groups, k = threadIdx.x;
-  const PackRow R = rows[row];
-  if (R.count[s] == 0) return;
-  const uint32_t sl = pack_slots(s, G.slots4), nw = (R.count[s] + sl - 1) / sl;
-  uint32_t woff = 0;
-  for (int s2 = 3; s2 > s; s2--) woff += (R.count[s2] + pack_slots(s2, G.slots4) - 1) / pack_slots(s2, G.slots4); // largest blocks first
-  const uint32_t dep = L > 0 ? rows[row - G.n_groups].n_waves : 0;
-  for (uint32_t c = k; c < nw; c += 64)
-    descs[R.wave_base + woff + c] = PackDesc{R.item_base[s] + c * sl, min(sl, R.count[s] - c * sl) | ((uint32_t)s << 28), (uint32_t)row, dep};
+__global__ __launch_bounds__(64) void k_pack_fill(const PackPic *pics, const PackRow *rows, PackDesc *descs, FTu *items, PackGeom G, int n_rows) {
+  __shared__ uint32_t cnts[64];
+  const int rpw = 64 / G.I, sub = threadIdx.x / G.I, k = threadIdx.x - sub * G.I, seg0 = threadIdx.x - k;
+  const int row = blockIdx.x * rpw + sub;
+  const bool live = sub < rpw && row < n_rows;
+  const int L = live ? row / G.n_groups : 0, g = live ? row - L * G.n_groups : 0;
+  const PackRow R = rows[live ? row : 0];
   const int pic = g * G.I + k;
-  uint32_t cnt = 0, start = 0;
+  LevelRow lr{};
   const FTu *ltus = nullptr;
-  if (k < G.I && pic < G.n_pics && L < pics[pic].n_levels) {
-    const LevelRow r = pics[pic].ltab[L];
-    cnt = r.count[s], start = r.start[s];
+  if (live && pic < G.n_pics && L < pics[pic].n_levels) {
+    lr = pics[pic].ltab[L];
     ltus = as_global(pics[pic].ltus);
   }
-  uint32_t maxc = cnt;
-  for (int off = 32; off > 0; off >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, off, 64));
-  uint32_t off = R.item_base[s];
-  const unsigned long long below = (1ull << k) - 1ull;
-  for (uint32_t r = 0; r < maxc; r++) {
-    const unsigned long long m = __ballot(cnt > r);
-    if (cnt > r) {
+  const uint32_t dep = (live && L > 0) ? rows[row - G.n_groups].n_waves : 0;
+  uint32_t woff = 0;
+#pragma unroll
+  for (int s = 3; s >= 0; s--) { // largest blocks first
+    const uint32_t sl = pack_slots(s, G.slots4), total = live ? R.count[s] : 0, nw = (total + sl - 1) / sl;
+    for (uint32_t c = (uint32_t)k; c < nw; c += (uint32_t)G.I)
+      descs[R.wave_base + woff + c] = PackDesc{R.item_base[s] + c * sl, min(sl, total - c * sl) | ((uint32_t)s << 28), (uint32_t)row, dep};
+    woff += nw;
+    // item (rank r, picture k) of the bucket sits behind every item of a lower rank and the same-rank items of the pictures
+    // before k:  sum over k' of min(count[k'], r)  +  #{k' < k : count[k'] > r}
+    const uint32_t cnt = ltus ? lr.count[s] : 0, start = lr.start[s];
+    wave_sync();
+    cnts[threadIdx.x] = cnt; // the counts of the row's pictures, for lanes that loop longer than their neighbours
+    wave_sync();
+    for (uint32_t r = 0; r < cnt; r++) {
+      uint32_t off = 0;
+      for (int q = 0; q < G.I; q++) {
+        const uint32_t cq = cnts[seg0 + q];
+        off += min(cq, r) + ((q < k && cq > r) ? 1u : 0u);
+      }
       FTu f = ltus[start + r];
       f.t.plane = (uint8_t)(f.t.plane | (k << 2)); // picture of the group in the upper six bits
-      items[off + (uint32_t)__popcll(m & below)] = f;
+      items[R.item_base[s] + off] = f;
     }
-    off += (uint32_t)__popcll(m);
   }
 }
 
@@ -2496,9 +2515,10 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
     HIPCHK(c, hipMemcpyAsync(pk.d_pics, hp.data(), sizeof(PackPic) * n_pics, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st)); // hp goes out of scope
     HIPCHK(c, hipMemsetAsync(pk.d_hdr, 0, sizeof(PackHdr), st));
-    hipLaunchKernelGGL(k_pack_count, dim3((unsigned)n_rows), dim3(64), 0, st, pk.d_pics, pk.d_rows, G);
+    const unsigned prep_waves = (unsigned)((n_rows + (uint64_t)(64 / G.I) - 1) / (uint64_t)(64 / G.I));
+    hipLaunchKernelGGL(k_pack_count, dim3(prep_waves), dim3(64), 0, st, pk.d_pics, pk.d_rows, G, (int)n_rows);
     hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, st, pk.d_rows, pk.d_hdr, G);
-    hipLaunchKernelGGL(k_pack_fill, dim3((unsigned)(n_rows * 4)), dim3(64), 0, st, pk.d_pics, pk.d_rows, pk.d_descs, pk.d_items, G);
+    hipLaunchKernelGGL(k_pack_fill, dim3(prep_waves), dim3(64), 0, st, pk.d_pics, pk.d_rows, pk.d_descs, pk.d_items, G, (int)n_rows);
     HIPCHK(c, hipGetLastError());
     pk.key = c->table_key;
     pk.G = G;
