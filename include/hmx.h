@@ -266,8 +266,10 @@ int hmx_batch_invtransformNxN(hmx_ctx *ctx, const hmx_tu_list *list, const hmx_l
 /* RDOQ over a list of blocks (host list): Int coefficients in `coef` (plane geometry, e.g. the output of the
  * xT drop-in or of a batch transform without quantisation) -> levels in `lev`; d_abs_sum[i] (device, may be
  * NULL) receives block i's absolute sum.  side[i] carries what the reference reads from the CU for block i
- * and which bit-estimate table (est[side[i].est_idx], host array) applies.  8x8 and larger blocks: one wave per block,
- * coefficient groups walked in parallel (thevc_amd/csrc/hmx_rdoq_core.h); 4x4 blocks: one lane per block. */
+ * and which bit-estimate table (est[side[i].est_idx], host array) applies.  8x8 and larger blocks: a wave shares 8 / 4 / 1
+ * blocks in LDS, coefficient groups walked in parallel (thevc_amd/csrc/hmx_rdoq_core.h); 4x4 blocks: one lane per block.
+ * Coefficients are what xT / xTransformSkip produce: |c| <= 32768 (levels of 8x8 and larger blocks travel as 16-bit words
+ * inside the kernel).  The block list and the tables stay resident on the device while the arguments repeat. */
 typedef struct hmx_rdoq_side {
   uint16_t est_idx;
   uint8_t root_cbf, cbf_ctx;
