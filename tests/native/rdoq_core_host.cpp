@@ -127,7 +127,7 @@ struct LevelSink {
   void add(int, double) {}
   void pos(int k, unsigned, int level, double, double, int, int, int, int, double) { out[k] = level; }
 };
-static long g_rewalk_last = 0, g_rewalk_hide = 0;
+static long g_rewalk_last = 0, g_rewalk_hide = 0, g_rounds = 0, g_round_groups = 0, g_round_tasks = 0;
 static void rdoq_block_rewalk(const int *src, int *dst, int N, int B, const hmo_rdoq_cfg &cfg, const EstBitsDev &E, uint32_t *abs_sum) {
   const int lg = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5, nn = N * N, n_cg = nn / 16, inc = B - 8, G = N >> 2;
   const int tshift = 15 - B - lg;
@@ -169,20 +169,65 @@ static void rdoq_block_rewalk(const int *src, int *dst, int N, int B, const hmo_
   std::vector<unsigned char> sel(n_cg, 0xff);
   std::vector<double> cgs(n_cg, 0.0);
   int carry = 0;
-  for (int top = last_cg; top >= 0; top -= groups_per_round) { // a round
+  // rounds composed at run time: a group gets one lane per variant it can still take (rdoq_variant_mask), a block as many
+  // groups per round as its share of the 64 lanes and of the 16 cost-of-zero rows holds
+  std::vector<int> gmax(n_cg, 0), ginv(G * G, 0);
+  for (int sp = 0; sp < nn; sp++) {
+    int l;
+    double z;
+    rdoq_prep(src[scan[sp]], C, l, z);
+    const int m = (int)rdoq_max_level(l, C.qbits);
+    gmax[sp >> 4] = std::max(gmax[sp >> 4], std::min(m, 2));
+  }
+  for (int cg = 0; cg < n_cg; cg++) {
+    const unsigned g = gpos_of(cg);
+    ginv[(g >> 8) * G + (g & 255u)] = cg;
+  }
+  const int slots = N == 32 ? 64 : N == 16 ? 16 : 8, groups_max = N == 32 ? 16 : N == 16 ? 4 : 2;
+  (void)groups_per_round;
+  auto gmax_of = [&](int cg) { return gmax[cg]; };
+  auto cg_at = [&](int gy, int gx) { return ginv[gy * G + gx]; };
+  for (int top = last_cg; top >= 0;) { // a round
+    struct Grp {
+      int cg, base;
+      unsigned mask;
+    } grp[16];
+    int ng = 0, used = 0;
+    for (int cg = top; cg >= 0 && ng < groups_max; cg--) { // the block's resolving lane plans
+      const unsigned mask = rdoq_variant_mask(C, cg, last_cg, top, gpos_of(cg), R, carry, gmax_of, cg_at);
+      const int cnt = __builtin_popcount(mask);
+      if (used + cnt > slots) break;
+      grp[ng++] = Grp{cg, used, mask};
+      used += cnt;
+    }
+    if (ng < 1) {
+      printf("round planning: no group fits\n");
+      exit(3);
+    }
+    g_round_groups += ng, g_round_tasks += used, g_rounds++;
     RdoqSpec buf[64];
-    for (int task = 0; task < groups_per_round * 8; task++) { // one lane each
-      const int cg = top - (task >> 3), v = task & 7;
-      if (cg < 0) continue;
-      RdoqSpecSink sink{&buf[task]};
-      auto in = [&](int, unsigned bp) { return src[bp]; };
-      buf[task].S = rdoq_walk_cg_in(C, E, cg, bp_of, in, v & 3, v >> 2, last_pos, sink);
+    for (int q = 0; q < ng; q++) // one lane per (group, possible variant)
+      for (int v = 0, rank = 0; v < 8; v++)
+        if ((grp[q].mask >> v) & 1) {
+          RdoqSpecSink sink{&buf[grp[q].base + rank]};
+          auto in = [&](int, unsigned bp) { return src[bp]; };
+          buf[grp[q].base + rank].S = rdoq_walk_cg_in(C, E, grp[q].cg, bp_of, in, v & 3, v >> 2, last_pos, sink);
+          rank++;
+        }
+    for (int q = 0; q < ng; q++) { // the block's resolving lane
+      const int cg = grp[q].cg;
+      const unsigned mask = grp[q].mask;
+      const RdoqSpec *b0 = buf + grp[q].base;
+      auto spec_of = [&](int v) -> const RdoqSpec & {
+        if (!((mask >> v) & 1)) {
+          printf("variant %d of group %d was ruled out (mask %02x)\n", v, cg, mask);
+          exit(4);
+        }
+        return b0[__builtin_popcount(mask & ((1u << v) - 1u))];
+      };
+      sel[cg] = (unsigned char)rdoq_resolve_group_fn(C, E, cg, last_cg, gpos_of(cg), spec_of, [&](int k) { return cz_at(cg * 16 + k); }, R, carry, cgs[cg]);
     }
-    for (int j = 0; j < groups_per_round; j++) { // the block's resolving lane
-      const int cg = top - j;
-      if (cg < 0) break;
-      sel[cg] = (unsigned char)rdoq_resolve_group(C, E, cg, last_cg, gpos_of(cg), buf + j * 8, [&](int k) { return cz_at(cg * 16 + k); }, R, carry, cgs[cg]);
-    }
+    top = grp[ng - 1].cg - 1;
   }
   // levels as walked, one lane per group; the upper groups also leave the two costs per entry the search needs
   const int REC = N == 32 ? 32 : N == 16 ? 8 : N == 8 ? 4 : 1;
@@ -341,6 +386,7 @@ int main(int argc, char **argv) {
   printf("rdoq_core_host: %ld blocks identical to the oracle (%ld with levels; %ld groups zeroed by the group decision, %ld entered with a carry, "
          "%ld changed by sign hiding)\n", checked, nonzero, g_zeroed_groups, g_carried_groups, g_sign_hidden);
   printf("re-walk decomposition: identical too (%ld groups beyond the search records walked again for the last position, %ld for sign hiding)\n", g_rewalk_last, g_rewalk_hide);
+  printf("rounds: %ld, %.2f groups and %.1f lanes per round and block\n", g_rounds, (double)g_round_groups / g_rounds, (double)g_round_tasks / g_rounds);
   if (!g_zeroed_groups || !g_carried_groups || !g_sign_hidden || !g_rewalk_hide) {
     printf("coverage hole\n");
     return 2;

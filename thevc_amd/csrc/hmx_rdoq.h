@@ -397,6 +397,9 @@ struct RdoqWaveLdsT {
   long long rdf[8];          // (fetched once per block: a load from global memory per phase otherwise)
   double rcz[8][16];         // the costs of zero of the round's groups, left by the lane of variant 0 for the resolving lane
   unsigned short scan[1024]; // the size class's scan tables: [scan_idx][position] (32x32: the diagonal scan only)
+  unsigned char ginv[192];   // and their inverse for groups: [scan_idx][gy * G + gx] -> scan index of the group
+  unsigned short task[64];   // the round's lanes: group | variant << 6 | (cost-of-zero row + 1) << 9; 0xffff: none
+  unsigned ginfo[16];        // the round's groups [block][rank]: group | variant mask << 8 | first lane of the block's share << 16
   unsigned char sel[64];     // variant taken [block][group]
   unsigned long long zeroed[8], cg_flag[8];
   EstBitsDev est[NEST]; // the chain: [picture of the group][luma, chroma] for the wave-item's size class; line[9] of a block selects
@@ -411,6 +414,14 @@ __device__ __forceinline__ void rdoq_stage_scan(WL &W, int s, int lane) { // the
   } else if (s > 0) {
     const int nn = 16 << (2 * s);
     for (int i = lane; i < 3 * nn; i += 64) W.scan[i] = (unsigned short)rdoq_scan_pos(s + 2, i / nn, i % nn);
+  }
+  if (s > 0) { // straight from the constant tables: nothing here waits for the stores above
+    const int lg = s + 2, gl = s, n_cg = 1 << (2 * gl), n_sc = s == 3 ? 1 : 3;
+    for (int i = lane; i < n_sc * n_cg; i += 64) {
+      const int sc = i / n_cg, cg = i - sc * n_cg;
+      const unsigned p0 = rdoq_scan_pos(lg, sc, cg * 16);
+      W.ginv[sc * 64 + (((p0 >> lg) >> 2) << gl) + ((p0 & ((1u << lg) - 1u)) >> 2)] = (unsigned char)cg;
+    }
   }
 }
 // stage the tables of (picture group g, size class s = log2n - 2); I = pictures per group
@@ -488,6 +499,9 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
   static_assert(SL * NCG <= 64 && SL * NN <= 1024 && SL * GPR * 8 == 64, "one lane per group, one round per 64 variants");
   RQ_T0;
   // line[5] = last position, [6] = last position + 1 after the search, [7] = sum of levels, [8] = highest group with a level
+  constexpr int GM0 = N == 8 ? 12 : 32; // line[GM0 + cg]: min(the group's highest candidate level, 2)
+  static_assert(GM0 + NCG <= 4 * N + 2, "the block's scratch line holds the groups' candidate classes");
+  if (lane < SL * NCG) Ls[lane / NCG].line[GM0 + lane % NCG] = 0;
   if (lane < SL) {
     TuLds<N> &L = Ls[lane];
     L.line[5] = -1, L.line[6] = 0, L.line[7] = 0, L.line[8] = -1;
@@ -505,7 +519,11 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
     int l;
     double z;
     rdoq_prep(L.tile[bp >> LG][bp & (N - 1)], C, l, z);
-    if (rdoq_max_level(l, C.qbits) > 0) atomicMax(&L.line[5], sp);
+    const unsigned m = rdoq_max_level(l, C.qbits);
+    if (m > 0) {
+      atomicMax(&L.line[5], sp);
+      atomicMax(&L.line[GM0 + (sp >> 4)], (int)(m < 2u ? m : 2u));
+    }
   }
   wave_sync();
   for (int t = lane; t < SL * NN; t += 64) { // the costs of zero above the last position's group, for the resolving lane
@@ -526,46 +544,124 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
   TuLds<N> &LR = Ls[lane < SL ? lane : 0];
   RdoqConst CR;
   RdoqRun R;
-  int carry = 0, rounds = 0;
+  int carry = 0;
   const int my_last_pos = LR.line[5], my_last_cg = my_last_pos >> 4;
   if (resolver) {
     CR = rdoq_chain_const<N>(LR, RC, P, W, lane);
     rdoq_run_init(R);
     for (int sp = NN - 1; sp >= (my_last_cg + 1) * 16; sp--) rdoq_resolve_above(R, W.u.cz[lane * NN + sp]);
-    rounds = (my_last_cg + GPR) / GPR;
   }
-  for (int off = 32; off > 0; off >>= 1) rounds = max(rounds, __shfl_xor(rounds, off, 64));
   wave_sync(); // the buffer changes hands
   RQ_T(1);
   const EstBitsDev &ER = W.est[LR.line[9]];
-  for (int r = 0; r < rounds; r++) {
-    { // one lane per (block, group of the round, carry, pattern)
-      const int b = lane / (GPR * 8), j = (lane >> 3) % GPR, v = lane & 7;
-      TuLds<N> &L = Ls[b];
-      const int last_pos = L.line[5], cg = (last_pos >> 4) - r * GPR - j;
-      if (L.line[0] && last_pos >= 0 && cg >= 0) {
+  // Rounds composed at run time.  A group gets one lane per variant it can STILL take (rdoq_variant_mask: what earlier rounds
+  // resolved is known; what the same round leaves open the candidates often close -- a group without a candidate level stays
+  // uncoded, a group without a candidate above 1 hands on no carry), a block as many groups per round as its share of the 64
+  // lanes holds (at most 16 / SL).  The block's resolving lane plans, every lane walks, the resolving lane resolves.
+  constexpr int SLOTS = 64 / SL, GMAXB = 16 / SL, RCZB = 8 / SL;
+  static_assert(GPR == RCZB, "cost-of-zero rows per block");
+  int next = resolver ? my_last_cg : -1;
+  if constexpr (SL == 1) {
+    // 32x32: one block, one planning lane -- composing rounds of up to 16 groups costs more than it saves (measured: 206 us
+    // against 188 us of rounds per block): fixed rounds of 8 groups x 8 variants
+    const int rounds = __shfl(resolver ? (my_last_cg + GPR) / GPR : 0, 0, 64);
+    for (int r = 0; r < rounds; r++) {
+      { // one lane per (group of the round, carry, pattern)
+        const int j = lane >> 3, v = lane & 7;
+        TuLds<N> &L = Ls[0];
+        const int last_pos = L.line[5], cg = (last_pos >> 4) - r * GPR - j;
+        if (cg >= 0) {
+          const RdoqConst C = rdoq_chain_const<N>(L, RC, P, W, 0);
+          const EstBitsDev &E = W.est[L.line[9]];
+          const int scan_idx = C.scan_idx;
+          auto bp_of = [&](int sp) { return scan_of(scan_idx, sp); };
+          RdoqSpecCzSink sink{&W.u.spec[lane], v == 0 ? W.rcz[lane >> 3] : nullptr};
+          const RdoqCgSums S = rdoq_walk_cg_in(C, E, cg, bp_of, RdoqTileIn<N>{&L, &C}, v & 3, v >> 2, last_pos, sink);
+          W.u.spec[lane].S = S;
+        }
+      }
+      wave_sync();
+      if (resolver) {
+        for (int j = 0; j < GPR; j++) {
+          const int cg = my_last_cg - r * GPR - j;
+          if (cg < 0) break;
+          const unsigned p0 = scan_of(CR.scan_idx, cg * 16), g = ((p0 & (unsigned)(N - 1)) >> 2) | (((p0 >> LG) >> 2) << 8);
+          const double *rcz = W.rcz[j];
+          auto cz_of = [rcz](int k) { return rcz[k]; };
+          double cg_sig;
+          const int v = rdoq_resolve_group(CR, ER, cg, my_last_cg, g, &W.u.spec[j * 8], cz_of, R, carry, cg_sig);
+          W.sel[cg] = (unsigned char)v;
+          W.cgs[cg] = cg_sig;
+        }
+      }
+      wave_sync();
+    }
+    next = -1;
+  }
+  for (; SL > 1;) {
+    W.task[lane] = 0xffffu;
+    wave_sync();
+    int ng = 0;
+    if (next >= 0) {
+      const int scan_idx = CR.scan_idx;
+      auto gmax_of = [&](int cg) { return LR.line[GM0 + cg]; };
+      auto cg_at = [&](int gy, int gx) { return (int)W.ginv[(N == 32 ? 0 : scan_idx * 64) + gy * G + gx]; };
+      int used = 0;
+      for (int cg = next; cg >= 0 && ng < GMAXB; cg--) {
+        const unsigned p0 = scan_of(scan_idx, cg * 16), g = ((p0 & (unsigned)(N - 1)) >> 2) | (((p0 >> LG) >> 2) << 8);
+        const unsigned mask = rdoq_variant_mask(CR, cg, my_last_cg, next, g, R, carry, gmax_of, cg_at);
+        const int cnt = __builtin_popcount(mask);
+        if (used + cnt > SLOTS) break;
+        W.ginfo[lane * GMAXB + ng] = (unsigned)cg | (mask << 8) | ((unsigned)used << 16);
+        for (int v = 0, rank = 0; v < 8; v++)
+          if ((mask >> v) & 1) {
+            W.task[lane * SLOTS + used + rank] = (unsigned short)(cg | (v << 6) | ((rank == 0 && ng < RCZB ? ng + 1 : 0) << 9));
+            rank++;
+          }
+        used += cnt;
+        ng++;
+      }
+    }
+    if (!__ballot(ng > 0)) break; // every block is through
+    wave_sync();
+    { // one lane per (block, group of the round, variant it can take)
+      const unsigned t = W.task[lane];
+      if (t != 0xffffu) {
+        const int b = lane / SLOTS, cg = (int)(t & 63u), v = (int)((t >> 6) & 7u), row = (int)((t >> 9) & 15u);
+        TuLds<N> &L = Ls[b];
+        const int last_pos = L.line[5];
         const RdoqConst C = rdoq_chain_const<N>(L, RC, P, W, b);
         const EstBitsDev &E = W.est[L.line[9]];
         const int scan_idx = C.scan_idx;
         auto bp_of = [&](int sp) { return scan_of(scan_idx, sp); };
-        RdoqSpecCzSink sink{&W.u.spec[lane], v == 0 ? W.rcz[lane >> 3] : nullptr};
+        RdoqSpecCzSink sink{&W.u.spec[lane], row ? W.rcz[b * RCZB + row - 1] : nullptr};
         const RdoqCgSums S = rdoq_walk_cg_in(C, E, cg, bp_of, RdoqTileIn<N>{&L, &C}, v & 3, v >> 2, last_pos, sink);
         W.u.spec[lane].S = S;
       }
     }
     wave_sync();
-    if (resolver) {
-      for (int j = 0; j < GPR; j++) {
-        const int cg = my_last_cg - r * GPR - j;
-        if (cg < 0) break;
-        const unsigned p0 = scan_of(CR.scan_idx, cg * 16), g = ((p0 & (unsigned)(N - 1)) >> 2) | (((p0 >> LG) >> 2) << 8);
-        const double *rcz = W.rcz[lane * GPR + j];
-        auto cz_of = [rcz](int k) { return rcz[k]; };
-        double cg_sig;
-        const int v = rdoq_resolve_group(CR, ER, cg, my_last_cg, g, &W.u.spec[(lane * GPR + j) * 8], cz_of, R, carry, cg_sig);
-        W.sel[lane * NCG + cg] = (unsigned char)v;
-        W.cgs[lane * NCG + cg] = cg_sig;
-      }
+    for (int q = 0; q < ng; q++) { // the resolving lane: the round's groups in the reference's order
+      const unsigned info = W.ginfo[lane * GMAXB + q], mask = (info >> 8) & 255u;
+      const int cg = (int)(info & 255u);
+      const RdoqSpec *b0 = &W.u.spec[lane * SLOTS + (int)(info >> 16)];
+      const int scan_idx = CR.scan_idx;
+      const unsigned p0 = scan_of(scan_idx, cg * 16), g = ((p0 & (unsigned)(N - 1)) >> 2) | (((p0 >> LG) >> 2) << 8);
+      auto spec_of = [b0, mask](int v) -> const RdoqSpec & { return b0[__builtin_popcount(mask & ((1u << v) - 1u))]; };
+      const double *rcz = W.rcz[lane * RCZB + (q < RCZB ? q : 0)];
+      const bool have_cz = q < RCZB;
+      auto cz_of = [&](int k) { // the round's first groups find their costs of zero in LDS, the others form them again
+        if (have_cz) return rcz[k];
+        const unsigned bp = scan_of(scan_idx, cg * 16 + k);
+        int l;
+        double z;
+        rdoq_prep(LR.tile[bp >> LG][bp & (N - 1)], CR, l, z);
+        return z;
+      };
+      double cg_sig;
+      const int v = rdoq_resolve_group_fn(CR, ER, cg, my_last_cg, g, spec_of, cz_of, R, carry, cg_sig);
+      W.sel[lane * NCG + cg] = (unsigned char)v;
+      W.cgs[lane * NCG + cg] = cg_sig;
+      next = cg - 1;
     }
     wave_sync();
   }

@@ -333,11 +333,39 @@ HMX_HD void rdoq_resolve_above(RdoqRun &R, double cz) {
   R.uncoded += cz;
   R.base += cz;
 }
-// group cg <= last_cg.  gpos = gx | gy << 8; spec8 = the group's variants [carry * 4 + pattern]; cz_of(k) the cost of zero of
+// Which variants [carry * 4 + right + 2 * lower] can group cg still take when the groups above round_top are resolved (their
+// flags in R.cg_flag, `carry` the carry of group round_top + 1) and the groups round_top .. cg + 1 are walked in the same round?
+// What the same round leaves open, the candidates often close: a group none of whose coefficients can get a level
+// (gmax == 0) stays uncoded, and a group none of whose coefficients can get a level above 1 (gmax <= 1) hands on no carry
+// (c1 only drops to 0 behind a level above 1).  gmax_of(cg) -> min(highest candidate level of the group, 2);
+// cg_at(gy, gx) -> scan index of the group at that position.  Returns a bit per variant; never empty.
+template <typename GmaxFn, typename CgAtFn>
+HMX_HD unsigned rdoq_variant_mask(const RdoqConst &C, int cg, int last_cg, int round_top, unsigned g, const RdoqRun &R, int carry, GmaxFn gmax_of,
+                                  CgAtFn cg_at) {
+  const int G = (1 << C.lg) >> 2;
+  const unsigned gx = g & 255u, gy = g >> 8;
+  unsigned cset, rset = 1u, lset = 1u; // bit 0: the value 0 is possible, bit 1: the value 1
+  if (cg == last_cg) cset = 1u;        // the state starts inside this group: no carry
+  else if (cg == round_top) cset = 1u << carry;
+  else cset = gmax_of(cg + 1) <= 1 ? 1u : 3u;
+  if (gx < (unsigned)G - 1) {
+    const int n = cg_at((int)gy, (int)gx + 1);
+    rset = n > round_top ? 1u << ((R.cg_flag >> (gy * G + gx + 1)) & 1) : (gmax_of(n) == 0 ? 1u : 3u);
+  }
+  if (gy < (unsigned)G - 1) {
+    const int n = cg_at((int)gy + 1, (int)gx);
+    lset = n > round_top ? 1u << ((R.cg_flag >> ((gy + 1) * G + gx)) & 1) : (gmax_of(n) == 0 ? 1u : 3u);
+  }
+  unsigned mask = 0;
+  for (int v = 0; v < 8; v++)
+    if (((cset >> (v >> 2)) & 1) && ((rset >> (v & 1)) & 1) && ((lset >> ((v >> 1) & 1)) & 1)) mask |= 1u << v;
+  return mask;
+}
+// group cg <= last_cg.  gpos = gx | gy << 8; spec_of(v) = the group's variant v = carry * 4 + pattern; cz_of(k) the cost of zero of
 // entry k; carry: the previous group's (in/out).  Returns the variant taken; cg_sig = cost_cg_sig[cg] as the reference keeps it.
-template <typename CzFn>
-HMX_HD int rdoq_resolve_group(const RdoqConst &C, const EstBitsDev &E, int cg, int last_cg, unsigned g, const RdoqSpec *spec8, CzFn cz_of, RdoqRun &R,
-                              int &carry, double &cg_sig) {
+template <typename SpecFn, typename CzFn>
+HMX_HD int rdoq_resolve_group_fn(const RdoqConst &C, const EstBitsDev &E, int cg, int last_cg, unsigned g, SpecFn spec_of, CzFn cz_of, RdoqRun &R,
+                                 int &carry, double &cg_sig) {
   const int N = 1 << C.lg, G = N >> 2;
   const double lambda = C.lambda;
   cg_sig = 0;
@@ -345,7 +373,7 @@ HMX_HD int rdoq_resolve_group(const RdoqConst &C, const EstBitsDev &E, int cg, i
   const unsigned right = gx < (unsigned)G - 1 ? (unsigned)((R.cg_flag >> (gy * G + gx + 1)) & 1) : 0u;
   const unsigned lower = gy < (unsigned)G - 1 ? (unsigned)((R.cg_flag >> ((gy + 1) * G + gx)) & 1) : 0u;
   const int v = (cg == last_cg ? 0 : carry * 4) + (int)(right + (lower << 1));
-  const RdoqSpec &S = spec8[v];
+  const RdoqSpec &S = spec_of(v);
   for (int k = 15; k >= 0; k--) {
     R.uncoded += cz_of(k);
     R.base += S.add[k];
@@ -382,6 +410,11 @@ HMX_HD int rdoq_resolve_group(const RdoqConst &C, const EstBitsDev &E, int cg, i
   }
   carry = S.S.carry_out;
   return v;
+}
+template <typename CzFn>
+HMX_HD int rdoq_resolve_group(const RdoqConst &C, const EstBitsDev &E, int cg, int last_cg, unsigned g, const RdoqSpec *spec8, CzFn cz_of, RdoqRun &R,
+                              int &carry, double &cg_sig) {
+  return rdoq_resolve_group_fn(C, E, cg, last_cg, g, [spec8](int v) -> const RdoqSpec & { return spec8[v]; }, cz_of, R, carry, cg_sig);
 }
 // the whole pass over arrays: spec[cg * 8 + carry * 4 + pattern], cz in scan order.  gpos_of(cg) -> gx | gy << 8.
 // sel[cg] = the variant taken (0xff above the last position's group).
