@@ -707,18 +707,25 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
       if (my_last_cg - cg < REC) {
         const auto &RR = W.u.a.rec[lane * REC + (my_last_cg - cg)];
         const short *l16 = &W.u.a.lev[lane * NN + cg * 16];
-        for (int k = 15; k >= 0 && !T.found; k--) {
-          const int sp = cg * 16 + k;
-          if (sp > my_last_pos) continue;
-          const int lv = l16[k];
-          unsigned bp = 0;
-          double cz = 0;
-          if (lv) {
-            int l;
-            bp = bp_of(sp);
-            rdoq_prep(LR.tile[bp >> LG][bp & (N - 1)], CR, l, cz);
+        for (int k4 = 12; k4 >= 0 && !T.found; k4 -= 4) { // four entries' records at a time: one LDS round trip, not four
+          int lv4[4];
+          double cc4[4], cs4[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) lv4[i] = l16[k4 + i], cc4[i] = RR.cc[k4 + i], cs4[i] = RR.cs[k4 + i];
+#pragma unroll
+          for (int i = 3; i >= 0; i--) {
+            const int sp = cg * 16 + k4 + i;
+            if (sp > my_last_pos || T.found) continue;
+            const int lv = lv4[i];
+            unsigned bp = 0;
+            double cz = 0;
+            if (lv) {
+              int l;
+              bp = bp_of(sp);
+              rdoq_prep(LR.tile[bp >> LG][bp & (N - 1)], CR, l, cz);
+            }
+            rdoq_last_pos(CR, ER, T, sp, bp, lv, cc4[i], cs4[i], cz);
           }
-          rdoq_last_pos(CR, ER, T, sp, bp, lv, RR.cc[k], RR.cs[k], cz);
         }
       } else { // deeper than the records reach (rare): the group walked once more with the search as the sink
         RdoqLastSink sink{CR, ER, T, cg * 16, my_last_pos};
