@@ -374,7 +374,8 @@ HMX_HD int rdoq_resolve_group_fn(const RdoqConst &C, const EstBitsDev &E, int cg
   const unsigned lower = gy < (unsigned)G - 1 ? (unsigned)((R.cg_flag >> ((gy + 1) * G + gx)) & 1) : 0u;
   const int v = (cg == last_cg ? 0 : carry * 4) + (int)(right + (lower << 1));
   const RdoqSpec &S = spec_of(v);
-  for (int k = 15; k >= 0; k--) {
+#pragma unroll
+  for (int k = 15; k >= 0; k--) { // (unrolled: the 32 loads go out together, the two chains of additions follow)
     R.uncoded += cz_of(k);
     R.base += S.add[k];
   }
