@@ -549,7 +549,11 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
   if (resolver) {
     CR = rdoq_chain_const<N>(LR, RC, P, W, lane);
     rdoq_run_init(R);
-    for (int sp = NN - 1; sp >= (my_last_cg + 1) * 16; sp--) rdoq_resolve_above(R, W.u.cz[lane * NN + sp]);
+    for (int cg = NCG - 1; cg > my_last_cg; cg--) { // (a group's 16 loads go out together)
+      const double *z = &W.u.cz[lane * NN + cg * 16];
+#pragma unroll
+      for (int k = 15; k >= 0; k--) rdoq_resolve_above(R, z[k]);
+    }
   }
   wave_sync(); // the buffer changes hands
   RQ_T(1);
@@ -743,6 +747,7 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
     if (L.line[0] && L.line[5] >= 0 && cg <= (L.line[5] >> 4)) {
       const int blp1 = L.line[6], scan_idx = L.line[3];
       int sum = 0;
+#pragma unroll
       for (int k = 0; k < 16; k++) {
         const int sp = cg * 16 + k, l = sp < blp1 ? (int)l16[k] : 0;
         const unsigned bp = scan_of(scan_idx, sp);
@@ -770,6 +775,7 @@ __device__ __forceinline__ void rdoq_wave_tiles(TuLds<N> *Ls, WL &W, const RdoqC
         const int scan_idx = C.scan_idx;
         auto bp_of = [&](int sp) { return scan_of(scan_idx, sp); };
         unsigned neg = 0;
+#pragma unroll
         for (int k = 0; k < 16; k++) {
           const unsigned bp = bp_of(cg * 16 + k);
           neg |= (L.tile[bp >> LG][bp & (N - 1)] < 0 ? 1u : 0u) << k;

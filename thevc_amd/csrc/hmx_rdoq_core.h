@@ -533,20 +533,21 @@ struct RdoqHide {
 // lev_of(n): final signed level of entry n.  false: nothing to hide in this group.
 template <typename LevFn>
 HMX_HD bool rdoq_hide_begin(bool first_nz_group, LevFn lev_of, RdoqHide &H) {
-  int first = 16, lastnz = -1, sum = 0;
-  for (int n = 15; n >= 0; n--)
-    if (lev_of(n)) {
-      lastnz = n;
-      break;
-    }
-  for (int n = 0; n < 16; n++)
-    if (lev_of(n)) {
-      first = n;
-      break;
-    }
-  for (int n = first; n <= lastnz; n++) sum += lev_of(n);
+  // one pass over the 16 levels (their loads go out together): which are non-zero, which negative, their sum -- the levels
+  // outside [first, lastnz] are zero, so the sum over that range is the sum over the group
+  unsigned nzm = 0, ngm = 0;
+  int sum = 0;
+#pragma unroll
+  for (int n = 0; n < 16; n++) {
+    const int l = lev_of(n);
+    nzm |= (l != 0 ? 1u : 0u) << n;
+    ngm |= (l < 0 ? 1u : 0u) << n;
+    sum += l;
+  }
+  if (!nzm) return false;
+  const int first = __builtin_ctz(nzm), lastnz = 31 - __builtin_clz(nzm);
   if (lastnz - first < 4) return false;
-  H.signbit = lev_of(first) > 0 ? 0u : 1u;
+  H.signbit = (ngm >> first) & 1u;
   if (H.signbit == (unsigned)(sum & 1)) return false;
   H.min_cost = 0x7fffffffffffffffll, H.min_pos = -1, H.final_change = 0;
   H.first = first, H.lastnz = lastnz, H.top = first_nz_group, H.start = first_nz_group ? lastnz : 15;
