@@ -124,3 +124,44 @@ def test_ldp_pipeline_vs_oracle():
             for p in range(3):
                 assert np.array_equal(got[p], recs[poc][p]), ("P picture", poc, p)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_ra_pipeline_overlapped_steps():
+    """run_steps() with enable_overlap(): the I pictures (second context, second stream, double-buffered reconstructions) of
+    step n + 1 run beside the inter pictures of step n.  Every step codes the same pictures, so after three pipelined steps
+    every picture must equal what one sequential pass leaves -- including the last step's I pictures in the alternate
+    buffers having been used as references."""
+    import torch
+    from thevc_amd import capi
+    from thevc_amd import ra_pipeline as ra
+    w, h, qp, B = 192, 128, 30, 8
+    wl = ra.RAWorkload(w, h, B, qp, intra_period=8, gop=4, n_segments=3, seed=9)
+    stream = torch.cuda.Stream()
+    ctx = capi.Context(bit_depth=B, stream=stream.cuda_stream)
+    ref_pipe = ra.RAPipeline(ctx, torch, wl, stream=stream)
+    ref_pipe.load_originals()
+    ref_pipe.run()
+    torch.cuda.synchronize()
+    want = {poc: t.download() for poc, t in ref_pipe.rec.items()}
+    stream_i = torch.cuda.Stream()
+    ctx_i = capi.Context(bit_depth=B, stream=stream_i.cuda_stream)
+    pipe = ra.RAPipeline(ctx, torch, wl, stream=stream)
+    pipe.load_originals()
+    pipe.enable_overlap(ctx_i, stream_i)
+    for steps in (3, 2):  # odd and even: the last step's I pictures sit in either buffer set
+        for t in pipe.rec.values():
+            for pl in t.t:
+                pl.zero_()
+        px = pipe.run_steps(steps)
+        torch.cuda.synchronize()
+        assert px == steps * 25 * w * h  # 4 I pictures + 3 x 7 inter pictures per step
+        last = (pipe.rec_main, pipe.rec_alt)[(steps - 1) % 2]
+        for poc in want:
+            got = (last[poc] if poc in last else pipe.rec[poc]).download()
+            for p in range(3):
+                assert np.array_equal(got[p], want[poc][p]), ("picture", poc, p, steps)
+    pipe.free()
+    ref_pipe.free()
+    ctx_i.close()
+    ctx.close()

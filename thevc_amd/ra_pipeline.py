@@ -169,6 +169,8 @@ class RAPipeline:
         self.pred = [TorchPicture(torch, self.dev, w, h, 0) for _ in self.my_segments]
         self.lev = [capi.DevPicture(ctx, w, h, dtype=np.int32) for _ in self.my_segments]
         self.lev_i = None
+        self.ctx_i = self.stream_i = self.plan_i = None  # enable_overlap()
+        self.rec_alt = {}
 
     def _pic(self, store, poc):
         if poc not in store:
@@ -184,6 +186,54 @@ class RAPipeline:
         """One pass: intra pictures, exchange, inter pictures of every owned segment.  Returns pixels coded."""
         with self.torch.cuda.stream(self.stream):
             return self._run()
+
+    def enable_overlap(self, ctx_i, stream_i):
+        """A second context on a second stream for the I pictures.  The intra chain of a handful of pictures is bound by the
+        latency of its dependency levels and leaves the chip mostly idle (16 pictures of 2160p: 40 ms, 42 % of a step): in
+        run_steps() the I pictures (and their exchange) of step n + 1 run BESIDE the inter pictures of step n.  Their
+        reconstructions -- references of the inter pictures -- are double-buffered; call after load_originals()."""
+        self.ctx_i, self.stream_i = ctx_i, stream_i
+        self.plan_i = ctx_i.intra_plan(self.wl.intra_tus, self.pp_i)
+        ip = self.wl.ip
+        pocs = {k * ip for k in self.my_i}
+        if self.wl.structure == "ra":
+            pocs |= {(k + 1) * ip for k in self.my_segments}  # landing buffers of received I pictures
+        self.rec_alt = {poc: TorchPicture(self.torch, self.dev, self.wl.w, self.wl.h, MARGIN) for poc in sorted(pocs)}
+        self.rec_main = {poc: self.rec[poc] for poc in self.rec_alt}
+
+    def run_steps(self, steps):
+        """`steps` passes of run(); with enable_overlap() as a two-stage software pipeline over the steps."""
+        torch = self.torch
+        if self.ctx_i is None:
+            return sum(self.run() for _ in range(steps))
+        torch.cuda.synchronize()  # uploads, earlier passes
+        store = [self.rec_main, self.rec_alt]
+        ev_i = [torch.cuda.Event(), torch.cuda.Event()]
+        ev_done = [torch.cuda.Event(), torch.cuda.Event()]
+
+        def intra(n):
+            with torch.cuda.stream(self.stream_i):
+                if n >= 2:
+                    self.stream_i.wait_event(ev_done[n % 2])  # the inter pictures of step n - 2 have read these buffers
+                for poc, t in store[n % 2].items():
+                    self.rec[poc] = t
+                self._run_intra(self.ctx_i, self.plan_i, self.stream_i)
+                ev_i[n % 2].record(self.stream_i)
+
+        pixels = 0
+        intra(0)
+        for n in range(steps):
+            if n + 1 < steps:
+                intra(n + 1)
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev_i[n % 2])
+                for poc, t in store[n % 2].items():
+                    self.rec[poc] = t
+                pixels += len(self.my_i) * self.wl.w * self.wl.h + self._run_inter()
+                ev_done[n % 2].record(self.stream)
+        for poc, t in self.rec_main.items():
+            self.rec[poc] = t
+        return pixels
 
     def exchange_stats(self):
         """What the boundary-picture exchange of the last run() moved on this rank, and how long it took on the stream."""
@@ -205,6 +255,10 @@ class RAPipeline:
             d["pus_b"].free()
             d["pus_p"].free()
         L.hmx_intra_plan_destroy(self.ctx.h, self.plan)
+        if self.plan_i is not None:
+            L.hmx_intra_plan_destroy(self.ctx_i.h, self.plan_i)
+            self.plan_i = None
+        self.rec_alt = {}
         self.rec.clear()
         self.org.clear()
         self.pred = []
@@ -224,7 +278,11 @@ class RAPipeline:
         return len(pocs)
 
     def _run(self):
-        ctx, L, wl = self.ctx, self.L, self.wl
+        pixels = self._run_intra(self.ctx, self.plan, self.stream)
+        return pixels + self._run_inter()
+
+    def _run_intra(self, ctx, plan, stream):
+        L, wl = self.L, self.wl
         w, h = wl.w, wl.h
         # phase 1: all my I pictures in one whole-picture call, then their borders
         ipocs = [k * wl.ip for k in self.my_i]
@@ -233,19 +291,24 @@ class RAPipeline:
             org = (capi.Pic * n)(*[self.org[p].as_pic() for p in ipocs])
             rec = (capi.Pic * n)(*[self.rec[p].as_pic() for p in ipocs])
             lev = (capi.Levels * n)(*[l.as_pic() for l in self.lev_i])
-            ctx._chk(L.hmx_frame_intra_encode(ctx.h, self.plan, n, org, rec, lev))
+            ctx._chk(L.hmx_frame_intra_encode(ctx.h, plan, n, org, rec, lev))
             ctx._chk(L.hmx_pic_extend_border_multi(ctx.h, n, rec, w, h, MARGIN, MARGIN))
         # phase 2: boundary I pictures travel to the owner of the previous segment (RCCL send/recv)
         if self.world > 1 and wl.structure == "ra":
             if self._ev is None:
                 self._ev = (self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True))
-            self._ev[0].record(self.stream)
+            self._ev[0].record(stream)
             run_exchange(self.dist, self.rank, self.world, wl.n_segments, lambda ki: self.rec[ki * wl.ip].t)
-            self._ev[1].record(self.stream)
-            plan = exchange_plan(wl.n_segments, self.world)
-            self._moved = (sum(1 for (_, s_, _d) in plan if s_ == self.rank), sum(1 for (_, _s, d_) in plan if d_ == self.rank))
+            self._ev[1].record(stream)
+            plan_x = exchange_plan(wl.n_segments, self.world)
+            self._moved = (sum(1 for (_, s_, _d) in plan_x if s_ == self.rank), sum(1 for (_, _s, d_) in plan_x if d_ == self.rank))
+        return n * w * h
+
+    def _run_inter(self):
         # phase 3: inter pictures in coding order; position j of every owned segment in one call per stage
-        pixels = n * w * h
+        ctx, L, wl = self.ctx, self.L, self.wl
+        w, h = wl.w, wl.h
+        pixels = 0
         S = len(self.my_segments)
         if not S:
             return pixels
