@@ -401,7 +401,7 @@ def main():
             raise SystemExit("--rdoq is the encoder direction's quantiser")
         tus_list = [workload.with_cbf_ctx(t) for t in tus_list]
     pp = capi.PicParam(w, h_c, qp, 0, capi.I_SLICE, 1)
-    plans = [ctx.intra_plan(t, pp) for t in tus_list]
+    plans = ctx.intra_plans(tus_list, pp)  # the host-side dependency analysis of the plans on all host threads
 
     # Batch size: throughput comes from pictures in flight; the default fills most of the HBM (planes 6 + levels 6 +
     # tiled working pool 6.2 bytes per luma sample, plus 16 B per block of the packed schedule's item table).

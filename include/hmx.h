@@ -301,6 +301,11 @@ int hmx_batch_predIntra_cost(hmx_ctx *ctx, const hmx_tu_list *list, const hmx_pi
 typedef struct hmx_intra_plan hmx_intra_plan;
 int hmx_intra_plan_create(hmx_ctx *ctx, const hmx_tu *tus, int n_tu, const hmx_pic_param *pp,
                           hmx_intra_plan **plan);
+/* The plans of n_pics pictures (picture i: tus[i][0 .. n_tu[i])): the dependency analysis -- host work, about 45 ms per
+ * 2160p picture on one core -- runs on as many host threads as the machine has (at most 32), the uploads follow.
+ * Same plans as n_pics calls of hmx_intra_plan_create; on an error no plan is left behind. */
+int hmx_intra_plan_create_multi(hmx_ctx *ctx, const hmx_tu *const *tus, const int *n_tu, int n_pics, const hmx_pic_param *pp,
+                                hmx_intra_plan **plans);
 void hmx_intra_plan_destroy(hmx_ctx *ctx, hmx_intra_plan *plan);
 /* Size of the dependency schedules of a plan: blocks, picture-wide dependency levels (= launches of
  * the level schedule) and CTU diagonals (= launches of the wave schedule). */

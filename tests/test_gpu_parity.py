@@ -1441,3 +1441,49 @@ def test_frame_intra_rdoq_resident_with_sse(ctx, hmx_opts):
         L.hmx_intra_plan_destroy(ctx.h, pl)
     for d in d_org + d_out + d_lev + [b for row in d_sse for b in row]:
         d.free()
+
+
+def test_intra_plan_create_multi(ctx):
+    """hmx_intra_plan_create_multi: the host-side analysis of several pictures on host threads gives the plans of the one-picture
+    call (same schedule sizes level by level) and the same results through the packed path; a bad picture leaves no plan."""
+    B, L = ctx.bit_depth, capi.lib()
+    w, h, n, qp = 200, 136, 9, 29
+    pp = capi.PicParam(w, h, qp, 0, capi.I_SLICE, 1)
+    tus = [workload.make_tus(5100 + i, w, h, "mix") for i in range(n)]
+    single = [ctx.intra_plan(t, pp) for t in tus]
+    multi = ctx.intra_plans(tus, pp)
+    for a, b in zip(single, multi):
+        ia, ib = [(C.c_int(), C.c_int(), C.c_int()) for _ in range(2)]
+        L.hmx_intra_plan_info(a, *[C.byref(x) for x in ia])
+        L.hmx_intra_plan_info(b, *[C.byref(x) for x in ib])
+        assert [x.value for x in ia] == [x.value for x in ib]
+        for lvl in range(ia[1].value):
+            ca, cb, wa, wb = (C.c_uint32 * 4)(), (C.c_uint32 * 4)(), C.c_uint32(), C.c_uint32()
+            L.hmx_intra_plan_level(a, lvl, ca, C.byref(wa))
+            L.hmx_intra_plan_level(b, lvl, cb, C.byref(wb))
+            assert list(ca) == list(cb) and wa.value == wb.value
+    orgs = [workload.make_planes(5200 + i, w, h, B, "texture") for i in range(n)]
+    d_org = [capi.DevPicture(ctx, w, h).upload(o) for o in orgs]
+    d_rec = [capi.DevPicture(ctx, w, h).zero() for _ in range(n)]
+    d_lev = [capi.DevPicture(ctx, w, h, dtype=np.int32).zero() for _ in range(n)]
+    A = lambda lst, T: (T * n)(*[x.as_pic() for x in lst])
+    parr = (C.c_void_p * n)(*[p.value for p in multi])
+    ctx._chk(L.hmx_frame_intra_encode_multi(ctx.h, parr, n, A(d_org, capi.Pic), A(d_rec, capi.Pic), A(d_lev, capi.Levels)))
+    ctx.sync()
+    for i in range(n):
+        rr, lr = ol.o_intra_frame_encode(tus[i], w, h, B, qp, orgs[i])
+        rec, lev = d_rec[i].download(), d_lev[i].download()
+        for p in range(3):
+            assert np.array_equal(rec[p], rr[p]) and np.array_equal(lev[p], lr[p]), (i, p)
+    bad = [t.copy() for t in tus[:3]]
+    bad[1]["x"][5] = 4000  # outside the picture
+    arrs = [np.ascontiguousarray(t, capi.TU_DTYPE) for t in bad]
+    ptrs = (C.c_void_p * 3)(*[a.ctypes.data for a in arrs])
+    cnts = (C.c_int * 3)(*[len(a) for a in arrs])
+    out = (C.c_void_p * 3)()
+    assert L.hmx_intra_plan_create_multi(ctx.h, ptrs, cnts, 3, C.byref(pp), out) != 0
+    assert all(not out[i] for i in range(3))
+    for pl in single + multi:
+        L.hmx_intra_plan_destroy(ctx.h, pl)
+    for d in d_org + d_rec + d_lev:
+        d.free()

@@ -152,6 +152,7 @@ def lib():
         L.hmx_batch_predIntra.argtypes = [vp, vp, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(PicParam), vp, ci,
                                           C.POINTER(C.c_size_t * 3)]
         L.hmx_intra_plan_create.argtypes = [vp, vp, ci, C.POINTER(PicParam), C.POINTER(vp)]
+        L.hmx_intra_plan_create_multi.argtypes = [vp, C.POINTER(vp), C.POINTER(ci), ci, C.POINTER(PicParam), C.POINTER(vp)]
         L.hmx_intra_plan_destroy.argtypes = [vp, vp]
         L.hmx_intra_plan_destroy.restype = None
         L.hmx_intra_plan_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
@@ -432,6 +433,16 @@ class Context:
         h = C.c_void_p()
         self._chk(lib().hmx_intra_plan_create(self.h, _hp(tus), len(tus), C.byref(pp), C.byref(h)))
         return h
+
+    def intra_plans(self, tus_list, pp):
+        """hmx_intra_plan_create_multi: the plans of several pictures, their host-side analysis on all host threads."""
+        arrs = [np.ascontiguousarray(t, TU_DTYPE) for t in tus_list]
+        n = len(arrs)
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        cnts = (C.c_int * n)(*[len(a) for a in arrs])
+        out = (C.c_void_p * n)()
+        self._chk(lib().hmx_intra_plan_create_multi(self.h, ptrs, cnts, n, C.byref(pp), out))
+        return [C.c_void_p(out[i]) for i in range(n)]
 
 
 def qp_for(qpy, text_type, bit_depth, chroma_qp_offset=0):
