@@ -1,4 +1,4 @@
-"""Throughput of the RDOQ block-list entry (one wave per block from 8x8 up; HMX_RDOQ_LANE=1: one lane per block) on one 1080p picture's worth of blocks,
+"""Throughput of the RDOQ block-list entry (8x8 and larger blocks shared by the lanes of a wave in LDS, k_rdoq_tiles; HMX_RDOQ_LANE=1: one lane per block) on one 1080p picture's worth of blocks,
 next to the CPU oracle on a sample.  Not part of bench.py's headline; numbers go to DESIGN.md section 5."""
 import ctypes as C
 import os

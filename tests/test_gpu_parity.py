@@ -1169,7 +1169,7 @@ def test_example_end_to_end(tmp_path):
 
 
 def test_rdoq_lane_kernel_still_agrees(ctx, hmx_opts):
-    """The block-list RDOQ runs 8x8 and larger blocks one WAVE per block (k_rdoq_wave, hmx_rdoq_core.h) since round 2;
+    """The block-list RDOQ runs 8x8 and larger blocks through the wave-cooperative routine (k_rdoq_tiles, hmx_rdoq_core.h) since round 2;
     round 1's one-lane-per-block kernel (all sizes; HMX_RDOQ_LANE) is kept as a cross-check of the same vectors."""
     hmx_opts(ctx, HMX_RDOQ_LANE="1")
     test_rdoq_batch_vs_oracle(ctx)

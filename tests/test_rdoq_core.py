@@ -1,8 +1,10 @@
-"""The lane decomposition of RDOQ (thevc_amd/csrc/hmx_rdoq_core.h: coefficient groups walked in parallel for every (carry,
-neighbour pattern), one serial pass over the groups, a second parallel walk of the chosen variants, last position, sign
-hiding per group) emulated on the CPU lane by lane and held against the oracle's sequential restatement, which
-tests/test_oracle_vs_ref.py pins to the reference's xRateDistOptQuant.  The same header is what the device kernel
-(k_rdoq_wave) is made of; this test needs no GPU."""
+"""The lane decompositions of RDOQ (thevc_amd/csrc/hmx_rdoq_core.h) emulated on the CPU lane by lane and held against the
+oracle's sequential restatement, which tests/test_oracle_vs_ref.py pins to the reference's xRateDistOptQuant: (1) every
+coefficient group walked for every (carry, neighbour pattern), one serial pass over the groups, a second walk of the chosen
+variants, last position, sign hiding per group over arrays; (2) the form the device runs (rdoq_wave_tiles in hmx_rdoq.h):
+rounds composed at run time from the variants a group can still take, levels and the search's records from a second walk, sign
+hiding as a third walk with a sink -- the harness fails if a variant that was ruled out is ever needed.  The same header is
+what the device routines are made of; this test needs no GPU."""
 import os
 import subprocess
 
