@@ -299,6 +299,13 @@ int hmx_batch_predIntra_cost(hmx_ctx *ctx, const hmx_tu_list *list, const hmx_pi
  * derives the dependency schedule (CTU diagonals x in-CTU levels) and launches one kernel per CTU
  * diagonal over all pictures of the batch. */
 typedef struct hmx_intra_plan hmx_intra_plan;
+/* The neighbour units (bits as in the availability flags of initAdiPattern: below-left bottom first, left, corner, above,
+ * above-right; units of 4 luma / 2 chroma samples) whose reconstruction the prediction of a block of n_samples x n_samples
+ * with this mode can depend on, given which units are available: what the mode reads (TComPrediction.cpp:179-290, 689-730),
+ * one sample wider where the smoothed reference line is used, and the units the padding of unavailable ones copies from.
+ * The dependency order of a plan follows these bits, not the availability flags (a horizontal mode does not wait for the
+ * block above-right).  Pure host function (no device work); exported for the test that holds it against the oracle. */
+unsigned long long hmx_intra_dependency_mask(int n_samples, int is_luma, int mode, unsigned long long avail);
 int hmx_intra_plan_create(hmx_ctx *ctx, const hmx_tu *tus, int n_tu, const hmx_pic_param *pp,
                           hmx_intra_plan **plan);
 /* The plans of n_pics pictures (picture i: tus[i][0 .. n_tu[i])): the dependency analysis -- host work, about 45 ms per

@@ -1,0 +1,70 @@
+"""hmx_intra_dependency_mask (the dependency order of a plan follows what a mode READS, not which neighbours exist) against the
+oracle, by perturbation: for every block size, luma / chroma, all 35 modes and a spread of availability patterns, the
+oracle's prediction (fillReferenceSamples -> smoothing -> predIntra*Ang) must not change when every sample of an AVAILABLE
+neighbour unit outside the mask is replaced by another value -- those units may hold a stale reconstruction when the block
+runs.  No GPU: the function is host code of the library."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from thevc_amd import capi
+
+
+def _predict(O, plane, x0, y0, N, luma, mode, flags, B):
+    W = 2 * N + 1
+    adi = np.zeros(2 * W * W, np.int32)
+    fl = (C.c_uint8 * len(flags))(*flags)
+    rec = plane[y0:, x0:]
+    O.hmo_fillReferenceSamples(C.c_void_p(plane.ctypes.data + 2 * (y0 * plane.shape[1] + x0)), plane.shape[1], fl, int(sum(flags)),
+                               4 if luma else 2, N, B, adi.ctypes.data_as(C.c_void_p))
+    pred = np.zeros((N, N), np.int16)
+    if luma:
+        O.hmo_filterAdi(adi.ctypes.data_as(C.c_void_p), N)
+        O.hmo_predIntraLumaAng(adi.ctypes.data_as(C.c_void_p), mode, pred.ctypes.data_as(C.c_void_p), N, N, B)
+    else:
+        O.hmo_predIntraChromaAng(adi.ctypes.data_as(C.c_void_p), mode, pred.ctypes.data_as(C.c_void_p), N, N, B)
+    return pred
+
+
+@pytest.mark.parametrize("luma", [True, False])
+@pytest.mark.parametrize("N", [4, 8, 16, 32])
+def test_dependency_mask_covers_what_the_prediction_reads(N, luma):
+    O, L = ol.oracle(), capi.lib()
+    for f in (O.hmo_fillReferenceSamples, O.hmo_filterAdi, O.hmo_predIntraLumaAng, O.hmo_predIntraChromaAng):
+        f.restype = None
+    O.hmo_fillReferenceSamples.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    O.hmo_filterAdi.argtypes = [C.c_void_p, C.c_int]
+    O.hmo_predIntraLumaAng.argtypes = O.hmo_predIntraChromaAng.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    if not luma and N == 32:
+        pytest.skip("chroma blocks are at most 16x16 in 4:2:0 with 32x32 luma transforms")
+    B, U = 10, 4 if luma else 2
+    n = N // U
+    rng = np.random.default_rng(N * 2 + luma)
+    x0 = y0 = 2 * N + 8
+    side = 4 * N + 32
+    patterns = [[1] * (4 * n + 1), [0] * n + [1] * (3 * n + 1), [1] * (3 * n + 1) + [0] * n, [0] * n + [1] * (2 * n + 1) + [0] * n,
+                [0] * (2 * n + 1) + [1] * (2 * n), [1] * (2 * n) + [0] * (2 * n + 1), [0] * (2 * n) + [1] + [0] * (2 * n)]
+    patterns += [list(rng.integers(0, 2, 4 * n + 1)) for _ in range(6)]
+    pruned = 0
+    for flags in patterns:
+        avail = sum(int(b) << u for u, b in enumerate(flags))
+        for mode in range(35):
+            dep = L.hmx_intra_dependency_mask(N, int(luma), mode, avail)
+            assert dep & ~avail == 0
+            pruned += bin(avail & ~dep).count("1")
+            for trial in range(3):
+                plane = rng.integers(0, 1 << B, (side, side)).astype(np.int16)
+                want = _predict(O, plane, x0, y0, N, luma, mode, flags, B)
+                other = plane.copy()
+                for u in range(4 * n + 1):
+                    if not flags[u] or (dep >> u) & 1:
+                        continue
+                    for j in range(1 if u == 2 * n else U):  # the samples of unit u, by line position p
+                        p = u * U + j if u < 2 * n else (2 * N if u == 2 * n else 2 * N + 1 + (u - 2 * n - 1) * U + j)
+                        xx, yy = (-1, 2 * N - 1 - p) if p < 2 * N else ((-1, -1) if p == 2 * N else (p - 2 * N - 1, -1))
+                        other[y0 + yy, x0 + xx] = rng.integers(0, 1 << B)
+                got = _predict(O, other, x0, y0, N, luma, mode, flags, B)
+                assert np.array_equal(got, want), (N, luma, mode, flags, hex(dep))
+    assert pruned > 0  # the mask does rule units out

@@ -152,6 +152,8 @@ def lib():
         L.hmx_batch_predIntra.argtypes = [vp, vp, C.POINTER(Pic), C.POINTER(Pic), C.POINTER(PicParam), vp, ci,
                                           C.POINTER(C.c_size_t * 3)]
         L.hmx_intra_plan_create.argtypes = [vp, vp, ci, C.POINTER(PicParam), C.POINTER(vp)]
+        L.hmx_intra_dependency_mask.argtypes = [ci, ci, ci, C.c_uint64]
+        L.hmx_intra_dependency_mask.restype = C.c_uint64
         L.hmx_intra_plan_create_multi.argtypes = [vp, C.POINTER(vp), C.POINTER(ci), ci, C.POINTER(PicParam), C.POINTER(vp)]
         L.hmx_intra_plan_destroy.argtypes = [vp, vp]
         L.hmx_intra_plan_destroy.restype = None

@@ -2195,6 +2195,88 @@ extern "C" int hmx_batch_predIntra_cost(hmx_ctx *c, const hmx_tu_list *l, const 
 }
 
 // ---- intra frame plan: dependency schedule ----
+// Which neighbour units can the prediction of a block actually DEPEND on?  The availability mask says which neighbours exist;
+// a mode reads only part of the reference line (a horizontal mode never looks above-right, DC and the negative angles stay
+// inside left + above), and the order of the blocks only has to respect what is read.  The kernels still gather the whole
+// line -- a unit nobody depends on may hold a stale reconstruction, which then sits in line positions the prediction does
+// not touch.  Exactly as the prediction indexes its references (TComPrediction.cpp:179-290 xPredIntraAng, :689-730 planar,
+// :129-167 DC, :1010-1029 DC filter), widened by one sample either side where the smoothed line is used (TComPattern.cpp:
+// 265-306), and closed under the padding rule: an unavailable unit that is read takes its value from the nearest available
+// unit before it (the first available one for a leading run, TComPattern.cpp:368-552).
+// n_s = block size in samples, avail = intra_avail_mask's bits (units of 4 luma / 2 chroma samples).  Returns unit bits.
+static unsigned long long intra_dependency_mask(int n_s, bool luma, int mode, unsigned long long avail) {
+  static const int ang_tab[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32}, inv_tab[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};
+  const int N = n_s, U = luma ? 4 : 2, n = N / U, lg = ilog2i(N);
+  bool need[4 * 32 + 1] = {};
+  // line position of above[k] (k = -1: corner) and left[k]
+  auto above = [&](int k) { need[2 * N + 1 + k] = true; };
+  auto left = [&](int k) { need[2 * N - 1 - k] = true; };
+  if (mode == 0) { // planar
+    for (int k = 0; k <= N; k++) above(k), left(k);
+  } else if (mode == 1) { // DC (and its edge filter): left and above, N each
+    for (int k = 0; k < N; k++) above(k), left(k);
+  } else {
+    const bool ver = mode >= 18;
+    const int idx = ver ? mode - 26 : -(mode - 10);
+    const int angle = (idx < 0 ? -1 : 1) * ang_tab[abs(idx)], inv_angle = inv_tab[abs(idx)];
+    auto mainr = [&](int j) { // refMain[j], j >= 0; 0 = corner
+      if (j == 0) need[2 * N] = true;
+      else if (ver) above(j - 1);
+      else left(j - 1);
+    };
+    auto side = [&](int j) {
+      if (j == 0) need[2 * N] = true;
+      else if (ver) left(j - 1);
+      else above(j - 1);
+    };
+    if (angle == 0) {
+      for (int l = 0; l < N; l++) mainr(l + 1);
+      if (luma)
+        for (int k = 0; k <= N; k++) side(k); // edge filter: refSide[k + 1] - refSide[0]
+    } else {
+      int acc = 128;
+      const int lim = (N * angle) >> 5;
+      int side_of[33]; // refMain[-j] = refSide[side_of[j]], j = 1 .. -lim - 1
+      for (int k = -1; k > lim; k--) {
+        acc += inv_angle;
+        side_of[-k] = acc >> 8;
+      }
+      int pos = 0;
+      for (int k = 0; k < N; k++) {
+        pos += angle;
+        const int di = pos >> 5, df = pos & 31;
+        for (int l = 0; l < N; l++)
+          for (int i = l + di + 1; i <= l + di + 1 + (df ? 1 : 0); i++) {
+            if (i >= 0) mainr(i);
+            else side(side_of[-i]);
+          }
+      }
+    }
+  }
+  if (luma && mode != 1) { // the smoothed line: a sample of it is (raw[p - 1] + 2 raw[p] + raw[p + 1] + 2) >> 2
+    const int dh = abs(mode - 10), dv = abs(mode - 26);
+    static const int thr[4] = {10, 7, 1, 0};
+    if ((dh < dv ? dh : dv) > thr[lg - 2]) {
+      bool wide[4 * 32 + 1];
+      for (int p = 0; p <= 4 * N; p++) wide[p] = need[p] || (p > 0 && need[p - 1]) || (p < 4 * N && need[p + 1]);
+      for (int p = 0; p <= 4 * N; p++) need[p] = wide[p];
+    }
+  }
+  unsigned long long units = 0;
+  for (int p = 0; p <= 4 * N; p++)
+    if (need[p]) units |= 1ull << (p < 2 * N ? p / U : p == 2 * N ? 2 * n : 2 * n + 1 + (p - 2 * N - 1) / U);
+  unsigned long long dep = units & avail;
+  for (int u = 0; u <= 4 * n; u++) // padding: the value of an unavailable unit that is read
+    if (((units >> u) & 1) && !((avail >> u) & 1) && avail) {
+      const unsigned long long below = avail & ((1ull << u) - 1ull);
+      dep |= below ? 1ull << (63 - __builtin_clzll(below)) : avail & (0 - avail);
+    }
+  return dep;
+}
+extern "C" unsigned long long hmx_intra_dependency_mask(int n_samples, int is_luma, int mode, unsigned long long avail) {
+  return intra_dependency_mask(n_samples, is_luma != 0, mode, avail);
+}
+
 // The host half of a plan: the dependency analysis of one picture's decisions.  Touches nothing of the context but its
 // configuration, so the pictures of a batch are analysed on as many host threads as there are (hmx_intra_plan_create_multi):
 // 45 ms per 2160p picture on one core is 500x the picture's share of a whole-picture call.
@@ -2225,7 +2307,7 @@ static const char *plan_build_host(const hmx_ctx *c, const hmx_tu *tus, int n_tu
   }
   std::vector<FTu> stus;
   stus.reserve(n_tu);
-  std::vector<unsigned long long> masks(n_tu);
+  std::vector<unsigned long long> masks(n_tu), deps(n_tu);
   std::vector<Seg> segs;
   std::vector<uint32_t> seg_range((size_t)n_ctu * 3 * 2);
   std::vector<int> level(n_tu);
@@ -2239,6 +2321,8 @@ static const char *plan_build_host(const hmx_ctx *c, const hmx_tu *tus, int n_tu
       const int n = ls / 4, cx = (lx % ctu) / 4, cy = (ly % ctu) / 4;
       unsigned long long m = intra_avail_mask(lx, ly, ls, P);
       masks[id] = m;
+      m = intra_dependency_mask(1 << t.log2n, t.plane == 0, t.mode, m); // the order follows what the mode reads
+      deps[id] = m;
       int lv = 0;
       auto dep = [&](int ux, int uy) { // unit coordinates relative to the CTU
         if (ux >= 0 && uy >= 0 && ux < U && uy < U) lv = std::max(lv, grid[uy * U + ux]);
@@ -2294,7 +2378,7 @@ static const char *plan_build_host(const hmx_ctx *c, const hmx_tu *tus, int n_tu
       const int sh = t.plane ? 1 : 0, lx = t.x << sh, ly = t.y << sh, ls = (1 << t.log2n) << sh;
       const int n = ls / 4, ux = lx / 4, uy = ly / 4;
       int *g = g3.data() + (size_t)t.plane * uw * uh;
-      const unsigned long long m = masks[i];
+      const unsigned long long m = deps[i];
       int lv = 0;
       for (int u = 0; u < 4 * n + 1; u++) {
         if (!((m >> u) & 1)) continue;
