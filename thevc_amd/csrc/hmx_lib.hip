@@ -2687,10 +2687,7 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
     }
     resident = c->crq.max_waves;
   }
-  uint64_t want = std::max<uint64_t>(256, 2 * wpl);
-  // mid-size batches are bound by the latency of a wave-item, which grows with the waves that share a SIMD: fewer waves than
-  // two levels' worth (measured optimum 1536-2048 / 2560 / 3072 / 4096 waves at 256 / 512 / 768 / 1024 pictures: +4..10 %)
-  if (!rdoq && n_pics > 128) want = std::min<uint64_t>(want, 1024 + 3ull * (uint64_t)n_pics);
+  const uint64_t want = std::max<uint64_t>(256, 2 * wpl);
   pk.n_wg = c->knob.pack_waves ? std::min(c->knob.pack_waves, resident) : (int)std::min<uint64_t>((uint64_t)resident, want);
   PackArgs A{};
   A.pics = pk.d_pics;
