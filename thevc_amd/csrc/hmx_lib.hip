@@ -2618,7 +2618,9 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
     for (int s = 0; s < 4; s++) sz[s] += pl->size_total[s];
   }
   // one lane per 4x4 block is the throughput shape, four lanes per block make more, shorter waves (small batches)
-  G.slots4 = c->knob.slots4 ? c->knob.slots4 : (n_pics >= 256 ? 64 : 16);
+  // (measured with the mode-aware dependency order, 2160p mix: 64 lanes/wave-item ahead at 8..128 and from 384 pictures,
+  // 16 ahead at 192 and 256)
+  G.slots4 = c->knob.slots4 ? c->knob.slots4 : ((n_pics >= 160 && n_pics < 320) ? 16 : 64);
   const bool rdoq = enc && c->crq.n > 0;
   if (rdoq) {
     if (c->crq.n != 1 && c->crq.n != n_pics) return fail(c, HMX_ERR_ARG, "frame_intra: hmx_set_rdoq described another number of pictures");
