@@ -13,30 +13,25 @@ from thevc_amd import capi
 
 
 def _predict(O, plane, x0, y0, N, luma, mode, flags, B):
+    """oracle_lib's argument types: numpy arrays (flags uint8, adi int32, prediction int16), the plane by address"""
     W = 2 * N + 1
     adi = np.zeros(2 * W * W, np.int32)
-    fl = (C.c_uint8 * len(flags))(*flags)
-    rec = plane[y0:, x0:]
-    O.hmo_fillReferenceSamples(C.c_void_p(plane.ctypes.data + 2 * (y0 * plane.shape[1] + x0)), plane.shape[1], fl, int(sum(flags)),
-                               4 if luma else 2, N, B, adi.ctypes.data_as(C.c_void_p))
-    pred = np.zeros((N, N), np.int16)
+    fl = np.ascontiguousarray(flags, np.uint8)
+    flat = plane.reshape(-1)
+    O.hmo_fillReferenceSamples(ol.ptr(flat, y0 * plane.shape[1] + x0), plane.shape[1], fl, int(fl.sum()), 4 if luma else 2, N, B, adi)
+    pred = np.zeros(N * N, np.int16)
     if luma:
-        O.hmo_filterAdi(adi.ctypes.data_as(C.c_void_p), N)
-        O.hmo_predIntraLumaAng(adi.ctypes.data_as(C.c_void_p), mode, pred.ctypes.data_as(C.c_void_p), N, N, B)
+        O.hmo_filterAdi(adi, N)
+        O.hmo_predIntraLumaAng(adi, mode, pred, N, N, B)
     else:
-        O.hmo_predIntraChromaAng(adi.ctypes.data_as(C.c_void_p), mode, pred.ctypes.data_as(C.c_void_p), N, N, B)
-    return pred
+        O.hmo_predIntraChromaAng(adi, mode, pred, N, N, B)
+    return pred.reshape(N, N)
 
 
 @pytest.mark.parametrize("luma", [True, False])
 @pytest.mark.parametrize("N", [4, 8, 16, 32])
 def test_dependency_mask_covers_what_the_prediction_reads(N, luma):
     O, L = ol.oracle(), capi.lib()
-    for f in (O.hmo_fillReferenceSamples, O.hmo_filterAdi, O.hmo_predIntraLumaAng, O.hmo_predIntraChromaAng):
-        f.restype = None
-    O.hmo_fillReferenceSamples.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-    O.hmo_filterAdi.argtypes = [C.c_void_p, C.c_int]
-    O.hmo_predIntraLumaAng.argtypes = O.hmo_predIntraChromaAng.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
     if not luma and N == 32:
         pytest.skip("chroma blocks are at most 16x16 in 4:2:0 with 32x32 luma transforms")
     B, U = 10, 4 if luma else 2
