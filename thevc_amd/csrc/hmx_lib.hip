@@ -2206,6 +2206,7 @@ extern "C" int hmx_batch_predIntra_cost(hmx_ctx *c, const hmx_tu_list *l, const 
 // n_s = block size in samples, avail = intra_avail_mask's bits (units of 4 luma / 2 chroma samples).  Returns unit bits.
 static unsigned long long intra_dependency_mask(int n_s, bool luma, int mode, unsigned long long avail) {
   static const int ang_tab[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32}, inv_tab[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};
+  if ((n_s != 4 && n_s != 8 && n_s != 16 && n_s != 32) || mode < 0 || mode > 34) return avail; // not a mode this function knows: every neighbour
   const int N = n_s, U = luma ? 4 : 2, n = N / U, lg = ilog2i(N);
   bool need[4 * 32 + 1] = {};
   // line position of above[k] (k = -1: corner) and left[k]
