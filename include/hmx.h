@@ -308,7 +308,7 @@ typedef struct hmx_intra_plan hmx_intra_plan;
 unsigned long long hmx_intra_dependency_mask(int n_samples, int is_luma, int mode, unsigned long long avail);
 int hmx_intra_plan_create(hmx_ctx *ctx, const hmx_tu *tus, int n_tu, const hmx_pic_param *pp,
                           hmx_intra_plan **plan);
-/* The plans of n_pics pictures (picture i: tus[i][0 .. n_tu[i])): the dependency analysis -- host work, about 45 ms per
+/* The plans of n_pics pictures (picture i: tus[i][0 .. n_tu[i])): the dependency analysis -- host work, about 43 ms per
  * 2160p picture on one core -- runs on as many host threads as the machine has (at most 32), the uploads follow.
  * Same plans as n_pics calls of hmx_intra_plan_create; on an error no plan is left behind. */
 int hmx_intra_plan_create_multi(hmx_ctx *ctx, const hmx_tu *const *tus, const int *n_tu, int n_pics, const hmx_pic_param *pp,

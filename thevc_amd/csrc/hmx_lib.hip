@@ -2204,9 +2204,8 @@ extern "C" int hmx_batch_predIntra_cost(hmx_ctx *c, const hmx_tu_list *l, const 
 // 265-306), and closed under the padding rule: an unavailable unit that is read takes its value from the nearest available
 // unit before it (the first available one for a leading run, TComPattern.cpp:368-552).
 // n_s = block size in samples, avail = intra_avail_mask's bits (units of 4 luma / 2 chroma samples).  Returns unit bits.
-static unsigned long long intra_dependency_mask(int n_s, bool luma, int mode, unsigned long long avail) {
+static unsigned long long intra_needed_units(int n_s, bool luma, int mode) {
   static const int ang_tab[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32}, inv_tab[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};
-  if ((n_s != 4 && n_s != 8 && n_s != 16 && n_s != 32) || mode < 0 || mode > 34) return avail; // not a mode this function knows: every neighbour
   const int N = n_s, U = luma ? 4 : 2, n = N / U, lg = ilog2i(N);
   bool need[4 * 32 + 1] = {};
   // line position of above[k] (k = -1: corner) and left[k]
@@ -2266,7 +2265,23 @@ static unsigned long long intra_dependency_mask(int n_s, bool luma, int mode, un
   unsigned long long units = 0;
   for (int p = 0; p <= 4 * N; p++)
     if (need[p]) units |= 1ull << (p < 2 * N ? p / U : p == 2 * N ? 2 * n : 2 * n + 1 + (p - 2 * N - 1) / U);
+  return units;
+}
+static unsigned long long intra_dependency_mask(int n_s, bool luma, int mode, unsigned long long avail) {
+  if ((n_s != 4 && n_s != 8 && n_s != 16 && n_s != 32) || mode < 0 || mode > 34) return avail; // not a mode this function knows: every neighbour
+  struct Table { // what a mode reads depends on (size, texture type, mode) only: 280 masks, formed once
+    unsigned long long u[4][2][35];
+    Table() {
+      for (int lg = 2; lg <= 5; lg++)
+        for (int l = 0; l < 2; l++)
+          for (int m = 0; m < 35; m++) u[lg - 2][l][m] = intra_needed_units(1 << lg, l != 0, m);
+    }
+  };
+  static const Table T;
+  const int n = n_s / (luma ? 4 : 2);
+  const unsigned long long units = T.u[ilog2i(n_s) - 2][luma ? 1 : 0][mode];
   unsigned long long dep = units & avail;
+  if (!(units & ~avail)) return dep;
   for (int u = 0; u <= 4 * n; u++) // padding: the value of an unavailable unit that is read
     if (((units >> u) & 1) && !((avail >> u) & 1) && avail) {
       const unsigned long long below = avail & ((1ull << u) - 1ull);
