@@ -221,7 +221,8 @@ def run_random_access(args, torch, dist, rank, local_rank, world, workload_name,
             # the I pictures of the next step (few pictures: latency-bound, the chip mostly idle) beside this step's inter pictures
             stream_i = torch.cuda.Stream()
             ctx_i = capi.Context(bit_depth=B, device=local_rank, stream=stream_i.cuda_stream)
-            pipe.enable_overlap(ctx_i, stream_i)
+            ctx_i2 = capi.Context(bit_depth=B, device=local_rank, stream=stream_i.cuda_stream)  # one context per buffer set
+            pipe.enable_overlap(ctx_i, stream_i, ctx_i2)
 
         def fence():
             if world > 1:
@@ -240,9 +241,7 @@ def run_random_access(args, torch, dist, rank, local_rank, world, workload_name,
             dist.all_reduce(t)
             px = float(t.item())
         exch = pipe.exchange_stats()
-        ctx.sync()
-        if ctx_i is not None:
-            ctx_i.sync()
+        pipe.check()  # the abort word of every context the steps ran on
     out = {
         "metric": METRIC,
         "value": round(px / dt / 1e6, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -261,6 +260,7 @@ def run_random_access(args, torch, dist, rank, local_rank, world, workload_name,
     ctx.close()
     if ctx_i is not None:
         ctx_i.close()
+        ctx_i2.close()
     return out
 
 

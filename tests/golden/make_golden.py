@@ -159,6 +159,37 @@ def sao(R, B, rng):
     return {"y": y, "cb": cb, "cr": cr, "prm": prm.view(np.uint8).reshape(3, n_lcu, 6), "oy": ry, "ocb": rcb, "ocr": rcr}
 
 
+def intra64(R, B, rng):
+    """64x64 luma prediction units (the PU of a 64x64 CU: initAdiPattern + the 35 modes of estIntraPredQT,
+    TEncSearch.cpp:2509-2540) at every CTU position of a picture whose width cuts the last CTU column: the above-right
+    neighbour is whole, cut by the picture edge, or missing."""
+    out = {}
+    w, h = 168, 136
+    R.ref_init(B, w, h, 1)
+    y, cb, cr = (rng.integers(0, 1 << B, n).astype(np.int16) for n in (w * h, w * h // 4, w * h // 4))
+    R.ref_set_recon(y, cb, cr)
+    out["pic_y"], out["pic_cb"], out["pic_cr"] = y.reshape(h, w), cb.reshape(h // 2, w // 2), cr.reshape(h // 2, w // 2)
+    N, W = 64, 129
+    pos, adis, preds = [], [], []
+    for (bx, by) in ((0, 0), (64, 0), (0, 64), (64, 64)):
+        a = np.zeros(2 * W * W, np.int32)
+        R.ref_initAdiPattern(bx, by, N, 0, 0, a)
+        keep = np.zeros_like(a)
+        for off in (0, W * W):
+            keep[off:off + W] = a[off:off + W]
+            keep[off:off + W * W:W] = a[off:off + W * W:W]
+        pr = np.zeros((35, N * N), np.int16)
+        for m in range(35):
+            R.ref_predIntraLumaAng(keep, m, pr[m], N, N)
+        pos.append((bx, by))
+        adis.append(keep)
+        preds.append(pr)
+    out["il64_pos"] = np.array(pos, np.int32)
+    out["il64_adi"] = np.stack(adis)
+    out["il64_pred"] = np.stack(preds)
+    return out
+
+
 def intra(R, B, rng):
     """initAdiPattern on a real picture + all 35 modes, luma and chroma."""
     out = {}
@@ -280,6 +311,10 @@ def main():
     if sys.argv[1:] == ["sao"]:
         for B in (8, 10):
             np.savez_compressed(os.path.join(HERE, f"sao_b{B}.npz"), **sao(R, B, np.random.default_rng(7096 + B)))
+        return
+    if sys.argv[1:] == ["intra64"]:  # round 3: the 64x64 luma prediction units
+        for B in (8, 10):
+            np.savez_compressed(os.path.join(HERE, f"intra64_b{B}.npz"), **intra64(R, B, np.random.default_rng(8120 + B)))
         return
     if sys.argv[1:] == ["deblock"]:
         for B in (8, 10):

@@ -223,6 +223,39 @@ def test_gpu_transforms_quant(gctx):
             assert np.array_equal(r, g[f"q{N}_inv"][k])
 
 
+@pytest.mark.parametrize("B", [8, 10])
+def test_oracle_intra64(B):
+    """64x64 luma prediction units (TEncSearch.cpp:2509-2540 runs initAdiPattern and the 35 modes at the PU size)."""
+    g, O = load(f"intra64_b{B}.npz"), ol.oracle()
+    h, w = g["pic_y"].shape
+    flags = np.zeros(65, np.uint8)
+    y = np.ascontiguousarray(g["pic_y"]).reshape(-1)
+    N, W = 64, 129
+    for k, (bx, by) in enumerate(g["il64_pos"]):
+        adi = np.zeros(2 * W * W, np.int32)
+        nav = O.hmo_intra_avail(int(bx), int(by), N, w, h, 64, flags)
+        O.hmo_fillReferenceSamples(ol.ptr(y, int(by) * w + int(bx)), w, flags, nav, 4, N, B, adi)
+        O.hmo_filterAdi(adi, N)
+        assert np.array_equal(adi, g["il64_adi"][k])
+        for m in range(35):
+            p = np.zeros(N * N, np.int16)
+            O.hmo_predIntraLumaAng(adi, m, p, N, N, B)
+            assert np.array_equal(p, g["il64_pred"][k][m]), (k, m)
+
+
+@pytest.mark.gpu
+def test_gpu_intra64(gctx):
+    B = gctx.bit_depth
+    g = load(f"intra64_b{B}.npz")
+    h, w = g["pic_y"].shape
+    y = np.ascontiguousarray(g["pic_y"]).reshape(-1)
+    for k, (bx, by) in enumerate(g["il64_pos"]):
+        adi = gctx.initAdiPattern(y, w, int(bx), int(by), 64, 0, w, h)
+        assert np.array_equal(adi, g["il64_adi"][k]), (k, "initAdiPattern")
+        for m in range(35):
+            assert np.array_equal(gctx.predIntraLumaAng(adi, m, 64, 64), g["il64_pred"][k][m]), (k, m)
+
+
 @pytest.mark.gpu
 def test_gpu_intra(gctx):
     B = gctx.bit_depth

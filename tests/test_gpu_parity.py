@@ -104,15 +104,15 @@ def test_scalar_intra(ctx):
     planes = workload.make_planes(3 + B, w, h, B)
     rng = np.random.default_rng(B)
     flags = np.zeros(65, np.uint8)
-    for N in (4, 8, 16, 32):
+    for N in (4, 8, 16, 32, 64):  # 64: the luma prediction unit of a 64x64 coding unit (no transform of that size)
         W = 2 * N + 1
         for chroma in (0, 1):
-            if chroma and N == 32:
+            if chroma and N >= 32:
                 continue
             pl = planes[1] if chroma else planes[0]
             pw, ph = pl.shape[1], pl.shape[0]
             flat = pl.reshape(-1).copy()
-            for it in range(14):
+            for it in range(14 if N < 64 else 6):
                 bx = int(rng.integers(0, (pw - N) // N + 1)) * N
                 by = int(rng.integers(0, (ph - N) // N + 1)) * N
                 if it == 0:
@@ -322,6 +322,68 @@ def test_frame_intra_many_pictures_one_plan(ctx, pic, n_pics, across, hmx_opts):
             assert np.array_equal(a[p], recs[i][p]), ("decode", i, p)
     L.hmx_intra_plan_destroy(ctx.h, plan)
     for d in d_org + d_rec + d_rec2 + d_lev:
+        d.free()
+
+
+def test_batch_pred64(ctx):
+    """HOT LOOP A at the size of a 64x64 coding unit (TEncSearch.cpp:2509-2540: initAdiPattern, 35 x predIntraLumaAng + calcHAD
+    with uiWidth = 64): hmx_batch_predIntra / _cost on lists that hold 64x64 luma prediction units next to smaller blocks, at
+    every CTU position of a picture whose right edge cuts the last CTU column (above-right whole / cut / missing)."""
+    O, B, L = ol.oracle(), ctx.bit_depth, capi.lib()
+    O.hmo_calcHAD.restype = C.c_uint32
+    w, h = 232, 136
+    rec = workload.make_planes(17 + B, w, h, B)
+    org = workload.make_planes(18 + B, w, h, B, "texture")
+    flat = rec[0].reshape(-1).copy()
+    tus = np.zeros(8, capi.TU_DTYPE)
+    pos = [(0, 0, 6), (64, 0, 6), (128, 0, 6), (0, 64, 6), (64, 64, 6), (128, 64, 6), (192, 32, 5), (200, 128, 3)]
+    for i, (x, y, lg) in enumerate(pos):
+        tus[i]["x"], tus[i]["y"], tus[i]["log2n"], tus[i]["plane"], tus[i]["mode"] = x, y, lg, 0, (7 * i + 3) % 35
+    lst = ctx.tu_list(tus)
+    pp = capi.PicParam(w, h, 30, 0, capi.I_SLICE, 1)
+    d_rec = capi.DevPicture(ctx, w, h).upload(rec)
+    d_org = capi.DevPicture(ctx, w, h).upload(org)
+    d_pr = capi.DevPicture(ctx, w, h).zero()
+    # the block's own mode
+    ctx._chk(L.hmx_batch_predIntra(ctx.h, lst, C.byref(d_rec.as_pic()), C.byref(d_pr.as_pic()), C.byref(pp), None, 0, None))
+    ctx.sync()
+    got = d_pr.download()[0]
+    for i, t in enumerate(tus):
+        N, x, y = 1 << int(t["log2n"]), int(t["x"]), int(t["y"])
+        ref = ol.o_intra_pred(flat, w, x, y, N, int(t["mode"]), B, w, h, False)
+        assert np.array_equal(got[y:y + N, x:x + N], ref), ("own mode", i, N)
+    # the 35-mode fan-out, written out and costed in place
+    modes = np.arange(35, dtype=np.uint8)
+    d_modes = ctx.to_device(modes)
+    fan = [ctx.alloc(2 * 35 * w * h), ctx.alloc(4), ctx.alloc(4)]
+    fp = capi.Pic()
+    fp.plane[0], fp.plane[1], fp.plane[2] = fan[0].ptr, fan[1].ptr, fan[2].ptr
+    fp.stride[0], fp.stride[1], fp.stride[2] = w, w // 2, w // 2
+    elems = (C.c_size_t * 3)(w * h, 0, 0)
+    ctx._chk(L.hmx_batch_predIntra(ctx.h, lst, C.byref(d_rec.as_pic()), C.byref(fp), C.byref(pp), d_modes.ptr, 35, C.byref(elems)))
+    d_cost = ctx.alloc(4 * len(tus) * 35)
+    ctx._chk(L.hmx_batch_predIntra_cost(ctx.h, lst, C.byref(d_rec.as_pic()), C.byref(d_org.as_pic()), C.byref(pp), d_modes.ptr, 35, d_cost.ptr))
+    ctx.sync()
+    cand = fan[0].download(np.int16).reshape(35, h, w)
+    cost = d_cost.download(np.uint32).reshape(len(tus), 35)
+    for i, t in enumerate(tus):
+        N, x, y = 1 << int(t["log2n"]), int(t["x"]), int(t["y"])
+        ob = np.ascontiguousarray(org[0][y:y + N, x:x + N])
+        for m in range(35):
+            ref = np.ascontiguousarray(ol.o_intra_pred(flat, w, x, y, N, m, B, w, h, False))
+            assert np.array_equal(cand[m, y:y + N, x:x + N], ref), ("fan-out", i, N, m)
+            want = O.hmo_calcHAD(ob.ctypes.data_as(C.c_void_p), N, ref.ctypes.data_as(C.c_void_p), N, N, N, B)
+            assert cost[i, m] == want, ("satd", i, N, m)
+    # a list with a 64x64 block is a prediction list: the transform entry points refuse it (there is no 64x64 transform)
+    d_lev = capi.DevPicture(ctx, w, h, dtype=np.int32).zero()
+    assert L.hmx_batch_transformNxN(ctx.h, lst, C.byref(d_rec.as_pic()), C.byref(d_lev.as_pic()), None, C.byref(pp)) == -1
+    # a 64x64 block must be a whole luma CTU
+    bad = tus[:1].copy()
+    bad["x"] = 32
+    out = C.c_void_p()
+    assert L.hmx_tu_list_create(ctx.h, bad.ctypes.data_as(C.c_void_p), 1, C.byref(out)) == -1
+    L.hmx_tu_list_destroy(ctx.h, lst)
+    for d in (d_rec, d_org, d_pr, d_lev):
         d.free()
 
 

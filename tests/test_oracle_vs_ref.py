@@ -266,7 +266,7 @@ def test_init_adi_pattern_geometry(pic):
     y, cb, cr = _planes(rng, w, h, B)
     R.ref_set_recon(y, cb, cr)
     flags = np.zeros(65, np.uint8)
-    for N in (4, 8, 16, 32):
+    for N in (4, 8, 16, 32, 64):  # 64: the luma prediction unit of a 64x64 CU (TEncSearch.cpp:2509)
         W = 2 * N + 1
         for by in range(0, h - N + 1, N):
             for bx in range(0, w - N + 1, N):

@@ -409,6 +409,23 @@ __host__ __device__ __forceinline__ unsigned long long intra_avail_mask(int x, i
   return m;
 }
 
+// The same for a 64 x 64 LUMA block = a whole CTU (the prediction unit of a 64 x 64 coding unit, TEncSearch.cpp:2509-2540:
+// initAdiPattern and the 35 modes run at the PU size; no transform of that size exists).  4n + 1 = 65 units of four samples
+// do not fit the 64-bit mask, and need not: below-left of a CTU is never coded before it, left / above are all-or-nothing,
+// and the picture's right edge cuts the above-right CTU at a multiple of the minimum CU size (8).  So the mask is kept in
+// units of EIGHT samples (n = 8, 33 bits, same bit order); build_ref_line takes the unit size as an argument.
+__host__ __device__ __forceinline__ unsigned long long intra_avail_mask_ctu(int x, int y, const PicDev &P) {
+  unsigned long long m = 0;
+  if (x > 0 && y > 0) m |= 1ull << 16;
+  if (x > 0) m |= 0xffull << 8;
+  if (y > 0) {
+    m |= 0xffull << 17;
+    for (int o = 0; o < 8; o++)
+      if (x + 64 + 8 * o < P.pic_w) m |= 1ull << (25 + o);
+  }
+  return m;
+}
+
 // Reference line of a block: L[0..4N], L[0] = lowest below-left sample, L[2N] = corner,
 // L[4N] = right-most above-right sample (fillReferenceSamples, TComPattern.cpp:368-552).
 // Every sample is one independent load: an unavailable sample copies the nearest available
@@ -460,7 +477,7 @@ __device__ __forceinline__ void smooth_ref_line(const int *L, int *F, int gl) { 
 }
 
 __device__ __forceinline__ bool use_filtered_refs(int mode, int log2n) { // TComPattern.cpp:49-56,577-605
-  const int thr = log2n == 2 ? 10 : log2n == 3 ? 7 : log2n == 4 ? 1 : log2n == 5 ? 0 : 10;
+  const int thr = log2n == 2 ? 10 : log2n == 3 ? 7 : log2n == 4 ? 1 : log2n == 5 ? 0 : 10; // m_aucIntraFilter: {10, 7, 1, 0, 10 (64x64)}
   if (mode == 1) return false;
   return min(abs(mode - 10), abs(mode - 26)) > thr;
 }
@@ -517,7 +534,7 @@ __device__ __forceinline__ void build_main_ref(const int *R, int *ME, int mode, 
 template <int N, int NS, typename RowFn, typename ColFn>
 __device__ __forceinline__ void intra_pred_samples(const int *R, const int *ME, int mode, bool luma, int bit_depth, int dc_sum,
                                                    RowFn row, ColFn col, int *p) {
-  constexpr int LOG2N = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+  constexpr int LOG2N = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : N == 32 ? 5 : 6;
   const int *top = R + 2 * N; // top[k]; left(k) = R[2N - k]
   if (mode == 0) { // planar, closed form of the accumulators
     const int tr = top[N + 1], bl = R[2 * N - (N + 1)];

@@ -13,7 +13,7 @@ namespace hmx {
 
 template <int N>
 struct Log2 {
-  static constexpr int v = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+  static constexpr int v = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : N == 32 ? 5 : 6;
 };
 
 struct PlanesDev { // one picture: three planes, element strides
@@ -358,7 +358,8 @@ __device__ __forceinline__ void inv_tq_block(TuLds<N> &L, int gl, bool active, b
 template <int N, int NL, typename Fetch>
 __device__ __forceinline__ void intra_refs(TuLds<N> &L, int gl, bool active, Fetch fetch, bool luma,
                                            unsigned long long avail, const PicDev &P) {
-  if (active) build_ref_line<N, NL>(fetch, avail, luma ? 2 : 1, P.bit_depth, gl, L.line);
+  // N = 64 (a whole CTU, luma only): the mask counts units of eight samples (intra_avail_mask_ctu)
+  if (active) build_ref_line<N, NL>(fetch, avail, N == 64 ? 3 : luma ? 2 : 1, P.bit_depth, gl, L.line);
   wave_sync();
   if (active && luma && N > 4) smooth_ref_line<N, NL>(L.line, L.fline, gl); // 4x4 never uses the smoothed line
   wave_sync();

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -33,11 +34,11 @@ __device__ __forceinline__ DTu load_dtu(const DTu *p) { // one 12-byte load inst
 // list kernels: 256-thread workgroups = four autonomous waves; blocks per workgroup
 template <int N>
 struct Slots {
-  static constexpr int v = N == 32 ? 4 : 256 / N; // 32x32 scratch (9.5 KB) is kept to four blocks
+  static constexpr int v = N == 64 ? 1 : N == 32 ? 4 : 256 / N; // 32x32 scratch (9.5 KB) is kept to four blocks; 64x64 (prediction only, 19.5 KB): one
 };
 #define HMX_SMEM_BYTES (16 * (int)sizeof(TuLds<16>)) /* largest of Slots<N> * sizeof(TuLds<N>) */
 static_assert(64 * sizeof(TuLds<4>) <= HMX_SMEM_BYTES && 32 * sizeof(TuLds<8>) <= HMX_SMEM_BYTES &&
-                  4 * sizeof(TuLds<32>) <= HMX_SMEM_BYTES,
+                  4 * sizeof(TuLds<32>) <= HMX_SMEM_BYTES && sizeof(TuLds<64>) <= HMX_SMEM_BYTES,
               "LDS scratch");
 
 enum ListOp { OP_TRANSFORM_NXN, OP_INVTRANSFORM_NXN, OP_XT, OP_XIT, OP_XQUANT, OP_XDEQUANT, OP_PRED, OP_TRANSFORM_RECON };
@@ -200,7 +201,9 @@ __global__ __launch_bounds__(256) void k_list(ListArgs A) {
     }
   } else { // OP_PRED
     const int sh = luma ? 0 : 1;
-    const unsigned long long avail = active ? intra_avail_mask(x << sh, y << sh, N << sh, A.P) : 0;
+    unsigned long long avail = 0;
+    if constexpr (N == 64) avail = active ? intra_avail_mask_ctu(x, y, A.P) : 0; // a whole CTU, luma (hmx_tu_list_create checks)
+    else avail = active ? intra_avail_mask(x << sh, y << sh, N << sh, A.P) : 0;
     const short *rec0 = a_p + (size_t)y * a_s + x;
     const int rst = a_s;
     intra_refs<N, N>(L, gl, active, [&](int dx, int dy) { return (int)rec0[(ptrdiff_t)dy * rst + dx]; }, luma, avail, A.P);
@@ -1885,7 +1888,9 @@ static int check_packed_abort(hmx_ctx *c) {
 #endif
   uint32_t ab = 0;
   HIPCHK(c, hipMemcpy(&ab, &c->pk.d_hdr->abort, sizeof(ab), hipMemcpyDeviceToHost));
-  return ab ? fail(c, HMX_ERR_DEVICE, "packed schedule: a dependency wait timed out, the call's outputs are invalid") : HMX_OK;
+  if (!ab) return HMX_OK;
+  HIPCHK(c, hipMemset(&c->pk.d_hdr->abort, 0, sizeof(ab))); // read and reported: the next call starts clean
+  return fail(c, HMX_ERR_DEVICE, "packed schedule: a dependency wait timed out, the outputs of every call since the last hmx_sync are invalid");
 }
 extern "C" int hmx_sync(hmx_ctx *c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1945,6 +1950,13 @@ static int launch_list(hmx_ctx *c, int log2n, const ListArgs &A) {
   case 3: hipLaunchKernelGGL((k_list<8, OP>), dim3((A.n + Slots<8>::v - 1) / Slots<8>::v, ny), blk, 0, c->stream, A); break;
   case 4: hipLaunchKernelGGL((k_list<16, OP>), dim3((A.n + Slots<16>::v - 1) / Slots<16>::v, ny), blk, 0, c->stream, A); break;
   case 5: hipLaunchKernelGGL((k_list<32, OP>), dim3((A.n + Slots<32>::v - 1) / Slots<32>::v, ny), blk, 0, c->stream, A); break;
+  case 6: // 64 x 64: the luma prediction unit of a 64 x 64 coding unit (TEncSearch.cpp:2509-2540); no transform of that size exists
+    if constexpr (OP == OP_PRED) {
+      hipLaunchKernelGGL((k_list<64, OP>), dim3((unsigned)A.n, ny), blk, 0, c->stream, A);
+      break;
+    } else {
+      return fail(c, HMX_ERR_ARG, "64x64 blocks: intra prediction only (the largest transform is 32x32)");
+    }
   default: return fail(c, HMX_ERR_ARG, "unsupported block size");
   }
   HIPCHK(c, hipGetLastError());
@@ -1967,7 +1979,7 @@ static int launch_op(hmx_ctx *c, int op, int log2n, const ListArgs &A) {
 // A block list resident on the device, bucketed by block size.
 struct hmx_tu_list {
   DTu *d = nullptr;
-  int off[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
+  int off[5] = {0, 0, 0, 0, 0}, cnt[5] = {0, 0, 0, 0, 0}; // size classes 4 .. 64 (64: luma prediction units, hmx_batch_predIntra[_cost] only)
   int n = 0;
 };
 
@@ -1976,10 +1988,11 @@ extern "C" int hmx_tu_list_create(hmx_ctx *c, const hmx_tu *tus, int n, hmx_tu_l
   hmx_tu_list *l = new hmx_tu_list;
   std::vector<DTu> v;
   v.reserve(n);
-  for (int s = 2; s <= 5; s++) {
+  for (int s = 2; s <= 6; s++) {
     l->off[s - 2] = (int)v.size();
     for (int i = 0; i < n; i++)
-      if (tus[i].log2n == s) v.push_back(DTu{tus[i], (uint32_t)i});
+      if (tus[i].log2n == s && (s < 6 || (tus[i].plane == 0 && tus[i].x % 64 == 0 && tus[i].y % 64 == 0 && c->cfg.ctu_size == 64)))
+        v.push_back(DTu{tus[i], (uint32_t)i});
     l->cnt[s - 2] = (int)v.size() - l->off[s - 2];
     // The blocks of a list call are independent, so the order inside a size class is ours: raster order per plane
     // puts horizontally adjacent blocks on adjacent lanes, whose row accesses then share cache lines (coding order
@@ -1992,7 +2005,7 @@ extern "C" int hmx_tu_list_create(hmx_ctx *c, const hmx_tu *tus, int n, hmx_tu_l
   }
   if ((int)v.size() != n) {
     delete l;
-    return fail(c, HMX_ERR_ARG, "hmx_tu_list_create: block size outside 4..32");
+    return fail(c, HMX_ERR_ARG, "hmx_tu_list_create: block size outside 4..32 (64: luma, CTU-aligned, CTU size 64 only)");
   }
   l->n = n;
   if (n) {
@@ -2057,7 +2070,8 @@ static void *arena_push(hmx_ctx *c, const void *src, size_t bytes) {
 }
 
 static int run_list(hmx_ctx *c, int op, const hmx_tu_list *l, ListArgs A) {
-  for (int s = 0; s < 4; s++) {
+  if (l->cnt[4] && op != OP_PRED) return fail(c, HMX_ERR_ARG, "the list holds 64x64 blocks: intra prediction only (the largest transform is 32x32)");
+  for (int s = 0; s < 5; s++) {
     if (!l->cnt[s]) continue;
     A.tus = l->d + l->off[s];
     A.n = l->cnt[s];
@@ -2470,7 +2484,7 @@ static const char *plan_build_host(const hmx_ctx *c, const hmx_tu *tus, int n_tu
 // the device half: the tables go up in ONE allocation and one copy
 static int plan_upload(hmx_ctx *c, PlanHost &H, const hmx_pic_param *pp, hmx_intra_plan **out) {
   hmx_intra_plan *pl = new hmx_intra_plan;
-  static uint64_t plan_serial = 0;
+  static std::atomic<uint64_t> plan_serial{0}; // plans are created from several host threads / contexts: the serial is part of a cache key
   pl->serial = ++plan_serial;
   pl->level_chunks = H.level_chunks;
   for (const LevelRow &lr : H.ltab)
@@ -2520,15 +2534,40 @@ extern "C" int hmx_intra_plan_create_multi(hmx_ctx *c, const hmx_tu *const *tus,
   int r = HMX_OK;
   for (int base = 0; base < n_pics && !r; base += 2 * T) { // chunks: a 2160p picture's host tables are ~15 MB
     const int n = std::min(2 * T, n_pics - base);
-    std::vector<PlanHost> H(n);
-    std::vector<const char *> err(n, nullptr);
+    // nothing thrown inside may leave a C entry point: allocation failures and thread-creation errors become HMX_ERR_NOMEM,
+    // after every thread that did start has been joined
     std::vector<std::thread> th;
-    for (int t = 0; t < T; t++)
-      th.emplace_back([&, t]() {
-        for (int i = t; i < n; i += T) err[i] = plan_build_host(c, tus[base + i], n_tu[base + i], pp, H[i]);
-      });
-    for (auto &x : th) x.join();
-    for (int i = 0; i < n && !r; i++) r = err[i] ? fail(c, HMX_ERR_ARG, err[i]) : plan_upload(c, H[i], pp, &out[base + i]);
+    bool oom = false;
+    try {
+      std::vector<PlanHost> H(n);
+      std::vector<const char *> err(n, nullptr);
+      static const char *const kOom = "hmx_intra_plan_create_multi: out of host memory";
+      auto work = [&](int t) {
+        for (int i = t; i < n; i += T) {
+          try {
+            err[i] = plan_build_host(c, tus[base + i], n_tu[base + i], pp, H[i]);
+          } catch (...) {
+            err[i] = kOom;
+          }
+        }
+      };
+      try {
+        for (int t = 1; t < T; t++) th.emplace_back(work, t);
+      } catch (...) { // std::system_error: fewer threads than planned; their shares are picked up below
+      }
+      const int started = (int)th.size() + 1;
+      work(0);
+      for (auto &x : th) x.join();
+      th.clear();
+      for (int t = started; t < T; t++) work(t); // shares of the threads that could not be started
+      for (int i = 0; i < n && !r; i++)
+        r = err[i] == kOom ? fail(c, HMX_ERR_NOMEM, err[i]) : err[i] ? fail(c, HMX_ERR_ARG, err[i]) : plan_upload(c, H[i], pp, &out[base + i]);
+    } catch (...) {
+      oom = true;
+    }
+    for (auto &x : th)
+      if (x.joinable()) x.join();
+    if (oom) r = fail(c, HMX_ERR_NOMEM, "hmx_intra_plan_create_multi: out of host memory");
   }
   if (r)
     for (int i = 0; i < n_pics; i++)
@@ -2657,7 +2696,10 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
     if (!r) r = grow_dev(c, (void **)&pk.d_items, &pk.cap_items, sizeof(FTu) * items);
     if (!r) r = grow_dev(c, (void **)&pk.d_rows, &pk.cap_rows, sizeof(PackRow) * n_rows);
     if (!r) r = grow_dev(c, (void **)&pk.d_done, &pk.cap_done, sizeof(uint32_t) * kDoneStride * n_rows);
-    if (!r && !pk.d_hdr && hipMalloc((void **)&pk.d_hdr, sizeof(PackHdr)) != hipSuccess) r = fail(c, HMX_ERR_NOMEM, "hipMalloc packed header");
+    if (!r && !pk.d_hdr) {
+      if (hipMalloc((void **)&pk.d_hdr, sizeof(PackHdr)) != hipSuccess) r = fail(c, HMX_ERR_NOMEM, "hipMalloc packed header");
+      else if (hipMemsetAsync(pk.d_hdr, 0, sizeof(PackHdr), st) != hipSuccess) r = fail(c, HMX_ERR_DEVICE, "hipMemsetAsync packed header");
+    }
     if (r) return r;
     std::vector<PackPic> hp(n_pics);
     for (int i = 0; i < n_pics; i++) {
@@ -2670,7 +2712,7 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
     }
     HIPCHK(c, hipMemcpyAsync(pk.d_pics, hp.data(), sizeof(PackPic) * n_pics, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st)); // hp goes out of scope
-    HIPCHK(c, hipMemsetAsync(pk.d_hdr, 0, sizeof(PackHdr), st));
+    HIPCHK(c, hipMemsetAsync(pk.d_hdr, 0, offsetof(PackHdr, abort), st)); // everything but the sticky abort word (below)
     const unsigned prep_waves = (unsigned)((n_rows + (uint64_t)(64 / G.I) - 1) / (uint64_t)(64 / G.I));
     hipLaunchKernelGGL(k_pack_count, dim3(prep_waves), dim3(64), 0, st, pk.d_pics, pk.d_rows, G, (int)n_rows);
     hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, st, pk.d_rows, pk.d_hdr, G);
@@ -2683,7 +2725,10 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
   }
   // counters and ticket words start from zero every call
   HIPCHK(c, hipMemsetAsync(pk.d_done, 0, sizeof(uint32_t) * kDoneStride * n_rows, st));
-  HIPCHK(c, hipMemsetAsync(&pk.d_hdr->abort, 0, sizeof(PackHdr) - offsetof(PackHdr, abort), st));
+  // The abort word is STICKY: it is cleared only by check_packed_abort after the host has read it (hmx_sync / hmx_download).
+  // Calls queued behind a call whose dependency wait timed out see it set, leave at once and the next hmx_sync reports it --
+  // a per-call clear would let call k+1 erase the failure of call k.
+  HIPCHK(c, hipMemsetAsync(pk.d_hdr->ticket, 0, sizeof(PackHdr) - offsetof(PackHdr, ticket), st));
   const uint64_t wpl = waves_bound / (uint64_t)std::max(1, G.max_levels); // wave-items per dependency level, all groups
   if (!c->max_resident_waves) {
     int nb = 0;
@@ -3368,19 +3413,23 @@ extern "C" int hmx_frame_intra_decode_multi(hmx_ctx *c, const hmx_intra_plan *co
 extern "C" int hmx_set_rdoq(hmx_ctx *c, const hmx_rdoq_pic *pics, int n_pics) {
   if (!c || (pics && n_pics <= 0)) return HMX_ERR_ARG;
   auto &q = c->crq;
+  // every input is checked BEFORE the context's state moves: a rejected call leaves the previous setting as it was
+  if (pics)
+    for (int i = 0; i < n_pics; i++)
+      if (!(pics[i].lambda_luma > 0) || !(pics[i].lambda_chroma > 0)) return fail(c, HMX_ERR_ARG, "hmx_set_rdoq: lambda must be positive");
   q.serial++;
   if (!pics) {
     q.n = 0;
     return HMX_OK;
   }
   static_assert(sizeof(hmx_rdoq_pic) == 8 * sizeof(EstBitsDev) + 2 * sizeof(double), "hmx_rdoq_pic: eight tables and two multipliers");
+  q.n = 0; // from here on a failure (device memory, copy) leaves RDOQ OFF, never a half-written table set
   HIPCHK(c, hipStreamSynchronize(c->stream)); // a queued call may still read the previous tables
   int r = grow_dev(c, (void **)&q.d_est, &q.cap_est, sizeof(EstBitsDev) * 8 * (size_t)n_pics);
   if (!r) r = grow_dev(c, (void **)&q.d_lambda, &q.cap_lambda, sizeof(double) * 4 * (size_t)n_pics);
   if (r) return r;
   q.lambda.resize((size_t)n_pics * 2);
   for (int i = 0; i < n_pics; i++) {
-    if (!(pics[i].lambda_luma > 0) || !(pics[i].lambda_chroma > 0)) return fail(c, HMX_ERR_ARG, "hmx_set_rdoq: lambda must be positive");
     q.lambda[(size_t)i * 2] = pics[i].lambda_luma, q.lambda[(size_t)i * 2 + 1] = pics[i].lambda_chroma;
     HIPCHK(c, hipMemcpyAsync(q.d_est + (size_t)i * 8, pics[i].est, sizeof(EstBitsDev) * 8, hipMemcpyHostToDevice, c->stream));
   }
@@ -3452,6 +3501,8 @@ int one_block(hmx_ctx *c, Scratch &s, One &o, int n, int plane, unsigned mode, u
   return HMX_OK;
 }
 bool size_ok(int w, int h) { return w == h && (w == 4 || w == 8 || w == 16 || w == 32); }
+// intra prediction also runs at 64 x 64, the prediction unit of a 64 x 64 coding unit (TComPrediction.cpp:343-345 asserts 4..128)
+bool size_ok_intra(int w, int h) { return size_ok(w, h) || (w == 64 && h == 64); }
 
 PicDev scalar_picdev(hmx_ctx *c, const hmx_qp *qp, int per_base, int slice_type, int sign_hide) {
   PicDev P{};
@@ -3896,9 +3947,11 @@ __global__ __launch_bounds__(64) void k_adi(const short *win, int stride, int bx
   const bool on = gl < N;
   constexpr int W = 2 * N + 1;
   if (on) {
-    unsigned long long avail = intra_avail_mask(x << chroma, y << chroma, N << chroma, P);
+    unsigned long long avail;
+    if constexpr (N == 64) avail = intra_avail_mask_ctu(x, y, P); // a whole CTU, luma: units of eight samples
+    else avail = intra_avail_mask(x << chroma, y << chroma, N << chroma, P);
     const short *rec0 = win + (size_t)by * stride + bx;
-    build_ref_line<N, N>([&](int dx, int dy) { return (int)rec0[(ptrdiff_t)dy * stride + dx]; }, avail, chroma ? 1 : 2,
+    build_ref_line<N, N>([&](int dx, int dy) { return (int)rec0[(ptrdiff_t)dy * stride + dx]; }, avail, N == 64 ? 3 : chroma ? 1 : 2,
                          P.bit_depth, gl, L.line);
   }
   __syncthreads();
@@ -3960,7 +4013,9 @@ __global__ __launch_bounds__(64) void k_pred_adi(const int *adi, int mode, int l
 
 extern "C" int hmx_initAdiPattern(hmx_ctx *c, const hmx_pel *rec, int stride, int x, int y, int n, int is_chroma,
                                   int pic_w, int pic_h, int32_t *adi) {
-  if (!c || !rec || !adi || !size_ok(n, n)) return fail(c, HMX_ERR_ARG, "hmx_initAdiPattern: unsupported size or null");
+  if (!c || !rec || !adi || !size_ok_intra(n, n)) return fail(c, HMX_ERR_ARG, "hmx_initAdiPattern: unsupported size or null");
+  if (n == 64 && (is_chroma || c->cfg.ctu_size != 64 || x % 64 || y % 64))
+    return fail(c, HMX_ERR_ARG, "hmx_initAdiPattern: a 64x64 block is the luma prediction unit of a whole CTU (CTU size 64, aligned)");
   const int pw = is_chroma ? pic_w / 2 : pic_w, ph = is_chroma ? pic_h / 2 : pic_h;
   if (x < 0 || y < 0 || x + n > pw || y + n > ph) return fail(c, HMX_ERR_ARG, "hmx_initAdiPattern: block outside picture");
   const int x0 = std::max(x - 1, 0), y0 = std::max(y - 1, 0), x1 = std::min(x + 2 * n, pw), y1 = std::min(y + 2 * n, ph);
@@ -3977,7 +4032,8 @@ extern "C" int hmx_initAdiPattern(hmx_ctx *c, const hmx_pel *rec, int stride, in
   case 4: hipLaunchKernelGGL(k_adi<4>, dim3(1), dim3(64), 0, c->stream, d_win, ww, bx, by, x, y, is_chroma, P, d_adi); break;
   case 8: hipLaunchKernelGGL(k_adi<8>, dim3(1), dim3(64), 0, c->stream, d_win, ww, bx, by, x, y, is_chroma, P, d_adi); break;
   case 16: hipLaunchKernelGGL(k_adi<16>, dim3(1), dim3(64), 0, c->stream, d_win, ww, bx, by, x, y, is_chroma, P, d_adi); break;
-  default: hipLaunchKernelGGL(k_adi<32>, dim3(1), dim3(64), 0, c->stream, d_win, ww, bx, by, x, y, is_chroma, P, d_adi); break;
+  case 32: hipLaunchKernelGGL(k_adi<32>, dim3(1), dim3(64), 0, c->stream, d_win, ww, bx, by, x, y, is_chroma, P, d_adi); break;
+  default: hipLaunchKernelGGL(k_adi<64>, dim3(1), dim3(64), 0, c->stream, d_win, ww, bx, by, x, y, is_chroma, P, d_adi); break;
   }
   HIPCHK(c, hipGetLastError());
   return hmx_download(c, adi, d_adi, sizeof(int) * 2 * W * W);
@@ -3985,7 +4041,7 @@ extern "C" int hmx_initAdiPattern(hmx_ctx *c, const hmx_pel *rec, int stride, in
 
 static int pred_from_adi(hmx_ctx *c, const int32_t *adi, unsigned mode, hmx_pel *pred, unsigned stride, int w, int h,
                          int luma, int raw_line = 0) {
-  if (!c || !adi || !pred || !size_ok(w, h) || mode > 34) return fail(c, HMX_ERR_ARG, "predIntra: unsupported size/mode or null");
+  if (!c || !adi || !pred || !size_ok_intra(w, h) || mode > 34) return fail(c, HMX_ERR_ARG, "predIntra: unsupported size/mode or null");
   const int W = 2 * w + 1;
   Scratch s{c};
   int *d_adi = s.take<int>((size_t)2 * W * W);
@@ -3998,7 +4054,8 @@ static int pred_from_adi(hmx_ctx *c, const int32_t *adi, unsigned mode, hmx_pel 
   case 4: hipLaunchKernelGGL(k_pred_adi<4>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred, raw_line); break;
   case 8: hipLaunchKernelGGL(k_pred_adi<8>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred, raw_line); break;
   case 16: hipLaunchKernelGGL(k_pred_adi<16>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred, raw_line); break;
-  default: hipLaunchKernelGGL(k_pred_adi<32>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred, raw_line); break;
+  case 32: hipLaunchKernelGGL(k_pred_adi<32>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred, raw_line); break;
+  default: hipLaunchKernelGGL(k_pred_adi<64>, dim3(1), dim3(64), 0, c->stream, d_adi, (int)mode, luma, P, d_pred, raw_line); break;
   }
   HIPCHK(c, hipGetLastError());
   return down2d(c, pred, stride, d_pred, 2, w, h);
@@ -4016,7 +4073,7 @@ extern "C" int hmx_predIntraChromaAng(hmx_ctx *c, const int32_t *adi, unsigned m
 // (2w+1) x (2w+1) border buffer (the caller chose raw or smoothed, as the reference's callers do by
 // passing a pointer); the reference's pSrc is its cell (1,1).
 extern "C" int hmx_predIntraGetPredValDC(hmx_ctx *c, const int32_t *adi, int w, int h, int above, int left, hmx_pel *dc) {
-  if (!c || !adi || !dc || !size_ok(w, h)) return fail(c, HMX_ERR_ARG, "hmx_predIntraGetPredValDC: unsupported size or null");
+  if (!c || !adi || !dc || !size_ok_intra(w, h)) return fail(c, HMX_ERR_ARG, "hmx_predIntraGetPredValDC: unsupported size or null");
   const int W = 2 * w + 1;
   Scratch s{c};
   int *d_adi = s.take<int>((size_t)W * W), *d_out = s.take<int>(1);
@@ -4034,7 +4091,7 @@ extern "C" int hmx_xPredIntraPlanar(hmx_ctx *c, const int32_t *adi, hmx_pel *pre
 }
 extern "C" int hmx_xPredIntraAng(hmx_ctx *c, const int32_t *adi, hmx_pel *pred, unsigned stride, int w, int h, unsigned dir_mode,
                                  int above, int left, int filter) {
-  if (!c || !adi || !pred || !size_ok(w, h) || dir_mode < 1 || dir_mode > 34)
+  if (!c || !adi || !pred || !size_ok_intra(w, h) || dir_mode < 1 || dir_mode > 34)
     return fail(c, HMX_ERR_ARG, "hmx_xPredIntraAng: unsupported size, null or mode outside 1..34");
   if (dir_mode == 1) { // DC from the sides flagged available; no edge smoothing here (xDCPredFiltering is the wrapper's)
     const int W = 2 * w + 1;

@@ -187,13 +187,19 @@ class RAPipeline:
         with self.torch.cuda.stream(self.stream):
             return self._run()
 
-    def enable_overlap(self, ctx_i, stream_i):
+    def enable_overlap(self, ctx_i, stream_i, ctx_i2=None):
         """A second context on a second stream for the I pictures.  The intra chain of a handful of pictures is bound by the
         latency of its dependency levels and leaves the chip mostly idle (16 pictures of 2160p: 40 ms, 42 % of a step): in
         run_steps() the I pictures (and their exchange) of step n + 1 run BESIDE the inter pictures of step n.  Their
-        reconstructions -- references of the inter pictures -- are double-buffered; call after load_originals()."""
+        reconstructions -- references of the inter pictures -- are double-buffered; call after load_originals().
+        ctx_i2 (a third context, same stream): the odd steps' buffer set gets its own context, so each context sees the SAME
+        picture table every time it is called and keeps its device tables (one context alternating between the two buffer sets
+        re-uploads the table and rebuilds the packed schedule every step, with two host synchronisations that serialise the
+        enqueueing of the two stages)."""
         self.ctx_i, self.stream_i = ctx_i, stream_i
+        self.ctx_i_set = [ctx_i, ctx_i2 if ctx_i2 is not None else ctx_i]
         self.plan_i = ctx_i.intra_plan(self.wl.intra_tus, self.pp_i)
+        self.plan_i_set = [self.plan_i, ctx_i2.intra_plan(self.wl.intra_tus, self.pp_i) if ctx_i2 is not None else self.plan_i]
         ip = self.wl.ip
         pocs = {k * ip for k in self.my_i}
         if self.wl.structure == "ra":
@@ -217,7 +223,7 @@ class RAPipeline:
                     self.stream_i.wait_event(ev_done[n % 2])  # the inter pictures of step n - 2 have read these buffers
                 for poc, t in store[n % 2].items():
                     self.rec[poc] = t
-                self._run_intra(self.ctx_i, self.plan_i, self.stream_i)
+                self._run_intra(self.ctx_i_set[n % 2], self.plan_i_set[n % 2], self.stream_i)
                 ev_i[n % 2].record(self.stream_i)
 
         pixels = 0
@@ -234,6 +240,13 @@ class RAPipeline:
         for poc, t in self.rec_main.items():
             self.rec[poc] = t
         return pixels
+
+    def check(self):
+        """After the caller's fence: read the packed schedule's abort word of every context this pipeline launched on (a
+        dependency wait that timed out fails HERE instead of passing as a finished step)."""
+        self.ctx.sync()
+        for c in dict.fromkeys(getattr(self, "ctx_i_set", [])):
+            c.sync()
 
     def exchange_stats(self):
         """What the boundary-picture exchange of the last run() moved on this rank, and how long it took on the stream."""
@@ -257,6 +270,8 @@ class RAPipeline:
         L.hmx_intra_plan_destroy(self.ctx.h, self.plan)
         if self.plan_i is not None:
             L.hmx_intra_plan_destroy(self.ctx_i.h, self.plan_i)
+            if self.plan_i_set[1] is not self.plan_i:
+                L.hmx_intra_plan_destroy(self.ctx_i_set[1].h, self.plan_i_set[1])
             self.plan_i = None
         self.rec_alt = {}
         self.rec.clear()
