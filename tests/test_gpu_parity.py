@@ -118,7 +118,7 @@ def test_scalar_intra(ctx):
                 if it == 0:
                     bx = by = 0
                 if it == 1:
-                    bx, by = pw - N, ph - N
+                    bx, by = (pw - N, ph - N) if N < 64 else ((pw - N) // N * N, (ph - N) // N * N)  # a 64x64 unit is a whole CTU
                 adi = ctx.initAdiPattern(flat, pw, bx, by, N, chroma, w, h)
                 ref = np.zeros(2 * W * W, np.int32)
                 nav = O.hmo_intra_avail(bx << chroma, by << chroma, N << chroma, w, h, 64, flags)

@@ -1,0 +1,1122 @@
+// hmx_chain_dev.h -- device side of the whole-picture all-intra chain: the block chains (wave_chain_*), the
+// level-synchronous kernels, the layout conversion and the packed schedule (tables' prep kernels, k_intra_packed).
+// Included by hmx_chain.hip (defines HMX_CHAIN_MAIN: also gets the non-template kernels), hmx_chain_rdoq.hip (the RDOQ
+// instantiations of k_intra_packed) and hmx_list.hip (the one-lane 4x4 transform halves).
+#pragma once
+#include "hmx_host.h"
+
+#define HMX_WAVE_SMEM 7680 /* max(4 * sizeof(TuLds<16>), sizeof(Lane4Lds), ...) - checked below */
+static_assert(4 * sizeof(TuLds<16>) <= HMX_WAVE_SMEM, "per-wave LDS scratch");
+static_assert(16 * sizeof(TuLds<4>) <= HMX_WAVE_SMEM && 8 * sizeof(TuLds<8>) <= HMX_WAVE_SMEM &&
+                  sizeof(TuLds<32>) <= HMX_WAVE_SMEM,
+              "per-wave LDS scratch");
+
+// What a block chain needs of the picture it works on, for the plane of its block.
+struct PlaneView {
+  const short *org; // tiled working copy of the original
+  TiledPlane rec;   // tiled working reconstruction
+  int *lev;
+  int lev_stride;   // > 0: plane geometry; 0: the reference's Z-order coefficient layout
+  uint32_t *sse = nullptr; // != NULL (encoder direction): xGetSSE(org, rec) of every block, at the index of its first 4x4 unit
+};
+// Two ways a wave finds its work.  "Own": every item of the wave is another block of ONE picture
+// (descriptor i of a list).  "Across": every item is the SAME block of another picture -- pictures that
+// follow one plan (same decisions) run in SIMD across pictures: the descriptor, its mode, position and
+// availability are wave-uniform (scalar registers, no divergent mode branches), and a wave is full
+// whenever the batch holds at least 64/N pictures.
+// The lane index as a value the optimiser cannot see through.  Inside a persistent loop (k_intra_packed) everything
+// derived from threadIdx.x is loop-invariant: the compiler hoists all of it -- slot, row, LDS addresses of four chains --
+// out of the loop and, out of registers, parks it in scratch memory (176 bytes per lane, reloaded every iteration).
+__device__ __forceinline__ int lane_id() {
+  int l = threadIdx.x;
+  asm volatile("" : "+v"(l));
+  return l;
+}
+struct OwnPicture {
+  static constexpr bool kCoherent = false; // producer and consumer are separated by a kernel boundary
+  static constexpr bool kWriteThrough = false;
+  static constexpr bool kSse = false; // distortion output: packed schedule only
+  static constexpr bool kRdoq = false; // RDOQ as the chain's quantiser: packed schedule only
+  const PicWork &W;
+  const FTu *tus;
+  __device__ __forceinline__ void wait() const {}
+  __device__ __forceinline__ FTu desc(int i) const { return tus[i]; }
+  __device__ __forceinline__ PlaneView view(int, int pl) const {
+    TiledPlane r = W.rec[pl];
+    r.p = as_global(r.p);
+    return PlaneView{as_global(W.org[pl].p), r, as_global(W.lev[pl]), W.lev_stride[pl]};
+  }
+};
+struct AcrossPictures {
+  static constexpr bool kCoherent = false;
+  static constexpr bool kWriteThrough = false;
+  static constexpr bool kSse = false;
+  static constexpr bool kRdoq = false;
+  __device__ __forceinline__ void wait() const {}
+  const PicWork *pics;
+  const FTu *ft; // the one block this wave works on (wave-uniform address: scalar loads)
+  int pic0, n_pics;
+  const short *pool_org; // pictures interleaved quad by quad (TiledPlane::qstride = 64 * n_pics)
+  short *pool_rec;
+  uint32_t luma_elems, chroma_elems; // plane sizes of one picture (Y, Cb, Cr in this order)
+  int ctu_w, clog_luma;
+  __device__ __forceinline__ FTu desc(int) const { return *ft; }
+  __device__ __forceinline__ PlaneView view(int i, int pl) const {
+    const size_t o = (size_t)((pl > 0 ? luma_elems : 0u) + (pl > 1 ? chroma_elems : 0u)) * n_pics + (size_t)(pic0 + i) * 64;
+    // the table row is read with computed addresses: an indexed member array would live in scratch
+    const char *row = reinterpret_cast<const char *>(&pics[pic0 + i]);
+    int *lv = *reinterpret_cast<int *const *>(row + offsetof(PicWork, lev) + pl * sizeof(int *));
+    const int ls = *reinterpret_cast<const int *>(row + offsetof(PicWork, lev_stride) + pl * sizeof(int));
+    return PlaneView{pool_org + o, TiledPlane{pool_rec + o, ctu_w, pl ? clog_luma - 1 : clog_luma, 64u * n_pics}, as_global(lv), ls};
+  }
+};
+
+// element offset of row r of the N x N block at (x,y) in a level buffer
+// (a level plane holds fewer than 2^32 elements; rows and strides are below 2^24: full-rate multiply)
+template <int N>
+__device__ __forceinline__ unsigned lev_row_off(const PlaneView &V, int x, int y, int r) {
+  return V.lev_stride ? __umul24((unsigned)(y + r), (unsigned)V.lev_stride) + x : tile_base(V.rec.ctu_w, V.rec.clog, x, y) + (unsigned)r * N;
+}
+
+template <int N, bool ENC, bool ONCE = false, typename SRC>
+__device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, const PicDev &P, int count) {
+  constexpr int SL = 64 / N;
+  const int lane = lane_id(), slot = lane / N, gl = lane % N;
+  TuLds<N> &L = reinterpret_cast<TuLds<N> *>(smem)[slot];
+  for (int base = 0; ONCE ? base < 1 : base < count; base += SL) { // ONCE: the level schedule hands a wave at most one pass
+    const int i = base + slot;
+    const bool active = i < count;
+    const FTu ft = src.desc(active ? i : 0);
+    const hmx_tu t = ft.t;
+    const int pl = t.plane, x = t.x, y = t.y;
+    const bool luma = pl == 0, ts = t.flags & HMX_TU_TRANSFORM_SKIP;
+    const int scan_idx = coef_scan_idx(N, luma, true, t.mode);
+    const unsigned long long avail = (unsigned long long)ft.avail_lo | ((unsigned long long)ft.avail_hi << 32);
+    const PlaneView V = src.view(active ? i : 0, pl);
+    const TiledPlane &R = V.rec;
+    const unsigned b0 = tile_base(R.ctu_w, R.clog, x, y); // same geometry for org and rec
+    int pred[N], row[N];
+    int *lev_row = V.lev + lev_row_off<N>(V, x, y, gl);
+    const size_t pb0 = tphys(R.qstride, b0);
+    if (ENC && active) tload_row<N>(V.org + pb0, R.qstride, gl, row); // independent of the references
+    src.wait(); // packed schedule: the blocks this one predicts from belong to earlier rows of the same launch
+    intra_refs_tiled<N, N, SRC::kCoherent>(L, gl, active, R, x, y, pb0, luma, avail, P);
+    intra_pred_block<N>(L, gl, t.mode, luma, P, pred);
+    if (ENC) {
+#pragma unroll
+      for (int k = 0; k < N; k++) row[k] = wrap16(row[k] - pred[k]);
+      if constexpr (SRC::kRdoq) { // xRateDistOptQuant in the quantiser's place (transform-skip blocks keep the flat one)
+        static_assert(N >= 8, "4x4 blocks with RDOQ run in the lane-per-block chain");
+        wave_sync(); // the prediction has read the reference line
+        if (gl == 0)
+          L.line[0] = active && !ts, L.line[1] = src.picture(), L.line[2] = luma, L.line[3] = scan_idx, L.line[4] = src.cbf_ctx(), L.line[9] = src.group_slot() * 2 + (luma ? 0 : 1), L.line[10] = 0;
+        fwd_tq_block<N>(L, gl, active, row, ts, luma, luma, scan_idx, ts, P);
+        rdoq_wave_tiles<N, SL>(reinterpret_cast<TuLds<N> *>(smem), src.rdoq_lds(), src.rdoq(), P, lane);
+      } else {
+        fwd_tq_block<N>(L, gl, active, row, ts, luma, luma, scan_idx, true, P);
+      }
+      if (active) {
+        load_row32<N>(&L.tile[gl][0], row);
+#pragma unroll
+        for (int k = 0; k < N; k++) row[k] = level_of(row[k]);
+#ifdef HMX_STREAM_NT
+        if (V.lev_stride == 0) stream_store_row32<N>(lev_row, row); // the reference's coefficient layout: 16-byte aligned rows
+        else
+#endif
+          store_row32<N>(lev_row, row);
+      }
+    } else {
+      if (active) {
+        load_row32<N>(lev_row, row);
+#pragma unroll
+        for (int k = 0; k < N; k++) row[k] = clip3(-32768, 32767, row[k]) & 0xffff;
+        store_row32<N>(&L.tile[gl][0], row);
+      }
+      wave_sync();
+    }
+    // inverse of all-zero levels is exactly zero, so the reference's "if (uiAbsSum)" needs no branch
+    inv_tq_block<N>(L, gl, active, ts, luma, luma, true, P, row);
+    if (active) {
+      const int mx = (1 << P.bit_depth) - 1;
+#pragma unroll
+      for (int k = 0; k < N; k++) row[k] = clip3(0, mx, pred[k] + row[k]);
+      tstore_row<N, SRC::kWriteThrough>(R.p + pb0, R.qstride, gl, row);
+    }
+    if constexpr (ENC && SRC::kSse) {
+      if (src.want_sse()) { // wave-uniform: getDistPart right behind the reconstruction (TEncSearch.cpp:1163), fused
+        int o[N];
+        unsigned d = 0;
+        if (active) {
+          tload_row<N>(V.org + pb0, R.qstride, gl, o); // the original row again (it went into the residual): an L2 hit
+          d = sse_samples<N>(o, row, P.bit_depth);
+        }
+        d = (unsigned)group_sum((int)d, N);
+        if (active && gl == 0) V.sse[b0 >> 4] = d;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4x4 blocks, one LANE per block (64 blocks per wave).  Everything a 4x4 block needs fits one lane's
+// registers: the two transposes of the separable transform are register renaming, sign-bit hiding
+// runs in every lane instead of one lane in four, and no lane idles while its group waits.
+// Only the reference line goes through LDS (the angular modes index it at run time).
+// ---------------------------------------------------------------------------------------------
+struct Lane4Lds {
+  int line[64][17]; // line[lane][p], p = 0..16 as in build_ref_line (odd stride: conflict-free)
+  int me[64][13];   // extended main reference per lane (3N+1 entries)
+};
+static_assert(sizeof(Lane4Lds) <= HMX_WAVE_SMEM, "per-wave LDS scratch");
+
+__device__ __forceinline__ int scan4_pos(int scan_idx, int i) { // raster position of scan entry i of a 4x4 block
+  constexpr unsigned char dg[16] = {0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15};
+  const int hor = i, ver = ((i & 3) << 2) | (i >> 2);
+  return scan_idx == 1 ? hor : (scan_idx == 2 ? ver : dg[i]);
+}
+
+// The transform half of a 4x4 block held by ONE lane (used by the lane-per-block chain and by the inter list kernel).
+// lane4_forward: residual (row-major) -> packed words (level | neg << 16 | deltaU << 17) after sign-bit hiding.
+__device__ __forceinline__ void lane4_coef(const int *resid, bool use_dst, bool ts, const PicDev &P, int *coef) {
+  const int B = P.bit_depth, tshift = 15 - B - 2;
+  if (ts) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) coef[k] = resid[k] << tshift; // tshift >= 1 for B <= 12
+  } else {
+    int t1[16];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { // tmp[k][r] = pass1(row r)[k]
+      int yk[4];
+      fwd_pass<4>(resid + 4 * r, yk, 1 + (B - 8), use_dst);
+#pragma unroll
+      for (int k = 0; k < 4; k++) t1[4 * k + r] = yk[k];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { // coeff[k][r] = pass2(row r of tmp)[k]
+      int yk[4];
+      fwd_pass<4>(t1 + 4 * r, yk, 8, use_dst);
+#pragma unroll
+      for (int k = 0; k < 4; k++) coef[4 * k + r] = yk[k];
+    }
+  }
+}
+__device__ __forceinline__ void lane4_forward(const int *resid, bool use_dst, bool ts, bool luma, int scan_idx, const PicDev &P, int *w) {
+  const int B = P.bit_depth, tshift = 15 - B - 2;
+  int coef[16];
+  lane4_coef(resid, use_dst, ts, P, coef);
+  const QuantDev qd = pick_qd(P, luma);
+  const int qbits = 14 + qd.per_qbits + tshift;
+  int sum = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    int al;
+    w[k] = quant_one<false>(coef[k], qd.q, qbits, qd.rnd_factor, al);
+    sum += al;
+  }
+  if (P.sign_hide && sum >= 2) { // one coefficient group = the whole block; it is "the last group"
+    // the scan differs per lane, but there are only three of them: scan entry k of each is a
+    // compile-time register, so the reorder is two selects per entry
+    constexpr int dg[16] = {0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15};
+    const bool hor = scan_idx == 1, ver = scan_idx == 2;
+    int ws[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int d = w[dg[k]], hv = w[k], vv = w[((k & 3) << 2) | (k >> 2)];
+      ws[k] = hor ? hv : (ver ? vv : d);
+    }
+    int nw;
+    const int bi = sbh_decide(ws, true, nw);
+    if (bi >= 0) {
+      const int bd = (int)((0xfbe7ad369c258140ull >> (4 * bi)) & 15); // dg[bi], one nibble per entry
+      const int bp = hor ? bi : (ver ? (((bi & 3) << 2) | (bi >> 2)) : bd);
+#pragma unroll
+      for (int q = 0; q < 16; q++) w[q] = (q == bp) ? nw : w[q];
+    }
+  }
+}
+// lane4_inverse: levels (row-major) -> residual
+__device__ __forceinline__ void lane4_inverse(const int *lv, bool use_dst, bool ts, bool luma, const PicDev &P, int *out) {
+  const int B = P.bit_depth, tshift = 15 - B - 2;
+  const QuantDev qd = pick_qd(P, luma);
+  int c[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) c[k] = dequant_one(lv[k], qd.iq_scale, 6 - tshift);
+  if (ts) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[k] = wrap16((c[k] + (1 << (tshift - 1))) >> tshift);
+    return;
+  }
+  int t1[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) c[k] = wrap16(c[k]);
+#pragma unroll
+  for (int j = 0; j < 4; j++) { // tmp[j][n] = sum_k M[k][n] * c[k][j]
+    int col[4], yn[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) col[k] = c[4 * k + j];
+    inv_pass<4>(col, yn, 7, use_dst);
+#pragma unroll
+    for (int nn = 0; nn < 4; nn++) t1[4 * j + nn] = yn[nn];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) { // block[j][n] = sum_k M[k][n] * tmp[k][j]
+    int col[4], yn[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) col[k] = t1[4 * k + j];
+    inv_pass<4>(col, yn, 12 - (B - 8), use_dst);
+#pragma unroll
+    for (int nn = 0; nn < 4; nn++) out[4 * j + nn] = yn[nn];
+  }
+}
+
+template <bool ENC, bool ONCE = false, typename SRC>
+__device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, const PicDev &P, int count) {
+  Lane4Lds &LS = *reinterpret_cast<Lane4Lds *>(smem);
+  const int lane = lane_id();
+  const int B = P.bit_depth, mx = (1 << B) - 1;
+  for (int base = 0; ONCE ? base < 1 : base < count; base += 64) {
+    const int i = base + lane;
+    const bool active = i < count;
+    const FTu ft = src.desc(active ? i : 0);
+    const hmx_tu t = ft.t;
+    const int pl = t.plane, x = t.x, y = t.y, mode = t.mode;
+    const bool luma = pl == 0, ts = t.flags & HMX_TU_TRANSFORM_SKIP;
+    const unsigned avail = ft.avail_lo; // 4n+1 <= 9 units
+    const PlaneView V = src.view(active ? i : 0, pl);
+    const TiledPlane &R = V.rec;
+    const unsigned b0 = tile_base(R.ctu_w, R.clog, x, y);
+    const size_t pb0 = tphys(R.qstride, b0); // a tile never straddles quads
+    int v[16];
+    if (ENC && active) {
+      const i4v o0 = stream_load(reinterpret_cast<const i4v *>(V.org + pb0)), o1 = stream_load(reinterpret_cast<const i4v *>(V.org + pb0 + 8));
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        v[2 * k] = (short)(o0[k] & 0xffff), v[2 * k + 1] = o0[k] >> 16;
+        v[8 + 2 * k] = (short)(o1[k] & 0xffff), v[8 + 2 * k + 1] = o1[k] >> 16;
+      }
+    }
+    src.wait(); // the whole wave (packed schedule): the neighbours belong to earlier rows of the same launch
+    if (!active) continue; // from here a lane works alone: nothing below needs the other lanes
+    // ---- reference line (fillReferenceSamples): sequential padding is natural inside one lane.
+    int *line = LS.line[lane];
+    {
+      const int ul = luma ? 2 : 1, n = 4 >> ul; // unit = 4 (luma) / 2 (chroma) samples
+      // The 17 reference samples lie in five neighbour tiles: column 3 of the below-left and left
+      // tiles, sample (3,3) of the corner tile, row 3 of the above and above-right tiles.  One tile
+      // address each; a tile none of whose units is available is replaced by the block's own tile
+      // (a valid address; the availability mask drops the values).  11 loads, one round trip.
+      int raw[17];
+      {
+        const unsigned m_bl = (1u << n) - 1, m_lf = m_bl << n, m_c = 1u << (2 * n), m_a = m_bl << (2 * n + 1), m_ar = m_a << n;
+        const bool has_bl = avail & m_bl, has_lf = avail & m_lf, has_c = avail & m_c, has_a = avail & m_a, has_ar = avail & m_ar;
+        const short *t_bl = R.p + (has_bl ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x - 4, y + 4)) : pb0);
+        const short *t_lf = R.p + (has_lf ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x - 4, y)) : pb0);
+        const short *t_c = R.p + (has_c ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x - 4, y - 4)) : pb0);
+        const short *t_a = R.p + (has_a ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x, y - 4)) : pb0);
+        const short *t_ar = R.p + (has_ar ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x + 4, y - 4)) : pb0);
+        // whole tile rows (8 bytes): the access width of the coherent path, and no narrower request reaches the L2
+        constexpr bool COH = SRC::kCoherent;
+        const s4v va = ld_rec4<COH>(t_a + 12), var = ld_rec4<COH>(t_ar + 12), vc = ld_rec4<COH>(t_c + 12);
+        s4v vb[4], vl[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) vb[k] = ld_rec4<COH>(t_bl + 4 * (3 - k)), vl[k] = ld_rec4<COH>(t_lf + 4 * (3 - k));
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          raw[k] = vb[k][3];     // p = 0..3: (x-1, y+7-p)
+          raw[4 + k] = vl[k][3]; // p = 4..7: (x-1, y+7-p)
+          raw[9 + k] = va[k];
+          raw[13 + k] = var[k];
+        }
+        raw[8] = vc[3];
+      }
+      const int dc = 1 << (B - 1);
+      int carry = dc;
+      bool have = false;
+      int lead = dc; // value of a leading unavailable run = first sample of the first available unit
+#pragma unroll
+      for (int p = 16; p >= 0; p--) {
+        const int u = p < 8 ? (p >> ul) : (p == 8 ? 2 * n : 2 * n + 1 + ((p - 9) >> ul));
+        const bool first_of_unit = p < 8 ? (p & ((1 << ul) - 1)) == 0 : (p == 8 ? true : ((p - 9) & ((1 << ul) - 1)) == 0);
+        if (((avail >> u) & 1) && first_of_unit) lead = raw[p];
+      }
+#pragma unroll
+      for (int p = 0; p <= 16; p++) {
+        const int u = p < 8 ? (p >> ul) : (p == 8 ? 2 * n : 2 * n + 1 + ((p - 9) >> ul));
+        int val;
+        if ((avail >> u) & 1) {
+          val = raw[p];
+          have = true;
+        } else {
+          val = have ? carry : lead; // an unavailable unit repeats the last sample before it
+        }
+        carry = val;
+        line[p] = avail ? val : dc;
+      }
+    }
+    // ---- prediction (4x4 never uses the smoothed line)
+    int pred[16];
+    {
+      int dcs = 0;
+#pragma unroll
+      for (int k = 1; k <= 4; k++) dcs += line[8 + k] + line[8 - k];
+      int *me = LS.me[lane];
+      build_main_ref<4, 1>(line, me, mode, 0);
+      intra_pred_samples<4, 16>(line, me, mode, luma, B, dcs, [](int s) { return s >> 2; }, [](int s) { return s & 3; }, pred);
+    }
+    int *lev_ptr = V.lev;
+    const bool zlev = V.lev_stride == 0;
+    const unsigned l0 = zlev ? b0 : __umul24((unsigned)y, (unsigned)V.lev_stride) + x;
+    const int lrow = zlev ? 4 : V.lev_stride;
+    int w[16];
+    if (ENC) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) v[k] = wrap16(v[k] - pred[k]);
+      bool flat = true;
+      if constexpr (SRC::kRdoq) {
+        if (!ts) { // transform-skip blocks keep the flat quantiser
+          int coef[16];
+          lane4_coef(v, luma, false, P, coef);
+          // the lane's coefficients in scan order and its levels go through its LDS rows (the reference line and the main
+          // reference are spent): no private array is indexed at run time
+          const int scan_idx = coef_scan_idx(4, luma, true, mode);
+          const bool hor = scan_idx == 1, ver = scan_idx == 2;
+          constexpr int dg[16] = {0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15}, inv_dg[16] = {0, 2, 5, 9, 1, 4, 8, 12, 3, 7, 11, 14, 6, 10, 13, 15};
+          int *c16 = LS.line[lane];
+          short *l16 = reinterpret_cast<short *>(LS.me[lane]);
+#pragma unroll
+          for (int k = 0; k < 16; k++) c16[k] = hor ? coef[k] : (ver ? coef[((k & 3) << 2) | (k >> 2)] : coef[dg[k]]);
+          rdoq_lane_4x4(c16, l16, src.picture(), src.group_slot() * 2 + (luma ? 0 : 1), luma, scan_idx, src.cbf_ctx(), src.rdoq(), src.rdoq_lds(), P);
+#pragma unroll
+          for (int q = 0; q < 16; q++) w[q] = l16[hor ? q : (ver ? (((q & 3) << 2) | (q >> 2)) : inv_dg[q])];
+          flat = false;
+        }
+      }
+      if (flat) {
+        lane4_forward(v, luma, ts, luma, coef_scan_idx(4, luma, true, mode), P, w);
+#pragma unroll
+        for (int k = 0; k < 16; k++) w[k] = level_of(w[k]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        i4v o = {w[4 * r], w[4 * r + 1], w[4 * r + 2], w[4 * r + 3]};
+        stream_store(reinterpret_cast<i4v *>(lev_ptr + l0 + (unsigned)r * (unsigned)lrow), o);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const i4v o = *reinterpret_cast<const i4v *>(lev_ptr + l0 + (unsigned)r * (unsigned)lrow);
+        w[4 * r] = o[0], w[4 * r + 1] = o[1], w[4 * r + 2] = o[2], w[4 * r + 3] = o[3];
+      }
+    }
+    int out[16];
+    lane4_inverse(w, luma, ts, luma, P, out);
+    i4v r0, r1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      r0[k] = (clip3(0, mx, pred[2 * k] + out[2 * k]) & 0xffff) | (clip3(0, mx, pred[2 * k + 1] + out[2 * k + 1]) << 16);
+      r1[k] = (clip3(0, mx, pred[8 + 2 * k] + out[8 + 2 * k]) & 0xffff) | (clip3(0, mx, pred[8 + 2 * k + 1] + out[8 + 2 * k + 1]) << 16);
+    }
+    if constexpr (ENC && SRC::kSse) {
+      if (src.want_sse()) {
+        const i4v o0 = *reinterpret_cast<const i4v *>(V.org + pb0), o1 = *reinterpret_cast<const i4v *>(V.org + pb0 + 8);
+        int o[16], rc[16];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          o[2 * k] = (short)(o0[k] & 0xffff), o[2 * k + 1] = o0[k] >> 16;
+          o[8 + 2 * k] = (short)(o1[k] & 0xffff), o[8 + 2 * k + 1] = o1[k] >> 16;
+          rc[2 * k] = r0[k] & 0xffff, rc[2 * k + 1] = (int)((unsigned)r0[k] >> 16);
+          rc[8 + 2 * k] = r1[k] & 0xffff, rc[8 + 2 * k + 1] = (int)((unsigned)r1[k] >> 16);
+        }
+        V.sse[b0 >> 4] = sse_samples<16>(o, rc, B);
+      }
+    }
+    if constexpr (SRC::kWriteThrough) { // write-through, one tile row per store
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        s4v a, b;
+        const int a2[2] = {r0[2 * k], r0[2 * k + 1]}, b2[2] = {r1[2 * k], r1[2 * k + 1]};
+        __builtin_memcpy(&a, a2, 8);
+        __builtin_memcpy(&b, b2, 8);
+        st_rec4<true>(R.p + pb0 + 4 * k, a);
+        st_rec4<true>(R.p + pb0 + 8 + 4 * k, b);
+      }
+    } else {
+      *reinterpret_cast<i4v *>(R.p + pb0) = r0;
+      *reinterpret_cast<i4v *>(R.p + pb0 + 8) = r1;
+    }
+  }
+}
+
+template <bool ENC, bool ONCE = false, typename SRC>
+__device__ __forceinline__ void wave_chain_32(char *smem, const SRC &src, const PicDev &P, int count) {
+  const int lane = lane_id(), r = lane & 31, h = lane >> 5;
+  TuLds<32> &L = *reinterpret_cast<TuLds<32> *>(smem);
+  constexpr int LG = 5;
+  for (int i = 0; ONCE ? i < 1 : i < count; i++) {
+    const FTu ft = src.desc(i);
+    const hmx_tu t = ft.t;
+    const int pl = t.plane, x = t.x, y = t.y;
+    const bool luma = pl == 0;
+    const unsigned long long avail = (unsigned long long)ft.avail_lo | ((unsigned long long)ft.avail_hi << 32);
+    const PlaneView V = src.view(i, pl);
+    const TiledPlane &R = V.rec;
+    const unsigned b0 = tile_base(R.ctu_w, R.clog, x, y);
+    // this lane's samples of row r: columns mrow(s,h) = tile column 2*(s>>2)+h, all four samples of the tile row
+    const size_t row_off = tphys(R.qstride, b0) + ((r & 3) << 2);
+    int pred[16], v[16];
+    s4v org4[4]; // kept packed until the residual is formed
+    if (ENC) {
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        org4[q] = stream_load(reinterpret_cast<const s4v *>(V.org + row_off + trel<32>(R.qstride, tile_in_block(2 * q + h, r >> 2))));
+    }
+    src.wait();
+    intra_refs_tiled<32, 64, SRC::kCoherent>(L, lane, true, R, x, y, tphys(R.qstride, b0), luma, avail, P);
+    const int *RL = (luma && use_filtered_refs(t.mode, LG)) ? L.fline : L.line;
+    const int dcs = dc_sum_block<32, 64>(L, lane);
+    build_main_ref<32, 64>(RL, L.me, t.mode, lane);
+    wave_sync();
+    intra_pred_samples<32, 16>(RL, L.me, t.mode, luma, P.bit_depth, dcs, [&](int) { return r; }, [&](int s) { return mrow(s, h); }, pred);
+    const bool zlev = V.lev_stride == 0;
+    int *lev0 = V.lev + (zlev ? b0 + r : __umul24((unsigned)y, (unsigned)V.lev_stride) + x + r);
+    const int lstep = zlev ? 32 : V.lev_stride;
+    // the prediction is needed again only for the reconstruction: it waits as 8 packed registers
+    unsigned pred2[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) pred2[s] = (unsigned)pred[2 * s] | ((unsigned)pred[2 * s + 1] << 16);
+    if (ENC) {
+      int coef[16];
+#pragma unroll
+      for (int s = 0; s < 16; s++) v[s] = wrap16((int)org4[s >> 2][s & 3] - pred[s]);
+      fwd32_mfma(v, r, h, P.bit_depth, coef);
+      if constexpr (SRC::kRdoq) {
+        wave_sync();
+        if (lane == 0) L.line[0] = 1, L.line[1] = src.picture(), L.line[2] = luma, L.line[3] = 0, L.line[4] = src.cbf_ctx(), L.line[9] = src.group_slot() * 2 + (luma ? 0 : 1), L.line[10] = 0;
+#pragma unroll
+        for (int g = 0; g < 16; g++) L.tile[mrow(g, h)][r] = coef[g];
+        wave_sync();
+        rdoq_wave_tiles<32, 1>(&L, src.rdoq_lds(), src.rdoq(), P, lane);
+      } else {
+        quant_sbh_block<32, 64, 16, false>(
+            L, lane, true, coef, [&](int k) { return mrow(k, h); }, [&](int) { return r; }, luma, 0, P);
+      }
+#pragma unroll
+      for (int g = 0; g < 16; g++) {
+        v[g] = level_of(L.tile[mrow(g, h)][r]);
+        stream_store(&lev0[__umul24((unsigned)mrow(g, h), (unsigned)lstep)], v[g]);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 16; g++) v[g] = lev0[__umul24((unsigned)mrow(g, h), (unsigned)lstep)];
+    }
+    const int tshift = 15 - P.bit_depth - LG;
+    const QuantDev qd = pick_qd(P, luma);
+    int out[16];
+#pragma unroll
+    for (int g = 0; g < 16; g++) v[g] = wrap16(dequant_one(v[g], qd.iq_scale, 6 - tshift));
+    inv32_mfma(v, r, h, P.bit_depth, out);
+    const int mx = (1 << P.bit_depth) - 1;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int p0 = pred2[2 * q] & 0xffff, p1 = pred2[2 * q] >> 16, p2 = pred2[2 * q + 1] & 0xffff, p3 = pred2[2 * q + 1] >> 16;
+      s4v o = {(short)clip3(0, mx, p0 + out[4 * q]), (short)clip3(0, mx, p1 + out[4 * q + 1]),
+               (short)clip3(0, mx, p2 + out[4 * q + 2]), (short)clip3(0, mx, p3 + out[4 * q + 3])};
+      st_rec4<SRC::kWriteThrough>(R.p + row_off + trel<32>(R.qstride, tile_in_block(2 * q + h, r >> 2)), o);
+    }
+    if constexpr (ENC && SRC::kSse) {
+      if (src.want_sse()) {
+        int o[16], rc[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const s4v ov = *reinterpret_cast<const s4v *>(V.org + row_off + trel<32>(R.qstride, tile_in_block(2 * q + h, r >> 2)));
+          const int p0 = pred2[2 * q] & 0xffff, p1 = pred2[2 * q] >> 16, p2 = pred2[2 * q + 1] & 0xffff, p3 = pred2[2 * q + 1] >> 16;
+          const int pr4[4] = {p0, p1, p2, p3};
+#pragma unroll
+          for (int k = 0; k < 4; k++) o[4 * q + k] = ov[k], rc[4 * q + k] = clip3(0, mx, pr4[k] + out[4 * q + k]);
+        }
+        const unsigned d = (unsigned)group_sum((int)sse_samples<16>(o, rc, P.bit_depth), 64);
+        if (lane == 0) V.sse[b0 >> 4] = d;
+      }
+    }
+    wave_sync();
+  }
+}
+
+// A 256-thread workgroup moves a 64 x 64 region, a thread one 4x4 tile: four 8-byte accesses on the plane side (16
+// consecutive threads cover a 128-byte line of each row) and the tile's 32 contiguous bytes on the tiled side (the
+// four threads of a quad complete its 128-byte line).  grid = (picture, region, plane): consecutive workgroups take
+// the same region of consecutive pictures, which are consecutive lines of the interleaved pool.
+// Rows [y0, y1) of the luma plane (and the chroma rows below them): a band of CTU rows, so that the conversion of one
+// band can overlap the dependency chain working on the others.
+template <bool TO_TILED>
+__global__ __launch_bounds__(256) void k_convert_tiled(const ConvJob *jobs, int y0, int y1) {
+  const ConvJob J = jobs[blockIdx.x * 3 + blockIdx.z];
+  const int stride = J.stride, w = J.w, h = J.h;
+  const TiledPlane T = J.T;
+  const int c = blockIdx.z ? 1 : 0;
+  const int spr = ((T.ctu_w << T.clog) + 63) >> 6; // regions per row of this plane
+  const int sx = blockIdx.y % spr, sy = blockIdx.y / spr;
+  const int x = (sx << 6) + ((threadIdx.x & 15) << 2), y = (y0 >> c) + (sy << 6) + ((threadIdx.x >> 4) << 2);
+  const int yend = min(h, y1 >> c);
+  if (x >= w || y >= yend) return;
+  short *tp = T.p + tphys(T.qstride, tile_base(T.ctu_w, T.clog, x, y));
+  short *pp = J.plane + (size_t)y * stride + x;
+  const bool vec = (((reinterpret_cast<uintptr_t>(pp) | (uintptr_t)(2 * stride)) & 7) == 0) && x + 4 <= w && y + 4 <= yend;
+  if (vec) { // the common case: whole tile inside the picture, 8-byte aligned plane rows
+    if (TO_TILED) {
+      s4v r[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) r[k] = *reinterpret_cast<const s4v *>(pp + (size_t)k * stride);
+#pragma unroll
+      for (int k = 0; k < 4; k++) *reinterpret_cast<s4v *>(tp + 4 * k) = r[k];
+    } else {
+      s4v r[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) r[k] = *reinterpret_cast<const s4v *>(tp + 4 * k);
+#pragma unroll
+      for (int k = 0; k < 4; k++) *reinterpret_cast<s4v *>(pp + (size_t)k * stride) = r[k];
+    }
+    return;
+  }
+  for (int j = 0; j < 4 && y + j < yend; j++)
+    for (int k = 0; k < 4 && x + k < w; k++) {
+      if (TO_TILED)
+        tp[4 * j + k] = pp[(size_t)j * stride + k];
+      else
+        pp[(size_t)j * stride + k] = tp[4 * j + k];
+    }
+}
+
+// Level-synchronous schedule: one launch per picture-wide dependency level.  Every block of a level
+// is independent of every other, so the launch is a plain list kernel: blockIdx.y = picture,
+// blockIdx.x = chunk of 64/N blocks (one 32x32 block) of that picture's level, all sizes in one grid.
+struct LevelArgs {
+  const PicWork *pics;
+  int level;
+  // pictures that share one plan: the level's row and block list travel as kernel arguments, so a
+  // wave can fetch its block descriptors without first chasing the picture table (two dependent
+  // memory hops less on the critical path of every launch)
+  int shared;
+  LevelRow row;
+  const FTu *ltus;
+  PicDev P;
+};
+template <bool ENC>
+__global__ __launch_bounds__(64, 4) void k_intra_level(LevelArgs A) {
+  __shared__ __attribute__((aligned(16))) char smem[HMX_WAVE_SMEM];
+  const PicWork &W = A.pics[blockIdx.y];
+  if (!A.shared && A.level >= W.n_levels) return;
+  const LevelRow row = A.shared ? A.row : W.ltab[A.level];
+  const FTu *ltus = A.shared ? A.ltus : W.ltus;
+  int c = blockIdx.x;
+#pragma unroll
+  for (int s = 3; s >= 0; s--) { // largest blocks first (see k_intra_level_across)
+    const int per = s == 3 ? 1 : (16 >> (2 * s)) * 1; // blocks per wave: 16, 8(=64/8), 4, 1
+    const int slots = s == 0 ? kSlots4Own : s == 1 ? 8 : s == 2 ? 4 : 1;
+    (void)per;
+    const int chunks = (int)(row.count[s] + slots - 1) / slots;
+    if (c < chunks) {
+      const FTu *tus = ltus + row.start[s] + (size_t)c * slots;
+      const int n = min(slots, (int)row.count[s] - c * slots);
+      const OwnPicture src{W, tus};
+      if (s == 0) {
+        if constexpr (kSlots4Own == 64) wave_chain_4_lane<ENC, true>(smem, src, A.P, n);
+        else wave_chain_valu<4, ENC, true>(smem, src, A.P, n);
+      } else if (s == 1) wave_chain_valu<8, ENC, true>(smem, src, A.P, n);
+      else if (s == 2) wave_chain_valu<16, ENC, true>(smem, src, A.P, n);
+      else wave_chain_32<ENC, true>(smem, src, A.P, n);
+      return;
+    }
+    c -= chunks;
+  }
+}
+
+// Level schedule for pictures that follow ONE plan: a wave takes one block of the level and works
+// it for 64/N pictures at once (see AcrossPictures).  1-D grid: for each size class, count x cpb
+// waves, cpb = picture chunks per block.
+struct AcrossArgs {
+  const PicWork *pics;
+  const FTu *ltus;
+  LevelRow row;
+  int n_pics;
+  uint32_t cpb[4];
+  const short *pool_org;
+  short *pool_rec;
+  size_t pic_elems;
+  uint32_t plane_off[3];
+  int ctu_w, clog;
+  PicDev P;
+};
+template <bool ENC>
+__global__ __launch_bounds__(64, 4) void k_intra_level_across(AcrossArgs A) {
+  __shared__ __attribute__((aligned(16))) char smem[HMX_WAVE_SMEM];
+  uint32_t c = blockIdx.x;
+#pragma unroll
+  // The size classes of a level in descending block size: waves are dispatched in workgroup order, the 32x32 waves
+  // run longest, and a level lasts until its last wave ends (4x4 first: 84.4 Gpx/s, 32x32 first: 87.4, 1536 pictures).
+  for (int s = 3; s >= 0; s--) {
+    const int slots = s == 0 ? kSlots4 : s == 1 ? 8 : s == 2 ? 4 : 1;
+    const uint32_t waves = A.row.count[s] * A.cpb[s];
+    if (c < waves) {
+      const uint32_t blk = c / A.cpb[s], chunk = c - blk * A.cpb[s];
+      const int pic0 = (int)chunk * slots, n = min(slots, A.n_pics - pic0);
+      const AcrossPictures src{A.pics, A.ltus + A.row.start[s] + blk, pic0, A.n_pics, A.pool_org, A.pool_rec,
+                               A.plane_off[1], A.plane_off[2] - A.plane_off[1], A.ctu_w, A.clog};
+      if (s == 0) {
+        if constexpr (kSlots4 == 64) wave_chain_4_lane<ENC, true>(smem, src, A.P, n);
+        else wave_chain_valu<4, ENC, true>(smem, src, A.P, n);
+      } else if (s == 1) wave_chain_valu<8, ENC, true>(smem, src, A.P, n);
+      else if (s == 2) wave_chain_valu<16, ENC, true>(smem, src, A.P, n);
+      else wave_chain_32<ENC, true>(smem, src, A.P, n);
+      return;
+    }
+    c -= waves;
+  }
+}
+
+template <bool ENC>
+__global__ __launch_bounds__(64, 4) void k_intra_wave(FrameArgs A) {
+  __shared__ __attribute__((aligned(16))) char smem[HMX_WAVE_SMEM];
+  int w = blockIdx.x;
+  const int plane = w % 3;
+  w /= 3;
+  const int ctu = A.wave_ctus[w % A.n_wave_ctus];
+  const PicWork &W = A.pics[w / A.n_wave_ctus];
+  const uint32_t sb = W.seg_range[(ctu * 3 + plane) * 2], se = W.seg_range[(ctu * 3 + plane) * 2 + 1];
+  for (uint32_t s = sb; s < se; s++) {
+    const Seg sg = W.segs[s];
+    const FTu *tus = W.tus + sg.start;
+    // a new dependency level gathers references from the reconstruction written by the previous one
+    if (sg.new_level) wave_global_sync();
+    wave_sync(); // the LDS scratch is re-interpreted per block size
+    const OwnPicture src{W, tus};
+    switch (sg.log2n) {
+    case 2: wave_chain_4_lane<ENC>(smem, src, A.P, sg.count); break;
+    case 3: wave_chain_valu<8, ENC>(smem, src, A.P, sg.count); break;
+    case 4: wave_chain_valu<16, ENC>(smem, src, A.P, sg.count); break;
+    default: wave_chain_32<ENC>(smem, src, A.P, sg.count); break;
+    }
+  }
+}
+
+// =============================================================================================
+// Packed schedule: ONE persistent launch per whole-picture call.
+//
+// The level schedules pay one kernel launch per picture-wide dependency level (4844 at 2160p) and every launch lasts at
+// least one block-chain latency however little work it carries.  Here the dependency order lives in memory instead:
+//   * pictures form GROUPS of I <= 64 (the interleave domain of the working pool); a ROW = (dependency level, group)
+//     holds every block of that level of the group's pictures -- each picture following ITS OWN plan -- bucketed by
+//     transform size.  A WAVE-ITEM is one wave's worth of a bucket: 64/N blocks (one 32x32 block) taken from whichever
+//     pictures have them, so waves are full whether the pictures share a plan or not (per item: picture + descriptor);
+//   * groups are dealt to SHARDS (group mod n_shards, at most 8); the wave-items of a shard are numbered row after row,
+//     level-major (tickets).  A persistent wave draws the next ticket of its shard with an atomic add, WAITS until the
+//     previous row of the same group is complete (one counter per row, polled with an L1-bypassing load), runs the
+//     block chain, drains its stores and adds 1 to its row's counter.
+// A shard belongs to ONE XCD: the first wave that touches it claims it for the XCD it runs on (compare-and-swap on the
+// shard's owner word with the hardware's XCC id; a wave starts at the shard with its XCD's number, moves on to shards its
+// XCD already owns or that nobody owns when those are drained, and never works on another XCD's).  So every producer and
+// every consumer of a group's reconstruction runs on the same XCD BY CONSTRUCTION -- read from the hardware, not assumed
+// from the dispatch order -- and the hand-off stays inside that XCD's L2: plain stores (the vector L1 is write-through;
+// a store whose vmcnt has drained is in the L2), loads that bypass the L1 (sc1), no write-through to HBM and no round
+// trip to it on the dependency path.  An XCD is a 32-CU machine with its own L2; this schedule runs eight of them side
+// by side on independent pictures.
+// Forward progress: a wave waits only for wave-items with SMALLER tickets of the same shard, and a ticket is drawn by a
+// wave that is already running, in ticket order.  So the unfinished wave-item with the smallest ticket of a shard is always
+// held by a running wave whose own dependencies are complete: it finishes, and by induction all do, whatever the number of
+// resident waves, the dispatch order or the placement (an XCD that gets no wave of the launch owns nothing: its shards
+// are claimed by the waves of another XCD once those have drained their own).  There is no barrier between workgroups.
+// (A spin that exceeds ~2^22 polls -- seconds -- raises the abort word and every wave leaves: a bug fails loudly.)
+// Rows of different groups are independent, so while one group waits for its row's last wave-item the others compute.
+// Latency hiding inside a wave: the ticket, the descriptor and the items of the NEXT wave-item are fetched while the current
+// one runs (ticket drawn before the chain, descriptor loaded behind the dependency poll, items loaded behind the chain's
+// stores), so that a wave-item starts with its block descriptors in registers.
+// Reference for the dependency a row encodes: TLibCommon/TComPattern.cpp:389-425 (which neighbours a block reads).
+// =============================================================================================
+#ifdef HMX_CHAIN_MAIN
+// prep 1: blocks per size class of every row (one wave per row, lane = picture of the group)
+// (a wave covers 64 / I rows: lane = (row of the wave, picture of the group); the first cut spent one wave per row with
+// I <= 4 lanes at work -- 9 M workgroups for 2048 pictures of 2160p, 115 ms of launch overhead for the fill alone)
+__device__ __forceinline__ int seg_sum(int v, int I, int k) { // sum over the I lanes of a segment (k = lane in segment), any I <= 64
+  const int lane = threadIdx.x, base = lane - k;
+  int t = 0;
+  for (int q = 0; q < I; q++) t += __shfl(v, base + q, 64);
+  return t;
+}
+__global__ __launch_bounds__(64) void k_pack_count(const PackPic *pics, PackRow *rows, PackGeom G, int n_rows) {
+  const int rpw = 64 / G.I, sub = threadIdx.x / G.I, k = threadIdx.x - sub * G.I;
+  const int row = blockIdx.x * rpw + sub;
+  const bool live = sub < rpw && row < n_rows;
+  const int L = live ? row / G.n_groups : 0, g = live ? row - L * G.n_groups : 0;
+  const int pic = g * G.I + k;
+  uint32_t c[4] = {0, 0, 0, 0};
+  if (live && pic < G.n_pics && L < pics[pic].n_levels) {
+    const LevelRow r = pics[pic].ltab[L];
+#pragma unroll
+    for (int s = 0; s < 4; s++) c[s] = r.count[s];
+  }
+#pragma unroll
+  for (int s = 0; s < 4; s++) c[s] = (uint32_t)seg_sum((int)c[s], G.I, k);
+  if (live && k == 0) {
+    PackRow R{};
+    uint32_t nw = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      R.count[s] = c[s];
+      const uint32_t sl = pack_slots(s, G.slots4);
+      nw += (c[s] + sl - 1) / sl;
+    }
+    R.n_waves = nw;
+    rows[row] = R;
+  }
+}
+// position p of the ticket order (shard-major, then level, then group) -> row
+__device__ __forceinline__ int pack_row_at(const PackGeom &G, int p, int &shard) {
+  int sh = 0;
+  for (;; sh++) {
+    const int ng = (G.n_groups - sh + G.n_shards - 1) / G.n_shards, n = ng * G.max_levels;
+    if (p < n || sh == G.n_shards - 1) {
+      shard = sh;
+      const int L = p / ng, gi = p - L * ng;
+      return L * G.n_groups + sh + gi * G.n_shards;
+    }
+    p -= n;
+  }
+}
+// prep 2: exclusive prefix of wave-items and items over the rows in ticket order (one workgroup)
+__global__ __launch_bounds__(1024) void k_pack_scan(PackRow *rows, PackHdr *hdr, PackGeom G) {
+  __shared__ uint32_t sw[1024], si[1024];
+  const int n_rows = G.max_levels * G.n_groups, tid = threadIdx.x;
+  const int chunk = (n_rows + 1023) / 1024, lo = min(tid * chunk, n_rows), hi = min(lo + chunk, n_rows);
+  uint32_t w = 0, it = 0;
+  for (int p = lo; p < hi; p++) {
+    int sh;
+    const PackRow &R = rows[pack_row_at(G, p, sh)];
+    w += R.n_waves;
+    it += R.count[0] + R.count[1] + R.count[2] + R.count[3];
+  }
+  sw[tid] = w, si[tid] = it;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) { // inclusive scan
+    const uint32_t a = tid >= off ? sw[tid - off] : 0, b = tid >= off ? si[tid - off] : 0;
+    __syncthreads();
+    sw[tid] += a, si[tid] += b;
+    __syncthreads();
+  }
+  uint32_t wb = sw[tid] - w, ib = si[tid] - it;
+  int prev_shard = lo > 0 ? -2 : -1; // -2: find out
+  if (lo > 0 && lo < n_rows) pack_row_at(G, lo - 1, prev_shard);
+  for (int p = lo; p < hi; p++) {
+    int sh;
+    PackRow &R = rows[pack_row_at(G, p, sh)];
+    if (sh != prev_shard)
+      for (int q = prev_shard + 1; q <= sh; q++) hdr->shard_base[q] = wb; // empty shards in between do not occur, but stay safe
+    prev_shard = sh;
+    R.wave_base = wb;
+    wb += R.n_waves;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      R.item_base[s] = ib;
+      ib += R.count[s];
+    }
+  }
+  if (tid == 1023) {
+    for (int q = G.n_shards; q <= 8; q++) hdr->shard_base[q] = sw[1023];
+    hdr->total_items = si[1023];
+  }
+}
+// prep 3: the wave-item descriptors and the item array of one (row, size class) per wave.  Items of a bucket are ordered
+// by rank inside their picture's bucket, then by picture: pictures that share a plan put the SAME block of consecutive
+// pictures on consecutive lanes (consecutive lines of the interleaved pool, uniform control flow); pictures with their
+// own plans put blocks of similar code path (the plan sorts a bucket by plane, transform skip, mode) next to each other.
+__global__ __launch_bounds__(64) void k_pack_fill(const PackPic *pics, const PackRow *rows, PackDesc *descs, FTu *items, PackGeom G, int n_rows) {
+  __shared__ uint32_t cnts[64];
+  const int rpw = 64 / G.I, sub = threadIdx.x / G.I, k = threadIdx.x - sub * G.I, seg0 = threadIdx.x - k;
+  const int row = blockIdx.x * rpw + sub;
+  const bool live = sub < rpw && row < n_rows;
+  const int L = live ? row / G.n_groups : 0, g = live ? row - L * G.n_groups : 0;
+  const PackRow R = rows[live ? row : 0];
+  const int pic = g * G.I + k;
+  LevelRow lr{};
+  const FTu *ltus = nullptr;
+  if (live && pic < G.n_pics && L < pics[pic].n_levels) {
+    lr = pics[pic].ltab[L];
+    ltus = as_global(pics[pic].ltus);
+  }
+  const uint32_t dep = (live && L > 0) ? rows[row - G.n_groups].n_waves : 0;
+  uint32_t woff = 0;
+#pragma unroll
+  for (int s = 3; s >= 0; s--) { // largest blocks first
+    const uint32_t sl = pack_slots(s, G.slots4), total = live ? R.count[s] : 0, nw = (total + sl - 1) / sl;
+    for (uint32_t c = (uint32_t)k; c < nw; c += (uint32_t)G.I)
+      descs[R.wave_base + woff + c] = PackDesc{R.item_base[s] + c * sl, min(sl, total - c * sl) | ((uint32_t)s << 28), (uint32_t)row, dep};
+    woff += nw;
+    // item (rank r, picture k) of the bucket sits behind every item of a lower rank and the same-rank items of the pictures
+    // before k:  sum over k' of min(count[k'], r)  +  #{k' < k : count[k'] > r}
+    const uint32_t cnt = ltus ? lr.count[s] : 0, start = lr.start[s];
+    wave_sync();
+    cnts[threadIdx.x] = cnt; // the counts of the row's pictures, for lanes that loop longer than their neighbours
+    wave_sync();
+    for (uint32_t r = 0; r < cnt; r++) {
+      uint32_t off = 0;
+      for (int q = 0; q < G.I; q++) {
+        const uint32_t cq = cnts[seg0 + q];
+        off += min(cq, r) + ((q < k && cq > r) ? 1u : 0u);
+      }
+      FTu f = ltus[start + r];
+      f.t.plane = (uint8_t)(f.t.plane | (k << 2)); // picture of the group in the upper six bits
+      items[R.item_base[s] + off] = f;
+    }
+  }
+}
+
+#endif // HMX_CHAIN_MAIN
+
+// The completion counters of different rows live on different 128-byte lines: the adds of a row's wave-items serialise
+// on their word anyway (~12 ns each), but with neighbouring rows on one line every add and every poll of a whole level --
+// all groups -- queued on ONE L2 channel (measured: the first cut ran 5x slower than the level schedule it replaces).
+constexpr uint32_t kDoneStride = 32;
+struct PackArgs {
+  const PackPic *pics;
+  const PackRow *rows;
+  const PackDesc *descs;
+  const FTu *items;
+  uint32_t *done; // [rows][kDoneStride] completed wave-items, one 128-byte line per row (see kDoneStride)
+  int sleep0, sleep1; // poll back-off in units of 64 clocks: previous row not started / in progress
+  PackHdr *hdr;
+  const short *pool_org;
+  short *pool_rec;
+  size_t pic_elems;      // one picture, three planes
+  uint32_t plane_off[3]; // of one picture
+  int ctu_w, clog;
+  int n_groups, n_shards, I;
+  // level buffers of the call laid out as ONE slab per plane (picture i at lev_base[p] + i * lev_pic_elems[p], one stride):
+  // a wave-item then addresses its levels by arithmetic instead of a load from the picture table on its way to the wait
+  int want_sse; // encoder direction: write xGetSSE(org, rec) of every block through PackPic::sse
+  int lev_slab;
+  int *lev_base[3];
+  long long lev_pic_elems[3];
+  int lev_stride[3];
+  PicDev P;
+  RdoqChain rq; // RDOQ variant of the kernel only
+};
+// what a wave-item of the packed schedule prefetches for its successor (see k_intra_packed)
+struct PackNext {
+  uint32_t ticket_raw; // lane 0: the ticket drawn for the next wave-item (the atomic's return value)
+  uint32_t base, total;
+  const PackDesc *descs;
+  uint32_t t;          // the next ticket, wave-uniform (valid after the dependency wait)
+  PackDesc d;          // its descriptor (in flight after the dependency wait)
+};
+template <bool SSE, bool RDOQ = false>
+struct PackedSrc {
+  static constexpr bool kCoherent = true;      // reconstruction loads bypass the vector L1 (sc1)
+  static constexpr bool kWriteThrough = false; // producers and consumers share an XCD's L2: plain stores
+  static constexpr bool kSse = SSE;            // a kernel variant of its own: the extra live registers would spill in the common one
+  static constexpr bool kRdoq = RDOQ;          // likewise (doubles, and the 4x4 lane's private arrays)
+  __device__ __forceinline__ bool want_sse() const { return SSE; }
+  __device__ __forceinline__ int picture() const { return pic0 + (int)(ft.t.plane >> 2); }
+  __device__ __forceinline__ int cbf_ctx() const { return (ft.t.flags >> 4) & 15; } // hmx_tu::flags bits 4..7
+  __device__ __forceinline__ const RdoqChain &rdoq() const { return A->rq; }
+  __device__ __forceinline__ RdoqWaveLds &rdoq_lds() const { return *rq_lds; }
+  __device__ __forceinline__ int group_slot() const { return (int)(ft.t.plane >> 2); } // the picture's index in its group
+  FTu ft;               // this lane's item, fetched during the previous wave-item
+  const PackPic *gpics; // the group's pictures
+  const short *org_g;   // the group's region of the pools
+  short *rec_g;
+  uint32_t off1, off2;  // plane offsets inside the group region
+  uint32_t qstride;
+  int ctu_w, clog_luma;
+  const uint32_t *dep;  // counter of the previous row of the group (NULL: first level)
+  uint32_t target;
+  uint32_t *abort_word;
+  int sleep0, sleep1;
+  PackNext *nx;
+  const PackArgs *A;
+  int pic0; // first picture of the group
+  RdoqWaveLds *rq_lds; // RDOQ variant: the wave's tables and buffers
+#ifdef HMX_PACK_PROFILE
+  unsigned long long *pt; // [0] wait entry, [1] wait exit, [2] polls
+#endif
+  __device__ __forceinline__ FTu desc(int) const { // the chains ask for item i = lane / (lanes per block): that is what was fetched
+    FTu f = ft;
+    f.t.plane &= 3;
+    return f;
+  }
+  __device__ __forceinline__ PlaneView view(int, int pl) const {
+    const unsigned k = ft.t.plane >> 2;
+    const size_t o = (size_t)(pl == 0 ? 0u : pl == 1 ? off1 : off2) + (size_t)k * 64;
+    int *lv;
+    int ls;
+    if (A->lev_slab) {
+      int *const b = pl == 0 ? A->lev_base[0] : pl == 1 ? A->lev_base[1] : A->lev_base[2];
+      const long long e = pl == 0 ? A->lev_pic_elems[0] : pl == 1 ? A->lev_pic_elems[1] : A->lev_pic_elems[2];
+      lv = b + (long long)(pic0 + (int)k) * e;
+      ls = pl == 0 ? A->lev_stride[0] : pl == 1 ? A->lev_stride[1] : A->lev_stride[2];
+    } else {
+      const char *row = reinterpret_cast<const char *>(&gpics[k]);
+      lv = *reinterpret_cast<int *const *>(row + offsetof(PackPic, lev) + pl * sizeof(int *));
+      ls = *reinterpret_cast<const int *>(row + offsetof(PackPic, lev_stride) + pl * sizeof(int));
+    }
+    uint32_t *sp = nullptr;
+    if constexpr (SSE) sp = as_global(*reinterpret_cast<uint32_t *const *>(reinterpret_cast<const char *>(&gpics[k]) + offsetof(PackPic, sse) + pl * sizeof(uint32_t *)));
+    return PlaneView{org_g + o, TiledPlane{rec_g + o, ctu_w, pl ? clog_luma - 1 : clog_luma, qstride}, as_global(lv), ls, sp};
+  }
+  // Wait until the previous row of the group is complete.  One L1-bypassing load per poll (the whole wave reads one
+  // word: one request); everything the chain loads from the reconstruction afterwards is an sc1 load issued after this
+  // loop has seen the count, and the producers' stores had reached the L2 (vmcnt drained) before they counted.
+  __device__ __forceinline__ void wait() const {
+#ifdef HMX_PACK_PROFILE
+    pt[0] = wall_clock64();
+#endif
+    if (dep) {
+      unsigned spins = 0;
+      for (;;) {
+#ifdef HMX_PACK_PROFILE
+        pt[2]++;
+#endif
+        const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((gu32 *)dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (v >= target) break;
+        // back off: a row that has not finished a single wave-item is at least one block chain away, one in progress
+        // completes within a few hundred nanoseconds; every poll is a request to the L2 channel the producers add on
+        for (int q = v == 0 ? sleep0 : sleep1; q > 0; q--) __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023u) == 0) {
+          if (spins >= (1u << 22)) __hip_atomic_store((gu32 *)abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((gu32 *)abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler ordering: no reconstruction load moves above the poll
+    // the next wave-item's ticket has long returned: fetch its descriptor behind the reference loads that follow
+    nx->t = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx->ticket_raw);
+    if (nx->t < nx->total) nx->d = nx->descs[nx->base + nx->t];
+#ifdef HMX_PACK_PROFILE
+    pt[1] = wall_clock64();
+#endif
+  }
+};
+
+// item index of a lane inside a wave-item of size class s: lane / (lanes per block)
+template <int SL4>
+__device__ __forceinline__ int pack_lane_item(int lane, int s) {
+  return s == 0 ? (SL4 == 64 ? lane : lane >> 2) : s == 1 ? lane >> 3 : s == 2 ? lane >> 4 : 0;
+}
+
+template <bool ENC, int SL4, bool SSE = false, bool RDOQ = false>
+__global__ __launch_bounds__(64, RDOQ ? 2 : 4) void k_intra_packed(PackArgs A) {
+  static_assert(!RDOQ || (ENC && SL4 == 64), "RDOQ: encoder direction, 4x4 blocks one per lane");
+  // RDOQ variant: every byte of LDS decides how many waves a CU holds (the walks are latency chains); the lane-per-block 4x4
+  // chain, the largest user of the common scratch, borrows the round buffer its RDOQ does not need
+  constexpr int kSmem = RDOQ ? (int)(4 * sizeof(TuLds<16>)) : HMX_WAVE_SMEM;
+  static_assert(!RDOQ || (8 * sizeof(TuLds<8>) <= kSmem && sizeof(TuLds<32>) <= kSmem && sizeof(Lane4Lds) <= sizeof(RdoqWaveLds::u)), "RDOQ variant: LDS scratch");
+  __shared__ __attribute__((aligned(16))) char smem[kSmem];
+  __shared__ __attribute__((aligned(16))) char rq_raw[RDOQ ? sizeof(RdoqWaveLds) : 16];
+  RdoqWaveLds *rq_lds = reinterpret_cast<RdoqWaveLds *>(rq_raw);
+  char *const smem4 = RDOQ ? rq_lds->u.lane4 : smem;
+  if constexpr (RDOQ) {
+    if (lane_id() == 0) rq_lds->key = 0;
+    wave_sync();
+  }
+  int xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 15;
+  PackHdr *hdr = A.hdr;
+#ifdef HMX_PACK_PROFILE
+  unsigned long long acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt[3] = {0, 0, 0};
+  const unsigned long long t_start = wall_clock64();
+#define PROF_T(v) const unsigned long long v = wall_clock64()
+#else
+#define PROF_T(v)
+#endif
+  for (int si = 0; si < A.n_shards; si++) {
+    const int s0 = xcc % A.n_shards, sh = s0 + si < A.n_shards ? s0 + si : s0 + si - A.n_shards;
+    // whose shard?  mine if my XCD claimed it or nobody has yet (then it is mine from now on)
+    uint32_t own = 0;
+    if (lane_id() == 0) {
+      own = __hip_atomic_load((gu32 *)&hdr->owner[sh][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (own == 0) {
+        uint32_t expect = 0;
+        own = __hip_atomic_compare_exchange_strong((gu32 *)&hdr->owner[sh][0], &expect, (uint32_t)xcc + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT)
+                  ? (uint32_t)xcc + 1u
+                  : expect;
+      }
+    }
+    own = (uint32_t)__builtin_amdgcn_readfirstlane((int)own);
+    if (own != (uint32_t)xcc + 1u) continue;
+    if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((gu32 *)&hdr->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
+    PackNext nx;
+    nx.base = hdr->shard_base[sh], nx.total = hdr->shard_base[sh + 1] - nx.base;
+    nx.descs = A.descs;
+    gu32 *ticket = (gu32 *)&hdr->ticket[sh][0];
+    // prologue: the first wave-item's ticket, descriptor and items, unhidden
+    PROF_T(p0);
+    uint32_t t = 0;
+    if (lane_id() == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (t >= nx.total) continue;
+    PackDesc d = A.descs[nx.base + t];
+    FTu ft;
+    {
+      const int s = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)d.n_s) >> 28), n = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)d.n_s) & 0x0fffffffu);
+      ft = A.items[(uint32_t)__builtin_amdgcn_readfirstlane((int)d.item_off) + (uint32_t)min(pack_lane_item<SL4>(lane_id(), s), n - 1)];
+    }
+    PROF_T(p1);
+#ifdef HMX_PACK_PROFILE
+    acc[0] += p1 - p0;
+#endif
+    for (;;) {
+      PROF_T(p2);
+      // draw the NEXT ticket now: its latency hides behind this wave-item
+      nx.ticket_raw = 0;
+      if (lane_id() == 0) nx.ticket_raw = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      d.item_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.item_off), d.n_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.n_s);
+      d.row = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.row), d.dep_target = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.dep_target);
+      const int s = (int)(d.n_s >> 28), n = (int)(d.n_s & 0x0fffffffu);
+      const int g = (int)(d.row % (uint32_t)A.n_groups);
+      const size_t greg = (size_t)g * A.I * A.pic_elems;
+      const PackedSrc<SSE, RDOQ> src{ft, A.pics + (size_t)g * A.I, A.pool_org + greg, A.pool_rec + greg,
+                          A.plane_off[1] * (uint32_t)A.I, A.plane_off[2] * (uint32_t)A.I, 64u * (uint32_t)A.I, A.ctu_w, A.clog,
+                          d.dep_target ? A.done + (size_t)(d.row - (uint32_t)A.n_groups) * kDoneStride : nullptr, d.dep_target, &hdr->abort,
+                          A.sleep0, A.sleep1, &nx, &A, g * A.I, rq_lds
+#ifdef HMX_PACK_PROFILE
+                          , pt
+#endif
+      };
+      wave_sync(); // the LDS scratch is re-interpreted per block size
+      if constexpr (RDOQ) rdoq_stage_tables(*rq_lds, A.rq, g, s, A.I, lane_id());
+      PROF_T(p3);
+      if (s == 0) {
+        if constexpr (SL4 == 64) wave_chain_4_lane<ENC, true>(smem4, src, A.P, n);
+        else wave_chain_valu<4, ENC, true>(smem, src, A.P, n);
+      } else if (s == 1) wave_chain_valu<8, ENC, true>(smem, src, A.P, n);
+      else if (s == 2) wave_chain_valu<16, ENC, true>(smem, src, A.P, n);
+      else wave_chain_32<ENC, true>(smem, src, A.P, n);
+      // the next wave-item's items, behind this one's stores (its descriptor was fetched behind the dependency poll)
+      const bool more = nx.t < nx.total;
+      FTu ftn = ft;
+      if (more) {
+        const uint32_t ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx.d.n_s);
+        ftn = A.items[(uint32_t)__builtin_amdgcn_readfirstlane((int)nx.d.item_off) +
+                      (uint32_t)min(pack_lane_item<SL4>(lane_id(), (int)(ns >> 28)), (int)(ns & 0x0fffffffu) - 1)];
+      }
+      // publish: every store of this wave has reached the L2 before the row's count moves
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      PROF_T(p4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PROF_T(p5);
+      if (lane_id() == 0) __hip_atomic_fetch_add((gu32 *)(A.done + (size_t)d.row * kDoneStride), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef HMX_PACK_PROFILE
+      const unsigned long long p6 = wall_clock64();
+      acc[1] += p3 - p2, acc[2] += pt[0] - p3, acc[3] += pt[1] - pt[0], acc[4] += p4 - pt[1], acc[5] += p5 - p4, acc[6] += p6 - p5, acc[7] += 1;
+#endif
+      if (!more) break;
+      d = nx.d, ft = ftn;
+    }
+  }
+#ifdef HMX_PACK_PROFILE
+  acc[8] = pt[2], acc[9] = wall_clock64() - t_start;
+  if (lane_id() == 0)
+    for (int q = 0; q < 10; q++) atomicAdd(&hdr->prof[q], acc[q]);
+#endif
+}
+

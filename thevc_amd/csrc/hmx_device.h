@@ -208,10 +208,10 @@ struct ScanTab {
         }
   }
 };
-__constant__ ScanTab<4, unsigned char> kScan4 = ScanTab<4, unsigned char>();
-__constant__ ScanTab<8, unsigned char> kScan8 = ScanTab<8, unsigned char>();
-__constant__ ScanTab<16, unsigned char> kScan16 = ScanTab<16, unsigned char>();
-__constant__ ScanTab<32, unsigned short> kScan32 = ScanTab<32, unsigned short>();
+static __constant__ ScanTab<4, unsigned char> kScan4 = ScanTab<4, unsigned char>();
+static __constant__ ScanTab<8, unsigned char> kScan8 = ScanTab<8, unsigned char>();
+static __constant__ ScanTab<16, unsigned char> kScan16 = ScanTab<16, unsigned char>();
+static __constant__ ScanTab<32, unsigned short> kScan32 = ScanTab<32, unsigned short>();
 
 // the 16 raster positions of coefficient group g in scan order, kept PACKED as loaded (one or two
 // 16-byte loads: 4 dwords of bytes, or 8 dwords of halfwords for 32x32) -- they stay live across the

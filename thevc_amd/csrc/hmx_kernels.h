@@ -578,7 +578,7 @@ struct MfmaTables {
     }
   }
 };
-__constant__ MfmaTables kMfma = MfmaTables();
+static __constant__ MfmaTables kMfma = MfmaTables();
 
 // 16 int16-range values -> hi bytes / (lo bytes ^ 0x80) packed four per dword
 __device__ __forceinline__ void split_hi_lo(const int *v, v4i &hi, v4i &lo) {

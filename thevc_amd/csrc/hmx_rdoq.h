@@ -55,6 +55,7 @@ __device__ __forceinline__ unsigned rdoq_scan_pos(int log2n, int scan_idx, int s
   return log2n == 2 ? kScan4.t[scan_idx][sp] : log2n == 3 ? kScan8.t[scan_idx][sp] : log2n == 4 ? kScan16.t[scan_idx][sp] : kScan32.t[scan_idx][sp];
 }
 
+#ifdef HMX_RDOQ_KERNELS // non-template kernels: emitted by the one translation unit that launches them (hmx_scalar.hip)
 __global__ __launch_bounds__(64) void k_rdoq(RdoqArgs A) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= A.n) return;
@@ -352,6 +353,7 @@ __global__ __launch_bounds__(64) void k_rdoq(RdoqArgs A) {
 #undef SRC
 #undef DST
 }
+#endif // HMX_RDOQ_KERNELS
 
 // ---------------------------------------------------------------------------------------------------------------------
 // RDOQ as the quantiser of the whole-picture chain (k_intra_packed): the second decomposition of hmx_rdoq_core.h over the
@@ -478,7 +480,7 @@ struct RdoqRecordSink { // the chosen variant of a group: its levels as walked, 
   }
 };
 #ifdef HMX_PACK_PROFILE
-__device__ unsigned long long g_rdoq_prof[40]; // [log2n - 2][step 0..8, calls], 10 ns units
+static __device__ unsigned long long g_rdoq_prof[40]; // [log2n - 2][step 0..8, calls], 10 ns units
 #define RQ_T(i)                                                         \
   if (lane == 0) {                                                      \
     const unsigned long long now_ = wall_clock64();                     \
