@@ -162,6 +162,36 @@ def cpu_baseline(w, h, B, qp, tiling, checks, seconds_target=10.0, all_cores=Tru
     return out
 
 
+def fresh_variant(tus, k):
+    """Decisions of picture k of the fresh-decisions leg: the block structure of its plan with every LUMA mode rotated by 5k
+    (mod 35) -- another set of dependencies, levels and code paths per picture.  The same formula runs on the device
+    (fresh_decision_lists) and here for the pictures the CPU checks."""
+    t = tus.copy()
+    luma = t["plane"] == 0
+    t["mode"] = np.where(luma, (t["mode"].astype(np.int32) + 5 * k) % 35, t["mode"]).astype(np.uint8)
+    return t
+
+
+def fresh_decision_lists(torch, tus_list, F, device):
+    """The decision lists of F pictures back to back in HBM (hmx_tu, 8 bytes per block): picture i = plan i mod P with its luma
+    modes rotated by 5 * (i div P) -- F DISTINCT decision structures, formed on the device from the P uploaded ones."""
+    base = [torch.from_numpy(np.ascontiguousarray(t).view(np.uint8).reshape(-1, 8).copy()).to(device) for t in tus_list]
+    P = len(base)
+    offs = np.zeros(F + 1, np.int64)
+    for i in range(F):
+        offs[i + 1] = offs[i] + len(tus_list[i % P])
+    out = torch.empty((int(offs[F]), 8), dtype=torch.uint8, device=device)
+    for i in range(F):
+        b = base[i % P]
+        dst = out[int(offs[i]):int(offs[i + 1])]
+        dst.copy_(b)
+        k = i // P
+        if k:
+            luma = b[:, 5] == 0
+            dst[:, 6] = torch.where(luma, ((b[:, 6].to(torch.int32) + 5 * k) % 35).to(torch.uint8), b[:, 6])
+    return out, offs
+
+
 def rank_picture_seeds(rank, n_pics, n_distinct=64):
     """Sharding rule of the all-intra path: pictures are independent, rank r owns its
     own batch; picture i of rank r is synthetic picture seed 1000*r + (i mod n_distinct)."""
@@ -342,6 +372,10 @@ def main():
     ap.add_argument("--planar", action="store_true",
                     help="hand the pictures over in the reference's plane geometry (TComPicYuv): every call converts them into and out "
                          "of the working layout; default: pictures resident in the working layout (hmx_tpool)")
+    ap.add_argument("--no-fresh", action="store_true",
+                    help="skip the fresh-decisions leg (every picture of every step brings NEW decisions: the plans are analysed on the "
+                         "device and the packed schedule's tables rebuilt inside each timed step; reported as \"fresh_decisions\")")
+    ap.add_argument("--fresh-steps", type=int, default=3, help="timed steps of the fresh-decisions leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--one-core-only", action="store_true", help="cpu_baseline: skip the all-cores leg")
     ap.add_argument("--cpu-cores", type=int, default=16, help="cpu_baseline: worker processes of the all-cores leg (the host-core share of one GPU)")
@@ -407,7 +441,9 @@ def main():
     # tiled working pool 6.2 bytes per luma sample, plus 16 B per block of the packed schedule's item table).
     F = args.frames if args.frames else ((2048 if w >= 3840 else 8192) if not args.planar else (1536 if w >= 3840 else 4096))
     free_b, _total_b = torch.cuda.mem_get_info()
-    per_pic = int((18.3 if args.planar else 12.3) * w * h_c) + 18 * max(len(t) for t in tus_list)
+    fresh_leg = not args.no_fresh and not args.planar and not args.decode and not args.rdoq
+    # (+ 40 B per block for the fresh-decisions leg: the decision lists, the device-built plans and their work buffers)
+    per_pic = int((18.3 if args.planar else 12.3) * w * h_c) + (18 + (40 if fresh_leg else 0)) * max(len(t) for t in tus_list)
     if not args.frames and F * per_pic > 0.92 * free_b:
         F = max(8, int(0.92 * free_b / per_pic) // 64 * 64 or 8)
     n_plans = min(n_plans, F)
@@ -499,6 +535,71 @@ def main():
     L.hmx_last_call_shape(ctx.h, C.byref(sched), C.byref(groups))  # how the library issued the timed calls
     dt = max_over_ranks(dt, world, "cuda")
 
+    # ---- fresh decisions: nothing carried over from step to step (round-2 verdict, item 1) ----
+    # Every picture of the batch has its own decision list in HBM (F distinct structures); a step analyses them on the device
+    # (hmx_intra_plan_create_device), builds the packed schedule's tables for these plans and runs the chain.  The headline above
+    # repeats one batch, so its plans and tables are built once; this is the same chain fed the way an encoder feeds it.
+    fresh = None
+    if fresh_leg:
+        try:
+            d_lists, offs = fresh_decision_lists(torch, tus_list[:n_plans], F, torch.device("cuda", local_rank))
+            torch.cuda.synchronize()
+            t_plan, t_tab, t_chain, fplans = [], [], [], None
+            n_fresh = max(1, args.fresh_steps)
+            f0 = None
+            for it in range(n_fresh + 1):  # one untimed step first
+                if it == 1:
+                    fence()
+                    f0 = time.perf_counter()
+                a0 = time.perf_counter()
+                new_plans = ctx.intra_plans_device(d_lists.data_ptr(), offs, pp)  # returns when the tables are complete
+                a1 = time.perf_counter()
+                farr = (C.c_void_p * F)(*[p.value for p in new_plans])
+                ctx._chk(L.hmx_frame_intra_encode_resident(ctx.h, farr, 1, F, p_org.h_, p_rec.h_, lev_arr))
+                if fplans is not None:
+                    for p in fplans:  # (synchronises the stream: the previous step's call is long done)
+                        L.hmx_intra_plan_destroy(ctx.h, p)
+                fplans = new_plans
+                if it:
+                    fa, fb, fc, ft = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+                    L.hmx_last_call_timing(ctx.h, C.byref(fa), C.byref(fb), C.byref(fc))
+                    L.hmx_last_call_tables_ms(ctx.h, C.byref(ft))
+                    t_plan.append((a1 - a0) * 1e3), t_tab.append(ft.value), t_chain.append(fb.value - ft.value)
+            fence()
+            fdt = max_over_ranks(time.perf_counter() - f0, world, "cuda")
+            ctx.sync()
+            lv = [C.c_int() for _ in range(3)]
+            lvls = []
+            for p in fplans[:: max(1, F // 16)]:
+                L.hmx_intra_plan_info(p, C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]))
+                lvls.append(lv[1].value)
+            fresh = {"value": round(whole_job_value(w * h_c * F, n_fresh, world, fdt), 2), "unit": "Mpixels/s", "steps": n_fresh,
+                     "ms_per_step": round(fdt / n_fresh * 1e3, 3), "ms_plan": round(float(np.mean(t_plan)), 3),
+                     "ms_tables": round(float(np.mean(t_tab)), 3), "ms_chain": round(float(np.mean(t_chain)), 3),
+                     "distinct_plans": F, "levels_per_picture_sampled": [min(lvls), max(lvls)],
+                     "what": "every step: the F pictures' decision lists (resident in HBM, F distinct structures) -> plans analysed on the device "
+                             "(hmx_intra_plan_create_device) -> packed-schedule tables -> the chain; nothing re-used between steps"}
+            if world == 1 and not args.no_cpu_baseline:
+                # three pictures of the last fresh step against the CPU (first, one from the middle of the batch, last)
+                kind, fn = _cpu_fn()
+                same = True
+                for i in sorted({0, F // 2 + 1, F - 1}):
+                    tv = fresh_variant(tus_list[i % n_plans], i // n_plans)
+                    rec_c, lev_c = fn(tv, w, h_c, B, qp, src[i])
+                    rec_g, lev_g = reconstruction(i), lev_slab.picture(i).to_planes(tv)
+                    same = same and all(np.array_equal(rec_g[p], rec_c[p]) and np.array_equal(lev_g[p], lev_c[p]) for p in range(3))
+                fresh["gpu_pictures_checked"] = sorted({0, F // 2 + 1, F - 1})
+                fresh["gpu_pictures_identical"] = bool(same)
+                fresh["checked_against"] = kind
+            for p in fplans:
+                L.hmx_intra_plan_destroy(ctx.h, p)
+            del d_lists
+            # leave the pools as the headline steps left them (the cpu_baseline leg reads picture 0)
+            step()
+            fence()
+        except Exception as e:  # noqa: BLE001  (the headline line is printed whatever happens here)
+            fresh = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     out = None
     if rank == 0:
         px_step = w * h_c * F
@@ -559,6 +660,8 @@ def main():
                          # conversion in / out as phases of their own
                          "layout_conversion_ms": [round(ta.value, 3), round(tc.value, 3)]},
         }
+        if fresh is not None:
+            out["fresh_decisions"] = fresh
         if world == 1 and (args.verify or not args.no_cpu_baseline):
             # --verify: one picture of every few packing groups, first and last included
             idx = sorted({0, F - 1} | set(range(0, F, max(64, F // 6 // 64 * 64 or 64)))) if args.verify else [0]

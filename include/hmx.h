@@ -212,7 +212,7 @@ int hmx_xPredInterChromaBlk(hmx_ctx *ctx, const hmx_pel *ref, int ref_stride, in
 /* One transform / prediction block.  8 bytes, identical on host and device. */
 typedef struct {
   uint16_t x, y;  /* position in samples of its plane */
-  uint8_t log2n;  /* 2..5 */
+  uint8_t log2n;  /* 2..5; 6 = the 64x64 luma prediction unit of a 64x64 coding unit, prediction entry points only */
   uint8_t plane;  /* 0 Y, 1 Cb, 2 Cr */
   uint8_t mode;   /* intra prediction mode 0..34 (also selects DST for 4x4 luma and the scan) */
   uint8_t flags;  /* HMX_TU_* */
@@ -306,6 +306,11 @@ typedef struct hmx_intra_plan hmx_intra_plan;
  * The dependency order of a plan follows these bits, not the availability flags (a horizontal mode does not wait for the
  * block above-right).  Pure host function (no device work); exported for the test that holds it against the oracle. */
 unsigned long long hmx_intra_dependency_mask(int n_samples, int is_luma, int mode, unsigned long long avail);
+/* The availability flags of initAdiPattern for a block at luma position (x, y) of luma size size_luma (a chroma block: its
+ * luma-scaled position and size), CTU size 64: bit u in the bNeighborFlags order, units of four luma samples.  closed_form 0:
+ * the unit-by-unit rule (TComPattern.cpp:607-786); 1: the closed form the device plan builder uses.  Pure host functions,
+ * exported for the test that holds one against the other. */
+unsigned long long hmx_intra_avail_mask(int x, int y, int size_luma, int pic_w, int pic_h, int closed_form);
 int hmx_intra_plan_create(hmx_ctx *ctx, const hmx_tu *tus, int n_tu, const hmx_pic_param *pp,
                           hmx_intra_plan **plan);
 /* The plans of n_pics pictures (picture i: tus[i][0 .. n_tu[i])): the dependency analysis -- host work, about 43 ms per
@@ -313,7 +318,24 @@ int hmx_intra_plan_create(hmx_ctx *ctx, const hmx_tu *tus, int n_tu, const hmx_p
  * Same plans as n_pics calls of hmx_intra_plan_create; on an error no plan is left behind. */
 int hmx_intra_plan_create_multi(hmx_ctx *ctx, const hmx_tu *const *tus, const int *n_tu, int n_pics, const hmx_pic_param *pp,
                                 hmx_intra_plan **plans);
+/* The same plans analysed ON THE DEVICE, for pipelines whose every batch brings new decisions (the host analysis above is
+ * ~550x a picture's share of a whole-picture call).  d_tus (DEVICE): the decision lists of n_pics pictures back to back,
+ * picture i = d_tus[offsets[i] .. offsets[i+1]) (offsets: HOST array of n_pics + 1 entries), each list in coding order --
+ * CTUs in raster order, the blocks of a CTU together, in the order the reference codes them (TEncSearch.cpp:1394-1700).
+ * The dependency levels are a wavefront over the CTU diagonals with one lane per (picture, CTU, plane) walking its CTU's
+ * blocks; the bucket order is a counting sort.  plans[i] equals what hmx_intra_plan_create builds from the same list,
+ * entry for entry; such plans serve the packed schedule (default) and the level schedule, not the CTU-wave schedule.
+ * The lists may be freed or overwritten when the call returns.  The plans of one call share their device tables: destroy
+ * each with hmx_intra_plan_destroy (the memory is kept for the next call of this context). */
+int hmx_intra_plan_create_device(hmx_ctx *ctx, const hmx_tu *d_tus, const uint32_t *offsets, int n_pics, const hmx_pic_param *pp,
+                                 hmx_intra_plan **plans);
 void hmx_intra_plan_destroy(hmx_ctx *ctx, hmx_intra_plan *plan);
+/* The two tables of a plan that the packed and the level schedule run on, copied to the HOST (for tests and tools that hold a
+ * device-built plan against a host-built one): blocks[n_blocks] = the blocks sorted by (dependency level, size, code path,
+ * coding index), 16 bytes each: the hmx_tu followed by the 64-bit neighbour-availability mask of initAdiPattern;
+ * levels[n_levels] = per dependency level {uint32 start[4], count[4]} by transform size (4, 8, 16, 32), starts into blocks.
+ * Either pointer may be NULL. */
+int hmx_intra_plan_download(hmx_ctx *ctx, const hmx_intra_plan *plan, void *blocks, void *levels);
 /* Size of the dependency schedules of a plan: blocks, picture-wide dependency levels (= launches of
  * the level schedule) and CTU diagonals (= launches of the wave schedule). */
 int hmx_intra_plan_info(const hmx_intra_plan *plan, int *n_blocks, int *n_levels, int *n_diagonals);
@@ -328,6 +350,9 @@ int hmx_last_call_shape(const hmx_ctx *ctx, int *schedule, int *stream_groups);
  * in, dependency chain, layout conversion out, of the LAST call issued after hmx_set_timing(ctx, 1). */
 int hmx_set_timing(hmx_ctx *ctx, int enable);
 int hmx_last_call_timing(hmx_ctx *ctx, float *to_tiled_ms, float *chain_ms, float *from_tiled_ms);
+/* Packed schedule: the part of chain_ms the LAST timed call spent building its schedule tables on the device (0 when it re-used
+ * the tables of an earlier call with the same pictures and plans). */
+int hmx_last_call_tables_ms(hmx_ctx *ctx, float *ms);
 /* Which schedule a whole-picture call with n_pics pictures uses: 1 = level, 0 = wave. */
 int hmx_intra_schedule_for(const hmx_ctx *ctx, int n_pics);
 /* n_pics pictures share one plan (same block structure); org/rec/lev are arrays of n_pics entries. */

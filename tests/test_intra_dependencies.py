@@ -63,3 +63,24 @@ def test_dependency_mask_covers_what_the_prediction_reads(N, luma):
                 got = _predict(O, other, x0, y0, N, luma, mode, flags, B)
                 assert np.array_equal(got, want), (N, luma, mode, flags, hex(dep))
     assert pruned > 0  # the mask does rule units out
+
+
+@pytest.mark.parametrize("pic", [(416, 240), (200, 136), (64, 64), (1920, 1080), (72, 200)])
+def test_availability_closed_form(pic):
+    """The closed form of the neighbour-availability mask (a Z-order argument on the block's position, used by the device plan
+    builder) against the unit-by-unit rule the kernels use and against the oracle's rule (pinned on the reference's getPU* walk
+    by test_oracle_vs_ref.py), at EVERY aligned block position and size of pictures that cut the last CTU row and column."""
+    O, L = ol.oracle(), capi.lib()
+    w, h = pic
+    flags = np.zeros(65, np.uint8)
+    step = 1 if w * h < 300000 else 5  # the large picture: every fifth position per size (all CTU columns and rows still occur)
+    for size in (4, 8, 16, 32):
+        n = size // 4
+        pos = [(x, y) for y in range(0, h - size + 1, size) for x in range(0, w - size + 1, size)]
+        for (x, y) in pos[::step] + pos[-3:]:
+            a = L.hmx_intra_avail_mask(x, y, size, w, h, 0)
+            b = L.hmx_intra_avail_mask(x, y, size, w, h, 1)
+            assert a == b, (pic, size, x, y, hex(a), hex(b))
+            O.hmo_intra_avail(x, y, size, w, h, 64, flags)
+            o = sum(int(flags[u]) << u for u in range(4 * n + 1))
+            assert a == o, ("oracle", pic, size, x, y, hex(a), hex(o))

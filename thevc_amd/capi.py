@@ -154,7 +154,12 @@ def lib():
         L.hmx_intra_plan_create.argtypes = [vp, vp, ci, C.POINTER(PicParam), C.POINTER(vp)]
         L.hmx_intra_dependency_mask.argtypes = [ci, ci, ci, C.c_uint64]
         L.hmx_intra_dependency_mask.restype = C.c_uint64
+        L.hmx_intra_avail_mask.argtypes = [ci, ci, ci, ci, ci, ci]
+        L.hmx_intra_avail_mask.restype = C.c_uint64
         L.hmx_intra_plan_create_multi.argtypes = [vp, C.POINTER(vp), C.POINTER(ci), ci, C.POINTER(PicParam), C.POINTER(vp)]
+        L.hmx_intra_plan_create_device.argtypes = [vp, vp, C.POINTER(C.c_uint32), ci, C.POINTER(PicParam), C.POINTER(vp)]
+        L.hmx_intra_plan_download.argtypes = [vp, vp, vp, vp]
+        L.hmx_last_call_tables_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.hmx_intra_plan_destroy.argtypes = [vp, vp]
         L.hmx_intra_plan_destroy.restype = None
         L.hmx_intra_plan_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
@@ -445,6 +450,27 @@ class Context:
         out = (C.c_void_p * n)()
         self._chk(lib().hmx_intra_plan_create_multi(self.h, ptrs, cnts, n, C.byref(pp), out))
         return [C.c_void_p(out[i]) for i in range(n)]
+
+
+    def intra_plans_device(self, d_tus, offsets, pp):
+        """hmx_intra_plan_create_device: d_tus = device address of the pictures' decision lists back to back (hmx_tu, coding
+        order), offsets = n_pics + 1 block offsets.  Returns the plan handles."""
+        n = len(offsets) - 1
+        off = (C.c_uint32 * (n + 1))(*[int(o) for o in offsets])
+        out = (C.c_void_p * n)()
+        self._chk(lib().hmx_intra_plan_create_device(self.h, d_tus, off, n, C.byref(pp), out))
+        return [C.c_void_p(out[i]) for i in range(n)]
+
+
+    def plan_tables(self, plan):
+        """hmx_intra_plan_download: (blocks, levels) of a plan as numpy arrays -- blocks: the sorted block list (hmx_tu fields +
+        `avail`), levels: per dependency level start[4], count[4]."""
+        nb, nl, nd = C.c_int(), C.c_int(), C.c_int()
+        lib().hmx_intra_plan_info(plan, C.byref(nb), C.byref(nl), C.byref(nd))
+        blocks = np.zeros(nb.value, np.dtype(TU_DTYPE.descr + [("avail", "<u8")]))
+        levels = np.zeros((nl.value, 8), np.uint32)
+        self._chk(lib().hmx_intra_plan_download(self.h, plan, _hp(blocks), _hp(levels)))
+        return blocks, levels
 
 
 def qp_for(qpy, text_type, bit_depth, chroma_qp_offset=0):

@@ -103,6 +103,7 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
   for (int s = 0; s < 4; s++) waves_bound += sz[s] / pack_slots(s, G.slots4);
   if (items >= 0xffffffffull || waves_bound >= 0x0fffffffull || n_rows >= 0x7fffffffull / 4)
     return fail(c, HMX_ERR_ARG, "frame_intra: batch too large for one packed call (split it)");
+  c->tev_prep_valid = false;
   const bool same = pk.valid && pk.key == c->table_key && pk.G.n_pics == G.n_pics && pk.G.I == G.I && pk.G.slots4 == G.slots4 &&
                     pk.G.max_levels == G.max_levels;
   if (!same) {
@@ -134,6 +135,10 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
     hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, st, pk.d_rows, pk.d_hdr, G);
     hipLaunchKernelGGL(k_pack_fill, dim3(prep_waves), dim3(64), 0, st, pk.d_pics, pk.d_rows, pk.d_descs, pk.d_items, G, (int)n_rows);
     HIPCHK(c, hipGetLastError());
+    if (c->timing && c->tev_prep) {
+      HIPCHK(c, hipEventRecord(c->tev_prep, st));
+      c->tev_prep_valid = true;
+    }
     pk.key = c->table_key;
     pk.G = G;
     pk.waves_bound = waves_bound;

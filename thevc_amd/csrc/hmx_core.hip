@@ -151,6 +151,7 @@ extern "C" void hmx_destroy(hmx_ctx *c) {
   if (c->ev_conv_join) hipEventDestroy(c->ev_conv_join);
   for (int i = 0; i < 4; i++)
     if (c->tev[i]) hipEventDestroy(c->tev[i]);
+  if (c->tev_prep) hipEventDestroy(c->tev_prep);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
 }

@@ -409,6 +409,44 @@ __host__ __device__ __forceinline__ unsigned long long intra_avail_mask(int x, i
   return m;
 }
 
+// The same mask in closed form (no loop over the units; the plan kernels form it for every block of every picture).  The n
+// above-right units of an n-aligned block lie in ONE n-aligned neighbour position (a + 1, b - 1) in units of n, so inside the
+// CTU they share one answer: is that position earlier in Z-order?  The most significant differing Morton bit decides: the y bit
+// at ctz(b) (set in b, clear in b - 1) against the x bit at cto(a) = trailing ones of a (clear in a, set in a + 1); y bits
+// outrank x bits of the same position, so the neighbour precedes iff ctz(b) >= cto(a).  Below-left, (a - 1, b + 1): the y bit at
+// cto(b) (clear in b) against the x bit at ctz(a) (set in a): the neighbour precedes iff cto(b) < ctz(a).  The picture's right and
+// lower edges then cut the runs.  CTU size 64; held against intra_avail_mask at every position by tests/test_intra_dependencies.py.
+__host__ __device__ __forceinline__ unsigned long long intra_avail_mask_fast(int x, int y, int size, const PicDev &P) {
+  const int n = size >> 2, lgn = n == 1 ? 0 : n == 2 ? 1 : n == 4 ? 2 : 3;
+  const int cx = (x & 63) >> 2, cy = (y & 63) >> 2;
+  const unsigned a = (unsigned)cx >> lgn, b = (unsigned)cy >> lgn;
+  const unsigned long long run = (1ull << n) - 1;
+  unsigned long long m = 0;
+  if (x > 0 && y > 0) m |= 1ull << (2 * n);
+  if (y > 0) m |= run << (2 * n + 1);
+  if (x > 0) m |= run << n;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int ctz_a = __ffs((int)(a | 16u)) - 1, ctz_b = __ffs((int)(b | 16u)) - 1, cto_a = __ffs((int)(~a)) - 1, cto_b = __ffs((int)(~b)) - 1;
+#else
+  const int ctz_a = __builtin_ctz(a | 16u), ctz_b = __builtin_ctz(b | 16u), cto_a = __builtin_ctz(~a), cto_b = __builtin_ctz(~b);
+#endif
+  bool ar;
+  if (cx + n < 16) ar = cy > 0 ? ctz_b >= cto_a : y > 0;
+  else ar = cy == 0 && y > 0 && (x >> 6) < ((P.pic_w + 63) >> 6) - 1;
+  if (ar) {
+    int k = (P.pic_w - x - size + 3) >> 2; // units of the run that start inside the picture
+    k = k < 0 ? 0 : k > n ? n : k;
+    m |= ((1ull << k) - 1) << (3 * n + 1);
+  }
+  const bool bl = cy + n < 16 && (cx > 0 ? cto_b < ctz_a : x > 0);
+  if (bl) {
+    int k = (P.pic_h - y - size + 3) >> 2;
+    k = k < 0 ? 0 : k > n ? n : k;
+    m |= ((1ull << k) - 1) << (n - k); // below-left counts upwards from the bottom: the k units nearest the block
+  }
+  return m;
+}
+
 // The same for a 64 x 64 LUMA block = a whole CTU (the prediction unit of a 64 x 64 coding unit, TEncSearch.cpp:2509-2540:
 // initAdiPattern and the 35 modes run at the PU size; no transform of that size exists).  4n + 1 = 65 units of four samples
 // do not fit the 64-bit mask, and need not: below-left of a CTU is never coded before it, left / above are all-or-nothing,

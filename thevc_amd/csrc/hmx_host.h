@@ -215,6 +215,8 @@ struct hmx_ctx {
   // optional timing of the last whole-picture call: events around the layout conversions and the chain
   bool timing = false;
   hipEvent_t tev[4] = {};
+  hipEvent_t tev_prep = nullptr; // packed schedule: behind the tables' prep kernels, when the timed call rebuilt them
+  bool tev_prep_valid = false;
   bool tev_valid = false;
   // level schedule: picture groups run on side streams so that launches of different groups overlap
   static const int kMaxSide = 8;
@@ -278,8 +280,8 @@ struct hmx_ctx {
   // hmx_intra_plan_create_device: work buffers (grow-only) and a cache of freed slabs (a pipeline that rebuilds its plans every
   // batch gets the previous batch's memory back instead of a hipMalloc / hipFree pair per call)
   struct PlanDev {
-    void *buf[10] = {};
-    size_t cap[10] = {};
+    void *buf[12] = {};
+    size_t cap[12] = {};
     unsigned long long *d_need = nullptr; // what a mode reads: [4 sizes][chroma, luma][35 modes] unit masks
     std::vector<std::pair<void *, size_t>> slabs;
   } pd;
