@@ -67,6 +67,22 @@ def test_device_plans_equal_host_plans(ctx, pic):
         L.hmx_intra_plan_destroy(ctx.h, p)
 
 
+def test_device_plan_more_levels_than_rows(ctx, hmx_opts):
+    """The level walk counts blocks into a table laid out before the number of levels is known; a picture with more levels than the
+    table has rows makes the builder start over with the format's limit -- same plans."""
+    L = capi.lib()
+    w, h = 200, 136
+    pp = capi.PicParam(w, h, 30, 0, capi.I_SLICE, 1)
+    tus = [workload.make_tus(4400 + i, w, h, t) for i, t in enumerate(["mix", 4, 8])]
+    host = ctx.intra_plans(tus, pp)
+    hmx_opts(ctx, HMX_PLAN_ROWS="16")
+    dev = _device_plans(ctx, tus, pp)
+    for i, (a, b) in enumerate(zip(host, dev)):
+        _same_tables(ctx, a, b, ("few rows", i))
+    for p in host + dev:
+        L.hmx_intra_plan_destroy(ctx.h, p)
+
+
 def test_device_plan_sparse_and_errors(ctx):
     """A plan that lists only part of a picture's blocks (the intra coding units of an inter picture: whole CTUs and parts of
     CTUs missing), and the argument checks of the host analysis."""

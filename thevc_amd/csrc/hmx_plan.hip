@@ -467,7 +467,7 @@ extern "C" void hmx_intra_plan_destroy(hmx_ctx *c, hmx_intra_plan *pl) {
 //
 // The host analysis above costs 43 ms per 2160p picture and core -- 550x the picture's share of a whole-picture call -- so
 // a pipeline whose every batch brings new decisions was bound by it (round-2 verdict, Weak 4).  Here the same tables come
-// out of seven kernels over the decision lists as they lie in HBM, for all pictures of a call at once:
+// out of five kernels over the decision lists as they lie in HBM, for all pictures of a call at once:
 //   k_plan_ctus     one thread per block: where each CTU's blocks start in its picture's list (the lists are in coding order:
 //                   CTU raster order, a CTU's blocks contiguous), the checks plan_build_host makes, and the block's record for
 //                   the level walk: availability (intra_avail_mask) and what its mode reads of it, closed under the padding
@@ -480,10 +480,11 @@ extern "C" void hmx_intra_plan_destroy(hmx_ctx *c, hmx_intra_plan *pl) {
 //                   Sequential per lane by nature, and 64 CTUs wide per wave: 2048 pictures x ~16 CTUs per diagonal keep
 //                   the chip full.
 //   (one 8-byte-per-picture read-back: the number of levels sizes the level tables)
-//   k_plan_hist     blocks per (level, size) -> the level table's counts;  k_plan_scan -> its starts (one workgroup per picture)
+//                   The walk also counts its blocks into the level table, (level, size) by (level, size).
+//   k_plan_scan     the starts of the level table's buckets from their counts (one workgroup per picture)
 //   k_plan_scatter  every block's sort key (code path | coding index) into its (level, size) bucket, unordered
-//   k_plan_gather   rank of each key inside its bucket (buckets average ~60 blocks: a count of smaller keys) -> position;
-//                   the block descriptor with its availability mask is written there.
+//   k_plan_gather   one wave per bucket: rank of each key inside its bucket (buckets average ~60 blocks: a count of smaller keys,
+//                   the keys broadcast to the wave as scalars) -> position; the block descriptor moves there.
 // The result is the host's table entry for entry: the same levels (the longest path in the dependency graph does not depend
 // on the visiting order as long as every dependency precedes its dependent, which coding order guarantees) and the same
 // order inside a bucket (plane class, transform skip, mode class, mode, plane, coding index).
@@ -519,7 +520,7 @@ __device__ __forceinline__ unsigned long long plan_dep_mask(const unsigned long 
   return dep;
 }
 // What the level walk needs of a block, one 64-bit word: bits 0..39 the units it depends on (4n + 1 <= 33 of them), 40..43 / 44..47
-// its unit column / row inside the CTU, 48..51 its size n in units (1..8), 52..53 its plane.  Formed here, one thread per block,
+// its unit column / row inside the CTU, 48..51 its size n in units (1..8), 52..53 its plane, 54..55 its transform size class.  Formed here, one thread per block,
 // so that the walk -- sequential per CTU -- is left with LDS reads and one maximum per dependency.
 __global__ __launch_bounds__(256) void k_plan_ctus(const hmx_tu *tus, const uint32_t *pic_off, uint32_t *ctu_start, uint32_t *size_total,
                                                    uint32_t *err, const unsigned long long *need, unsigned long long *rec, FTu *ftu, PlanGeomDev G) {
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256) void k_plan_ctus(const hmx_tu *tus, const uint
         ftu[b0 + i] = FTu{t, (uint32_t)avail, (uint32_t)(avail >> 32)}; // the descriptor as the chain wants it, moved into place by k_plan_gather
         const unsigned long long dep = plan_dep_mask(need, t.log2n, t.plane == 0, t.mode, avail);
         rec[b0 + i] = dep | (unsigned long long)((lx & 63) >> 2) << 40 | (unsigned long long)((ly & 63) >> 2) << 44 | (unsigned long long)(ls >> 2) << 48 |
-                      (unsigned long long)t.plane << 52;
+                      (unsigned long long)t.plane << 52 | (unsigned long long)(t.log2n - 2) << 54;
       }
       int prev = -1;
       if (i > 0) {
@@ -562,12 +563,7 @@ __global__ __launch_bounds__(256) void k_plan_ctus(const hmx_tu *tus, const uint
         for (int c = ctu + 1; c <= G.n_ctu; c++) cs[c] = n;
     }
   }
-  // blocks per transform size of the picture: one atomic per wave and size
-#pragma unroll
-  for (int s = 0; s < 4; s++) {
-    const unsigned long long m = __ballot(sz == s);
-    if (m && (threadIdx.x & 63) == 0) atomicAdd(&size_total[pic * 4 + s], (uint32_t)__popcll(m));
-  }
+  (void)sz, (void)size_total; // (blocks per size: summed from the level table by k_plan_scan -- atomics here all hit four words per picture)
   if (n == 0 && i == 0)
     for (int c = 0; c <= G.n_ctu; c++) cs[c] = 0;
 }
@@ -584,6 +580,9 @@ struct PlanLevelArgs {
   unsigned short *bot;   // [pic][plane][CTU row][uw]  bottom unit row of every CTU row (level + 1; 0 = no block)
   unsigned short *right; // [pic][plane][CTU][16]      right unit column of every CTU
   uint32_t *pic_max;     // [pic] highest level + 1
+  LevelRow *ltab;        // [pic][cap] the level tables: the walk counts its blocks into them as it goes
+  uint32_t cap;          // rows per picture
+  uint32_t *overflow;    // set when a picture has more levels than rows (the host then repeats the build with more)
   PlanGeomDev G;
 };
 // max of the grid entries named by the bits of `bits`: entry of bit u at halfword base + u * step (step may be negative).
@@ -660,6 +659,8 @@ __global__ __launch_bounds__(64) void k_plan_levels(PlanLevelArgs A, int d) {
     lv = plan_max_over(g, left_bits, left_base, left_step, lv);
     lv = plan_max_over(g, above_bits, above_base, 1, lv);
     level[b] = (unsigned short)lv;
+    if (lv < A.cap) atomicAdd(&A.ltab[(size_t)pic * A.cap + lv].count[(hi >> 22) & 3], 1u); // nothing waits for it
+    else *A.overflow = 1u;
     const unsigned nv = lv + 1;
     top = max(top, nv);
     const unsigned w2 = nv | (nv << 16);
@@ -691,16 +692,10 @@ struct PlanTabArgs {
   uint32_t *cursor;         // [rows][4] next free entry of every (level, size) bucket
   uint32_t *keys;           // per block position of the sorted list: code path << 20 | coding index
   const FTu *ftu;           // the descriptors in coding order
+  uint32_t *size_total;     // [pic][4] blocks per transform size
   FTu *ltus;
   PlanGeomDev G;
 };
-__global__ __launch_bounds__(256) void k_plan_hist(PlanTabArgs A) {
-  const int pic = blockIdx.y;
-  const uint32_t b0 = A.pic_off[pic], n = A.pic_off[pic + 1] - b0, i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const hmx_tu t = A.tus[b0 + i];
-  atomicAdd(&A.ltab[A.ltab_off[pic] + A.level[b0 + i]].count[t.log2n - 2], 1u);
-}
 // starts of the (level, size) buckets of a picture: exclusive prefix over its level table, one workgroup per picture
 __global__ __launch_bounds__(1024) void k_plan_scan(PlanTabArgs A) {
   __shared__ uint32_t part[1024];
@@ -720,6 +715,15 @@ __global__ __launch_bounds__(1024) void k_plan_scan(PlanTabArgs A) {
     __syncthreads();
   }
   uint32_t at = part[tid] - sum;
+  { // blocks per transform size of the picture (what issue_packed sizes its tables by)
+    uint32_t c4[4] = {0, 0, 0, 0};
+    for (uint32_t l = lo; l < hi; l++)
+#pragma unroll
+      for (int s = 0; s < 4; s++) c4[s] += tab[l].count[s];
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+      if (c4[s]) atomicAdd(&A.size_total[pic * 4 + s], c4[s]);
+  }
   for (uint32_t l = lo; l < hi; l++)
 #pragma unroll
     for (int s = 0; s < 4; s++) {
@@ -733,26 +737,52 @@ __device__ __forceinline__ uint32_t plan_path_key(const hmx_tu &t) {
   const int m = t.mode, mc = m == 0 ? 0 : m == 1 ? 1 : (m == 10 || m == 26) ? 2 : (m > 10 && m < 26) ? 3 : 4;
   return (t.plane ? 1u : 0u) << 11 | (uint32_t)(t.flags & 1u) << 10 | (uint32_t)mc << 7 | (uint32_t)(m & 63) << 1 | (t.plane == 2 ? 1u : 0u);
 }
-__global__ __launch_bounds__(256) void k_plan_scatter(PlanTabArgs A) {
-  const int pic = blockIdx.y;
-  const uint32_t b0 = A.pic_off[pic], n = A.pic_off[pic + 1] - b0, i = blockIdx.x * 256 + threadIdx.x;
+// Scatter and gather permute a picture's blocks inside its own few megabytes: random 4- and 16-byte accesses, each of which
+// costs a whole 128-byte line when it comes from HBM.  Workgroups are dealt to the XCDs round-robin by their id, so the id is
+// decoded such that ALL workgroups of a picture land on ONE XCD (eight pictures in flight, one per XCD): the picture's lists then
+// live in that XCD's L2 while they are permuted, and every line crosses the HBM interface about once.
+__device__ __forceinline__ bool plan_xcd_picture(uint32_t per_pic, int n_pics, int &pic, uint32_t &chunk) {
+  const uint32_t id = blockIdx.x, xcd = id & 7u, slot = id >> 3;
+  pic = (int)((slot / per_pic) * 8u + xcd);
+  chunk = slot % per_pic;
+  return pic < n_pics;
+}
+__global__ __launch_bounds__(256) void k_plan_scatter(PlanTabArgs A, uint32_t per_pic) {
+  int pic;
+  uint32_t chunk;
+  if (!plan_xcd_picture(per_pic, A.G.n_pics, pic, chunk)) return;
+  const uint32_t b0 = A.pic_off[pic], n = A.pic_off[pic + 1] - b0, i = chunk * 256 + threadIdx.x;
   if (i >= n) return;
   const hmx_tu t = A.tus[b0 + i];
   const uint32_t pos = atomicAdd(&A.cursor[((size_t)A.ltab_off[pic] + A.level[b0 + i]) * 4 + (t.log2n - 2)], 1u);
   A.keys[b0 + pos] = plan_path_key(t) << 20 | i;
 }
-__global__ __launch_bounds__(256) void k_plan_gather(PlanTabArgs A) {
-  const int pic = blockIdx.y;
-  const uint32_t b0 = A.pic_off[pic], n = A.pic_off[pic + 1] - b0, p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= n) return;
-  const uint32_t key = A.keys[b0 + p], i = key & 0xfffffu;
-  const int sz = A.tus[b0 + i].log2n - 2;
-  const LevelRow &row = A.ltab[A.ltab_off[pic] + A.level[b0 + i]];
-  const uint32_t s = row.start[sz], e = s + row.count[sz];
-  uint32_t rank = 0;
-  const uint32_t *k = A.keys + b0;
-  for (uint32_t q = s; q < e; q++) rank += k[q] < key ? 1u : 0u;
-  A.ltus[b0 + s + rank] = A.ftu[b0 + i];
+// The order inside a bucket, one WAVE per (level, size) bucket: a block's place is the number of keys of its bucket below its own
+// (the keys of a picture are distinct: the coding index is part of them).  A wave holds 64 keys at a time and counts against
+// the bucket's keys 64 at a time, each broadcast to the wave as a scalar (v_readlane): three instructions per comparison
+// for all 64 lanes, where one thread per block looping over its bucket in memory made a load per comparison.  Buckets average
+// ~60 blocks; a bucket of B blocks costs ceil(B / 64)^2 rounds.
+__global__ __launch_bounds__(256) void k_plan_gather(PlanTabArgs A, uint32_t per_pic) {
+  const uint32_t sz = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int pic;
+  uint32_t lvl;
+  if (!plan_xcd_picture(per_pic, A.G.n_pics, pic, lvl) || lvl >= A.n_levels[pic]) return;
+  const LevelRow &R = A.ltab[A.ltab_off[pic] + lvl];
+  const uint32_t n = R.count[sz];
+  if (n == 0) return;
+  const uint32_t b0 = A.pic_off[pic], start = R.start[sz];
+  const uint32_t *k = A.keys + b0 + start;
+  for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+    const bool mine = c0 + lane < n;
+    const uint32_t key = mine ? k[c0 + lane] : 0u;
+    uint32_t rank = 0;
+    for (uint32_t d0 = 0; d0 < n; d0 += 64) {
+      const uint32_t other = d0 + lane < n ? k[d0 + lane] : 0xffffffffu; // (re-read for c0 == d0: an L1 hit)
+      const int m = (int)min(64u, n - d0);
+      for (int q = 0; q < m; q++) rank += (uint32_t)__builtin_amdgcn_readlane((int)other, q) < key ? 1u : 0u;
+    }
+    if (mine) A.ltus[b0 + start + rank] = A.ftu[b0 + (key & 0xfffffu)];
+  }
 }
 
 int plan_grow(hmx_ctx *c, int slot, size_t need) { return grow_dev(c, &c->pd.buf[slot], &c->pd.cap[slot], need); }
@@ -799,10 +829,10 @@ extern "C" int hmx_intra_plan_create_device(hmx_ctx *c, const hmx_tu *d_tus, con
     if (hipMalloc((void **)&c->pd.d_need, need.size() * 8) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc plan tables");
     HIPCHK(c, hipMemcpy(c->pd.d_need, need.data(), need.size() * 8, hipMemcpyHostToDevice));
   }
-  // work buffers: 0 picture offsets | 1 CTU starts | 2 levels | 3 bottom edges | 4 right edges | 5 per-picture words (max level, 4 size totals,
-  // error) | 6 level-table offsets + level counts | 7 cursors | 8 keys | 9 the level walk's per-block records
+  // work buffers: picture offsets | CTU starts | levels | bottom edges | right edges | per-picture words (max level, 4 size totals; then
+  // error, overflow) | level-table offsets + level counts | cursors | keys | the level walk's per-block records | descriptors in coding order
   enum { B_OFF, B_CTU, B_LEVEL, B_BOT, B_RIGHT, B_META, B_LOFF, B_CURSOR, B_KEYS, B_REC, B_FTU };
-  const size_t meta_words = (size_t)n_pics * 5 + 1;
+  const size_t meta_words = (size_t)n_pics * 5 + 2;
   int r = plan_grow(c, B_OFF, sizeof(uint32_t) * (n_pics + 1));
   if (!r) r = plan_grow(c, B_CTU, sizeof(uint32_t) * (size_t)n_pics * (G.n_ctu + 1));
   if (!r) r = plan_grow(c, B_LEVEL, sizeof(unsigned short) * (size_t)total);
@@ -816,64 +846,106 @@ extern "C" int hmx_intra_plan_create_device(hmx_ctx *c, const hmx_tu *d_tus, con
   if (r) return r;
   uint32_t *d_off = (uint32_t *)c->pd.buf[B_OFF], *d_ctu = (uint32_t *)c->pd.buf[B_CTU], *d_meta = (uint32_t *)c->pd.buf[B_META];
   unsigned short *d_level = (unsigned short *)c->pd.buf[B_LEVEL], *d_bot = (unsigned short *)c->pd.buf[B_BOT], *d_right = (unsigned short *)c->pd.buf[B_RIGHT];
-  uint32_t *d_pic_max = d_meta, *d_size_total = d_meta + n_pics, *d_err = d_meta + (size_t)n_pics * 5;
-  {
-    std::vector<uint32_t> rel(n_pics + 1);
-    for (int i = 0; i <= n_pics; i++) rel[i] = offsets[i] - offsets[0];
-    HIPCHK(c, hipMemcpyAsync(d_off, rel.data(), sizeof(uint32_t) * (n_pics + 1), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st)); // pageable source
-  }
-  const hmx_tu *tus0 = d_tus + offsets[0];
-  HIPCHK(c, hipMemsetAsync(d_meta, 0, sizeof(uint32_t) * meta_words, st));
-  HIPCHK(c, hipMemsetAsync(d_bot, 0, sizeof(unsigned short) * (size_t)n_pics * 3 * G.ch * G.uw, st));
-  HIPCHK(c, hipMemsetAsync(d_right, 0, sizeof(unsigned short) * (size_t)n_pics * 3 * G.n_ctu * 16, st));
-  const dim3 per_block((max_tu + 255) / 256, (unsigned)n_pics);
+  uint32_t *d_pic_max = d_meta, *d_size_total = d_meta + n_pics, *d_err = d_meta + (size_t)n_pics * 5, *d_overflow = d_err + 1;
+  uint32_t *d_loff = (uint32_t *)c->pd.buf[B_LOFF];
   unsigned long long *d_rec = (unsigned long long *)c->pd.buf[B_REC];
   FTu *d_ftu = (FTu *)c->pd.buf[B_FTU];
-  hipLaunchKernelGGL(k_plan_ctus, per_block, dim3(256), 0, st, tus0, d_off, d_ctu, d_size_total, d_err, c->pd.d_need, d_rec, d_ftu, G);
-  PlanLevelArgs LA{d_rec, d_off, d_ctu, d_level, d_bot, d_right, d_pic_max, G};
-  for (int d = 0; d <= (G.cw - 1) + 2 * (G.ch - 1); d++) {
-    const int y_lo = std::max(0, (d - (G.cw - 1) + 1) >> 1), y_hi = std::min(G.ch - 1, d >> 1), n_diag = y_hi - y_lo + 1;
-    if (n_diag <= 0) continue;
-    hipLaunchKernelGGL(k_plan_levels, dim3((unsigned)(((size_t)n_diag * n_pics + 63) / 64), 3), dim3(64), 0, st, LA, d);
+  const hmx_tu *tus0 = d_tus + offsets[0];
+  const dim3 per_block((max_tu + 255) / 256, (unsigned)n_pics);
+  // Rows of the level table per picture.  The walk counts blocks into the table while it finds the levels, so the table is
+  // laid out before their number is known: a generous guess from the picture's size (the deepest plans measured -- every block
+  // 4x4 -- stay below a third of it), and the whole build again with the format's limit if a picture ever needs more.
+  uint32_t cap = (uint32_t)std::min(65536, c->knob.plan_rows > 0 ? c->knob.plan_rows : 256 + 64 * (G.cw + 2 * G.ch));
+  PlanSet *set = nullptr;
+  std::vector<uint32_t> meta(meta_words), loff((size_t)n_pics * 2);
+  for (int attempt = 0;; attempt++) {
+    const uint64_t rows = (uint64_t)n_pics * cap;
+    if (rows >= 0xffffffffull / 4) return fail(c, HMX_ERR_ARG, "hmx_intra_plan_create_device: too many pictures / dependency levels for one call (split it)");
+    if ((r = plan_grow(c, B_CURSOR, sizeof(uint32_t) * 4 * rows))) return r;
+    set = new PlanSet;
+    set->d_ltus = (FTu *)plan_slab(c, sizeof(FTu) * (size_t)total, &set->ltus_bytes);
+    set->d_ltab = set->d_ltus ? (LevelRow *)plan_slab(c, sizeof(LevelRow) * rows, &set->ltab_bytes) : nullptr;
+    if (!set->d_ltab) {
+      hipFree(set->d_ltus);
+      delete set;
+      return fail(c, HMX_ERR_NOMEM, "hipMalloc plan tables");
+    }
+    auto drop = [&]() {
+      c->pd.slabs.push_back({set->d_ltus, set->ltus_bytes});
+      c->pd.slabs.push_back({set->d_ltab, set->ltab_bytes});
+      delete set;
+      set = nullptr;
+    };
+    for (int i = 0; i < n_pics; i++) loff[i] = (uint32_t)((uint64_t)i * cap);
+    {
+      std::vector<uint32_t> rel(n_pics + 1);
+      for (int i = 0; i <= n_pics; i++) rel[i] = offsets[i] - offsets[0];
+      hipError_t e0 = hipMemcpyAsync(d_off, rel.data(), sizeof(uint32_t) * (n_pics + 1), hipMemcpyHostToDevice, st);
+      if (e0 == hipSuccess) e0 = hipMemcpyAsync(d_loff, loff.data(), sizeof(uint32_t) * n_pics, hipMemcpyHostToDevice, st);
+      if (e0 == hipSuccess) e0 = hipStreamSynchronize(st); // pageable sources
+      if (e0 != hipSuccess) {
+        drop();
+        return fail(c, HMX_ERR_DEVICE, "hmx_intra_plan_create_device: upload", e0);
+      }
+    }
+    hipError_t e1 = hipMemsetAsync(d_meta, 0, sizeof(uint32_t) * meta_words, st);
+    if (e1 == hipSuccess) e1 = hipMemsetAsync(d_bot, 0, sizeof(unsigned short) * (size_t)n_pics * 3 * G.ch * G.uw, st);
+    if (e1 == hipSuccess) e1 = hipMemsetAsync(d_right, 0, sizeof(unsigned short) * (size_t)n_pics * 3 * G.n_ctu * 16, st);
+    if (e1 == hipSuccess) e1 = hipMemsetAsync(set->d_ltab, 0, sizeof(LevelRow) * rows, st);
+    hipLaunchKernelGGL(k_plan_ctus, per_block, dim3(256), 0, st, tus0, d_off, d_ctu, d_size_total, d_err, c->pd.d_need, d_rec, d_ftu, G);
+    PlanLevelArgs LA{d_rec, d_off, d_ctu, d_level, d_bot, d_right, d_pic_max, set->d_ltab, cap, d_overflow, G};
+    for (int d = 0; d <= (G.cw - 1) + 2 * (G.ch - 1); d++) {
+      const int y_lo = std::max(0, (d - (G.cw - 1) + 1) >> 1), y_hi = std::min(G.ch - 1, d >> 1), n_diag = y_hi - y_lo + 1;
+      if (n_diag <= 0) continue;
+      hipLaunchKernelGGL(k_plan_levels, dim3((unsigned)(((size_t)n_diag * n_pics + 63) / 64), 3), dim3(64), 0, st, LA, d);
+    }
+    if (e1 == hipSuccess) e1 = hipGetLastError();
+    if (e1 == hipSuccess) e1 = hipMemcpyAsync(meta.data(), d_meta, sizeof(uint32_t) * meta_words, hipMemcpyDeviceToHost, st);
+    if (e1 == hipSuccess) e1 = hipStreamSynchronize(st);
+    if (e1 != hipSuccess) {
+      drop();
+      return fail(c, HMX_ERR_DEVICE, "hmx_intra_plan_create_device: level kernels", e1);
+    }
+    if (const uint32_t e = meta[(size_t)n_pics * 5]) {
+      static const char *const what[] = {"", "hmx_intra_plan_create: bad block", "hmx_intra_plan_create: block crosses a CTU", "hmx_intra_plan_create: block outside the picture",
+                                         "hmx_intra_plan_create_device: the blocks of a picture must come in coding order (CTU raster order, a CTU's blocks together)",
+                                         "hmx_intra_plan_create: picture too large for one plan"};
+      drop();
+      return fail(c, HMX_ERR_ARG, what[std::min<uint32_t>(e, 5)]);
+    }
+    bool too_deep = false;
+    for (int i = 0; i < n_pics; i++) too_deep = too_deep || meta[i] == 0 || meta[i] > 0xffffu;
+    if (too_deep) {
+      drop();
+      return fail(c, HMX_ERR_ARG, "hmx_intra_plan_create: picture too large for one plan");
+    }
+    if (meta[(size_t)n_pics * 5 + 1]) { // more levels than rows: once more with the most a plan can have
+      drop();
+      if (attempt > 0 || cap >= 65536) return fail(c, HMX_ERR_ARG, "hmx_intra_plan_create: picture too large for one plan");
+      cap = 65536;
+      continue;
+    }
+    break;
   }
-  HIPCHK(c, hipGetLastError());
-  std::vector<uint32_t> meta(meta_words);
-  HIPCHK(c, hipMemcpyAsync(meta.data(), d_meta, sizeof(uint32_t) * meta_words, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipStreamSynchronize(st));
-  if (const uint32_t e = meta[(size_t)n_pics * 5]) {
-    static const char *const what[] = {"", "hmx_intra_plan_create: bad block", "hmx_intra_plan_create: block crosses a CTU", "hmx_intra_plan_create: block outside the picture",
-                                       "hmx_intra_plan_create_device: the blocks of a picture must come in coding order (CTU raster order, a CTU's blocks together)",
-                                       "hmx_intra_plan_create: picture too large for one plan"};
-    return fail(c, HMX_ERR_ARG, what[std::min<uint32_t>(e, 5)]);
-  }
-  std::vector<uint32_t> loff((size_t)n_pics * 2);
-  uint64_t rows = 0;
-  for (int i = 0; i < n_pics; i++) {
-    const uint32_t nl = meta[i];
-    if (nl == 0 || nl > 0xffffu) return fail(c, HMX_ERR_ARG, "hmx_intra_plan_create: picture too large for one plan");
-    loff[i] = (uint32_t)rows, loff[(size_t)n_pics + i] = nl;
-    rows += nl;
-  }
-  if (rows >= 0xffffffffull / 4) return fail(c, HMX_ERR_ARG, "hmx_intra_plan_create_device: too many dependency levels in one call (split it)");
-  if ((r = plan_grow(c, B_CURSOR, sizeof(uint32_t) * 4 * rows))) return r;
-  PlanSet *set = new PlanSet;
-  set->d_ltus = (FTu *)plan_slab(c, sizeof(FTu) * (size_t)total, &set->ltus_bytes);
-  set->d_ltab = set->d_ltus ? (LevelRow *)plan_slab(c, sizeof(LevelRow) * rows, &set->ltab_bytes) : nullptr;
-  if (!set->d_ltab) {
-    hipFree(set->d_ltus);
-    delete set;
-    return fail(c, HMX_ERR_NOMEM, "hipMalloc plan tables");
-  }
-  uint32_t *d_loff = (uint32_t *)c->pd.buf[B_LOFF];
-  hipError_t e1 = hipMemcpyAsync(d_loff, loff.data(), sizeof(uint32_t) * loff.size(), hipMemcpyHostToDevice, st);
-  hipError_t e2 = hipMemsetAsync(set->d_ltab, 0, sizeof(LevelRow) * rows, st);
-  PlanTabArgs TA{tus0, d_off, d_level, d_loff + n_pics, d_loff, set->d_ltab, (uint32_t *)c->pd.buf[B_CURSOR], (uint32_t *)c->pd.buf[B_KEYS], d_ftu, set->d_ltus, G};
-  hipLaunchKernelGGL(k_plan_hist, per_block, dim3(256), 0, st, TA);
+  uint32_t max_levels = 0;
+  for (int i = 0; i < n_pics; i++) loff[(size_t)n_pics + i] = meta[i], max_levels = std::max(max_levels, meta[i]);
+  hipError_t e1 = hipMemcpyAsync(d_loff + n_pics, loff.data() + n_pics, sizeof(uint32_t) * n_pics, hipMemcpyHostToDevice, st);
+  PlanTabArgs TA{tus0, d_off, d_level, d_loff + n_pics, d_loff, set->d_ltab, (uint32_t *)c->pd.buf[B_CURSOR], (uint32_t *)c->pd.buf[B_KEYS], d_ftu, d_size_total, set->d_ltus, G};
   hipLaunchKernelGGL(k_plan_scan, dim3((unsigned)n_pics), dim3(1024), 0, st, TA);
-  hipLaunchKernelGGL(k_plan_scatter, per_block, dim3(256), 0, st, TA);
-  hipLaunchKernelGGL(k_plan_gather, per_block, dim3(256), 0, st, TA);
-  hipError_t e3 = hipGetLastError(), e4 = hipStreamSynchronize(st); // loff is a local; the plans are complete when this returns
+  const unsigned pics8 = ((unsigned)n_pics + 7u) / 8u * 8u; // the XCD-aware decoding of the workgroup id deals pictures in eights
+  if ((uint64_t)pics8 * per_block.x >= 0x7fffffffull || (uint64_t)pics8 * max_levels >= 0x7fffffffull)
+  {
+    c->pd.slabs.push_back({set->d_ltus, set->ltus_bytes});
+    c->pd.slabs.push_back({set->d_ltab, set->ltab_bytes});
+    delete set;
+    return fail(c, HMX_ERR_ARG, "hmx_intra_plan_create_device: too many pictures / dependency levels for one call (split it)");
+  }
+  hipLaunchKernelGGL(k_plan_scatter, dim3(pics8 * per_block.x), dim3(256), 0, st, TA, per_block.x);
+  hipLaunchKernelGGL(k_plan_gather, dim3(pics8 * max_levels), dim3(256), 0, st, TA, max_levels);
+  hipError_t e3 = hipGetLastError();
+  std::vector<uint32_t> sizes((size_t)n_pics * 4);
+  hipError_t e2 = hipMemcpyAsync(sizes.data(), d_size_total, sizeof(uint32_t) * sizes.size(), hipMemcpyDeviceToHost, st);
+  hipError_t e4 = hipStreamSynchronize(st); // loff / sizes are locals; the plans are complete when this returns
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
     hipFree(set->d_ltus), hipFree(set->d_ltab);
     delete set;
@@ -888,8 +960,8 @@ extern "C" int hmx_intra_plan_create_device(hmx_ctx *c, const hmx_tu *d_tus, con
     pl->n_levels = (int)meta[i];
     pl->n_diagonals = (G.cw - 1) + 2 * (G.ch - 1) + 1;
     pl->d_ltus = set->d_ltus + (offsets[i] - offsets[0]);
-    pl->d_ltab = set->d_ltab + loff[i];
-    for (int s = 0; s < 4; s++) pl->size_total[s] = meta[(size_t)n_pics + (size_t)i * 4 + s];
+    pl->d_ltab = set->d_ltab + (size_t)i * cap;
+    for (int s = 0; s < 4; s++) pl->size_total[s] = sizes[(size_t)i * 4 + s];
     pl->P = G.P;
     pl->n_tu = (int)(offsets[i + 1] - offsets[i]);
     pl->qp = pp->qp, pl->chroma_qp_offset = pp->chroma_qp_offset, pl->slice_type = pp->slice_type;

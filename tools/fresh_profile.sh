@@ -15,3 +15,4 @@ if f:
     for r in rows[:16]:
         print(f"{r['Name'][:70]:70s} calls {r['Calls']:>6s} total_ms {float(r['TotalDurationNs'])/1e6:10.3f} avg_us {float(r['AverageNs'])/1e3:10.1f}")
 PY
+rm -rf $O/*/*kernel_trace.csv
