@@ -399,7 +399,7 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         i4v o = {w[4 * r], w[4 * r + 1], w[4 * r + 2], w[4 * r + 3]};
-        stream_store(reinterpret_cast<i4v *>(lev_ptr + l0 + (unsigned)r * (unsigned)lrow), o);
+        piece_store(reinterpret_cast<i4v *>(lev_ptr + l0 + (unsigned)r * (unsigned)lrow), o);
       }
     } else {
 #pragma unroll

@@ -528,12 +528,26 @@ __device__ __forceinline__ void store_row32(int *dst, const int *x) {
 #pragma unroll
   for (int k = 0; k < N; k++) dst[k] = x[k];
 }
+// Levels written by ONE lane as several 16-byte pieces (a row of an 8x8 / 16x16 block, the 64 bytes of a 4x4 block): with the
+// non-temporal hint every piece goes out on its own, half a 32-byte sector at a time, and WRITE_SIZE counts 2.7x the bytes
+// (tools/issue_probe.hip, k_write<4> against k_write<5>: the 60 GB by which the chain's writes exceed levels + reconstruction).
+// Plain stores meet in the L2 first and write the bytes once -- and were measured 3 % SLOWER at 2048 pictures (104.3 against
+// 107.5 Gpx/s, tools/ab.sh): the levels then evict the reconstruction lines the next dependency level gathers from, and HBM
+// bandwidth is not what bounds the chain.  The hint stays; -DHMX_LEV_PIECES_PLAIN builds without it.
+template <typename T>
+__device__ __forceinline__ void piece_store(T *p, T v) {
+#ifdef HMX_LEV_PIECES_PLAIN
+  *p = v;
+#else
+  stream_store(p, v);
+#endif
+}
 template <int N>
 __device__ __forceinline__ void stream_store_row32(int *dst, const int *x) { // 16-byte aligned rows of levels (frame path)
 #pragma unroll
   for (int k = 0; k < N; k += 4) {
     const i4v v = {x[k], x[k + 1], x[k + 2], x[k + 3]};
-    stream_store(reinterpret_cast<i4v *>(dst + k), v);
+    piece_store(reinterpret_cast<i4v *>(dst + k), v);
   }
 }
 
