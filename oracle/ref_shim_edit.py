@@ -3,7 +3,8 @@
 /root/reference, replaces the BODIES of its hot-path members by the libhmx calls of INTEGRATION.md section 3 (signatures
 untouched) and writes the result to stdout for `g++ -x c++ -` (oracle/build_ref_shim.sh): nothing of the reference is
 stored in the repository, and no header, library or generated file of it is substituted.
-UNIT = TComTrQuant | TComPrediction | TComInterpolationFilter | TComYuv"""
+UNIT = TComTrQuant | TComPrediction | TComInterpolationFilter | TComYuv | TComRdCost (encoder shim only); a second argument
+`enc` adds the bodies of the members only the encoder calls (ENC_BODIES)."""
 import os
 import re
 import sys
@@ -38,8 +39,69 @@ BODIES = {
 }
 
 
+# The ENCODER shim (oracle/build_ref_enc_shim.sh, `ref_shim_edit.py UNIT enc`) replaces, on top of the bodies above, the members only
+# the encoder calls: the forward transform and transform skip, the quantiser in both its forms (xQuant's flat branch -> hmx_xQuant,
+# xRateDistOptQuant -> hmx_xRateDistOptQuant with the encoder's LIVE bit-estimate table and multiplier, TEncSearch.cpp:1101), the
+# Hadamard cost of the intra mode pre-selection (TEncSearch.cpp:2534-2537) and the per-block motion compensation.
+_SCAN_DIR = """UInt hmxScan = pcCU->getCoefScanIdx(uiAbsPartIdx, %(w)s, eTType == TEXT_LUMA, pcCU->isIntra(uiAbsPartIdx));
+  const int hmxDir = hmxScan == 1 ? 26 : hmxScan == 2 ? 10 : 0; /* a mode that selects the same scan (getCoefScanIdx resolved chroma DM already) */"""
+ENC_BODIES = {
+    "TComTrQuant": {
+        "TComTrQuant::xT": "HMX_SHIM_CHECK(hmx_xT(hmx_shim_ctx(), uiMode, piBlkResi, uiStride, psCoeff, iWidth, iHeight));",
+        "TComTrQuant::xTransformSkip": "HMX_SHIM_CHECK(hmx_xTransformSkip(hmx_shim_ctx(), piBlkResi, uiStride, psCoeff, width, height));",
+        "TComTrQuant::xQuant": """Bool useRDOQForTransformSkip = !(m_useTansformSkipFast && pcCU->getTransformSkip(uiAbsPartIdx,eTType));
+  if ( m_bUseRDOQ && (eTType == TEXT_LUMA || RDOQ_CHROMA) && useRDOQForTransformSkip) { /* TComTrQuant.cpp:1121-1128 */
+    xRateDistOptQuant( pcCU, pSrc, pDes, pArlDes, iWidth, iHeight, uiAcSum, eTType, uiAbsPartIdx );
+    return;
+  }
+  if (m_bUseAdaptQpSelect || getUseScalingList()) { fprintf(stderr, "libhmx shim: adaptive QP selection / scaling lists are outside the built path\\n"); exit(EXIT_FAILURE); }
+  """ + _SCAN_DIR % {"w": "iWidth"} + """
+  hmx_quant_param p;
+  p.qp.qp = m_cQP.m_iQP, p.qp.per = m_cQP.m_iPer, p.qp.rem = m_cQP.m_iRem, p.qp.bits = m_cQP.m_iBits;
+  p.per_base = -1; /* cQpBase differs from m_cQP only under adaptive QP selection (:1169-1203) */
+  p.slice_type = pcCU->getSlice()->getSliceType();
+  p.sign_hide = pcCU->getSlice()->getPPS()->getSignHideFlag();
+  p.is_intra = pcCU->isIntra(uiAbsPartIdx);
+  p.dir_mode = hmxDir;
+  uint32_t ac = uiAcSum;
+  HMX_SHIM_CHECK(hmx_xQuant(hmx_shim_ctx(), pSrc, pDes, iWidth, iHeight, &ac, eTType, &p));
+  uiAcSum = ac;""",
+        "TComTrQuant::xRateDistOptQuant": """static_assert(sizeof(estBitsSbacStruct) == sizeof(hmx_est_bits), "estBitsSbacStruct and hmx_est_bits share one layout");
+  if (m_bUseAdaptQpSelect || getUseScalingList()) { fprintf(stderr, "libhmx shim: adaptive QP selection / scaling lists are outside the built path\\n"); exit(EXIT_FAILURE); }
+  """ + _SCAN_DIR % {"w": "uiWidth"} + """
+  hmx_rdoq_param p;
+  p.qp.qp = m_cQP.m_iQP, p.qp.per = m_cQP.m_iPer, p.qp.rem = m_cQP.m_iRem, p.qp.bits = m_cQP.m_iBits;
+  p.sign_hide = pcCU->getSlice()->getPPS()->getSignHideFlag();
+  p.is_intra = pcCU->isIntra(uiAbsPartIdx);
+  p.dir_mode = hmxDir;
+  p.root_cbf = !pcCU->isIntra(uiAbsPartIdx) && eTType == TEXT_LUMA && pcCU->getTransformIdx(uiAbsPartIdx) == 0; /* :2104-2109 */
+  p.cbf_ctx = (eTType ? TEXT_CHROMA : eTType) * NUM_QT_CBF_CTX + pcCU->getCtxQtCbf(uiAbsPartIdx, eTType, pcCU->getTransformIdx(uiAbsPartIdx));
+  p.lambda = m_dLambda; /* what setLambda / selectLambda left for this component */
+  uint32_t s = 0;
+  HMX_SHIM_CHECK(hmx_xRateDistOptQuant(hmx_shim_ctx(), plSrcCoeff, piDstCoeff, uiWidth, uiHeight, &s, eTType, &p,
+                                       reinterpret_cast<const hmx_est_bits *>(m_pcEstBitsSbac)));
+  uiAbsSum = s;""",
+    },
+    "TComPrediction": {
+        "TComPrediction::xPredInterLumaBlk": """Pel *ref = refPic->getLumaAddr(cu->getAddr(), cu->getZorderIdxInCU() + partAddr);
+  HMX_SHIM_CHECK(hmx_xPredInterLumaBlk(hmx_shim_ctx(), ref, refPic->getStride(), mv->getHor(), mv->getVer(), width, height,
+                                       dstPic->getLumaAddr(partAddr), dstPic->getStride(), bi));""",
+        "TComPrediction::xPredInterChromaBlk": """Pel *refCb = refPic->getCbAddr(cu->getAddr(), cu->getZorderIdxInCU() + partAddr), *refCr = refPic->getCrAddr(cu->getAddr(), cu->getZorderIdxInCU() + partAddr);
+  HMX_SHIM_CHECK(hmx_xPredInterChromaBlk(hmx_shim_ctx(), refCb, refPic->getCStride(), mv->getHor(), mv->getVer(), width, height,
+                                         dstPic->getCbAddr(partAddr), dstPic->getCStride(), bi));
+  HMX_SHIM_CHECK(hmx_xPredInterChromaBlk(hmx_shim_ctx(), refCr, refPic->getCStride(), mv->getHor(), mv->getVer(), width, height,
+                                         dstPic->getCrAddr(partAddr), dstPic->getCStride(), bi));""",
+    },
+    "TComRdCost": {
+        "TComRdCost::calcHAD": """uint32_t satd = 0;
+  HMX_SHIM_CHECK(hmx_calcHAD(hmx_shim_ctx(), pi0, iStride0, pi1, iStride1, iWidth, iHeight, &satd));
+  return satd;""",
+    },
+}
+
+
 def replace_body(text, name, body):
-    m = re.search(r"^Void\s+" + re.escape(name) + r"\s*\(", text, re.M)
+    m = re.search(r"^(?:Void|UInt)\s+" + re.escape(name) + r"\s*\(", text, re.M)
     if not m:
         raise SystemExit(f"ref_shim_edit: {name} not found")
     i = text.index("{", text.index(")", m.end()))
@@ -62,7 +124,10 @@ def main():
     if unit == "TComTrQuant":  # the two pre-standard for-scope uses g++ rejects (oracle/build_ref.sh makes the same edit in its stream)
         text = text.replace("for (Int iCGScanPos = uiCGNum-1;", "Int iCGScanPos; for (iCGScanPos = uiCGNum-1;")
         text = text.replace("for ( Int scanPos = 0; scanPos < iBestLastIdxP1; scanPos++ )", "Int scanPos; for ( scanPos = 0; scanPos < iBestLastIdxP1; scanPos++ )")
-    for name, body in BODIES[unit].items():
+    bodies = dict(BODIES.get(unit, {}))
+    if sys.argv[2:] == ["enc"]:
+        bodies.update(ENC_BODIES.get(unit, {}))
+    for name, body in bodies.items():
         text = replace_body(text, name, body)
     text += f'\nstatic HmxShimReport g_hmx_shim_report = {{"{unit}"}};\n'
     sys.stdout.write(text)
