@@ -34,4 +34,10 @@ for u in $UNITS; do EXCL="$EXCL -e /$u.o"; done
 COMMON=$(ls "$OUT"/obj/*.o | grep -v -e ref_tap.o $EXCL)
 $CXX -o "$OUT/TAppEncoder_hmx" "$OUT"/obj_apps/enc_*.o "$OUT"/obj_apps/TLibEncoder_*.o "$OUT"/obj_apps/TAppCommon_*.o "$OUT"/obj_shim_enc/*.o $COMMON \
   -L"$ROOT/thevc_amd" -lhmx -Wl,-rpath,'$ORIGIN/../../thevc_amd'
-echo "build_ref_enc_shim: wrote $OUT/TAppEncoder_hmx"
+# The reference encoder with a RECORDER in front of its own xRateDistOptQuant (oracle/ref_rdoq_tap.h; no libhmx in this binary):
+# what the encoder's live CABAC state feeds RDOQ, block by block -> tests/golden/make_rdoq_enc_tap.py -> tests/golden/rdoq_enc_tap.npz
+mkdir -p "$OUT/obj_tap_enc"
+python3 "$HERE/ref_shim_edit.py" TComTrQuant rdoqtap | $CXX $FLAGS -include "$HERE/ref_rdoq_tap.h" -x c++ -c - -o "$OUT/obj_tap_enc/TComTrQuant.o"
+$CXX -o "$OUT/TAppEncoder_rdoqtap" "$OUT"/obj_apps/enc_*.o "$OUT"/obj_apps/TLibEncoder_*.o "$OUT"/obj_apps/TAppCommon_*.o "$OUT/obj_tap_enc/TComTrQuant.o" \
+  $(ls "$OUT"/obj/*.o | grep -v -e ref_tap.o -e /TComTrQuant.o)
+echo "build_ref_enc_shim: wrote $OUT/TAppEncoder_hmx and $OUT/TAppEncoder_rdoqtap"

@@ -100,6 +100,28 @@ ENC_BODIES = {
 }
 
 
+# `ref_shim_edit.py TComTrQuant rdoqtap`: the UNMODIFIED xRateDistOptQuant with a recorder at its entry (oracle/ref_rdoq_tap.h: an
+# object whose destructor writes the call's inputs -- the live bit-estimate table, the multiplier, the coefficients, what the
+# function reads of the CU -- and its outputs to the file named by HMX_RDOQ_TAP).  tests/golden/make_rdoq_enc_tap.py turns a
+# run of the reference encoder built this way into the fixture tests/golden/rdoq_enc_tap.npz.
+TAP_PREFIX = {
+    "TComTrQuant::xRateDistOptQuant": """HmxRdoqTap hmx_tap_(m_pcEstBitsSbac, sizeof(estBitsSbacStruct), m_dLambda, m_cQP.m_iQP, m_cQP.m_iPer, m_cQP.m_iRem, m_cQP.m_iBits,
+                      pcCU->getSlice()->getPPS()->getSignHideFlag(), pcCU->isIntra(uiAbsPartIdx),
+                      (int)pcCU->getCoefScanIdx(uiAbsPartIdx, uiWidth, eTType == TEXT_LUMA, pcCU->isIntra(uiAbsPartIdx)),
+                      !pcCU->isIntra(uiAbsPartIdx) && eTType == TEXT_LUMA && pcCU->getTransformIdx(uiAbsPartIdx) == 0,
+                      (eTType ? TEXT_CHROMA : eTType) * NUM_QT_CBF_CTX + pcCU->getCtxQtCbf(uiAbsPartIdx, eTType, pcCU->getTransformIdx(uiAbsPartIdx)),
+                      (int)eTType, pcCU->getQP(uiAbsPartIdx), pcCU->getSlice()->getPOC(), plSrcCoeff, piDstCoeff, (int)uiWidth, &uiAbsSum);""",
+}
+
+
+def prefix_body(text, name, code):
+    m = re.search(r"^(?:Void|UInt)\s+" + re.escape(name) + r"\s*\(", text, re.M)
+    if not m:
+        raise SystemExit(f"ref_shim_edit: {name} not found")
+    i = text.index("{", text.index(")", m.end()))
+    return text[:i + 1] + "\n  " + code + "\n" + text[i + 1:]
+
+
 def replace_body(text, name, body):
     m = re.search(r"^(?:Void|UInt)\s+" + re.escape(name) + r"\s*\(", text, re.M)
     if not m:
@@ -124,6 +146,11 @@ def main():
     if unit == "TComTrQuant":  # the two pre-standard for-scope uses g++ rejects (oracle/build_ref.sh makes the same edit in its stream)
         text = text.replace("for (Int iCGScanPos = uiCGNum-1;", "Int iCGScanPos; for (iCGScanPos = uiCGNum-1;")
         text = text.replace("for ( Int scanPos = 0; scanPos < iBestLastIdxP1; scanPos++ )", "Int scanPos; for ( scanPos = 0; scanPos < iBestLastIdxP1; scanPos++ )")
+    if sys.argv[2:] == ["rdoqtap"]:
+        for name, code in TAP_PREFIX.items():
+            text = prefix_body(text, name, code)
+        sys.stdout.write(text)
+        return
     bodies = dict(BODIES.get(unit, {}))
     if sys.argv[2:] == ["enc"]:
         bodies.update(ENC_BODIES.get(unit, {}))
