@@ -138,8 +138,9 @@ def cpu_baseline(w, h, B, qp, tiling, checks, seconds_target=10.0, all_cores=Tru
         out["gpu_pictures_checked"] = [c[0] for c in checks]
         out["gpu_pictures_identical"] = bool(same)
     if all_cores and seconds_target > 0:
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        cores = min(cores, max_cores)  # a one-GPU box of the pool is granted 16 host cores, whatever the affinity mask shows
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = min(avail, max_cores)  # --cpu-cores (default 16 = the host-core share of one GPU of the pool, whatever the affinity mask shows)
+        out["cores_in_affinity_mask"] = avail
         procs = []
         for k in range(cores):
             cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(w), str(h), str(B), str(qp), str(tiling),
@@ -616,14 +617,17 @@ def main():
             kernel = "k_intra_packed<true, 64, false, true>"
         per_plan_bytes = [algorithmic_bytes(t, args.decode) for t in tus_list[:n_plans]]
         bytes_step = sum(per_plan_bytes[i % n_plans] for i in range(F))
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        traffic, traffic_note = None, "no PMC record for this workload / batch under profiles/ (tools/pmc.py collects one)"
+        tj = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        if not os.path.exists(tj):
+            tj = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tj) and args.workload == "ai2160p10" and args.tiling == "mix" and not args.decode and not args.rdoq:
             t = json.load(open(tj))
             if t.get("frames") == F and t.get("plans") == n_plans and t.get("kernel", "").startswith(kernel.split("<")[0]):
                 # PMC bytes per launch (tools/pmc.sh): gfx950 FETCH_SIZE counts 64 B per 128-B request
                 # (MI355X_MICROARCH.md, HBM), hence the factor 2 on the read side
                 traffic = round((2 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024 / t["launches"])
+                traffic_note = f"from {os.path.basename(tj)} (a separate rocprofv3 --pmc run of this command; FETCH_SIZE x2: it counts 128-byte lines as 64, tools/issue_probe.hip)"
         step_ms = dt / args.steps * 1e3
         # the dominant kernel: HIP events around its launch(es) in the last step (the two layout-conversion launches are
         # timed separately); algorithmic bytes / that time.  `frac_step` prices the same bytes against the WHOLE step the
@@ -651,7 +655,7 @@ def main():
                        "quantiser": "rdoq" if args.rdoq else "flat", "distinct_plans": n_plans, "distinct_pictures": len(cache), "shared_decisions": n_plans == 1,
                        "pictures": "plane geometry, converted per call" if args.planar else "resident in the working layout (hmx_tpool)"},
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": kernel, "launches_per_step": n_launch, "concurrent_launches": groups.value,
                          "algorithmic_bytes_per_launch": round(bytes_step / n_launch),
                          "avg_launch_us": round(tb.value * 1e3 / n_launch, 2),
@@ -664,7 +668,8 @@ def main():
             out["fresh_decisions"] = fresh
         if world == 1 and (args.verify or not args.no_cpu_baseline):
             # --verify: one picture of every few packing groups, first and last included
-            idx = sorted({0, F - 1} | set(range(0, F, max(64, F // 6 // 64 * 64 or 64)))) if args.verify else [0]
+            # default: three pictures (the first, one from the middle of the batch -- another packing group, another plan -- and the last)
+            idx = sorted({0, F - 1} | set(range(0, F, max(64, F // 6 // 64 * 64 or 64)))) if args.verify else sorted({0, F // 2 + 1, F - 1})
             checks = [(i, tus_list[i % n_plans], plan_seeds[i % n_plans], seeds[i], src[i],
                        (reconstruction(i), lev_slab.picture(i).to_planes(tus_list[i % n_plans]))) for i in idx]
             out["cpu_baseline"] = cpu_baseline(w, h_c, B, qp, args.tiling, checks, 0.0 if args.no_cpu_baseline else 10.0,

@@ -76,6 +76,7 @@ def test_ra_pipeline_vs_oracle(B, fused):
     pipe.load_originals()
     px = pipe.run()
     torch.cuda.synchronize()
+    pipe.check()  # the packed schedule's abort word
     assert px == 17 * w * h  # 3 I pictures + 2 x 7 inter pictures
     i_recs = {}
     for k in range(3):
@@ -92,6 +93,49 @@ def test_ra_pipeline_vs_oracle(B, fused):
     # the margins of a referenced picture equal the oracle's border extension
     full = pipe.rec[4].download(with_margins=True)[0]
     assert (full[:80, 80:80 + w] == full[80, 80:80 + w]).all()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_ra_pipeline_loopback_exchange():
+    """The boundary-picture exchange on ONE GPU: the process plays two ranks (RAPipeline(loopback_ranks=2)); every segment's closing
+    I picture belongs to the other rank, so the inter pictures read it from a landing buffer that only the exchange fills --
+    exchange_plan / run_exchange as between processes, the copies issued on the pipeline's stream behind the chain that
+    reconstructed the pictures.  Landing buffers start as garbage: every inter picture still equals the oracle's, and the
+    landing buffers equal the owners' pictures margins included (a missing picture, a copy that overtakes the chain or the border
+    extension, or a wrong plan fails here)."""
+    import torch
+    import oracle_lib as ol
+    import ra_oracle
+    from thevc_amd import capi
+    from thevc_amd import ra_pipeline as ra
+    w, h, qp, B = 192, 128, 31, 8
+    wl = ra.RAWorkload(w, h, B, qp, intra_period=8, gop=4, n_segments=3, seed=11)
+    stream = torch.cuda.Stream()
+    ctx = capi.Context(bit_depth=B, stream=stream.cuda_stream)
+    pipe = ra.RAPipeline(ctx, torch, wl, stream=stream, loopback_ranks=2)
+    pipe.load_originals()
+    assert sorted(pipe.landing) == [(0, 8), (1, 16), (2, 24)]
+    for t in pipe.landing.values():
+        for pl in t.t:
+            pl.fill_(777)
+    for rep in range(2):  # the second pass overwrites landing buffers the first one filled
+        px = pipe.run()
+    torch.cuda.synchronize()
+    pipe.check()
+    assert px == (4 + 3 * 7) * w * h and pipe._moved == (3, 3)
+    i_recs = {k * 8: ol.o_intra_frame_encode(wl.intra_tus, w, h, B, qp, wl.original(k * 8))[0] for k in range(4)}
+    for (k, poc), t in pipe.landing.items():
+        got, own = t.download(with_margins=True), pipe.rec[poc].download(with_margins=True)
+        assert all(np.array_equal(got[p], own[p]) for p in range(3)), ("landing buffer", k, poc)
+        assert all(np.array_equal(t.download()[p], i_recs[poc][p]) for p in range(3))
+    for k in range(3):
+        recs = ra_oracle.oracle_segment(wl, k, {p: i_recs[p] for p in (k * 8, k * 8 + 8)})
+        for (poc, _, _, _) in wl.segment_jobs(k):
+            got = pipe.rec[poc].download()
+            for p in range(3):
+                assert np.array_equal(got[p], recs[poc][p]), ("inter picture", poc, p)
+    pipe.free()
     ctx.close()
 
 
@@ -146,15 +190,17 @@ def test_ra_pipeline_overlapped_steps():
     want = {poc: t.download() for poc, t in ref_pipe.rec.items()}
     stream_i = torch.cuda.Stream()
     ctx_i = capi.Context(bit_depth=B, stream=stream_i.cuda_stream)
+    ctx_i2 = capi.Context(bit_depth=B, stream=stream_i.cuda_stream)  # one context per buffer set: each keeps its device tables
     pipe = ra.RAPipeline(ctx, torch, wl, stream=stream)
     pipe.load_originals()
-    pipe.enable_overlap(ctx_i, stream_i)
+    pipe.enable_overlap(ctx_i, stream_i, ctx_i2)
     for steps in (3, 2):  # odd and even: the last step's I pictures sit in either buffer set
         for t in pipe.rec.values():
             for pl in t.t:
                 pl.zero_()
         px = pipe.run_steps(steps)
         torch.cuda.synchronize()
+        pipe.check()
         assert px == steps * 25 * w * h  # 4 I pictures + 3 x 7 inter pictures per step
         last = (pipe.rec_main, pipe.rec_alt)[(steps - 1) % 2]
         for poc in want:
@@ -164,4 +210,5 @@ def test_ra_pipeline_overlapped_steps():
     pipe.free()
     ref_pipe.free()
     ctx_i.close()
+    ctx_i2.close()
     ctx.close()

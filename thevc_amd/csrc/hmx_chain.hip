@@ -698,9 +698,12 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
   // re-uses its picture pools: the device copy of the table (and the packed schedule's tables) is then kept as it is,
   // and the call is queued behind the previous one without any synchronisation.
   uint64_t key = 1469598103934665603ull;
+  std::vector<unsigned char> kb; // the bytes the key is formed from: two calls are "the same" when these are, not when a hash says so
+  kb.reserve(sizeof(PicWork) * n_pics + sizeof(ConvJob) * jobs.size() + 24 * (size_t)n_pics + 64);
   auto mix = [&](const void *p, size_t n) {
     const unsigned char *b = (const unsigned char *)p;
     for (size_t i = 0; i < n; i++) key = (key ^ b[i]) * 1099511628211ull;
+    kb.insert(kb.end(), b, b + n);
   };
   mix(hw.data(), sizeof(PicWork) * n_pics);
   mix(jobs.data(), sizeof(ConvJob) * jobs.size());
@@ -719,6 +722,8 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
     mix(&pp, sizeof(pp));
     mix(&pp->serial, sizeof(pp->serial)); // a destroyed plan's address may come back
   }
+  if (c->table_valid && c->table_key == key && c->table_bytes != kb) // two different calls, one hash: never mistake one for the other
+    key = key * 1099511628211ull + ++c->table_salt;
   const bool use_graph = c->knob.graph && !packed; // measured: replay is not faster than eager launches here
   hmx_ctx::GraphEntry *hit = nullptr;
   for (auto &e : c->graphs)
@@ -748,6 +753,7 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
                                c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       c->table_key = key;
+      c->table_bytes.swap(kb);
       c->table_valid = true;
     }
     return issue_intra_launches(c, plans, plan_stride, n_pics, reinterpret_cast<PicWork *>(base),

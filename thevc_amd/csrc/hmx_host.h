@@ -288,6 +288,8 @@ struct hmx_ctx {
   std::vector<hmx_sse> sse_out; // hmx_set_sse_output: per-picture distortion arrays of the next whole-picture encode calls
   uint64_t table_key = 0;     // of the picture table resident in d_jobs (whole-picture calls)
   bool table_valid = false;
+  std::vector<unsigned char> table_bytes; // what table_key was hashed from (the table is re-used only when these bytes are equal)
+  uint64_t table_salt = 0;
   // knobs, read once from the environment in hmx_create (A/B runs and the cross-checks of the tests)
   struct Knobs {
     int schedule = -1;     // HMX_INTRA_SCHEDULE: wave / level / packed (default: packed)

@@ -67,6 +67,52 @@ def run_exchange(dist, rank, world, n_segments, tensors_of):
     return len(ops)
 
 
+class LoopbackDist:
+    """torch.distributed's point-to-point calls for ONE process that plays every rank in turn: P2POp / isend / irecv /
+    batch_isend_irecv with the signatures run_exchange uses.  Sends and receives posted for a (source, destination) pair are matched
+    in posting order and carried out as device copies on the CURRENT stream when flush() is called -- so the exchange plan, the
+    landing buffers (margins included), and the ordering of the copies against the kernels on the pipeline's stream are exercised
+    on a single GPU.  RAPipeline(loopback_ranks=V) uses it: not a substitute for RCCL between processes (gloo rehearsals and
+    the driver's N-GPU run cover that), a test of everything around it."""
+
+    class _Req:
+        def wait(self):
+            return None
+
+    def __init__(self):
+        self.rank = 0
+        self.sends, self.recvs = {}, {}
+
+    def isend(self, *a, **k):  # identity objects: P2POp compares them
+        raise RuntimeError("LoopbackDist: use batch_isend_irecv")
+
+    def irecv(self, *a, **k):
+        raise RuntimeError("LoopbackDist: use batch_isend_irecv")
+
+    def P2POp(self, op, tensor, peer):
+        return (op, tensor, peer)
+
+    def batch_isend_irecv(self, ops):
+        for (op, t, peer) in ops:
+            if op == self.isend:
+                self.sends.setdefault((self.rank, peer), []).append(t)
+            else:
+                self.recvs.setdefault((peer, self.rank), []).append(t)
+        return [LoopbackDist._Req() for _ in ops]
+
+    def flush(self):
+        moved = 0
+        assert set(self.sends) == set(self.recvs), (sorted(self.sends), sorted(self.recvs))
+        for pair, src in self.sends.items():
+            dst = self.recvs[pair]
+            assert len(src) == len(dst), pair
+            for a, b in zip(src, dst):
+                b.copy_(a, non_blocking=True)
+                moved += 1
+        self.sends, self.recvs = {}, {}
+        return moved
+
+
 class TorchPicture:
     """Three Pel planes with the reference's margins, backed by torch tensors (so that RCCL can move them)."""
 
@@ -145,9 +191,14 @@ class RAPipeline:
     reconstructions the intra chain has just written, and motion compensation reads what it received.  (A context
     created with stream handle 0 makes its own non-blocking stream, which nothing of torch's ever waits on.)"""
 
-    def __init__(self, ctx, torch, wl, rank=0, world=1, dist=None, fused=True, stream=None):
+    def __init__(self, ctx, torch, wl, rank=0, world=1, dist=None, fused=True, stream=None, loopback_ranks=0):
         self.ctx, self.torch, self.wl, self.rank, self.world, self.dist = ctx, torch, wl, rank, world, dist
         self.fused = fused
+        # loopback_ranks = V > 1 (world must be 1): this process plays V ranks.  Segment k "belongs" to rank k mod V; the closing I
+        # picture of a segment owned by another rank is NOT read where it was reconstructed but from a landing buffer of its own, filled
+        # by the exchange (exchange_plan / run_exchange as between processes, LoopbackDist carrying the copies out on the stream).
+        self.loopback = int(loopback_ranks) if world == 1 else 0
+        self.landing = {}  # (segment, poc) -> TorchPicture
         self.stream = stream if stream is not None else torch.cuda.current_stream()
         self._ev = None
         self._moved = (0, 0)
@@ -196,6 +247,7 @@ class RAPipeline:
         picture table every time it is called and keeps its device tables (one context alternating between the two buffer sets
         re-uploads the table and rebuilds the packed schedule every step, with two host synchronisations that serialise the
         enqueueing of the two stages)."""
+        assert self.loopback <= 1, "the loopback exchange keeps ONE set of landing buffers: not with the two-stage pipeline"
         self.ctx_i, self.stream_i = ctx_i, stream_i
         self.ctx_i_set = [ctx_i, ctx_i2 if ctx_i2 is not None else ctx_i]
         self.plan_i = ctx_i.intra_plan(self.wl.intra_tus, self.pp_i)
@@ -288,6 +340,8 @@ class RAPipeline:
         if self.wl.structure == "ra":
             for k in self.my_segments:  # landing buffers for the I pictures received from other ranks
                 self._pic(self.rec, (k + 1) * self.wl.ip)
+                if self.loopback > 1 and (k + 1) % self.loopback != k % self.loopback:
+                    self.landing[(k, (k + 1) * self.wl.ip)] = TorchPicture(self.torch, self.dev, self.wl.w, self.wl.h, MARGIN)
         n_i = len(self.my_i)
         self.lev_i = [capi.DevLevelsZ(self.ctx, self.wl.w, self.wl.h) for _ in range(n_i)]
         return len(pocs)
@@ -309,6 +363,16 @@ class RAPipeline:
             ctx._chk(L.hmx_frame_intra_encode(ctx.h, plan, n, org, rec, lev))
             ctx._chk(L.hmx_pic_extend_border_multi(ctx.h, n, rec, w, h, MARGIN, MARGIN))
         # phase 2: boundary I pictures travel to the owner of the previous segment (RCCL send/recv)
+        if self.loopback > 1 and wl.structure == "ra":
+            V, loop = self.loopback, LoopbackDist()
+            ops = 0
+            for vr in range(V):  # every virtual rank posts its sends and receives, as its process would
+                loop.rank = vr
+                ops += run_exchange(loop, vr, V, wl.n_segments,
+                                    lambda ki, vr=vr: self.rec[ki * wl.ip].t if ki % V == vr else self.landing[(ki - 1, ki * wl.ip)].t)
+            moved = loop.flush()  # device copies on this stream, behind the chain that reconstructed the pictures
+            assert 2 * moved == ops
+            self._moved = (moved // 3, moved // 3)
         if self.world > 1 and wl.structure == "ra":
             if self._ev is None:
                 self._ev = (self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True))
@@ -341,7 +405,8 @@ class RAPipeline:
                 pred, rec, org, lev = (capi.Pic * m)(), (capi.Pic * m)(), (capi.Pic * m)(), (capi.Levels * m)()
                 for q, si in enumerate(members):
                     poc, r0, r1, _ = jobs[si][j]
-                    refs = [self.rec[r0]] + ([self.rec[r1]] if r1 is not None else [])
+                    seg = self.my_segments[si]
+                    refs = [self.landing.get((seg, r0), self.rec[r0])] + ([self.landing.get((seg, r1), self.rec[r1])] if r1 is not None else [])
                     ref_arr = (capi.Pic * len(refs))(*[t.as_pic() for t in refs])
                     pred[q], rec[q], org[q] = self.pred[si].as_pic(), self.rec[poc].as_pic(), self.org[poc].as_pic()
                     lev[q] = self.lev[si].as_pic()
