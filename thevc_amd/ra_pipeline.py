@@ -116,10 +116,14 @@ class LoopbackDist:
 class TorchPicture:
     """Three Pel planes with the reference's margins, backed by torch tensors (so that RCCL can move them)."""
 
-    def __init__(self, torch, device, w, h, m=MARGIN):
+    def __init__(self, torch, device, w, h, m=MARGIN, zero=False):
+        """zero=False: the planes are NOT cleared (every sample of a picture is written before it is read: originals by upload(),
+        predictions by motion compensation, reconstructions by the chains and the border extension) -- at 2160p a fill per plane of
+        several hundred pictures was a visible share of a short bench run."""
         self.w, self.h, self.m = w, h, m
         self.dims = [(w, h, m), (w // 2, h // 2, m // 2), (w // 2, h // 2, m // 2)]
-        self.t = [torch.zeros((ph + 2 * pm, pw + 2 * pm), dtype=torch.int16, device=device) for (pw, ph, pm) in self.dims]
+        make = torch.zeros if zero else torch.empty
+        self.t = [make((ph + 2 * pm, pw + 2 * pm), dtype=torch.int16, device=device) for (pw, ph, pm) in self.dims]
 
     def as_pic(self):
         s = capi.Pic()
@@ -169,6 +173,31 @@ class RAWorkload:
             if not self.n_distinct:
                 return self._cache.pop(key)
         return self._cache[key]
+
+    def algorithmic_bytes(self):
+        """Bytes one segment's pictures must move (SURVEY.md section 8d's accounting at the C-ABI types, Pel = 2 B, TCoeff = 4 B), by stage:
+        "mc": per prediction unit and list, the (W + 7) x (H + 7) luma window and the two (W/2 + 3) x (H/2 + 3) chroma windows read, the
+        prediction written once; "chain": the fused inter block chain, 10 B per sample (original, prediction, level, reconstruction);
+        "border": the margin samples written by the border extension; "intra": one I picture through the intra chain (8 B per sample +
+        the reference samples a block gathers).  Returns per-picture dictionaries for a B picture, a P picture (by list index) and the I picture."""
+        def mc(pus):
+            w, h = pus["w"].astype(np.int64), pus["h"].astype(np.int64)
+            lists = 1 + (pus["ref1"] != 255).astype(np.int64)
+            read = lists * 2 * ((w + 7) * (h + 7) + 2 * (w // 2 + 3) * (h // 2 + 3))
+            write = 2 * (w * h + 2 * (w // 2) * (h // 2))
+            return int((read + write).sum())
+
+        def chain(tus):
+            n = 1 << tus["log2n"].astype(np.int64)
+            return int((10 * n * n).sum())
+
+        W, H, m = self.w, self.h, MARGIN
+        border = 2 * (((W + 2 * m) * (H + 2 * m) - W * H) + 2 * ((W // 2 + m) * (H // 2 + m) - (W // 2) * (H // 2)))
+        n = 1 << self.intra_tus["log2n"].astype(np.int64)
+        intra = int((8 * n * n + 2 * (4 * n + 1)).sum())
+        return {"b": [{"mc": mc(d["pus_b"]), "chain": chain(d["tus"]), "border": border} for d in self.inter],
+                "p": [{"mc": mc(d["pus_p"]), "chain": chain(d["tus"]), "border": border} for d in self.inter],
+                "i": {"intra": intra, "border": border}}
 
     def segment_jobs(self, k):
         """Coding order of segment k: (poc, ref0_poc, ref1_poc|None, list_index)."""
@@ -292,6 +321,17 @@ class RAPipeline:
         for poc, t in self.rec_main.items():
             self.rec[poc] = t
         return pixels
+
+    def step_bytes(self):
+        """Algorithmic bytes of ONE step of this rank (every owned I picture and segment), by stage."""
+        ab = self.wl.algorithmic_bytes()
+        out = {"intra": len(self.my_i) * ab["i"]["intra"], "mc": 0, "chain": 0, "border": len(self.my_i) * ab["i"]["border"]}
+        for k in self.my_segments:
+            for (_poc, _r0, r1, li) in self.wl.segment_jobs(k):
+                d = ab["p" if r1 is None else "b"][li]
+                for key in ("mc", "chain", "border"):
+                    out[key] += d[key]
+        return out
 
     def check(self):
         """After the caller's fence: read the packed schedule's abort word of every context this pipeline launched on (a
