@@ -451,8 +451,8 @@ def main():
     F = args.frames if args.frames else ((2048 if w >= 3840 else 8192) if not args.planar else (1536 if w >= 3840 else 4096))
     free_b, _total_b = torch.cuda.mem_get_info()
     fresh_leg = not args.no_fresh and not args.planar and not args.decode and not args.rdoq
-    # (+ 40 B per block for the fresh-decisions leg: the decision lists, the device-built plans and their work buffers)
-    per_pic = int((18.3 if args.planar else 12.3) * w * h_c) + (18 + (40 if fresh_leg else 0)) * max(len(t) for t in tus_list)
+    # (+ 72 B per block for the fresh-decisions leg: the decision lists, two generations of device-built plans and the builder's work buffers)
+    per_pic = int((18.3 if args.planar else 12.3) * w * h_c) + 18 * max(len(t) for t in tus_list) + (72 * int(np.mean([len(t) for t in tus_list])) if fresh_leg else 0)
     if not args.frames and F * per_pic > 0.92 * free_b:
         F = max(8, int(0.92 * free_b / per_pic) // 64 * 64 or 8)
     n_plans = min(n_plans, F)
@@ -556,8 +556,9 @@ def main():
             t_plan, t_tab, t_chain, fplans = [], [], [], None
             n_fresh = max(1, args.fresh_steps)
             f0 = None
-            for it in range(n_fresh + 1):  # one untimed step first
-                if it == 1:
+            n_warm = 2  # untimed: the builder's buffers and BOTH generations of plan tables (step n's plans live until step n + 1's exist) get allocated
+            for it in range(n_fresh + n_warm):
+                if it == n_warm:
                     fence()
                     f0 = time.perf_counter()
                 a0 = time.perf_counter()
@@ -565,11 +566,10 @@ def main():
                 a1 = time.perf_counter()
                 farr = (C.c_void_p * F)(*[p.value for p in new_plans])
                 ctx._chk(L.hmx_frame_intra_encode_resident(ctx.h, farr, 1, F, p_org.h_, p_rec.h_, lev_arr))
-                if fplans is not None:
-                    for p in fplans:  # (synchronises the stream: the previous step's call is long done)
-                        L.hmx_intra_plan_destroy(ctx.h, p)
+                if fplans is not None:  # (synchronises the stream once: the previous step's call is long done)
+                    L.hmx_intra_plan_destroy_many(ctx.h, (C.c_void_p * F)(*[p.value for p in fplans]), F)
                 fplans = new_plans
-                if it:
+                if it >= n_warm:
                     fa, fb, fc, ft = C.c_float(), C.c_float(), C.c_float(), C.c_float()
                     L.hmx_last_call_timing(ctx.h, C.byref(fa), C.byref(fb), C.byref(fc))
                     L.hmx_last_call_tables_ms(ctx.h, C.byref(ft))

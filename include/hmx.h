@@ -330,6 +330,8 @@ int hmx_intra_plan_create_multi(hmx_ctx *ctx, const hmx_tu *const *tus, const in
 int hmx_intra_plan_create_device(hmx_ctx *ctx, const hmx_tu *d_tus, const uint32_t *offsets, int n_pics, const hmx_pic_param *pp,
                                  hmx_intra_plan **plans);
 void hmx_intra_plan_destroy(hmx_ctx *ctx, hmx_intra_plan *plan);
+/* The plans of a batch at once (waits ONCE for the context's stream: hmx_intra_plan_destroy does so per plan). */
+void hmx_intra_plan_destroy_many(hmx_ctx *ctx, hmx_intra_plan *const *plans, int n);
 /* The two tables of a plan that the packed and the level schedule run on, copied to the HOST (for tests and tools that hold a
  * device-built plan against a host-built one): blocks[n_blocks] = the blocks sorted by (dependency level, size, code path,
  * coding index), 16 bytes each: the hmx_tu followed by the 64-bit neighbour-availability mask of initAdiPattern;

@@ -159,6 +159,8 @@ def lib():
         L.hmx_intra_plan_create_multi.argtypes = [vp, C.POINTER(vp), C.POINTER(ci), ci, C.POINTER(PicParam), C.POINTER(vp)]
         L.hmx_intra_plan_create_device.argtypes = [vp, vp, C.POINTER(C.c_uint32), ci, C.POINTER(PicParam), C.POINTER(vp)]
         L.hmx_intra_plan_download.argtypes = [vp, vp, vp, vp]
+        L.hmx_intra_plan_destroy_many.argtypes = [vp, C.POINTER(vp), ci]
+        L.hmx_intra_plan_destroy_many.restype = None
         L.hmx_last_call_tables_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.hmx_intra_plan_destroy.argtypes = [vp, vp]
         L.hmx_intra_plan_destroy.restype = None

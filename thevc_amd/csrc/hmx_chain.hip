@@ -133,7 +133,7 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
     const unsigned prep_waves = (unsigned)((n_rows + (uint64_t)(64 / G.I) - 1) / (uint64_t)(64 / G.I));
     hipLaunchKernelGGL(k_pack_count, dim3(prep_waves), dim3(64), 0, st, pk.d_pics, pk.d_rows, G, (int)n_rows);
     hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, st, pk.d_rows, pk.d_hdr, G);
-    hipLaunchKernelGGL(k_pack_fill, dim3(prep_waves), dim3(64), 0, st, pk.d_pics, pk.d_rows, pk.d_descs, pk.d_items, G, (int)n_rows);
+    hipLaunchKernelGGL(k_pack_fill, dim3((unsigned)((G.max_levels + kPackFillLevels - 1) / kPackFillLevels), (unsigned)(G.n_groups * G.I)), dim3(256), 0, st, pk.d_pics, pk.d_rows, pk.d_descs, pk.d_items, G);
     HIPCHK(c, hipGetLastError());
     if (c->timing && c->tev_prep) {
       HIPCHK(c, hipEventRecord(c->tev_prep, st));

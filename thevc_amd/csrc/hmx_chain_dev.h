@@ -828,43 +828,68 @@ __global__ __launch_bounds__(1024) void k_pack_scan(PackRow *rows, PackHdr *hdr,
 // by rank inside their picture's bucket, then by picture: pictures that share a plan put the SAME block of consecutive
 // pictures on consecutive lanes (consecutive lines of the interleaved pool, uniform control flow); pictures with their
 // own plans put blocks of similar code path (the plan sorts a bucket by plane, transform skip, mode) next to each other.
-__global__ __launch_bounds__(64) void k_pack_fill(const PackPic *pics, const PackRow *rows, PackDesc *descs, FTu *items, PackGeom G, int n_rows) {
-  __shared__ uint32_t cnts[64];
-  const int rpw = 64 / G.I, sub = threadIdx.x / G.I, k = threadIdx.x - sub * G.I, seg0 = threadIdx.x - k;
-  const int row = blockIdx.x * rpw + sub;
-  const bool live = sub < rpw && row < n_rows;
-  const int L = live ? row / G.n_groups : 0, g = live ? row - L * G.n_groups : 0;
-  const PackRow R = rows[live ? row : 0];
-  const int pic = g * G.I + k;
-  LevelRow lr{};
-  const FTu *ltus = nullptr;
-  if (live && pic < G.n_pics && L < pics[pic].n_levels) {
-    lr = pics[pic].ltab[L];
-    ltus = as_global(pics[pic].ltus);
-  }
-  const uint32_t dep = (live && L > 0) ? rows[row - G.n_groups].n_waves : 0;
-  uint32_t woff = 0;
+// One workgroup per (dependency level, picture), one wave per size class, a LANE per item (rank r of the picture's bucket, 64 at a
+// time): the item is read where the plan has it and written where its row wants it -- both ends coalesced over the wave.  (The
+// first cut gave each picture of a row ONE lane that walked its bucket entry by entry: a chain of dependent loads per lane,
+// 30 ms per 2048 pictures of 2160p when every step brings new plans.)  The wave of the group's first picture also writes the
+// row's wave-item descriptors.
+constexpr int kPackFillLevels = 8; // levels per workgroup: their table rows are fetched together, then the items move
+__global__ __launch_bounds__(256) void k_pack_fill(const PackPic *pics, const PackRow *rows, PackDesc *descs, FTu *items, PackGeom G) {
+  const int pic = blockIdx.y, s = 3 - (int)(threadIdx.x >> 6), lane = threadIdx.x & 63; // (largest blocks first in a row)
+  const int g = pic / G.I, k = pic - g * G.I, L0 = blockIdx.x * kPackFillLevels;
+  const bool have = pic < G.n_pics; // (a ragged last group)
+  const int n_levels = have ? pics[pic].n_levels : 0;
+  const FTu *ltus0 = have ? as_global(pics[pic].ltus) : nullptr;
+  const LevelRow *ltab = have ? as_global(pics[pic].ltab) : nullptr;
+  // lane q < I looks at picture q of the group: its level table, for the counts of this (level, size) over the group
+  const bool peer = lane < G.I && g * G.I + lane < G.n_pics;
+  const int peer_levels = peer ? pics[g * G.I + lane].n_levels : 0;
+  const LevelRow *peer_tab = peer ? as_global(pics[g * G.I + lane].ltab) : nullptr;
+  // phase 1: everything the levels of this workgroup need from the tables, all loads in flight together
+  uint32_t wave_base[kPackFillLevels], item_base[kPackFillLevels], dep[kPackFillLevels], cnt[kPackFillLevels], start[kPackFillLevels], cq[kPackFillLevels];
+  uint32_t rcount[kPackFillLevels][4];
 #pragma unroll
-  for (int s = 3; s >= 0; s--) { // largest blocks first
-    const uint32_t sl = pack_slots(s, G.slots4), total = live ? R.count[s] : 0, nw = (total + sl - 1) / sl;
-    for (uint32_t c = (uint32_t)k; c < nw; c += (uint32_t)G.I)
-      descs[R.wave_base + woff + c] = PackDesc{R.item_base[s] + c * sl, min(sl, total - c * sl) | ((uint32_t)s << 28), (uint32_t)row, dep};
-    woff += nw;
-    // item (rank r, picture k) of the bucket sits behind every item of a lower rank and the same-rank items of the pictures
-    // before k:  sum over k' of min(count[k'], r)  +  #{k' < k : count[k'] > r}
-    const uint32_t cnt = ltus ? lr.count[s] : 0, start = lr.start[s];
-    wave_sync();
-    cnts[threadIdx.x] = cnt; // the counts of the row's pictures, for lanes that loop longer than their neighbours
-    wave_sync();
-    for (uint32_t r = 0; r < cnt; r++) {
+  for (int q = 0; q < kPackFillLevels; q++) {
+    const int L = L0 + q;
+    const bool on = L < G.max_levels;
+    const PackRow *R = rows + (size_t)(on ? L : 0) * G.n_groups + g;
+    wave_base[q] = R->wave_base, item_base[q] = R->item_base[s];
+#pragma unroll
+    for (int t = 0; t < 4; t++) rcount[q][t] = on ? R->count[t] : 0;
+    dep[q] = (on && L > 0) ? (R - G.n_groups)->n_waves : 0;
+    const bool mine = on && L < n_levels;
+    cnt[q] = mine ? ltab[L].count[s] : 0, start[q] = mine ? ltab[L].start[s] : 0;
+    cq[q] = (on && L < peer_levels) ? peer_tab[L].count[s] : 0;
+  }
+  // phase 2: descriptors (the group's first picture) and items
+#pragma unroll
+  for (int q = 0; q < kPackFillLevels; q++) {
+    const int L = L0 + q;
+    if (L >= G.max_levels) break;
+    if (k == 0) { // the row's wave-items of this size class: they follow those of the larger classes
+      const uint32_t sl = pack_slots(s, G.slots4), total = rcount[q][s], nw = (total + sl - 1) / sl;
+      uint32_t woff = 0;
+      for (int t = 3; t > s; t--) woff += (rcount[q][t] + pack_slots(t, G.slots4) - 1) / pack_slots(t, G.slots4);
+      const uint32_t row = (uint32_t)(L * G.n_groups + g);
+      for (uint32_t c = (uint32_t)lane; c < nw; c += 64u)
+        descs[wave_base[q] + woff + c] = PackDesc{item_base[q] + c * sl, min(sl, total - c * sl) | ((uint32_t)s << 28), row, dep[q]};
+    }
+    // an item (rank r, picture k) sits behind every item of a lower rank and the same-rank items of the pictures before k:
+    //   sum over k' of min(count[k'], r)  +  #{k' < k : count[k'] > r}
+    const FTu *ltus = ltus0 + start[q];
+    FTu *dst = items + item_base[q];
+    for (uint32_t r0 = 0; r0 < cnt[q]; r0 += 64u) { // (whole rounds: the shuffles below need every lane)
+      const uint32_t r = r0 + (uint32_t)lane;
       uint32_t off = 0;
-      for (int q = 0; q < G.I; q++) {
-        const uint32_t cq = cnts[seg0 + q];
-        off += min(cq, r) + ((q < k && cq > r) ? 1u : 0u);
+      for (int t = 0; t < G.I; t++) {
+        const uint32_t c2 = (uint32_t)__shfl((int)cq[q], t, 64);
+        off += min(c2, r) + ((t < k && c2 > r) ? 1u : 0u);
       }
-      FTu f = ltus[start + r];
-      f.t.plane = (uint8_t)(f.t.plane | (k << 2)); // picture of the group in the upper six bits
-      items[R.item_base[s] + off] = f;
+      if (r < cnt[q]) {
+        FTu f = ltus[r];
+        f.t.plane = (uint8_t)(f.t.plane | (k << 2)); // picture of the group in the upper six bits
+        dst[off] = f;
+      }
     }
   }
 }
@@ -1002,7 +1027,10 @@ __device__ __forceinline__ int pack_lane_item(int lane, int s) {
 }
 
 template <bool ENC, int SL4, bool SSE = false, bool RDOQ = false>
-__global__ __launch_bounds__(64, RDOQ ? 2 : 4) void k_intra_packed(PackArgs A) {
+#ifndef HMX_PACKED_OCC
+#define HMX_PACKED_OCC 4 /* waves per SIMD the register allocation is held to (A/B: -DHMX_PACKED_OCC=5 | 6 spill) */
+#endif
+__global__ __launch_bounds__(64, RDOQ ? 2 : HMX_PACKED_OCC) void k_intra_packed(PackArgs A) {
   static_assert(!RDOQ || (ENC && SL4 == 64), "RDOQ: encoder direction, 4x4 blocks one per lane");
   // RDOQ variant: every byte of LDS decides how many waves a CU holds (the walks are latency chains); the lane-per-block 4x4
   // chain, the largest user of the common scratch, borrows the round buffer its RDOQ does not need

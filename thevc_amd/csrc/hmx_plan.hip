@@ -426,6 +426,7 @@ extern "C" int hmx_intra_schedule_for(const hmx_ctx *c, int n_pics) { // 3 = pac
   return c->knob.schedule >= 0 ? c->knob.schedule : 3;
 }
 
+static void plan_release(hmx_ctx *c, hmx_intra_plan *pl);
 extern "C" void hmx_intra_plan_destroy(hmx_ctx *c, hmx_intra_plan *pl) {
   if (!pl) return;
   if (c) { // recorded graphs may refer to this plan (and its addresses may be re-used): drop them
@@ -436,6 +437,23 @@ extern "C" void hmx_intra_plan_destroy(hmx_ctx *c, hmx_intra_plan *pl) {
     }
     c->graphs.clear();
   }
+  plan_release(c, pl);
+}
+// the plans of a batch in one go: ONE synchronisation of the stream instead of one per plan
+extern "C" void hmx_intra_plan_destroy_many(hmx_ctx *c, hmx_intra_plan *const *plans, int n) {
+  if (!plans || n <= 0) return;
+  if (c) {
+    hipStreamSynchronize(c->stream);
+    for (auto &e : c->graphs) {
+      hipGraphExecDestroy(e.exec);
+      hipFree(e.d_work);
+    }
+    c->graphs.clear();
+  }
+  for (int i = 0; i < n; i++)
+    if (plans[i]) plan_release(c, plans[i]);
+}
+static void plan_release(hmx_ctx *c, hmx_intra_plan *pl) {
   if (pl->set) { // built on the device: the slabs are shared by the plans of one call and go back to the context's cache
     PlanSet *st = pl->set;
     if (--st->refs == 0) {
@@ -640,11 +658,16 @@ __global__ __launch_bounds__(64) void k_plan_levels(PlanLevelArgs A, int d) {
   const unsigned long long *rec = A.rec + b0;
   unsigned short *level = A.level + b0;
   unsigned top = 0;
-  unsigned long long nx0 = first < last ? rec[first] : 0, nx1 = first + 1 < last ? rec[first + 1] : 0;
+  // Two records ahead (six were measured slower: 530 against 492 us per launch -- the rotation costs more than the slack buys).
+  constexpr int kAhead = 2;
+  unsigned long long nx[kAhead];
+#pragma unroll
+  for (int q = 0; q < kAhead; q++) nx[q] = first + q < last ? rec[first + q] : 0;
   for (uint32_t b = first; b < last; b++) {
-    const unsigned long long r = nx0;
-    nx0 = nx1;
-    if (b + 2 < last) nx1 = rec[b + 2]; // two records ahead: the walk never waits for memory
+    const unsigned long long r = nx[0];
+#pragma unroll
+    for (int q = 0; q + 1 < kAhead; q++) nx[q] = nx[q + 1];
+    if (b + kAhead < last) nx[kAhead - 1] = rec[b + kAhead];
     const unsigned hi = (unsigned)(r >> 32);
     if ((int)((hi >> 20) & 3) != plane) continue;
     const int cx = (int)(hi >> 8) & 15, cy = (int)(hi >> 12) & 15, n = (int)(hi >> 16) & 15;
@@ -762,26 +785,76 @@ __global__ __launch_bounds__(256) void k_plan_scatter(PlanTabArgs A, uint32_t pe
 // the bucket's keys 64 at a time, each broadcast to the wave as a scalar (v_readlane): three instructions per comparison
 // for all 64 lanes, where one thread per block looping over its bucket in memory made a load per comparison.  Buckets average
 // ~60 blocks; a bucket of B blocks costs ceil(B / 64)^2 rounds.
+constexpr uint32_t kPlanLevelsPerWg = 8; // a wave walks this many levels' buckets of its size class
+constexpr uint32_t kPlanSortChunks = 8;  // buckets of up to 8 x 64 keys are ranked through sorted chunks in LDS
+// ascending bitonic sort of one key per lane across the wave (padding keys 0xffffffff end up in the top lanes)
+__device__ __forceinline__ uint32_t plan_wave_sort(uint32_t key, uint32_t lane) {
+#pragma unroll
+  for (uint32_t k = 2; k <= 64; k <<= 1)
+#pragma unroll
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t other = (uint32_t)__shfl_xor((int)key, (int)j, 64);
+      const bool keep_min = ((lane & k) == 0) == ((lane & j) == 0);
+      key = keep_min ? min(key, other) : max(key, other);
+    }
+  return key;
+}
 __global__ __launch_bounds__(256) void k_plan_gather(PlanTabArgs A, uint32_t per_pic) {
+  __shared__ uint32_t sorted[4][kPlanSortChunks * 64];
   const uint32_t sz = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int pic;
-  uint32_t lvl;
-  if (!plan_xcd_picture(per_pic, A.G.n_pics, pic, lvl) || lvl >= A.n_levels[pic]) return;
-  const LevelRow &R = A.ltab[A.ltab_off[pic] + lvl];
-  const uint32_t n = R.count[sz];
-  if (n == 0) return;
-  const uint32_t b0 = A.pic_off[pic], start = R.start[sz];
-  const uint32_t *k = A.keys + b0 + start;
-  for (uint32_t c0 = 0; c0 < n; c0 += 64) {
-    const bool mine = c0 + lane < n;
-    const uint32_t key = mine ? k[c0 + lane] : 0u;
-    uint32_t rank = 0;
-    for (uint32_t d0 = 0; d0 < n; d0 += 64) {
-      const uint32_t other = d0 + lane < n ? k[d0 + lane] : 0xffffffffu; // (re-read for c0 == d0: an L1 hit)
-      const int m = (int)min(64u, n - d0);
-      for (int q = 0; q < m; q++) rank += (uint32_t)__builtin_amdgcn_readlane((int)other, q) < key ? 1u : 0u;
+  uint32_t chunk;
+  if (!plan_xcd_picture(per_pic, A.G.n_pics, pic, chunk)) return;
+  const uint32_t nl = A.n_levels[pic], b0 = A.pic_off[pic];
+  uint32_t *S = sorted[sz];
+  for (uint32_t lvl = chunk * kPlanLevelsPerWg; lvl < min(nl, (chunk + 1) * kPlanLevelsPerWg); lvl++) {
+    const LevelRow &R = A.ltab[A.ltab_off[pic] + lvl];
+    const uint32_t n = R.count[sz];
+    if (n == 0) continue;
+    const uint32_t start = R.start[sz];
+    const uint32_t *k = A.keys + b0 + start;
+    if (n <= 64) { // one chunk: every key against every key of the bucket, each broadcast as a scalar -- 3 n instructions
+      const bool mine = lane < n;
+      const uint32_t key = mine ? k[lane] : 0xffffffffu;
+      uint32_t rank = 0;
+      for (int q = 0; q < (int)n; q++) rank += (uint32_t)__builtin_amdgcn_readlane((int)key, q) < key ? 1u : 0u;
+      if (mine) A.ltus[b0 + start + rank] = A.ftu[b0 + (key & 0xfffffu)];
+    } else if (n <= kPlanSortChunks * 64) {
+      // several chunks: sort each across the wave (bitonic network), leave it in LDS; a key's rank is its place in its own chunk
+      // plus, by binary search, the number of smaller keys in every other chunk: ~170 + 25 (C - 1) instructions per chunk instead of 200 C
+      const uint32_t C = (n + 63) / 64;
+      wave_sync();
+      for (uint32_t c = 0; c < C; c++) S[c * 64 + lane] = plan_wave_sort(c * 64 + lane < n ? k[c * 64 + lane] : 0xffffffffu, lane);
+      wave_sync();
+      for (uint32_t c = 0; c < C; c++) {
+        const uint32_t key = S[c * 64 + lane];
+        uint32_t rank = lane;
+        for (uint32_t d = 0; d < C; d++) {
+          if (d == c) continue;
+          uint32_t lo = 0, hi = 64;
+#pragma unroll
+          for (int it = 0; it < 6; it++) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const bool less = S[d * 64 + mid] < key;
+            lo = less ? mid + 1 : lo, hi = less ? hi : mid;
+          }
+          rank += lo + (lo < 64 && S[d * 64 + lo] < key ? 1u : 0u); // (lo == hi after six halvings of 64: the last probe settles index 63)
+        }
+        if (key != 0xffffffffu) A.ltus[b0 + start + rank] = A.ftu[b0 + (key & 0xfffffu)];
+      }
+    } else { // very large buckets (uniform tilings): chunk against chunk
+      for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+        const bool mine = c0 + lane < n;
+        const uint32_t key = mine ? k[c0 + lane] : 0u;
+        uint32_t rank = 0;
+        for (uint32_t d0 = 0; d0 < n; d0 += 64) {
+          const uint32_t other = d0 + lane < n ? k[d0 + lane] : 0xffffffffu;
+          const int m = (int)min(64u, n - d0);
+          for (int q = 0; q < m; q++) rank += (uint32_t)__builtin_amdgcn_readlane((int)other, q) < key ? 1u : 0u;
+        }
+        if (mine) A.ltus[b0 + start + rank] = A.ftu[b0 + (key & 0xfffffu)];
+      }
     }
-    if (mine) A.ltus[b0 + start + rank] = A.ftu[b0 + (key & 0xfffffu)];
   }
 }
 
@@ -818,6 +891,10 @@ extern "C" int hmx_intra_plan_create_device(hmx_ctx *c, const hmx_tu *d_tus, con
   if (max_tu >= (1u << 20)) return fail(c, HMX_ERR_ARG, "hmx_intra_plan_create: picture too large for one plan");
   const uint32_t total = offsets[n_pics] - offsets[0];
   hipStream_t st = c->stream;
+  static const bool timing = getenv("HMX_PLAN_TIMING") != nullptr; // host clock at the call's synchronisation points, to stderr
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_start = now();
+  double t_setup = 0, t_levels = 0;
   PlanGeomDev G{};
   G.P = make_picdev(c, pp);
   G.cw = (pp->pic_w + 63) / 64, G.ch = (pp->pic_h + 63) / 64, G.n_ctu = G.cw * G.ch, G.n_pics = n_pics, G.uw = G.cw * 16, G.max_tu = max_tu;
@@ -888,6 +965,7 @@ extern "C" int hmx_intra_plan_create_device(hmx_ctx *c, const hmx_tu *d_tus, con
         return fail(c, HMX_ERR_DEVICE, "hmx_intra_plan_create_device: upload", e0);
       }
     }
+    t_setup = now();
     hipError_t e1 = hipMemsetAsync(d_meta, 0, sizeof(uint32_t) * meta_words, st);
     if (e1 == hipSuccess) e1 = hipMemsetAsync(d_bot, 0, sizeof(unsigned short) * (size_t)n_pics * 3 * G.ch * G.uw, st);
     if (e1 == hipSuccess) e1 = hipMemsetAsync(d_right, 0, sizeof(unsigned short) * (size_t)n_pics * 3 * G.n_ctu * 16, st);
@@ -927,6 +1005,7 @@ extern "C" int hmx_intra_plan_create_device(hmx_ctx *c, const hmx_tu *d_tus, con
     }
     break;
   }
+  t_levels = now();
   uint32_t max_levels = 0;
   for (int i = 0; i < n_pics; i++) loff[(size_t)n_pics + i] = meta[i], max_levels = std::max(max_levels, meta[i]);
   hipError_t e1 = hipMemcpyAsync(d_loff + n_pics, loff.data() + n_pics, sizeof(uint32_t) * n_pics, hipMemcpyHostToDevice, st);
@@ -941,7 +1020,8 @@ extern "C" int hmx_intra_plan_create_device(hmx_ctx *c, const hmx_tu *d_tus, con
     return fail(c, HMX_ERR_ARG, "hmx_intra_plan_create_device: too many pictures / dependency levels for one call (split it)");
   }
   hipLaunchKernelGGL(k_plan_scatter, dim3(pics8 * per_block.x), dim3(256), 0, st, TA, per_block.x);
-  hipLaunchKernelGGL(k_plan_gather, dim3(pics8 * max_levels), dim3(256), 0, st, TA, max_levels);
+  const unsigned level_chunks = (max_levels + kPlanLevelsPerWg - 1) / kPlanLevelsPerWg;
+  hipLaunchKernelGGL(k_plan_gather, dim3(pics8 * level_chunks), dim3(256), 0, st, TA, level_chunks);
   hipError_t e3 = hipGetLastError();
   std::vector<uint32_t> sizes((size_t)n_pics * 4);
   hipError_t e2 = hipMemcpyAsync(sizes.data(), d_size_total, sizeof(uint32_t) * sizes.size(), hipMemcpyDeviceToHost, st);
@@ -951,6 +1031,7 @@ extern "C" int hmx_intra_plan_create_device(hmx_ctx *c, const hmx_tu *d_tus, con
     delete set;
     return fail(c, HMX_ERR_DEVICE, "hmx_intra_plan_create_device: table kernels", e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3 != hipSuccess ? e3 : e4);
   }
+  const double t_tables = now();
   static std::atomic<uint64_t> dev_serial{1ull << 40}; // disjoint from the serials of host-analysed plans
   for (int i = 0; i < n_pics; i++) {
     hmx_intra_plan *pl = new hmx_intra_plan;
@@ -967,6 +1048,9 @@ extern "C" int hmx_intra_plan_create_device(hmx_ctx *c, const hmx_tu *d_tus, con
     pl->qp = pp->qp, pl->chroma_qp_offset = pp->chroma_qp_offset, pl->slice_type = pp->slice_type;
     out[i] = pl;
   }
+  if (timing)
+    fprintf(stderr, "[plan timing] %d pictures, %u blocks: setup %.2f ms, records + level walk %.2f ms, tables %.2f ms, plan objects %.2f ms\n", n_pics, total,
+            t_setup - t_start, t_levels - t_setup, t_tables - t_levels, now() - t_tables);
   return HMX_OK;
 }
 
