@@ -112,7 +112,7 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
     if (!r) r = grow_dev(c, (void **)&pk.d_descs, &pk.cap_descs, sizeof(PackDesc) * waves_bound);
     if (!r) r = grow_dev(c, (void **)&pk.d_items, &pk.cap_items, sizeof(FTu) * items);
     if (!r) r = grow_dev(c, (void **)&pk.d_rows, &pk.cap_rows, sizeof(PackRow) * n_rows);
-    if (!r) r = grow_dev(c, (void **)&pk.d_done, &pk.cap_done, sizeof(uint32_t) * kDoneStride * n_rows);
+    if (!r) r = grow_dev(c, (void **)&pk.d_done, &pk.cap_done, std::max<size_t>(sizeof(uint32_t) * kDoneStride * n_rows, sizeof(uint32_t) * 2 * kPackScanWgs)); // (also k_pack_scan's scratch)
     if (!r && !pk.d_hdr) {
       if (hipMalloc((void **)&pk.d_hdr, sizeof(PackHdr)) != hipSuccess) r = fail(c, HMX_ERR_NOMEM, "hipMalloc packed header");
       else if (hipMemsetAsync(pk.d_hdr, 0, sizeof(PackHdr), st) != hipSuccess) r = fail(c, HMX_ERR_DEVICE, "hipMemsetAsync packed header");
@@ -132,7 +132,9 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
     HIPCHK(c, hipMemsetAsync(pk.d_hdr, 0, offsetof(PackHdr, abort), st)); // everything but the sticky abort word (below)
     const unsigned prep_waves = (unsigned)((n_rows + (uint64_t)(64 / G.I) - 1) / (uint64_t)(64 / G.I));
     hipLaunchKernelGGL(k_pack_count, dim3(prep_waves), dim3(64), 0, st, pk.d_pics, pk.d_rows, G, (int)n_rows);
-    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, st, pk.d_rows, pk.d_hdr, G);
+    // (the completion counters are cleared behind the prep kernels: their array doubles as the scan's scratch)
+    hipLaunchKernelGGL(k_pack_scan<false>, dim3(kPackScanWgs), dim3(1024), 0, st, pk.d_rows, pk.d_hdr, G, pk.d_done);
+    hipLaunchKernelGGL(k_pack_scan<true>, dim3(kPackScanWgs), dim3(1024), 0, st, pk.d_rows, pk.d_hdr, G, pk.d_done);
     hipLaunchKernelGGL(k_pack_fill, dim3((unsigned)((G.max_levels + kPackFillLevels - 1) / kPackFillLevels), (unsigned)(G.n_groups * G.I)), dim3(256), 0, st, pk.d_pics, pk.d_rows, pk.d_descs, pk.d_items, G);
     HIPCHK(c, hipGetLastError());
     if (c->timing && c->tev_prep) {
@@ -700,9 +702,15 @@ static int frame_intra(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan_
   uint64_t key = 1469598103934665603ull;
   std::vector<unsigned char> kb; // the bytes the key is formed from: two calls are "the same" when these are, not when a hash says so
   kb.reserve(sizeof(PicWork) * n_pics + sizeof(ConvJob) * jobs.size() + 24 * (size_t)n_pics + 64);
-  auto mix = [&](const void *p, size_t n) {
+  auto mix = [&](const void *p, size_t n) { // FNV-1a over 8-byte words (the table of a 2048-picture call is ~1 MB, hashed on every call)
     const unsigned char *b = (const unsigned char *)p;
-    for (size_t i = 0; i < n; i++) key = (key ^ b[i]) * 1099511628211ull;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+      uint64_t w8;
+      memcpy(&w8, b + i, 8);
+      key = (key ^ w8) * 1099511628211ull;
+    }
+    for (; i < n; i++) key = (key ^ b[i]) * 1099511628211ull;
     kb.insert(kb.end(), b, b + n);
   };
   mix(hw.data(), sizeof(PicWork) * n_pics);
