@@ -391,7 +391,8 @@ int hmx_frame_intra_decode_multi(hmx_ctx *ctx, const hmx_intra_plan *const *plan
  * n_pics = the pictures of the following calls, or 1 = one set for every picture.  pics = NULL turns RDOQ off again.
  * Transform-skip blocks keep the flat quantiser (TComTrQuant.cpp:1121-1122 with TransformSkipFast, which every shipped
  * cfg that enables transform skip sets); packed schedule only, packing groups of at most 2 pictures (HMX_PACK_GROUP; the
- * tables of a group wait in LDS). */
+ * tables of a group wait in LDS).  Levels travel as 16-bit words inside the kernel: a call whose QP, bit depth and block sizes allow
+ * |level| = (32768 * quantScale) >> qbits > 32767 (e.g. 10-bit, QP < 5 with 32x32 blocks) is refused with HMX_ERR_ARG. */
 typedef struct hmx_rdoq_pic {
   hmx_est_bits est[8]; /* [luma, chroma][log2(size) - 2] */
   double lambda_luma, lambda_chroma;

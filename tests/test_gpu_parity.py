@@ -1391,6 +1391,50 @@ def test_frame_intra_decode_onto(ctx, n_pics, schedule, hmx_opts):
         d.free()
 
 
+def test_set_rdoq_keeps_its_state_when_it_refuses(ctx):
+    """hmx_set_rdoq checks every input before it touches the context (round-2 advisor finding): a good set, then a call with a
+    non-positive multiplier is REFUSED and the good set stays in force -- same levels as before the refused call, also when the encode
+    calls are queued back to back (the multiplier table goes up once, not per call).  And the chain refuses a QP at which RDOQ's
+    16-bit levels could overflow."""
+    B, L = ctx.bit_depth, capi.lib()
+    w, h, n, qp = 136, 72, 2, 30
+    rng = np.random.default_rng(5)
+    pp = capi.PicParam(w, h, qp, 0, capi.I_SLICE, 1)
+    tus = [workload.with_cbf_ctx(workload.make_tus(3300 + i, w, h, "mix")) for i in range(n)]
+    plans = [ctx.intra_plan(t, pp) for t in tus]
+    orgs = [workload.make_planes(3400 + i, w, h, B, "texture") for i in range(n)]
+    ests = [[ol.make_est_bits(rng) for _ in range(8)] for _ in range(n)]
+    lams = [(40.0 + i, 30.0 + i) for i in range(n)]
+    d_org = [capi.DevPicture(ctx, w, h).upload(o) for o in orgs]
+    d_rec = [capi.DevPicture(ctx, w, h).zero() for _ in range(n)]
+    d_lev = [capi.DevPicture(ctx, w, h, dtype=np.int32).zero() for _ in range(n)]
+    A = lambda lst, T: (T * n)(*[x.as_pic() for x in lst])
+    parr = (C.c_void_p * n)(*[p.value for p in plans])
+    ctx.set_rdoq([(ests[i], lams[i][0], lams[i][1]) for i in range(n)])
+    with pytest.raises(capi.HmxError):
+        ctx.set_rdoq([(ests[0], 10.0, 0.0)])  # one picture, chroma multiplier 0: refused
+    for rep in range(3):  # queued back to back
+        ctx._chk(L.hmx_frame_intra_encode_multi(ctx.h, parr, n, A(d_org, capi.Pic), A(d_rec, capi.Pic), A(d_lev, capi.Levels)))
+    ctx.sync()
+    for i in range(n):
+        rr, ll = ol.o_intra_frame_encode_rdoq(tus[i], w, h, B, qp, orgs[i], ests[i], lams[i])
+        rec, lev = d_rec[i].download(), d_lev[i].download()
+        assert all(np.array_equal(lev[p], ll[p]) and np.array_equal(rec[p], rr[p]) for p in range(3)), i
+    if B == 10:  # QP -12 at 10 bit (the lowest the bit depth allows: per = 0): a 32x32 level can reach ~52000
+        pp0 = capi.PicParam(w, h, -12, 0, capi.I_SLICE, 1)
+        big = workload.with_cbf_ctx(workload.make_tus(1, w, h, 32))
+        pl0 = ctx.intra_plan(big, pp0)
+        ctx.set_rdoq([(ests[0], 40.0, 30.0)])  # one set for every picture
+        rc = L.hmx_frame_intra_encode(ctx.h, pl0, 1, C.byref(d_org[0].as_pic()), C.byref(d_rec[0].as_pic()), C.byref(d_lev[0].as_pic()))
+        assert rc == -1 and b"16 bits" in L.hmx_last_error(ctx.h)
+        L.hmx_intra_plan_destroy(ctx.h, pl0)
+    ctx.set_rdoq(None)
+    for pl in plans:
+        L.hmx_intra_plan_destroy(ctx.h, pl)
+    for d in d_org + d_rec + d_lev:
+        d.free()
+
+
 @pytest.mark.parametrize("shared", [False, True])
 def test_frame_intra_rdoq_in_chain(ctx, shared):
     """hmx_set_rdoq: xRateDistOptQuant as the quantiser INSIDE the whole-picture chain (what TEncSearch::xIntraCodingLumaBlk /

@@ -97,6 +97,17 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
     if (c->crq.n != 1 && c->crq.n != n_pics) return fail(c, HMX_ERR_ARG, "frame_intra: hmx_set_rdoq described another number of pictures");
     if (G.I > kRdoqMaxGroup) return fail(c, HMX_ERR_ARG, "frame_intra: RDOQ keeps the bit-estimate tables of a packing group in LDS: at most 2 pictures per group (HMX_PACK_GROUP)");
     G.slots4 = 64; // a 4x4 block's RDOQ runs inside one lane
+    // Inside the kernel RDOQ's levels travel as 16-bit words (hmx_rdoq.h); the reference keeps TCoeff = Int.  A level can reach
+    // (32768 * q) >> qbits: at the lowest QPs of deep bit depths that exceeds 32767 for the large transforms (10 bit, per = 0, 32x32:
+    // ~52000) and would wrap silently -- refuse the call instead (the scalar and block-list entries carry 32-bit levels for 4x4 and
+    // the same bound otherwise: include/hmx.h).
+    for (int t = 0; t < 2; t++)
+      for (int lg = 2; lg <= 5; lg++) {
+        if (!sz[lg - 2]) continue;
+        const int qbits = 14 + p0->P.qd[t].per_qbits + (15 - p0->P.bit_depth - lg);
+        if (((32768ll * p0->P.qd[t].q) >> qbits) > 32767)
+          return fail(c, HMX_ERR_ARG, "frame_intra: RDOQ in the chain keeps levels in 16 bits; this QP / bit depth / block size can exceed them (raise the QP or use the flat quantiser)");
+      }
   }
   const uint64_t n_rows = (uint64_t)G.max_levels * G.n_groups;
   uint64_t waves_bound = 4 * n_rows + 4;
@@ -232,8 +243,16 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
         memcpy(&up[(size_t)q.n * 2 + (size_t)i * 2 + t], &f, sizeof(f));
       }
     }
-    HIPCHK(c, hipMemcpyAsync(q.d_lambda, up.data(), up.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st)); // `up` goes out of scope
+    // The table depends on hmx_set_rdoq's multipliers and the call's quantiser parameters only: it goes up when one of them changed
+    // (the first call after hmx_set_rdoq, or another QP), so that steady-state calls queue behind each other without a host wait.
+    uint64_t lkey = 1469598103934665603ull ^ q.serial;
+    for (int t = 0; t < 2; t++)
+      for (int v : {A.P.qd[t].q, A.P.qd[t].per_qbits, A.P.qd[t].iq_scale, B, q.n}) lkey = (lkey ^ (uint64_t)(uint32_t)v) * 1099511628211ull;
+    if (!q.lambda_valid || q.lambda_key != lkey) {
+      HIPCHK(c, hipMemcpyAsync(q.d_lambda, up.data(), up.size() * sizeof(double), hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipStreamSynchronize(st)); // `up` goes out of scope
+      q.lambda_key = lkey, q.lambda_valid = true;
+    }
     A.rq.est = q.d_est;
     A.rq.lambda = q.d_lambda;
     A.rq.rd_factor = reinterpret_cast<const long long *>(q.d_lambda + (size_t)q.n * 2);
@@ -845,6 +864,7 @@ extern "C" int hmx_set_rdoq(hmx_ctx *c, const hmx_rdoq_pic *pics, int n_pics) {
     for (int i = 0; i < n_pics; i++)
       if (!(pics[i].lambda_luma > 0) || !(pics[i].lambda_chroma > 0)) return fail(c, HMX_ERR_ARG, "hmx_set_rdoq: lambda must be positive");
   q.serial++;
+  q.lambda_valid = false;
   if (!pics) {
     q.n = 0;
     return HMX_OK;

@@ -277,6 +277,8 @@ struct hmx_ctx {
     size_t cap_lambda = 0;
     int max_waves = 0;            // resident waves of the RDOQ kernel variant
     uint64_t serial = 0;          // counts hmx_set_rdoq calls (part of the schedule key)
+    uint64_t lambda_key = 0;      // of the multiplier table resident in d_lambda (serial + quantiser parameters)
+    bool lambda_valid = false;
   } crq;
   // hmx_intra_plan_create_device: work buffers (grow-only) and a cache of freed slabs (a pipeline that rebuilds its plans every
   // batch gets the previous batch's memory back instead of a hipMalloc / hipFree pair per call)
