@@ -586,11 +586,17 @@ __global__ __launch_bounds__(256) void k_plan_ctus(const hmx_tu *tus, const uint
     for (int c = 0; c <= G.n_ctu; c++) cs[c] = 0;
 }
 
-// A lane's LDS row: the CTU's 16 x 16 grid of 16-bit unit levels (level + 1; 0 = no block), then the units beyond its top
-// edge (corner, 16 above, 16 above-right: 33) and beyond its left edge (16), fetched once from the edge arrays.  305 halfwords
-// in 154 words: rows start on 8-byte boundaries (a 16x16 or 32x32 block writes four units per store), and lanes that read the
-// same unit of their CTUs spread over 32 of the 64 banks.
-constexpr int kPlanTop = 256, kPlanLeft = 256 + 33, kPlanLaneWords = 154;
+// A lane's LDS row: the CTU's grid of 16-bit levels (level + 1; 0 = no block), then the cells beyond its top edge (corner, above,
+// above-right) and beyond its left edge, fetched once from the edge arrays.  LUMA: one cell per unit of four samples, 16 x 16 + 33
+// + 16 = 305 halfwords in 154 words.  CHROMA (RES = 1): its blocks are at least two units wide and aligned to that, so a cell is
+// 2 x 2 units: 8 x 8 + 17 + 8 = 89 halfwords in 46 words -- a quarter of the LDS, and LDS is what limits how many of these waves a CU
+// holds (4 luma waves, 13 chroma waves).  Rows start on 8-byte boundaries (a large block writes four cells per store); lanes that
+// read the same cell of their CTUs spread over 32 of the 64 banks.
+template <int RES>
+struct PlanGrid {
+  static constexpr int GS = 16 >> RES, kTop = GS * GS, kLeft = kTop + 1 + 2 * GS, kHalfwords = kLeft + GS;
+  static constexpr int kLaneWords = ((kHalfwords + 1) / 2 + 1) & ~1;
+};
 struct PlanLevelArgs {
   const unsigned long long *rec;
   const uint32_t *pic_off, *ctu_start;
@@ -603,8 +609,10 @@ struct PlanLevelArgs {
   uint32_t *overflow;    // set when a picture has more levels than rows (the host then repeats the build with more)
   PlanGeomDev G;
 };
-// max of the grid entries named by the bits of `bits`: entry of bit u at halfword base + u * step (step may be negative).
-// Four reads per round are in flight together: a wave of this kernel is alone on its SIMD, nothing else hides LDS latency.
+// max of the grid entries named by the bits of `bits` (one per UNIT): the cell of bit u at halfword base + (u >> RES) * step (step may
+// be negative; two units of a chroma cell read the same entry).  Four reads per round are in flight together: a luma wave of this
+// kernel is alone on its SIMD, nothing else hides LDS latency.
+template <int RES>
 __device__ __forceinline__ unsigned plan_max_over(const unsigned short *g, unsigned bits, int base, int step, unsigned lv) {
   while (bits) {
     int idx[4];
@@ -614,7 +622,7 @@ __device__ __forceinline__ unsigned plan_max_over(const unsigned short *g, unsig
       ok[q] = bits != 0;
       const int u = ok[q] ? __ffs((int)bits) - 1 : 0;
       bits &= bits - 1;
-      idx[q] = base + u * step;
+      idx[q] = base + (u >> RES) * step;
     }
     unsigned v[4];
 #pragma unroll
@@ -624,33 +632,48 @@ __device__ __forceinline__ unsigned plan_max_over(const unsigned short *g, unsig
   }
   return lv;
 }
+// RES = 0: a lane walks the LUMA blocks of its CTU; RES = 1: the blocks of BOTH chroma planes in one pass over the CTU's records (two
+// grids side by side in its LDS row: the records of the other planes are skipped once, not once per chroma plane)
+template <int RES>
 __global__ __launch_bounds__(64) void k_plan_levels(PlanLevelArgs A, int d) {
-  __shared__ __attribute__((aligned(16))) unsigned grid_lds[64 * kPlanLaneWords];
+  typedef PlanGrid<RES> PG;
+  constexpr int GS = PG::GS, NP = RES ? 2 : 1, P0 = RES ? 1 : 0; // planes per lane, the first of them
+  __shared__ __attribute__((aligned(16))) unsigned grid_lds[64 * NP * PG::kLaneWords];
   const PlanGeomDev &G = A.G;
   // CTUs of diagonal d: Y in [y_lo, y_hi], X = d - 2Y
   const int y_lo = max(0, (d - (G.cw - 1) + 1) >> 1), y_hi = min(G.ch - 1, d >> 1), n_diag = y_hi - y_lo + 1;
-  const int item = blockIdx.x * 64 + threadIdx.x, plane = blockIdx.y;
+  const int item = blockIdx.x * 64 + threadIdx.x;
   const bool on = n_diag > 0 && item < n_diag * G.n_pics;
   if (!on) return; // (nothing below crosses lanes)
   const int pic = item / n_diag, Y = y_lo + (item - pic * n_diag), X = d - 2 * Y, ctu = Y * G.cw + X;
-  unsigned *gw = grid_lds + threadIdx.x * kPlanLaneWords;
-  unsigned short *g = reinterpret_cast<unsigned short *>(gw);
-  const size_t pp = (size_t)pic * 3 + plane;
-  { // the neighbours' edges first (every load in flight before the first is used), the own grid zeroed meanwhile
-    const unsigned short *bot_above = A.bot + (pp * G.ch + (size_t)max(Y - 1, 0)) * G.uw + X * 16;
-    const unsigned short *right_left = A.right + (pp * G.n_ctu + (size_t)max(ctu - 1, 0)) * 16;
+  unsigned *gw0 = grid_lds + threadIdx.x * (NP * PG::kLaneWords);
+  { // the neighbours' edges first (every load in flight before the first is used), the own grids zeroed meanwhile
     const int ux_end = G.uw - X * 16; // units of the row above that exist to the right of this CTU's origin
-    unsigned short tv[33], lv[16];
+    unsigned short tv[NP][1 + 2 * GS], lv[NP][GS];
 #pragma unroll
-    for (int k = 0; k < 33; k++) tv[k] = (Y > 0 && (k > 0 || X > 0) && k - 1 < ux_end) ? bot_above[k - 1] : (unsigned short)0;
+    for (int q = 0; q < NP; q++) {
+      const size_t pp = (size_t)pic * 3 + P0 + q;
+      const unsigned short *bot_above = A.bot + (pp * G.ch + (size_t)max(Y - 1, 0)) * G.uw + X * 16;
+      const unsigned short *right_left = A.right + (pp * G.n_ctu + (size_t)max(ctu - 1, 0)) * 16;
 #pragma unroll
-    for (int k = 0; k < 16; k++) lv[k] = X > 0 ? right_left[k] : (unsigned short)0;
+      for (int k = 0; k <= 2 * GS; k++) {
+        const int ux = k == 0 ? -1 : (k - 1) << RES; // the first unit of the cell
+        tv[q][k] = (Y > 0 && (k > 0 || X > 0) && ux < ux_end) ? bot_above[ux] : (unsigned short)0;
+      }
+#pragma unroll
+      for (int k = 0; k < GS; k++) lv[q][k] = X > 0 ? right_left[k << RES] : (unsigned short)0;
+    }
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+      unsigned *gw = gw0 + q * PG::kLaneWords;
+      unsigned short *g = reinterpret_cast<unsigned short *>(gw);
 #pragma unroll 8
-    for (int k = 0; k < 128; k++) gw[k] = 0;
+      for (int k = 0; k < GS * GS / 2; k++) gw[k] = 0;
 #pragma unroll
-    for (int k = 0; k < 33; k++) g[kPlanTop + k] = tv[k];
+      for (int k = 0; k <= 2 * GS; k++) g[PG::kTop + k] = tv[q][k];
 #pragma unroll
-    for (int k = 0; k < 16; k++) g[kPlanLeft + k] = lv[k];
+      for (int k = 0; k < GS; k++) g[PG::kLeft + k] = lv[q][k];
+    }
   }
   const uint32_t b0 = A.pic_off[pic];
   const uint32_t *cs = A.ctu_start + (size_t)pic * (G.n_ctu + 1);
@@ -669,40 +692,49 @@ __global__ __launch_bounds__(64) void k_plan_levels(PlanLevelArgs A, int d) {
     for (int q = 0; q + 1 < kAhead; q++) nx[q] = nx[q + 1];
     if (b + kAhead < last) nx[kAhead - 1] = rec[b + kAhead];
     const unsigned hi = (unsigned)(r >> 32);
-    if ((int)((hi >> 20) & 3) != plane) continue;
-    const int cx = (int)(hi >> 8) & 15, cy = (int)(hi >> 12) & 15, n = (int)(hi >> 16) & 15;
+    const int plane = (int)((hi >> 20) & 3);
+    if (RES ? (plane != 1 && plane != 2) : plane != 0) continue;
+    unsigned *gw = gw0 + (RES && plane == 2 ? PG::kLaneWords : 0);
+    unsigned short *g = reinterpret_cast<unsigned short *>(gw);
+    const int n = (int)(hi >> 16) & 15;                                       // units per side
+    const int cx = ((int)(hi >> 8) & 15) >> RES, cy = ((int)(hi >> 12) & 15) >> RES, cn = n >> RES; // in cells
     // the dependency bits in three runs: left column (bits 0 .. 2n-1, bottom to top), corner (2n), row above (2n+1 .. 4n)
     const unsigned lo = (unsigned)r, left_bits = lo & ((1u << (2 * n)) - 1u), corner = (lo >> (2 * n)) & 1u;
     const unsigned above_bits = (unsigned)((r & 0x1ffffffffull) >> (2 * n + 1));
-    // where those units live: the lane's grid, or its copies of the neighbours' edges when the block touches the CTU's edge
-    const int left_base = cx ? (cy + 2 * n - 1) * 16 + cx - 1 : kPlanLeft + cy + 2 * n - 1, left_step = cx ? -16 : -1;
-    const int above_base = cy ? (cy - 1) * 16 + cx : kPlanTop + 1 + cx;
-    const int corner_idx = cy == 0 ? kPlanTop + cx : cx == 0 ? kPlanLeft + cy - 1 : (cy - 1) * 16 + cx - 1;
+    // where those cells live: the lane's grid, or its copies of the neighbours' edges when the block touches the CTU's edge
+    const int left_base = cx ? (cy + 2 * cn - 1) * GS + cx - 1 : PG::kLeft + cy + 2 * cn - 1, left_step = cx ? -GS : -1;
+    const int above_base = cy ? (cy - 1) * GS + cx : PG::kTop + 1 + cx;
+    const int corner_idx = cy == 0 ? PG::kTop + cx : cx == 0 ? PG::kLeft + cy - 1 : (cy - 1) * GS + cx - 1;
     unsigned lv = corner ? (unsigned)g[corner_idx] : 0u;
-    lv = plan_max_over(g, left_bits, left_base, left_step, lv);
-    lv = plan_max_over(g, above_bits, above_base, 1, lv);
+    lv = plan_max_over<RES>(g, left_bits, left_base, left_step, lv);
+    lv = plan_max_over<RES>(g, above_bits, above_base, 1, lv);
     level[b] = (unsigned short)lv;
     if (lv < A.cap) atomicAdd(&A.ltab[(size_t)pic * A.cap + lv].count[(hi >> 22) & 3], 1u); // nothing waits for it
     else *A.overflow = 1u;
     const unsigned nv = lv + 1;
     top = max(top, nv);
     const unsigned w2 = nv | (nv << 16);
-    if (n == 1) {
-      g[cy * 16 + cx] = (unsigned short)nv;
-    } else if (n == 2) { // n is even and the block is aligned to it: pairs of units as one word
-      gw[(cy * 16 + cx) >> 1] = w2, gw[((cy + 1) * 16 + cx) >> 1] = w2;
-    } else { // four units = one 8-byte store (a lane's row starts on an 8-byte boundary: kPlanLaneWords is even)
+    if (cn == 1) {
+      g[cy * GS + cx] = (unsigned short)nv;
+    } else if (cn == 2) { // the block is aligned to its size: pairs of cells as one word
+      gw[(cy * GS + cx) >> 1] = w2, gw[((cy + 1) * GS + cx) >> 1] = w2;
+    } else { // four cells = one 8-byte store (a lane's rows start on 8-byte boundaries: kLaneWords is even)
       const uint2 w4 = make_uint2(w2, w2);
-      for (int j = 0; j < n; j++)
-        for (int k = 0; k < n; k += 4) *reinterpret_cast<uint2 *>(&gw[((cy + j) * 16 + cx + k) >> 1]) = w4;
+      for (int j = 0; j < cn; j++)
+        for (int k = 0; k < cn; k += 4) *reinterpret_cast<uint2 *>(&gw[((cy + j) * GS + cx + k) >> 1]) = w4;
     }
   }
   if (top > 0xffffu) top = 0x10000u; // reported by the host as "too many levels"
   if (top) atomicMax(&A.pic_max[pic], top);
-  // hand the edges on: the bottom unit row and the right unit column
-  unsigned short *bot_own = A.bot + (pp * G.ch + Y) * G.uw + X * 16;
-  unsigned short *right_own = A.right + (pp * G.n_ctu + ctu) * 16;
-  for (int k = 0; k < 16; k++) bot_own[k] = g[15 * 16 + k], right_own[k] = g[k * 16 + 15];
+  // hand the edges on: the bottom unit row and the right unit column (per unit, whatever the grid's resolution)
+#pragma unroll
+  for (int q = 0; q < NP; q++) {
+    const size_t pp = (size_t)pic * 3 + P0 + q;
+    const unsigned short *g = reinterpret_cast<const unsigned short *>(gw0 + q * PG::kLaneWords);
+    unsigned short *bot_own = A.bot + (pp * G.ch + Y) * G.uw + X * 16;
+    unsigned short *right_own = A.right + (pp * G.n_ctu + ctu) * 16;
+    for (int k = 0; k < 16; k++) bot_own[k] = g[(GS - 1) * GS + (k >> RES)], right_own[k] = g[(k >> RES) * GS + GS - 1];
+  }
 }
 
 struct PlanTabArgs {
@@ -972,10 +1004,32 @@ extern "C" int hmx_intra_plan_create_device(hmx_ctx *c, const hmx_tu *d_tus, con
     if (e1 == hipSuccess) e1 = hipMemsetAsync(set->d_ltab, 0, sizeof(LevelRow) * rows, st);
     hipLaunchKernelGGL(k_plan_ctus, per_block, dim3(256), 0, st, tus0, d_off, d_ctu, d_size_total, d_err, c->pd.d_need, d_rec, d_ftu, G);
     PlanLevelArgs LA{d_rec, d_off, d_ctu, d_level, d_bot, d_right, d_pic_max, set->d_ltab, cap, d_overflow, G};
+    // A block depends on blocks of its own plane only: the luma walk and the chroma walk are two independent chains of launches,
+    // on two streams (one fills the tail of the other's rounds: a wave holds 39 KB / 23 KB of LDS for as long as it walks)
+    hipStream_t st_c = st;
+    if (e1 == hipSuccess && !getenv("HMX_PLAN_ONE_STREAM")) {
+      if (c->n_side < 1) {
+        if (!c->ev_fork) e1 = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+        if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&c->side[0], hipStreamNonBlocking);
+        if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&c->ev_join[0], hipEventDisableTiming);
+        if (e1 == hipSuccess) c->n_side = 1;
+      }
+      if (e1 == hipSuccess) e1 = hipEventRecord(c->ev_fork, st);
+      if (e1 == hipSuccess) e1 = hipStreamWaitEvent(c->side[0], c->ev_fork, 0);
+      if (e1 == hipSuccess) st_c = c->side[0];
+    }
     for (int d = 0; d <= (G.cw - 1) + 2 * (G.ch - 1); d++) {
       const int y_lo = std::max(0, (d - (G.cw - 1) + 1) >> 1), y_hi = std::min(G.ch - 1, d >> 1), n_diag = y_hi - y_lo + 1;
       if (n_diag <= 0) continue;
-      hipLaunchKernelGGL(k_plan_levels, dim3((unsigned)(((size_t)n_diag * n_pics + 63) / 64), 3), dim3(64), 0, st, LA, d);
+      const unsigned waves = (unsigned)(((size_t)n_diag * n_pics + 63) / 64);
+      hipLaunchKernelGGL(k_plan_levels<0>, dim3(waves, 1), dim3(64), 0, st, LA, d);   // luma
+      hipLaunchKernelGGL(k_plan_levels<1>, dim3(waves, 1), dim3(64), 0, st_c, LA, d); // Cb and Cr in one lane: two quarter-size grids
+    }
+    if (st_c != st) { // joined whatever happened in between
+      hipError_t ej = hipEventRecord(c->ev_join[0], st_c);
+      if (ej == hipSuccess) ej = hipStreamWaitEvent(st, c->ev_join[0], 0);
+      if (ej != hipSuccess) hipStreamSynchronize(st_c);
+      if (e1 == hipSuccess) e1 = ej;
     }
     if (e1 == hipSuccess) e1 = hipGetLastError();
     if (e1 == hipSuccess) e1 = hipMemcpyAsync(meta.data(), d_meta, sizeof(uint32_t) * meta_words, hipMemcpyDeviceToHost, st);

@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--sets", default="inst,wait,mfma,lds,fetch,write")
     ap.add_argument("--timeout", type=int, default=500)
     ap.add_argument("--meta", default="{}", help="JSON merged into the summary (frames, plans, ...)")
+    ap.add_argument("--issue-cycles", type=float, default=3.55,
+                    help="SIMD cycles per VALU instruction of the kernel's mix (default: k_intra_packed's static mix, 36 %% of its VALU "
+                         "instructions in the 2.4-cycle class, 64 %% in the 4.2-cycle class)")
     ap.add_argument("cmd", nargs=argparse.REMAINDER)
     a = ap.parse_args()
     cmd = a.cmd[1:] if a.cmd and a.cmd[0] == "--" else a.cmd
@@ -90,7 +93,19 @@ def main():
     # VALU utilisation of the chip: a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles; 256 CUs x 4 SIMDs; the
     # clock is taken as 2.4 GHz (the counters carry no clock), the kernel time is the trace's
     ns_inst = summary["passes"].get("inst", {}).get("kernel_ns") or 0
-    d["valu_utilisation"] = round(C["SQ_INSTS_VALU"] * 4 / (ns_inst * 2.4 * 1024), 4) if ns_inst and "SQ_INSTS_VALU" in C else None
+    # VALU issue: measured on gfx950 with 2..8 waves per SIMD (tools/issue_probe.hip, profiles/r03_issue_probe.txt): plain VOP2 integer /
+    # logic / shift-right / move / fp32 add-mul-fma instructions issue every ~2.4 SIMD cycles, everything else (all multiplies, VOP3
+    # three-operand forms, min / max / med3, bit-field ops, left shifts, DPP, SGPR-sourced operands, packed 16-bit, dot) every ~4.2;
+    # a wave alone on its SIMD ~5.5.  `valu_utilisation` keeps round 2's 4-cycle convention; the bracket below is what the mix allows.
+    if ns_inst and "SQ_INSTS_VALU" in C:
+        per = C["SQ_INSTS_VALU"] / (ns_inst * 2.4 * 1024)
+        d["valu_utilisation"] = round(per * 4, 4)
+        d["valu_utilisation_if_all_fast_2.4cyc"] = round(per * 2.4, 4)
+        d["valu_utilisation_if_all_slow_4.2cyc"] = round(per * 4.2, 4)
+        d["valu_utilisation_weighted"] = round(per * a.issue_cycles, 4)
+        d["valu_issue_cycles_assumed"] = a.issue_cycles
+    else:
+        d["valu_utilisation"] = None
     d["valu_share_of_wave_cycles"] = ratio("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES")
     d["valu_insts_per_wave"] = ratio("SQ_INSTS_VALU", "SQ_WAVES")
     d["salu_insts_per_wave"] = ratio("SQ_INSTS_SALU", "SQ_WAVES")
