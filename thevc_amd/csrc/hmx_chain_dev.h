@@ -269,6 +269,9 @@ __device__ __forceinline__ void lane4_inverse(const int *lv, bool use_dst, bool 
   }
 }
 
+#ifndef HMX_X_SKIP
+#define HMX_X_SKIP 0 /* timing experiments only (results are wrong): 1 no level stores, 2 no reference loads, 4 no source loads, 8 no reconstruction stores */
+#endif
 template <bool ENC, bool ONCE = false, typename SRC>
 __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, const PicDev &P, int count) {
   Lane4Lds &LS = *reinterpret_cast<Lane4Lds *>(smem);
@@ -287,7 +290,10 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
     const unsigned b0 = tile_base(R.ctu_w, R.clog, x, y);
     const size_t pb0 = tphys(R.qstride, b0); // a tile never straddles quads
     int v[16];
-    if (ENC && active) {
+    if ((HMX_X_SKIP & 4) && ENC) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) v[k] = (lane * 7 + k * 13 + x) & 255;
+    } else if (ENC && active) {
       const i4v o0 = stream_load(reinterpret_cast<const i4v *>(V.org + pb0)), o1 = stream_load(reinterpret_cast<const i4v *>(V.org + pb0 + 8));
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -296,7 +302,10 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
       }
     }
     src.wait(); // the whole wave (packed schedule): the neighbours belong to earlier rows of the same launch
-    if (!active) continue; // from here a lane works alone: nothing below needs the other lanes
+    // Packed schedule, encoder direction: the levels leave through LDS so that four lanes write one block's 64 bytes (below); the
+    // lanes without a block stay for that (they repeat item 0's arithmetic and store nothing).  Elsewhere a lane works alone from here.
+    constexpr bool COOP = ENC && ONCE && SRC::kCoherent && !SRC::kRdoq;
+    if (!COOP && !active) continue;
     // ---- reference line (fillReferenceSamples): sequential padding is natural inside one lane.
     int *line = LS.line[lane];
     {
@@ -314,19 +323,38 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
         const short *t_c = R.p + (has_c ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x - 4, y - 4)) : pb0);
         const short *t_a = R.p + (has_a ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x, y - 4)) : pb0);
         const short *t_ar = R.p + (has_ar ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x + 4, y - 4)) : pb0);
-        // whole tile rows (8 bytes): the access width of the coherent path, and no narrower request reaches the L2
+        // One request per tile.  A lane's load instruction is a request of its own to the L2 on the coherent path (sc1: the vector L1
+        // is bypassed), and the vector-memory pipe, not the ALU, bounds this chain (PMC, 2048 pictures of 4x4 blocks: texture addresser
+        // busy 0.99 of the time, 13 read requests per block, VALU 0.3): the right column of the two left tiles comes as the tile's two
+        // 16-byte halves instead of four 8-byte rows.
         constexpr bool COH = SRC::kCoherent;
-        const s4v va = ld_rec4<COH>(t_a + 12), var = ld_rec4<COH>(t_ar + 12), vc = ld_rec4<COH>(t_c + 12);
-        s4v vb[4], vl[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) vb[k] = ld_rec4<COH>(t_bl + 4 * (3 - k)), vl[k] = ld_rec4<COH>(t_lf + 4 * (3 - k));
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          raw[k] = vb[k][3];     // p = 0..3: (x-1, y+7-p)
-          raw[4 + k] = vl[k][3]; // p = 4..7: (x-1, y+7-p)
-          raw[9 + k] = va[k];
-          raw[13 + k] = var[k];
+        s4v va, var, vc;
+        i4v b0v, b1v, l0v, l1v; // rows 0-1 and rows 2-3 of the below-left and the left tile
+        if constexpr ((HMX_X_SKIP & 2) != 0) {
+          va = s4v{(short)x, (short)y, (short)lane, 3}, var = va, vc = va;
+          b0v = i4v{x, y, lane, x ^ y}, b1v = b0v, l0v = b0v, l1v = b0v;
+        } else if constexpr (COH) {
+          asm volatile("global_load_dwordx2 %0, %7, off sc1\n\t"
+                       "global_load_dwordx2 %1, %8, off sc1\n\t"
+                       "global_load_dwordx2 %2, %9, off sc1\n\t"
+                       "global_load_dwordx4 %3, %10, off sc1\n\t"
+                       "global_load_dwordx4 %4, %10, off offset:16 sc1\n\t"
+                       "global_load_dwordx4 %5, %11, off sc1\n\t"
+                       "global_load_dwordx4 %6, %11, off offset:16 sc1\n\t"
+                       "s_waitcnt vmcnt(0)"
+                       : "=&v"(va), "=&v"(var), "=&v"(vc), "=&v"(b0v), "=&v"(b1v), "=&v"(l0v), "=&v"(l1v)
+                       : "v"(t_a + 12), "v"(t_ar + 12), "v"(t_c + 12), "v"(t_bl), "v"(t_lf)
+                       : "memory");
+        } else {
+          va = ld_rec4<false>(t_a + 12), var = ld_rec4<false>(t_ar + 12), vc = ld_rec4<false>(t_c + 12);
+          b0v = *reinterpret_cast<const i4v *>(t_bl), b1v = *reinterpret_cast<const i4v *>(t_bl + 8);
+          l0v = *reinterpret_cast<const i4v *>(t_lf), l1v = *reinterpret_cast<const i4v *>(t_lf + 8);
         }
+        // p = 0..3: (x-1, y+7-p) = rows 3..0 of the below-left tile; p = 4..7: rows 3..0 of the left tile; column 3 = the odd words' high half
+        raw[0] = b1v[3] >> 16, raw[1] = b1v[1] >> 16, raw[2] = b0v[3] >> 16, raw[3] = b0v[1] >> 16;
+        raw[4] = l1v[3] >> 16, raw[5] = l1v[1] >> 16, raw[6] = l0v[3] >> 16, raw[7] = l0v[1] >> 16;
+#pragma unroll
+        for (int k = 0; k < 4; k++) raw[9 + k] = va[k], raw[13 + k] = var[k];
         raw[8] = vc[3];
       }
       const int dc = 1 << (B - 1);
@@ -396,10 +424,37 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
 #pragma unroll
         for (int k = 0; k < 16; k++) w[k] = level_of(w[k]);
       }
+      // A lane's four 16-byte stores are four requests and -- the level buffers stream to HBM -- four partial writes of one 64-byte
+      // line (timing experiment, 2048 pictures of 4x4 blocks: 254 ms with them, 155 ms without, against 14 ms for the reconstruction's
+      // two stores and 67 ms for the arithmetic alone).  In the reference's coefficient layout (stride 0) a block's levels are 64
+      // contiguous bytes: the lanes exchange rows through LDS and lanes 4j..4j+3 write block j's line in ONE store instruction.
+      bool coop_done = false;
+      if constexpr (COOP) {
+        if (__all(zlev)) { // (every plane of a call has the same layout)
+          wave_sync(); // the reference lines are spent in every lane
+          int *rows = reinterpret_cast<int *>(smem); // [64][20]: 16 levels, the block's address, padding to 80 bytes
+          int *mine = rows + lane * 20;
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        i4v o = {w[4 * r], w[4 * r + 1], w[4 * r + 2], w[4 * r + 3]};
-        piece_store(reinterpret_cast<i4v *>(lev_ptr + l0 + (unsigned)r * (unsigned)lrow), o);
+          for (int r = 0; r < 4; r++) *reinterpret_cast<i4v *>(mine + 4 * r) = i4v{w[4 * r], w[4 * r + 1], w[4 * r + 2], w[4 * r + 3]};
+          *reinterpret_cast<unsigned long long *>(mine + 16) = active ? (unsigned long long)(uintptr_t)(lev_ptr + l0) : 0ull;
+          wave_sync();
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int *from = rows + (16 * k + (lane >> 2)) * 20;
+            const i4v o = *reinterpret_cast<const i4v *>(from + 4 * (lane & 3));
+            const unsigned long long to = *reinterpret_cast<const unsigned long long *>(from + 16);
+            if (to && (!(HMX_X_SKIP & 1) || o[0] == 0x7fffffff)) piece_store(reinterpret_cast<i4v *>((int *)(uintptr_t)to) + (lane & 3), o);
+          }
+          wave_sync();
+          coop_done = true;
+        }
+      }
+      if (!coop_done && active) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          i4v o = {w[4 * r], w[4 * r + 1], w[4 * r + 2], w[4 * r + 3]};
+          if (!(HMX_X_SKIP & 1) || o[0] == 0x7fffffff) piece_store(reinterpret_cast<i4v *>(lev_ptr + l0 + (unsigned)r * (unsigned)lrow), o);
+        }
       }
     } else {
 #pragma unroll
@@ -427,7 +482,7 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
           rc[2 * k] = r0[k] & 0xffff, rc[2 * k + 1] = (int)((unsigned)r0[k] >> 16);
           rc[8 + 2 * k] = r1[k] & 0xffff, rc[8 + 2 * k + 1] = (int)((unsigned)r1[k] >> 16);
         }
-        V.sse[b0 >> 4] = sse_samples<16>(o, rc, B);
+        if (active) V.sse[b0 >> 4] = sse_samples<16>(o, rc, B);
       }
     }
     if constexpr (SRC::kWriteThrough) { // write-through, one tile row per store
@@ -440,7 +495,7 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
         st_rec4<true>(R.p + pb0 + 4 * k, a);
         st_rec4<true>(R.p + pb0 + 8 + 4 * k, b);
       }
-    } else {
+    } else if (active && (!(HMX_X_SKIP & 8) || r0[0] == 0x7fffffff)) {
       *reinterpret_cast<i4v *>(R.p + pb0) = r0;
       *reinterpret_cast<i4v *>(R.p + pb0 + 8) = r1;
     }
@@ -951,7 +1006,11 @@ struct PackNext {
 };
 template <bool SSE, bool RDOQ = false>
 struct PackedSrc {
+#ifdef HMX_PACKED_L1INV
+  static constexpr bool kCoherent = false;     // A/B: the vector L1 invalidated behind the dependency wait, plain loads after it
+#else
   static constexpr bool kCoherent = true;      // reconstruction loads bypass the vector L1 (sc1)
+#endif
   static constexpr bool kWriteThrough = false; // producers and consumers share an XCD's L2: plain stores
   static constexpr bool kSse = SSE;            // a kernel variant of its own: the extra live registers would spill in the common one
   static constexpr bool kRdoq = RDOQ;          // likewise (doubles, and the 4x4 lane's private arrays)
@@ -1027,7 +1086,11 @@ struct PackedSrc {
         }
       }
     }
+#ifdef HMX_PACKED_L1INV
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // buffer_inv sc1
+#else
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler ordering: no reconstruction load moves above the poll
+#endif
     // the next wave-item's ticket has long returned: fetch its descriptor behind the reference loads that follow
     nx->t = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx->ticket_raw);
     if (nx->t < nx->total) nx->d = nx->descs[nx->base + nx->t];

@@ -25,6 +25,11 @@ SETS = {
     "wait": "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS",
     "mfma": "SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU",
     "lds": "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_WAVE_CYCLES",
+    # the vector-memory pipe (texture addresser, L1): busy against GRBM_GUI_ACTIVE x 256 CUs, and who stalls whom
+    "mem1": "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_BUSY_avr TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_GATE_EN1_sum",
+    "mem2": "TA_FLAT_WAVEFRONTS_sum TA_BUFFER_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum",
+    "mem3": "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum",
+    "mem4": "TD_TD_BUSY_sum TD_TC_STALL_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum",
     "fetch": "FETCH_SIZE",
     "write": "WRITE_SIZE",
 }
@@ -127,6 +132,16 @@ def main():
         d["hbm_read_bytes_per_launch"] = round(2 * C["FETCH_SIZE"] * 1024 / n)
         d["hbm_write_bytes_per_launch"] = round(C["WRITE_SIZE"] * 1024 / n)
         d["note_fetch"] = "gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled (MI355X_MICROARCH.md, HBM)"
+    if "TA_TA_BUSY_sum" in C and C.get("GRBM_GUI_ACTIVE"):
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs' dispatches of the counter file: per-XCD cycles x 8; a TA per CU (256)
+        d["ta_busy_share"] = round(C["TA_TA_BUSY_sum"] / (C["GRBM_GUI_ACTIVE"] / 8 * 256), 4)
+        d["ta_busy_avr"] = C.get("TA_BUSY_avr")
+    for k in ("TA_FLAT_WAVEFRONTS_sum", "TA_BUFFER_WAVEFRONTS_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum",
+              "TCP_GATE_EN1_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum", "TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum",
+              "TD_TD_BUSY_sum", "TD_TC_STALL_sum", "TCP_TCC_READ_REQ_LATENCY_sum", "TCP_TA_TCP_STATE_READ_sum", "GRBM_GUI_ACTIVE", "TA_TA_BUSY_sum",
+              "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_FLAT", "SQ_ACTIVE_INST_VMEM", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"):
+        if k in C:
+            d[k] = C[k]
     summary["derived"] = d
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     path = os.path.join(ROOT, "gpurun_out", f"{a.tag}_pmc_summary.json")
