@@ -78,12 +78,18 @@ __device__ __forceinline__ unsigned lev_row_off(const PlaneView &V, int x, int y
   return V.lev_stride ? __umul24((unsigned)(y + r), (unsigned)V.lev_stride) + x : tile_base(V.rec.ctu_w, V.rec.clog, x, y) + (unsigned)r * N;
 }
 
+#ifdef HMX_MARKS /* tools/section_mix.py: section boundaries as comments in the ISA */
+#define HMX_MARK(n, id) asm volatile("; HMXMARK %0 %1" ::"n"(n), "n"(id) : "memory")
+#else
+#define HMX_MARK(n, id)
+#endif
 template <int N, bool ENC, bool ONCE = false, typename SRC>
 __device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, const PicDev &P, int count) {
   constexpr int SL = 64 / N;
   const int lane = lane_id(), slot = lane / N, gl = lane % N;
   TuLds<N> &L = reinterpret_cast<TuLds<N> *>(smem)[slot];
   for (int base = 0; ONCE ? base < 1 : base < count; base += SL) { // ONCE: the level schedule hands a wave at most one pass
+    HMX_MARK(N, 0);
     const int i = base + slot;
     const bool active = i < count;
     const FTu ft = src.desc(active ? i : 0);
@@ -99,9 +105,13 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, cons
     int *lev_row = V.lev + lev_row_off<N>(V, x, y, gl);
     const size_t pb0 = tphys(R.qstride, b0);
     if (ENC && active) tload_row<N>(V.org + pb0, R.qstride, gl, row); // independent of the references
+    HMX_MARK(N, 1);
     src.wait(); // packed schedule: the blocks this one predicts from belong to earlier rows of the same launch
+    HMX_MARK(N, 2);
     intra_refs_tiled<N, N, SRC::kCoherent>(L, gl, active, R, x, y, pb0, luma, avail, P);
+    HMX_MARK(N, 3);
     intra_pred_block<N>(L, gl, t.mode, luma, P, pred);
+    HMX_MARK(N, 4);
     if (ENC) {
 #pragma unroll
       for (int k = 0; k < N; k++) row[k] = wrap16(row[k] - pred[k]);
@@ -115,6 +125,7 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, cons
       } else {
         fwd_tq_block<N>(L, gl, active, row, ts, luma, luma, scan_idx, true, P);
       }
+      HMX_MARK(N, 5);
       if (active) {
         load_row32<N>(&L.tile[gl][0], row);
 #pragma unroll
@@ -135,13 +146,16 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, cons
       wave_sync();
     }
     // inverse of all-zero levels is exactly zero, so the reference's "if (uiAbsSum)" needs no branch
+    HMX_MARK(N, 6);
     inv_tq_block<N>(L, gl, active, ts, luma, luma, true, P, row);
+    HMX_MARK(N, 7);
     if (active) {
       const int mx = (1 << P.bit_depth) - 1;
 #pragma unroll
       for (int k = 0; k < N; k++) row[k] = clip3(0, mx, pred[k] + row[k]);
       tstore_row<N, SRC::kWriteThrough>(R.p + pb0, R.qstride, gl, row);
     }
+    HMX_MARK(N, 8);
     if constexpr (ENC && SRC::kSse) {
       if (src.want_sse()) { // wave-uniform: getDistPart right behind the reconstruction (TEncSearch.cpp:1163), fused
         int o[N];
@@ -289,22 +303,71 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
     const TiledPlane &R = V.rec;
     const unsigned b0 = tile_base(R.ctu_w, R.clog, x, y);
     const size_t pb0 = tphys(R.qstride, b0); // a tile never straddles quads
-    int v[16];
+    // Packed schedule: the vector-memory pipe, not the ALU, bounds this chain (PMC, 2048 pictures of 4x4 blocks: texture addresser
+    // busy 0.99 of the time, VALU 0.3; a lane's 16-byte access is a request of its own and a lane's four level stores are four partial
+    // writes of one 64-byte line).  So the lanes move a block's bytes TOGETHER and hand them to the block's lane through LDS: two
+    // lanes per 32-byte tile (source, reconstruction), four per 64 bytes of levels.  The lanes without a block stay for that (they
+    // repeat item 0's arithmetic and store nothing).  Elsewhere a lane works alone from the wait on.
+    constexpr bool COOP = ONCE && SRC::kCoherent && !SRC::kRdoq;
+    unsigned long long *const co_addr = reinterpret_cast<unsigned long long *>(smem); // [64] a block's address, by lane
+    i4v *const co_tile = reinterpret_cast<i4v *>(smem + 512);                          // [64][2] halves of the blocks' tiles
+    int *const co_rows = reinterpret_cast<int *>(smem);                                // [64][20]: 16 levels, the block's address, padding to 80 bytes
+    int *lev_ptr = V.lev;
+    const bool zlev = V.lev_stride == 0;
+    const unsigned l0 = zlev ? b0 : __umul24((unsigned)y, (unsigned)V.lev_stride) + x;
+    const int lrow = zlev ? 4 : V.lev_stride;
+    const bool co_lev = COOP && __all(zlev); // the reference's coefficient layout: a block's levels are 64 contiguous bytes (every plane of a call alike)
+    int v[16], w[16];
+    i4v o0, o1, lq[4];
     if ((HMX_X_SKIP & 4) && ENC) {
 #pragma unroll
       for (int k = 0; k < 16; k++) v[k] = (lane * 7 + k * 13 + x) & 255;
+    } else if (ENC && COOP) {
+      co_addr[lane] = (unsigned long long)(uintptr_t)(V.org + pb0);
+      wave_sync();
+      const i4v *a0 = reinterpret_cast<const i4v *>((uintptr_t)co_addr[lane >> 1]), *a1 = reinterpret_cast<const i4v *>((uintptr_t)co_addr[32 + (lane >> 1)]);
+      o0 = stream_load(a0 + (lane & 1)), o1 = stream_load(a1 + (lane & 1)); // blocks 0..31, 32..63: half (lane & 1) of block (lane >> 1)
     } else if (ENC && active) {
-      const i4v o0 = stream_load(reinterpret_cast<const i4v *>(V.org + pb0)), o1 = stream_load(reinterpret_cast<const i4v *>(V.org + pb0 + 8));
+      o0 = stream_load(reinterpret_cast<const i4v *>(V.org + pb0)), o1 = stream_load(reinterpret_cast<const i4v *>(V.org + pb0 + 8));
+    }
+    if (!ENC && co_lev) { // decoder direction: the levels are there before the neighbours are
+      wave_sync();
+      *reinterpret_cast<unsigned long long *>(co_rows + lane * 20 + 16) = (unsigned long long)(uintptr_t)(lev_ptr + l0);
+      wave_sync();
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        v[2 * k] = (short)(o0[k] & 0xffff), v[2 * k + 1] = o0[k] >> 16;
-        v[8 + 2 * k] = (short)(o1[k] & 0xffff), v[8 + 2 * k + 1] = o1[k] >> 16;
+        const i4v *from = reinterpret_cast<const i4v *>((uintptr_t) * reinterpret_cast<const unsigned long long *>(co_rows + (16 * k + (lane >> 2)) * 20 + 16));
+        lq[k] = stream_load(from + (lane & 3));
       }
     }
     src.wait(); // the whole wave (packed schedule): the neighbours belong to earlier rows of the same launch
-    // Packed schedule, encoder direction: the levels leave through LDS so that four lanes write one block's 64 bytes (below); the
-    // lanes without a block stay for that (they repeat item 0's arithmetic and store nothing).  Elsewhere a lane works alone from here.
-    constexpr bool COOP = ENC && ONCE && SRC::kCoherent && !SRC::kRdoq;
+    if (ENC && !(HMX_X_SKIP & 4)) {
+      if constexpr (COOP) {
+        wave_sync();
+        co_tile[lane] = o0, co_tile[64 + lane] = o1;
+        wave_sync();
+        o0 = co_tile[2 * lane], o1 = co_tile[2 * lane + 1];
+        wave_sync(); // the reference lines take the scratch
+      }
+      if (COOP || active) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          v[2 * k] = (short)(o0[k] & 0xffff), v[2 * k + 1] = o0[k] >> 16;
+          v[8 + 2 * k] = (short)(o1[k] & 0xffff), v[8 + 2 * k + 1] = o1[k] >> 16;
+        }
+      }
+    }
+    if (!ENC && co_lev) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) *reinterpret_cast<i4v *>(co_rows + (16 * k + (lane >> 2)) * 20 + 4 * (lane & 3)) = lq[k];
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const i4v o = *reinterpret_cast<const i4v *>(co_rows + lane * 20 + 4 * r);
+        w[4 * r] = o[0], w[4 * r + 1] = o[1], w[4 * r + 2] = o[2], w[4 * r + 3] = o[3];
+      }
+      wave_sync(); // the reference lines take the scratch
+    }
     if (!COOP && !active) continue;
     // ---- reference line (fillReferenceSamples): sequential padding is natural inside one lane.
     int *line = LS.line[lane];
@@ -391,11 +454,6 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
       build_main_ref<4, 1>(line, me, mode, 0);
       intra_pred_samples<4, 16>(line, me, mode, luma, B, dcs, [](int s) { return s >> 2; }, [](int s) { return s & 3; }, pred);
     }
-    int *lev_ptr = V.lev;
-    const bool zlev = V.lev_stride == 0;
-    const unsigned l0 = zlev ? b0 : __umul24((unsigned)y, (unsigned)V.lev_stride) + x;
-    const int lrow = zlev ? 4 : V.lev_stride;
-    int w[16];
     if (ENC) {
 #pragma unroll
       for (int k = 0; k < 16; k++) v[k] = wrap16(v[k] - pred[k]);
@@ -424,39 +482,32 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
 #pragma unroll
         for (int k = 0; k < 16; k++) w[k] = level_of(w[k]);
       }
-      // A lane's four 16-byte stores are four requests and -- the level buffers stream to HBM -- four partial writes of one 64-byte
-      // line (timing experiment, 2048 pictures of 4x4 blocks: 254 ms with them, 155 ms without, against 14 ms for the reconstruction's
-      // two stores and 67 ms for the arithmetic alone).  In the reference's coefficient layout (stride 0) a block's levels are 64
-      // contiguous bytes: the lanes exchange rows through LDS and lanes 4j..4j+3 write block j's line in ONE store instruction.
-      bool coop_done = false;
-      if constexpr (COOP) {
-        if (__all(zlev)) { // (every plane of a call has the same layout)
-          wave_sync(); // the reference lines are spent in every lane
-          int *rows = reinterpret_cast<int *>(smem); // [64][20]: 16 levels, the block's address, padding to 80 bytes
-          int *mine = rows + lane * 20;
+      // A lane's four 16-byte level stores cost more than the rest of the block's memory traffic together (timing experiment, 2048
+      // pictures of 4x4 blocks: 254 ms with them, 155 ms without, against 14 ms for the reconstruction's two stores and 67 ms for the
+      // arithmetic alone): lanes 4j..4j+3 write block j's line in ONE store instruction.
+      if (co_lev) {
+        wave_sync(); // the reference lines are spent in every lane
+        int *mine = co_rows + lane * 20;
 #pragma unroll
-          for (int r = 0; r < 4; r++) *reinterpret_cast<i4v *>(mine + 4 * r) = i4v{w[4 * r], w[4 * r + 1], w[4 * r + 2], w[4 * r + 3]};
-          *reinterpret_cast<unsigned long long *>(mine + 16) = active ? (unsigned long long)(uintptr_t)(lev_ptr + l0) : 0ull;
-          wave_sync();
+        for (int r = 0; r < 4; r++) *reinterpret_cast<i4v *>(mine + 4 * r) = i4v{w[4 * r], w[4 * r + 1], w[4 * r + 2], w[4 * r + 3]};
+        *reinterpret_cast<unsigned long long *>(mine + 16) = active ? (unsigned long long)(uintptr_t)(lev_ptr + l0) : 0ull;
+        wave_sync();
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const int *from = rows + (16 * k + (lane >> 2)) * 20;
-            const i4v o = *reinterpret_cast<const i4v *>(from + 4 * (lane & 3));
-            const unsigned long long to = *reinterpret_cast<const unsigned long long *>(from + 16);
-            if (to && (!(HMX_X_SKIP & 1) || o[0] == 0x7fffffff)) piece_store(reinterpret_cast<i4v *>((int *)(uintptr_t)to) + (lane & 3), o);
-          }
-          wave_sync();
-          coop_done = true;
+        for (int k = 0; k < 4; k++) {
+          const int *from = co_rows + (16 * k + (lane >> 2)) * 20;
+          const i4v o = *reinterpret_cast<const i4v *>(from + 4 * (lane & 3));
+          const unsigned long long to = *reinterpret_cast<const unsigned long long *>(from + 16);
+          if (to && (!(HMX_X_SKIP & 1) || o[0] == 0x7fffffff)) piece_store(reinterpret_cast<i4v *>((int *)(uintptr_t)to) + (lane & 3), o);
         }
-      }
-      if (!coop_done && active) {
+        wave_sync();
+      } else if (active) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           i4v o = {w[4 * r], w[4 * r + 1], w[4 * r + 2], w[4 * r + 3]};
           if (!(HMX_X_SKIP & 1) || o[0] == 0x7fffffff) piece_store(reinterpret_cast<i4v *>(lev_ptr + l0 + (unsigned)r * (unsigned)lrow), o);
         }
       }
-    } else {
+    } else if (!co_lev) {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const i4v o = *reinterpret_cast<const i4v *>(lev_ptr + l0 + (unsigned)r * (unsigned)lrow);
@@ -495,6 +546,18 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
         st_rec4<true>(R.p + pb0 + 4 * k, a);
         st_rec4<true>(R.p + pb0 + 8 + 4 * k, b);
       }
+    } else if constexpr (COOP) { // two lanes per tile: one 32-byte request instead of two of 16
+      wave_sync();
+      co_addr[lane] = active ? (unsigned long long)(uintptr_t)(R.p + pb0) : 0ull;
+      co_tile[2 * lane] = r0, co_tile[2 * lane + 1] = r1;
+      wave_sync();
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const unsigned long long to = co_addr[32 * j + (lane >> 1)];
+        const i4v o = co_tile[64 * j + lane];
+        if (to && (!(HMX_X_SKIP & 8) || o[0] == 0x7fffffff)) *(reinterpret_cast<i4v *>((uintptr_t)to) + (lane & 1)) = o;
+      }
+      wave_sync();
     } else if (active && (!(HMX_X_SKIP & 8) || r0[0] == 0x7fffffff)) {
       *reinterpret_cast<i4v *>(R.p + pb0) = r0;
       *reinterpret_cast<i4v *>(R.p + pb0 + 8) = r1;
