@@ -5,6 +5,9 @@
 #pragma once
 #include "hmx_host.h"
 
+#ifndef HMX_X_SKIP
+#define HMX_X_SKIP 0 /* timing experiments only (results are wrong), 4x4 lane chain: 1 no level stores, 2 no reference loads, 4 no source loads, 8 no reconstruction stores */
+#endif
 #define HMX_WAVE_SMEM 7680 /* max(4 * sizeof(TuLds<16>), sizeof(Lane4Lds), ...) - checked below */
 static_assert(4 * sizeof(TuLds<16>) <= HMX_WAVE_SMEM, "per-wave LDS scratch");
 static_assert(16 * sizeof(TuLds<4>) <= HMX_WAVE_SMEM && 8 * sizeof(TuLds<8>) <= HMX_WAVE_SMEM &&
@@ -283,9 +286,6 @@ __device__ __forceinline__ void lane4_inverse(const int *lv, bool use_dst, bool 
   }
 }
 
-#ifndef HMX_X_SKIP
-#define HMX_X_SKIP 0 /* timing experiments only (results are wrong): 1 no level stores, 2 no reference loads, 4 no source loads, 8 no reconstruction stores */
-#endif
 template <bool ENC, bool ONCE = false, typename SRC>
 __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, const PicDev &P, int count) {
   Lane4Lds &LS = *reinterpret_cast<Lane4Lds *>(smem);
