@@ -6,7 +6,7 @@
 #include "hmx_host.h"
 
 #ifndef HMX_X_SKIP
-#define HMX_X_SKIP 0 /* timing experiments only (results are wrong), 4x4 lane chain: 1 no level stores, 2 no reference loads, 4 no source loads, 8 no reconstruction stores */
+#define HMX_X_SKIP 0 /* timing experiments only (results are wrong), 4x4 lane chain: 1 no level stores, 2 no reference loads, 4 no source loads, 8 no reconstruction stores; 16: no level stores of 8x8 and 16x16 blocks */
 #endif
 #define HMX_WAVE_SMEM 7680 /* max(4 * sizeof(TuLds<16>), sizeof(Lane4Lds), ...) - checked below */
 static_assert(4 * sizeof(TuLds<16>) <= HMX_WAVE_SMEM, "per-wave LDS scratch");
@@ -134,8 +134,9 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, cons
 #pragma unroll
         for (int k = 0; k < N; k++) row[k] = level_of(row[k]);
 #ifdef HMX_STREAM_NT
-        if (V.lev_stride == 0) stream_store_row32<N>(lev_row, row); // the reference's coefficient layout: 16-byte aligned rows
-        else
+        if (V.lev_stride == 0) {
+          if (!(HMX_X_SKIP & 16) || row[0] == 0x7fffffff) stream_store_row32<N>(lev_row, row); // the reference's coefficient layout: 16-byte aligned rows
+        } else
 #endif
           store_row32<N>(lev_row, row);
       }
