@@ -491,12 +491,16 @@ static void plan_release(hmx_ctx *c, hmx_intra_plan *pl) {
 //                   the level walk: availability (intra_avail_mask) and what its mode reads of it, closed under the padding
 //                   rule (the same 280 unit masks, uploaded once) -- everything about a block that does not depend on others
 //   k_plan_levels   the dependency levels.  One launch per CTU diagonal d = X + 2Y (a CTU reads its left, above-left, above
-//                   and above-right neighbours only, all on earlier diagonals); a LANE owns (picture, CTU, plane) and walks
-//                   the CTU's blocks in coding order exactly as the host does: level = 1 + the highest level among the
-//                   units the block depends on.  The CTU's 16 x 16 grid of unit levels lives in the lane's
-//                   LDS row; the bottom row and right column go to small edge arrays in memory for the CTUs that follow.
+//                   and above-right neighbours only, all on earlier diagonals); a LANE owns a CTU of a picture and walks
+//                   its blocks in coding order exactly as the host does: level = 1 + the highest level among the
+//                   units the block depends on.  The CTU's grid of unit levels lives in the lane's LDS row; the bottom row
+//                   and right column go to small edge arrays in memory for the CTUs that follow.  A block depends on blocks
+//                   of its own plane only, so the walk is TWO independent chains of launches on two streams: luma lanes
+//                   (k_plan_levels<0>, a 16 x 16 grid of 4-sample units) and chroma lanes (k_plan_levels<1>, Cb and Cr in one
+//                   pass over the CTU's records, two 8 x 8 grids of 2 x 2-unit cells: chroma blocks are that coarse).
 //                   Sequential per lane by nature, and 64 CTUs wide per wave: 2048 pictures x ~16 CTUs per diagonal keep
-//                   the chip full.
+//                   the chip full (LDS per wave sets how many waves a CU holds: 4 luma / 6 chroma; one chain fills the
+//                   tail of the other's rounds).
 //   (one 8-byte-per-picture read-back: the number of levels sizes the level tables)
 //                   The walk also counts its blocks into the level table, (level, size) by (level, size).
 //   k_plan_scan     the starts of the level table's buckets from their counts (one workgroup per picture)
@@ -589,8 +593,8 @@ __global__ __launch_bounds__(256) void k_plan_ctus(const hmx_tu *tus, const uint
 // A lane's LDS row: the CTU's grid of 16-bit levels (level + 1; 0 = no block), then the cells beyond its top edge (corner, above,
 // above-right) and beyond its left edge, fetched once from the edge arrays.  LUMA: one cell per unit of four samples, 16 x 16 + 33
 // + 16 = 305 halfwords in 154 words.  CHROMA (RES = 1): its blocks are at least two units wide and aligned to that, so a cell is
-// 2 x 2 units: 8 x 8 + 17 + 8 = 89 halfwords in 46 words -- a quarter of the LDS, and LDS is what limits how many of these waves a CU
-// holds (4 luma waves, 13 chroma waves).  Rows start on 8-byte boundaries (a large block writes four cells per store); lanes that
+// 2 x 2 units: 8 x 8 + 17 + 8 = 89 halfwords in 46 words, two of them (Cb, Cr) per lane -- and LDS is what limits how many of these
+// waves a CU holds (4 luma waves, 6 chroma waves).  Rows start on 8-byte boundaries (a large block writes four cells per store); lanes that
 // read the same cell of their CTUs spread over 32 of the 64 banks.
 template <int RES>
 struct PlanGrid {
