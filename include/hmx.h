@@ -62,7 +62,8 @@ int hmx_sync(hmx_ctx *ctx);
  * changes one afterwards, value NULL restores the default.  HMX_INTRA_SCHEDULE = packed (default) | level | wave,
  * HMX_INTRA_ACROSS, HMX_INTRA_STREAMS, HMX_PIPELINE_CONV, HMX_GRAPH (level schedules), HMX_PACK_SLOTS4 = 16 | 64,
  * HMX_PACK_GROUP, HMX_PACK_WAVES, HMX_PACK_SLEEP0, HMX_PACK_SLEEP1 (packed schedule), HMX_RDOQ_LANE (RDOQ: every block
- * through the one-lane-per-block kernel), HMX_PLAN_ROWS (device plan builder: rows of the level table per picture to start with). */
+ * through the one-lane-per-block kernel), HMX_PLAN_ROWS (device plan builder: rows of the level table per picture to start with), HMX_PLAN_STREAMS (1: its luma and chroma
+ * level walks one after the other instead of side by side on two streams). */
 int hmx_set_option(hmx_ctx *ctx, const char *name, const char *value);
 /* device memory + timing plumbing so that callers need no HIP headers */
 int hmx_malloc(hmx_ctx *ctx, size_t bytes, void **dptr);

@@ -83,6 +83,22 @@ def test_device_plan_more_levels_than_rows(ctx, hmx_opts):
         L.hmx_intra_plan_destroy(ctx.h, p)
 
 
+def test_device_plan_walks_one_after_the_other(ctx, hmx_opts):
+    """The luma and the chroma level walk are independent launch chains on two streams; HMX_PLAN_STREAMS=1 runs them in sequence
+    on the context's own stream -- same plans either way."""
+    L = capi.lib()
+    w, h = 416, 240
+    pp = capi.PicParam(w, h, 30, 0, capi.I_SLICE, 1)
+    tus = [workload.make_tus(5200 + i, w, h, t) for i, t in enumerate(["mix", 8, "mix", 4])]
+    host = ctx.intra_plans(tus, pp)
+    hmx_opts(ctx, HMX_PLAN_STREAMS="1")
+    dev = _device_plans(ctx, tus, pp)
+    for i, (a, b) in enumerate(zip(host, dev)):
+        _same_tables(ctx, a, b, ("one stream", i))
+    for p in host + dev:
+        L.hmx_intra_plan_destroy(ctx.h, p)
+
+
 def test_device_plan_sparse_and_errors(ctx):
     """A plan that lists only part of a picture's blocks (the intra coding units of an inter picture: whole CTUs and parts of
     CTUs missing), and the argument checks of the host analysis."""

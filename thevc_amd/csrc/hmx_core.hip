@@ -53,7 +53,7 @@ PicDev make_picdev(const hmx_ctx *c, const hmx_pic_param *pp) {
 // Tuning knobs: read from the environment ONCE, in hmx_create; hmx_set_option changes one afterwards (A/B runs, and the
 // parity tests that hold the schedules against each other).  value == NULL restores the default.
 static const char *const kKnobNames[] = {"HMX_INTRA_SCHEDULE", "HMX_INTRA_ACROSS", "HMX_INTRA_STREAMS", "HMX_PIPELINE_CONV", "HMX_GRAPH",
-                                         "HMX_PACK_SLOTS4",    "HMX_PACK_GROUP",      "HMX_PACK_WAVES",    "HMX_PACK_SLEEP0",   "HMX_PACK_SLEEP1",  "HMX_PLAN_ROWS",
+                                         "HMX_PACK_SLOTS4",    "HMX_PACK_GROUP",      "HMX_PACK_WAVES",    "HMX_PACK_SLEEP0",   "HMX_PACK_SLEEP1",  "HMX_PLAN_ROWS",      "HMX_PLAN_STREAMS",
                                          "HMX_RDOQ_LANE"};
 static bool apply_knob(hmx_ctx *c, const char *name, const char *v) {
   auto &k = c->knob;
@@ -70,6 +70,7 @@ static bool apply_knob(hmx_ctx *c, const char *name, const char *v) {
   else if (n == "HMX_PACK_SLEEP1") k.pack_sleep1 = v ? std::max(0, atoi(v)) : -1;
   else if (n == "HMX_RDOQ_LANE") k.rdoq_lane_only = v && v[0] != '0';
   else if (n == "HMX_PLAN_ROWS") k.plan_rows = v ? std::max(1, atoi(v)) : 0;
+  else if (n == "HMX_PLAN_STREAMS") k.plan_one_stream = v && atoi(v) == 1;
   else return false;
   return true;
 }

@@ -303,6 +303,7 @@ struct hmx_ctx {
     int pack_group = 0;    // HMX_PACK_GROUP: pictures per group, 1..64 (0: by batch size, see pack_group_size)
     int pack_waves = 0;    // HMX_PACK_WAVES: persistent waves (0: by batch size)
     int pack_sleep0 = -1, pack_sleep1 = -1; // HMX_PACK_SLEEP0 / 1: poll back-off, units of 64 clocks (-1: default)
+    bool plan_one_stream = false; // HMX_PLAN_STREAMS=1: the luma and chroma level walks of the device plan builder one after the other (A/B)
     int plan_rows = 0;     // HMX_PLAN_ROWS: rows of the level table per picture the device plan builder starts with (0: from the picture size)
     bool rdoq_lane_only = false; // HMX_RDOQ_LANE: every block through the one-lane-per-block kernel (round 1's, A/B and cross-check)
   } knob;

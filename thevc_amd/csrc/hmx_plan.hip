@@ -1011,7 +1011,7 @@ extern "C" int hmx_intra_plan_create_device(hmx_ctx *c, const hmx_tu *d_tus, con
     // A block depends on blocks of its own plane only: the luma walk and the chroma walk are two independent chains of launches,
     // on two streams (one fills the tail of the other's rounds: a wave holds 39 KB / 23 KB of LDS for as long as it walks)
     hipStream_t st_c = st;
-    if (e1 == hipSuccess && !getenv("HMX_PLAN_ONE_STREAM")) {
+    if (e1 == hipSuccess && !c->knob.plan_one_stream) {
       if (c->n_side < 1) {
         if (!c->ev_fork) e1 = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
         if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&c->side[0], hipStreamNonBlocking);
