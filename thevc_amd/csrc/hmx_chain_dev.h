@@ -376,17 +376,22 @@ __device__ __forceinline__ void wave_chain_4_lane(char *smem, const SRC &src, co
       const int ul = luma ? 2 : 1, n = 4 >> ul; // unit = 4 (luma) / 2 (chroma) samples
       // The 17 reference samples lie in five neighbour tiles: column 3 of the below-left and left
       // tiles, sample (3,3) of the corner tile, row 3 of the above and above-right tiles.  One tile
-      // address each; a tile none of whose units is available is replaced by the block's own tile
-      // (a valid address; the availability mask drops the values).  11 loads, one round trip.
+      // address each.  `avail` is what the plan put into the descriptor: the units the block's mode READS among the available
+      // ones, closed under the padding rule (hmx_plan.hip) -- padding and gathering work on it as on the availability.
       int raw[17];
       {
         const unsigned m_bl = (1u << n) - 1, m_lf = m_bl << n, m_c = 1u << (2 * n), m_a = m_bl << (2 * n + 1), m_ar = m_a << n;
         const bool has_bl = avail & m_bl, has_lf = avail & m_lf, has_c = avail & m_c, has_a = avail & m_a, has_ar = avail & m_ar;
-        const short *t_bl = R.p + (has_bl ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x - 4, y + 4)) : pb0);
-        const short *t_lf = R.p + (has_lf ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x - 4, y)) : pb0);
-        const short *t_c = R.p + (has_c ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x - 4, y - 4)) : pb0);
-        const short *t_a = R.p + (has_a ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x, y - 4)) : pb0);
-        const short *t_ar = R.p + (has_ar ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, x + 4, y - 4)) : pb0);
+        // A tile the block does not read is not fetched: its lanes all name ONE address (the first lane's own tile -- inside the pool
+        // whatever picture that lane works on), which the memory pipe serves as a single request; the mask drops the values.
+        const short *own = R.p + pb0;
+        const short *idle = reinterpret_cast<const short *>((uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((uintptr_t)own >> 32)) << 32) |
+                                                                       (unsigned)__builtin_amdgcn_readfirstlane((int)(uintptr_t)own)));
+        const short *t_bl = has_bl ? R.p + tphys(R.qstride, tile_base(R.ctu_w, R.clog, x - 4, y + 4)) : idle;
+        const short *t_lf = has_lf ? R.p + tphys(R.qstride, tile_base(R.ctu_w, R.clog, x - 4, y)) : idle;
+        const short *t_c = has_c ? R.p + tphys(R.qstride, tile_base(R.ctu_w, R.clog, x - 4, y - 4)) : idle;
+        const short *t_a = has_a ? R.p + tphys(R.qstride, tile_base(R.ctu_w, R.clog, x, y - 4)) : idle;
+        const short *t_ar = has_ar ? R.p + tphys(R.qstride, tile_base(R.ctu_w, R.clog, x + 4, y - 4)) : idle;
         // One request per tile.  A lane's load instruction is a request of its own to the L2 on the coherent path (sc1: the vector L1
         // is bypassed), and the vector-memory pipe, not the ALU, bounds this chain (PMC, 2048 pictures of 4x4 blocks: texture addresser
         // busy 0.99 of the time, 13 read requests per block, VALU 0.3): the right column of the two left tiles comes as the tile's two

@@ -180,7 +180,7 @@ static const char *plan_build_host(const hmx_ctx *c, const hmx_tu *tus, int n_tu
       s.new_level = (k == 0 || level[ids[k]] != level[ids[k - 1]]) ? 1 : 0;
       segs.push_back(s);
       for (size_t q = k; q < e; q++)
-        stus.push_back(FTu{tus[ids[q]], (uint32_t)masks[ids[q]], (uint32_t)(masks[ids[q]] >> 32)});
+        stus.push_back(FTu{tus[ids[q]], (uint32_t)deps[ids[q]], (uint32_t)(deps[ids[q]] >> 32)}); // (see ltus below)
       k = e;
     }
     seg_range[(size_t)b * 2 + 1] = (uint32_t)segs.size();
@@ -257,7 +257,11 @@ static const char *plan_build_host(const hmx_ctx *c, const hmx_tu *tus, int n_tu
     std::sort(order.begin(), order.end());
     for (int k = 0; k < n_tu; k++) {
       const int i = (int)(order[k] & 0xfffffu);
-      ltus[k] = FTu{tus[i], (uint32_t)masks[i], (uint32_t)(masks[i] >> 32)};
+      // The descriptor carries the units the block DEPENDS on in the availability's place.  The chains gather and pad with it exactly as
+      // with the availability (the mask is closed under the padding rule: the source of every padded unit that is read is in it, and it
+      // is the nearest unit of the mask before the padded one because it is the nearest available one), positions the mode does not read
+      // get padded values instead of samples nobody looks at -- and a third to a half of the reference loads are not made at all.
+      ltus[k] = FTu{tus[i], (uint32_t)deps[i], (uint32_t)(deps[i] >> 32)};
     }
   }
   // CTU diagonals d = X + 2Y: (X,Y) needs (X-1,Y), (X-1,Y-1), (X,Y-1), (X+1,Y-1)
@@ -568,8 +572,8 @@ __global__ __launch_bounds__(256) void k_plan_ctus(const hmx_tu *tus, const uint
       {
         const int sh = t.plane ? 1 : 0, lx = t.x << sh, ly = t.y << sh, ls = (1 << t.log2n) << sh;
         const unsigned long long avail = intra_avail_mask_fast(lx, ly, ls, G.P);
-        ftu[b0 + i] = FTu{t, (uint32_t)avail, (uint32_t)(avail >> 32)}; // the descriptor as the chain wants it, moved into place by k_plan_gather
         const unsigned long long dep = plan_dep_mask(need, t.log2n, t.plane == 0, t.mode, avail);
+        ftu[b0 + i] = FTu{t, (uint32_t)dep, (uint32_t)(dep >> 32)}; // the descriptor as the chain wants it (plan_build_host: the units read stand for the availability), moved into place by k_plan_gather
         rec[b0 + i] = dep | (unsigned long long)((lx & 63) >> 2) << 40 | (unsigned long long)((ly & 63) >> 2) << 44 | (unsigned long long)(ls >> 2) << 48 |
                       (unsigned long long)t.plane << 52 | (unsigned long long)(t.log2n - 2) << 54;
       }
