@@ -370,7 +370,7 @@ __device__ __forceinline__ void intra_refs(TuLds<N> &L, int gl, bool active, Fet
 // sample of one tile row of the corner tile and N/2 whole tile rows above (above + above-right).  One 8-byte access
 // each, 2N + 1 + N/2 of them shared by the block's NL lanes in ceil(.. / NL) rounds, every one issued before the first
 // is consumed (the sample-by-sample gather made 4N+1 two-byte accesses, and HBM saw ~4x the bytes the block needs).
-// Unavailable units are not loaded (the block's own first tile row stands in as a valid address); the reference's
+// Units outside the mask are not loaded (one address stands in for all of them); the reference's
 // padding rule then runs on the raw samples in LDS: position p copies sample q(p), the nearest available sample
 // before it (the first available one for a leading run), exactly as build_ref_line picks its load address.
 // pb0 = element index of the block's first sample.  Leaves L.line (raw) and L.fline (smoothed, luma N > 4).
@@ -379,6 +379,11 @@ __device__ __forceinline__ void intra_refs_tiled(TuLds<N> &L, int gl, bool activ
                                                  bool luma, unsigned long long avail, const PicDev &P) {
   constexpr int T = 2 * N + 1 + N / 2, IT = (T + NL - 1) / NL;
   const int ul = luma ? 2 : 1, n = N >> ul;
+  // loads of units outside the mask name ONE address in the whole wave (the first lane's block: a valid address in any picture's
+  // pool), which the memory pipe serves as a single request
+  const short *own = R.p + pb0;
+  const short *idle = reinterpret_cast<const short *>((uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((uintptr_t)own >> 32)) << 32) |
+                                                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(uintptr_t)own)));
   if (active) {
     s4v v[IT];
 #pragma unroll
@@ -396,8 +401,7 @@ __device__ __forceinline__ void intra_refs_tiled(TuLds<N> &L, int gl, bool activ
           tx = x + 4 * j, ty = y - 1, u = 2 * n + 1 + ((4 * j) >> ul), um = luma ? 1u : 3u;
         }
         const bool on = ((avail >> u) & um) != 0;
-        const size_t o = on ? tphys(R.qstride, tile_base(R.ctu_w, R.clog, tx, ty) + ((unsigned)(ty & 3) << 2)) : pb0;
-        v[it] = ld_rec4<COH>(R.p + o);
+        v[it] = ld_rec4<COH>(on ? R.p + tphys(R.qstride, tile_base(R.ctu_w, R.clog, tx, ty) + ((unsigned)(ty & 3) << 2)) : idle);
       }
     }
 #pragma unroll
