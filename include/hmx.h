@@ -60,7 +60,7 @@ int hmx_sync(hmx_ctx *ctx);
 /* Tuning knobs (the reference has none: these select between schedules of the SAME arithmetic for A/B runs and
  * cross-checks).  Each is read once from the environment variable of the same name in hmx_create; hmx_set_option
  * changes one afterwards, value NULL restores the default.  HMX_INTRA_SCHEDULE = packed (default) | level | wave,
- * HMX_INTRA_ACROSS, HMX_INTRA_STREAMS, HMX_PIPELINE_CONV, HMX_GRAPH (level schedules), HMX_PACK_SLOTS4 = 16 | 64,
+ * HMX_INTRA_ACROSS, HMX_INTRA_STREAMS, HMX_PIPELINE_CONV, HMX_GRAPH (level schedules), HMX_PACK_SLOTS4 = 16 | 64, HMX_PACK_SLOTS8 = 8 | 16,
  * HMX_PACK_GROUP, HMX_PACK_WAVES, HMX_PACK_SLEEP0, HMX_PACK_SLEEP1 (packed schedule), HMX_RDOQ_LANE (RDOQ: every block
  * through the one-lane-per-block kernel), HMX_PLAN_ROWS (device plan builder: rows of the level table per picture to start with), HMX_PLAN_STREAMS (1: its luma and chroma
  * level walks one after the other instead of side by side on two streams). */

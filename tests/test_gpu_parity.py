@@ -597,13 +597,15 @@ def test_frame_intra_multi_plan(ctx, schedule, hmx_opts):
 
 
 @pytest.mark.parametrize("knobs", [{}, {"HMX_PACK_SLOTS4": "64"}, {"HMX_PACK_SLOTS4": "16", "HMX_PACK_GROUP": "64"},
-                                   {"HMX_PACK_WAVES": "3", "HMX_PACK_GROUP": "7"}, {"HMX_PACK_WAVES": "4096", "HMX_PACK_SLOTS4": "64", "HMX_PACK_GROUP": "3"}])
+                                   {"HMX_PACK_WAVES": "3", "HMX_PACK_GROUP": "7"}, {"HMX_PACK_WAVES": "4096", "HMX_PACK_SLOTS4": "64", "HMX_PACK_GROUP": "3"},
+                                   {"HMX_PACK_SLOTS8": "16"}, {"HMX_PACK_SLOTS8": "16", "HMX_PACK_GROUP": "5", "HMX_PACK_WAVES": "7"}])
 @pytest.mark.parametrize("pic,n", [((136, 72), 70), ((256, 192), 9), ((64, 64), 130)])
 def test_frame_intra_packed_own_plans(ctx, pic, n, knobs, hmx_opts):
     """The packed schedule (one persistent launch, k_intra_packed): n pictures, EVERY ONE with its own block structure
     and modes, packed into waves across pictures -- more pictures than a group holds (70 and 130 > 64: a full group
     plus a ragged one with 64-picture groups; groups of 3, 7, 9 and 17 pictures otherwise), plans with different numbers
-    of dependency levels (uniform 4x4 / 16x16 / 32x32 tilings next to mixed ones), both 4x4 wave shapes, three
+    of dependency levels (uniform 4x4 / 16x16 / 32x32 tilings next to mixed ones), both 4x4 wave shapes, both 8x8 shapes (eight
+    lanes per block, or four lanes with two rows each and sixteen blocks per wave: HMX_PACK_SLOTS8), three
     persistent waves only (at most three XCDs own all the shards; every wave-item waits behind tickets drawn much
     earlier) and far more waves than work.  Bit-exact vs the oracle, encoder and decoder direction, both level layouts."""
     hmx_opts(ctx, HMX_INTRA_SCHEDULE="packed", **knobs)
@@ -851,13 +853,16 @@ def test_resident_pictures(ctx, pic, n):
         d.free()
 
 
-@pytest.mark.parametrize("slots4", ["16", "64"])
+@pytest.mark.parametrize("slots4", ["16", "64", "64+16"])
 def test_frame_intra_sse_output(ctx, slots4, hmx_opts):
     """hmx_set_sse_output: the whole-picture encode also writes xGetSSE(org, rec) of every block (getDistPart right
     behind the reconstruction, TEncSearch.cpp:1163) at the block's first 4x4 unit in partition order.  All four block
     sizes, both 4x4 wave shapes, pictures with their own plans; vs the oracle's getSSE on the oracle's reconstruction
     (which the GPU's equals).  Switching the output off restores the plain kernel."""
-    hmx_opts(ctx, HMX_PACK_SLOTS4=slots4)
+    if "+" in slots4:  # the four-lane 8x8 shape beside the lane-per-block 4x4 one
+        hmx_opts(ctx, HMX_PACK_SLOTS4="64", HMX_PACK_SLOTS8="16")
+    else:
+        hmx_opts(ctx, HMX_PACK_SLOTS4=slots4)
     O, B, L = ol.oracle(), ctx.bit_depth, capi.lib()
     O.hmo_getSSE.restype = C.c_uint32
     w, h, n, qp = 200, 136, 5, 30

@@ -109,13 +109,16 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
           return fail(c, HMX_ERR_ARG, "frame_intra: RDOQ in the chain keeps levels in 16 bits; this QP / bit depth / block size can exceed them (raise the QP or use the flat quantiser)");
       }
   }
+  // 8x8 blocks: sixteen per wave-item on four lanes each (wave_chain_8x2) where throughput counts, eight on eight lanes where a
+  // wave-item's latency does (and under RDOQ, whose rounds are laid out for eight)
+  G.slots8 = rdoq || G.slots4 != 64 ? 8 : c->knob.slots8 ? c->knob.slots8 : (n_pics >= 512 ? 16 : 8);
   const uint64_t n_rows = (uint64_t)G.max_levels * G.n_groups;
   uint64_t waves_bound = 4 * n_rows + 4;
-  for (int s = 0; s < 4; s++) waves_bound += sz[s] / pack_slots(s, G.slots4);
+  for (int s = 0; s < 4; s++) waves_bound += sz[s] / pack_slots(s, G.slots4, G.slots8);
   if (items >= 0xffffffffull || waves_bound >= 0x0fffffffull || n_rows >= 0x7fffffffull / 4)
     return fail(c, HMX_ERR_ARG, "frame_intra: batch too large for one packed call (split it)");
   c->tev_prep_valid = false;
-  const bool same = pk.valid && pk.key == c->table_key && pk.G.n_pics == G.n_pics && pk.G.I == G.I && pk.G.slots4 == G.slots4 &&
+  const bool same = pk.valid && pk.key == c->table_key && pk.G.n_pics == G.n_pics && pk.G.I == G.I && pk.G.slots4 == G.slots4 && pk.G.slots8 == G.slots8 &&
                     pk.G.max_levels == G.max_levels;
   if (!same) {
     pk.valid = false;
@@ -262,6 +265,10 @@ static int issue_packed(hmx_ctx *c, const hmx_intra_plan *const *plans, int plan
   const dim3 grid((unsigned)pk.n_wg), blk(64);
   if (rdoq) {
     launch_packed_rdoq(A, A.want_sse != 0, grid.x, st); // hmx_chain_rdoq.hip
+  } else if (G.slots8 == 16) {
+    if (A.want_sse) hipLaunchKernelGGL((k_intra_packed<true, 64, true, false, 16>), grid, blk, 0, st, A);
+    else if (enc) hipLaunchKernelGGL((k_intra_packed<true, 64, false, false, 16>), grid, blk, 0, st, A);
+    else hipLaunchKernelGGL((k_intra_packed<false, 64, false, false, 16>), grid, blk, 0, st, A);
   } else if (A.want_sse) {
     if (G.slots4 == 64) hipLaunchKernelGGL((k_intra_packed<true, 64, true>), grid, blk, 0, st, A);
     else hipLaunchKernelGGL((k_intra_packed<true, 16, true>), grid, blk, 0, st, A);

@@ -8,7 +8,7 @@
 #ifndef HMX_X_SKIP
 #define HMX_X_SKIP 0 /* timing experiments only (results are wrong), 4x4 lane chain: 1 no level stores, 2 no reference loads, 4 no source loads, 8 no reconstruction stores; 16: no level stores of 8x8 and 16x16 blocks */
 #endif
-#define HMX_WAVE_SMEM 7680 /* max(4 * sizeof(TuLds<16>), sizeof(Lane4Lds), ...) - checked below */
+#define HMX_WAVE_SMEM 9088 /* max(16 * sizeof(TuLds8x2), 4 * sizeof(TuLds<16>), sizeof(Lane4Lds), ...) - checked below; 16 waves per CU have 10 KB each */
 static_assert(4 * sizeof(TuLds<16>) <= HMX_WAVE_SMEM, "per-wave LDS scratch");
 static_assert(16 * sizeof(TuLds<4>) <= HMX_WAVE_SMEM && 8 * sizeof(TuLds<8>) <= HMX_WAVE_SMEM &&
                   sizeof(TuLds<32>) <= HMX_WAVE_SMEM,
@@ -171,6 +171,171 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, cons
         d = (unsigned)group_sum((int)d, N);
         if (active && gl == 0) V.sse[b0 >> 4] = d;
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 8x8 blocks on FOUR lanes, two rows (then two columns) per lane: sixteen blocks per wave-item.  The arithmetic per sample is
+// wave_chain_valu<8>'s; what a block costs whatever its size -- descriptor and addresses, the reference gather and its padding,
+// sign-bit hiding (four coefficient groups: one per lane, where eight lanes left four idle) -- is spread over twice the samples.
+// PMC before: 3526 VALU instructions per 1024 samples of 8x8 blocks against 1972 / 2573 / 2158 for 4x4 / 16x16 / 32x32, and 37 % of
+// the mixed workload's instructions.  Packed schedule, large batches (a wave-item's chain is longer: not for latency-bound ones).
+// ---------------------------------------------------------------------------------------------
+template <bool ENC, typename SRC>
+__device__ __forceinline__ void wave_chain_8x2(char *smem, const SRC &src, const PicDev &P, int count) {
+  constexpr int N = 8, NL = 4, LG = 3;
+  const int lane = lane_id(), slot = lane >> 2, gl = lane & 3, r0 = 2 * gl;
+  TuLds8x2 &L = reinterpret_cast<TuLds8x2 *>(smem)[slot];
+  const bool active = slot < count;
+  const FTu ft = src.desc(active ? slot : 0);
+  const hmx_tu t = ft.t;
+  const int pl = t.plane, x = t.x, y = t.y;
+  const bool luma = pl == 0, ts = t.flags & HMX_TU_TRANSFORM_SKIP;
+  const int scan_idx = coef_scan_idx(N, luma, true, t.mode);
+  const unsigned long long avail = (unsigned long long)ft.avail_lo | ((unsigned long long)ft.avail_hi << 32);
+  const PlaneView V = src.view(active ? slot : 0, pl);
+  const TiledPlane &R = V.rec;
+  const unsigned b0 = tile_base(R.ctu_w, R.clog, x, y);
+  const size_t pb0 = tphys(R.qstride, b0);
+  const int B = P.bit_depth, tshift = 15 - B - LG, mx = (1 << B) - 1;
+  int pred[16], v[16];
+  if (ENC && active) {
+    tload_row<N>(V.org + pb0, R.qstride, r0, v);
+    tload_row<N>(V.org + pb0, R.qstride, r0 + 1, v + 8);
+  }
+  src.wait();
+  intra_refs_tiled<N, NL, SRC::kCoherent>(L, gl, active, R, x, y, pb0, luma, avail, P);
+  {
+    const int *RL = (luma && use_filtered_refs(t.mode, LG)) ? L.fline : L.line;
+    const int dcs = dc_sum_block<N, NL>(L, gl);
+    build_main_ref<N, NL>(RL, L.me, t.mode, gl);
+    wave_sync();
+    intra_pred_samples<N, 16>(RL, L.me, t.mode, luma, B, dcs, [&](int s) { return r0 + (s >> 3); }, [](int s) { return s & 7; }, pred);
+    wave_sync(); // the main reference shares the tile's memory
+  }
+  int *const lev_blk = V.lev + lev_row_off<N>(V, x, y, 0); // stride 0: the block's 64 levels are contiguous, row-major
+  if (ENC) {
+    int coef[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = wrap16(v[k] - pred[k]);
+    if (ts) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) coef[k] = tshift >= 0 ? v[k] << tshift : (v[k] + (1 << (-tshift - 1))) >> (-tshift);
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        int y1[N];
+        fwd_pass<N>(v + 8 * h, y1, LG - 1 + (B - 8), false);
+        if (active) {
+#pragma unroll
+          for (int k = 0; k < N; k++) L.tile[k][r0 + h] = y1[k]; // transposed store
+        }
+      }
+      wave_sync();
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        int z[N];
+#pragma unroll
+        for (int n = 0; n < N; n++) z[n] = L.tile[r0 + h][n];
+        fwd_pass<N>(z, coef + 8 * h, LG + 6, false); // coef[8h + k] = coefficient (row k, column r0 + h)
+      }
+      wave_sync();
+    }
+    quant_sbh_block<N, NL, 16, false>(
+        L, gl, active, coef, [&](int k) { return ts ? r0 + (k >> 3) : (k & 7); }, [&](int k) { return ts ? (k & 7) : r0 + (k >> 3); }, luma, scan_idx, P);
+    if (active) {
+      if (V.lev_stride == 0) { // four lanes, 16 bytes each, in the order of the addresses: an instruction writes one whole 64-byte line
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int p = 4 * j + gl, r = p >> 1, c0 = 4 * (p & 1);
+          const i4v o = {level_of(L.tile[r][c0]), level_of(L.tile[r][c0 + 1]), level_of(L.tile[r][c0 + 2]), level_of(L.tile[r][c0 + 3])};
+          piece_store(reinterpret_cast<i4v *>(lev_blk + 4 * p), o);
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          int w[N];
+          load_row32<N>(&L.tile[r0 + h][0], w);
+#pragma unroll
+          for (int k = 0; k < N; k++) w[k] = level_of(w[k]);
+          store_row32<N>(V.lev + lev_row_off<N>(V, x, y, r0 + h), w);
+        }
+      }
+    }
+  } else {
+    if (active) {
+      if (V.lev_stride == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int p = 4 * j + gl, r = p >> 1, c0 = 4 * (p & 1);
+          const i4v o = *reinterpret_cast<const i4v *>(lev_blk + 4 * p);
+#pragma unroll
+          for (int k = 0; k < 4; k++) L.tile[r][c0 + k] = clip3(-32768, 32767, o[k]) & 0xffff;
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          int w[N];
+          load_row32<N>(V.lev + lev_row_off<N>(V, x, y, r0 + h), w);
+#pragma unroll
+          for (int k = 0; k < N; k++) L.tile[r0 + h][k] = clip3(-32768, 32767, w[k]) & 0xffff;
+        }
+      }
+    }
+    wave_sync();
+  }
+  // inverse (inv_tq_block's steps for the two columns, then the two rows, of this lane)
+  const QuantDev qd = pick_qd(P, luma);
+  const int dshift = 6 - tshift;
+  int out[16];
+  if (ts) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int c = dequant_one(level_of(L.tile[r0 + (k >> 3)][k & 7]), qd.iq_scale, dshift);
+      out[k] = wrap16(tshift > 0 ? (c + (1 << (tshift - 1))) >> tshift : c << (-tshift));
+    }
+  } else {
+    int mid[16];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      int c[N];
+#pragma unroll
+      for (int k = 0; k < N; k++) c[k] = wrap16(dequant_one(level_of(L.tile[k][r0 + h]), qd.iq_scale, dshift));
+      inv_pass<N>(c, mid + 8 * h, 7, false);
+    }
+    wave_sync(); // every lane has read its levels
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) L.tile[r0 + (k >> 3)][k & 7] = mid[k];
+    }
+    wave_sync();
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      int u[N];
+#pragma unroll
+      for (int k = 0; k < N; k++) u[k] = L.tile[k][r0 + h];
+      inv_pass<N>(u, out + 8 * h, 12 - (B - 8), false);
+    }
+    wave_sync();
+  }
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[k] = clip3(0, mx, pred[k] + out[k]);
+    tstore_row<N, SRC::kWriteThrough>(R.p + pb0, R.qstride, r0, out);
+    tstore_row<N, SRC::kWriteThrough>(R.p + pb0, R.qstride, r0 + 1, out + 8);
+  }
+  if constexpr (ENC && SRC::kSse) {
+    if (src.want_sse()) {
+      int o[16];
+      unsigned d = 0;
+      if (active) {
+        tload_row<N>(V.org + pb0, R.qstride, r0, o);
+        tload_row<N>(V.org + pb0, R.qstride, r0 + 1, o + 8);
+        d = sse_samples<16>(o, out, B);
+      }
+      d = (unsigned)group_sum((int)d, NL);
+      if (active && gl == 0) V.sse[b0 >> 4] = d;
     }
   }
 }
@@ -886,7 +1051,7 @@ __global__ __launch_bounds__(64) void k_pack_count(const PackPic *pics, PackRow 
 #pragma unroll
     for (int s = 0; s < 4; s++) {
       R.count[s] = c[s];
-      const uint32_t sl = pack_slots(s, G.slots4);
+      const uint32_t sl = pack_slots(s, G.slots4, G.slots8);
       nw += (c[s] + sl - 1) / sl;
     }
     R.n_waves = nw;
@@ -1008,9 +1173,9 @@ __global__ __launch_bounds__(256) void k_pack_fill(const PackPic *pics, const Pa
     const int L = L0 + q;
     if (L >= G.max_levels) break;
     if (k == 0) { // the row's wave-items of this size class: they follow those of the larger classes
-      const uint32_t sl = pack_slots(s, G.slots4), total = rcount[q][s], nw = (total + sl - 1) / sl;
+      const uint32_t sl = pack_slots(s, G.slots4, G.slots8), total = rcount[q][s], nw = (total + sl - 1) / sl;
       uint32_t woff = 0;
-      for (int t = 3; t > s; t--) woff += (rcount[q][t] + pack_slots(t, G.slots4) - 1) / pack_slots(t, G.slots4);
+      for (int t = 3; t > s; t--) woff += (rcount[q][t] + pack_slots(t, G.slots4, G.slots8) - 1) / pack_slots(t, G.slots4, G.slots8);
       const uint32_t row = (uint32_t)(L * G.n_groups + g);
       for (uint32_t c = (uint32_t)lane; c < nw; c += 64u)
         descs[wave_base[q] + woff + c] = PackDesc{item_base[q] + c * sl, min(sl, total - c * sl) | ((uint32_t)s << 28), row, dep[q]};
@@ -1170,17 +1335,18 @@ struct PackedSrc {
 };
 
 // item index of a lane inside a wave-item of size class s: lane / (lanes per block)
-template <int SL4>
+template <int SL4, int SL8>
 __device__ __forceinline__ int pack_lane_item(int lane, int s) {
-  return s == 0 ? (SL4 == 64 ? lane : lane >> 2) : s == 1 ? lane >> 3 : s == 2 ? lane >> 4 : 0;
+  return s == 0 ? (SL4 == 64 ? lane : lane >> 2) : s == 1 ? (SL8 == 16 ? lane >> 2 : lane >> 3) : s == 2 ? lane >> 4 : 0;
 }
 
-template <bool ENC, int SL4, bool SSE = false, bool RDOQ = false>
+template <bool ENC, int SL4, bool SSE = false, bool RDOQ = false, int SL8 = 8>
 #ifndef HMX_PACKED_OCC
 #define HMX_PACKED_OCC 4 /* waves per SIMD the register allocation is held to (A/B: -DHMX_PACKED_OCC=5 | 6 spill) */
 #endif
 __global__ __launch_bounds__(64, RDOQ ? 2 : HMX_PACKED_OCC) void k_intra_packed(PackArgs A) {
-  static_assert(!RDOQ || (ENC && SL4 == 64), "RDOQ: encoder direction, 4x4 blocks one per lane");
+  static_assert(!RDOQ || (ENC && SL4 == 64 && SL8 == 8), "RDOQ: encoder direction, 4x4 blocks one per lane, 8x8 blocks on eight lanes (rdoq_wave_tiles)");
+  static_assert(SL8 == 8 || (SL8 == 16 && 16 * sizeof(TuLds8x2) <= HMX_WAVE_SMEM), "8x8 blocks per wave-item");
   // RDOQ variant: every byte of LDS decides how many waves a CU holds (the walks are latency chains); the lane-per-block 4x4
   // chain, the largest user of the common scratch, borrows the round buffer its RDOQ does not need
   constexpr int kSmem = RDOQ ? (int)(4 * sizeof(TuLds<16>)) : HMX_WAVE_SMEM;
@@ -1235,7 +1401,7 @@ __global__ __launch_bounds__(64, RDOQ ? 2 : HMX_PACKED_OCC) void k_intra_packed(
     FTu ft;
     {
       const int s = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)d.n_s) >> 28), n = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)d.n_s) & 0x0fffffffu);
-      ft = A.items[(uint32_t)__builtin_amdgcn_readfirstlane((int)d.item_off) + (uint32_t)min(pack_lane_item<SL4>(lane_id(), s), n - 1)];
+      ft = A.items[(uint32_t)__builtin_amdgcn_readfirstlane((int)d.item_off) + (uint32_t)min(pack_lane_item<SL4, SL8>(lane_id(), s), n - 1)];
     }
     PROF_T(p1);
 #ifdef HMX_PACK_PROFILE
@@ -1265,8 +1431,10 @@ __global__ __launch_bounds__(64, RDOQ ? 2 : HMX_PACKED_OCC) void k_intra_packed(
       if (s == 0) {
         if constexpr (SL4 == 64) wave_chain_4_lane<ENC, true>(smem4, src, A.P, n);
         else wave_chain_valu<4, ENC, true>(smem, src, A.P, n);
-      } else if (s == 1) wave_chain_valu<8, ENC, true>(smem, src, A.P, n);
-      else if (s == 2) wave_chain_valu<16, ENC, true>(smem, src, A.P, n);
+      } else if (s == 1) {
+        if constexpr (SL8 == 16) wave_chain_8x2<ENC>(smem, src, A.P, n);
+        else wave_chain_valu<8, ENC, true>(smem, src, A.P, n);
+      } else if (s == 2) wave_chain_valu<16, ENC, true>(smem, src, A.P, n);
       else wave_chain_32<ENC, true>(smem, src, A.P, n);
       // the next wave-item's items, behind this one's stores (its descriptor was fetched behind the dependency poll)
       const bool more = nx.t < nx.total;
@@ -1274,7 +1442,7 @@ __global__ __launch_bounds__(64, RDOQ ? 2 : HMX_PACKED_OCC) void k_intra_packed(
       if (more) {
         const uint32_t ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx.d.n_s);
         ftn = A.items[(uint32_t)__builtin_amdgcn_readfirstlane((int)nx.d.item_off) +
-                      (uint32_t)min(pack_lane_item<SL4>(lane_id(), (int)(ns >> 28)), (int)(ns & 0x0fffffffu) - 1)];
+                      (uint32_t)min(pack_lane_item<SL4, SL8>(lane_id(), (int)(ns >> 28)), (int)(ns & 0x0fffffffu) - 1)];
       }
       // publish: every store of this wave has reached the L2 before the row's count moves
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

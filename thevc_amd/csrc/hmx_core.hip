@@ -53,7 +53,7 @@ PicDev make_picdev(const hmx_ctx *c, const hmx_pic_param *pp) {
 // Tuning knobs: read from the environment ONCE, in hmx_create; hmx_set_option changes one afterwards (A/B runs, and the
 // parity tests that hold the schedules against each other).  value == NULL restores the default.
 static const char *const kKnobNames[] = {"HMX_INTRA_SCHEDULE", "HMX_INTRA_ACROSS", "HMX_INTRA_STREAMS", "HMX_PIPELINE_CONV", "HMX_GRAPH",
-                                         "HMX_PACK_SLOTS4",    "HMX_PACK_GROUP",      "HMX_PACK_WAVES",    "HMX_PACK_SLEEP0",   "HMX_PACK_SLEEP1",  "HMX_PLAN_ROWS",      "HMX_PLAN_STREAMS",
+                                         "HMX_PACK_SLOTS4",    "HMX_PACK_SLOTS8",    "HMX_PACK_GROUP",      "HMX_PACK_WAVES",    "HMX_PACK_SLEEP0",   "HMX_PACK_SLEEP1",  "HMX_PLAN_ROWS",      "HMX_PLAN_STREAMS",
                                          "HMX_RDOQ_LANE"};
 static bool apply_knob(hmx_ctx *c, const char *name, const char *v) {
   auto &k = c->knob;
@@ -64,6 +64,7 @@ static bool apply_knob(hmx_ctx *c, const char *name, const char *v) {
   else if (n == "HMX_PIPELINE_CONV") k.pipeline_conv = v && v[0] != '0';
   else if (n == "HMX_GRAPH") k.graph = v != nullptr;
   else if (n == "HMX_PACK_SLOTS4") k.slots4 = !v ? 0 : atoi(v) == 16 ? 16 : 64;
+  else if (n == "HMX_PACK_SLOTS8") k.slots8 = !v ? 0 : atoi(v) == 16 ? 16 : 8;
   else if (n == "HMX_PACK_GROUP") k.pack_group = v ? std::min(64, std::max(1, atoi(v))) : 0;
   else if (n == "HMX_PACK_WAVES") k.pack_waves = v ? std::max(1, atoi(v)) : 0;
   else if (n == "HMX_PACK_SLEEP0") k.pack_sleep0 = v ? std::max(0, atoi(v)) : -1;

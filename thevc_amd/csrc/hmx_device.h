@@ -274,6 +274,19 @@ struct TuLds {
   unsigned nzmask[2]; // bit g: coefficient group g (scan order) holds a non-zero level
 };
 
+// The scratch of an 8x8 block worked by FOUR lanes, sixteen blocks per wave (wave_chain_8x2): the extended main reference is
+// spent when the prediction is formed and the tile is first written behind it, so they share memory -- 568 bytes per block, 9 KB
+// per wave (sixteen TuLds<8> would be 10.5 KB, and sixteen waves per CU have 10 KB each).
+struct TuLds8x2 {
+  union {
+    int tile[8][9];
+    int me[3 * 8 + 2];
+  };
+  int line[4 * 8 + 2];
+  int fline[4 * 8 + 2];
+  unsigned nzmask[2];
+};
+
 __device__ __forceinline__ int level_of(int word) { return (int)(short)word; }
 
 // Flat quantisation of one coefficient (TComTrQuant.cpp:1241-1259) -> packed word.  WIDE = false is

@@ -173,9 +173,9 @@ struct PackPic { // per picture: where its levels go, and the plan it follows
   uint32_t *sse[3]; // distortion output per plane (hmx_set_sse_output), NULL = none
 };
 struct PackGeom {
-  int n_pics, I, n_groups, n_shards, max_levels, slots4;
+  int n_pics, I, n_groups, n_shards, max_levels, slots4, slots8;
 };
-__host__ __device__ __forceinline__ uint32_t pack_slots(int s, int slots4) { return s == 0 ? (uint32_t)slots4 : s == 1 ? 8u : s == 2 ? 4u : 1u; }
+__host__ __device__ __forceinline__ uint32_t pack_slots(int s, int slots4, int slots8) { return s == 0 ? (uint32_t)slots4 : s == 1 ? (uint32_t)slots8 : s == 2 ? 4u : 1u; }
 
 struct hmx_ctx {
   hmx_config cfg;
@@ -299,6 +299,7 @@ struct hmx_ctx {
     int across = -1;       // HMX_INTRA_ACROSS: 0 keeps shared-plan batches of the level schedule per picture
     int streams = 0;       // HMX_INTRA_STREAMS: picture groups of the across schedule
     bool pipeline_conv = false, graph = false;
+    int slots8 = 0;        // HMX_PACK_SLOTS8: 8 or 16 8x8 blocks per wave-item of the packed schedule: eight or four lanes per block (0: by batch size)
     int slots4 = 0;        // HMX_PACK_SLOTS4: 16 or 64 4x4 blocks per wave-item (0: by batch size)
     int pack_group = 0;    // HMX_PACK_GROUP: pictures per group, 1..64 (0: by batch size, see pack_group_size)
     int pack_waves = 0;    // HMX_PACK_WAVES: persistent waves (0: by batch size)

@@ -201,8 +201,8 @@ __device__ __forceinline__ unsigned sse_samples(const int *org, const int *rec, 
 // Leaves packed words (level in the low half) in L.tile[row][col]; returns uiAbsSum (before sign-bit
 // hiding, :1256).  WIDE: see quant_one.
 // ---------------------------------------------------------------------------------------------
-template <int N, int NL, int NCOEF, bool WIDE, typename RowFn, typename ColFn>
-__device__ __forceinline__ int quant_sbh_block(TuLds<N> &L, int gl, bool active, const int *coef, RowFn row_of, ColFn col_of,
+template <int N, int NL, int NCOEF, bool WIDE, typename LT, typename RowFn, typename ColFn>
+__device__ __forceinline__ int quant_sbh_block(LT &L, int gl, bool active, const int *coef, RowFn row_of, ColFn col_of,
                                                bool luma, int scan_idx, const PicDev &P) {
   constexpr int LG = Log2<N>::v;
   const int tshift = 15 - P.bit_depth - LG;
@@ -374,8 +374,8 @@ __device__ __forceinline__ void intra_refs(TuLds<N> &L, int gl, bool active, Fet
 // padding rule then runs on the raw samples in LDS: position p copies sample q(p), the nearest available sample
 // before it (the first available one for a leading run), exactly as build_ref_line picks its load address.
 // pb0 = element index of the block's first sample.  Leaves L.line (raw) and L.fline (smoothed, luma N > 4).
-template <int N, int NL, bool COH>
-__device__ __forceinline__ void intra_refs_tiled(TuLds<N> &L, int gl, bool active, const TiledPlane &R, int x, int y, size_t pb0,
+template <int N, int NL, bool COH, typename LT>
+__device__ __forceinline__ void intra_refs_tiled(LT &L, int gl, bool active, const TiledPlane &R, int x, int y, size_t pb0,
                                                  bool luma, unsigned long long avail, const PicDev &P) {
   constexpr int T = 2 * N + 1 + N / 2, IT = (T + NL - 1) / NL;
   const int ul = luma ? 2 : 1, n = N >> ul;
@@ -448,8 +448,8 @@ __device__ __forceinline__ void intra_refs_tiled(TuLds<N> &L, int gl, bool activ
 }
 
 // sum of the N above + N left neighbours, shared by the block's NL lanes (DC mode)
-template <int N, int NL>
-__device__ __forceinline__ int dc_sum_block(const TuLds<N> &L, int gl) {
+template <int N, int NL, typename LT>
+__device__ __forceinline__ int dc_sum_block(const LT &L, int gl) {
   int s = 0;
   for (int i = gl; i < 2 * N; i += NL) s += i < N ? L.line[2 * N + 1 + i] : L.line[2 * N - 1 - (i - N)];
   return group_sum(s, NL);
