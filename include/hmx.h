@@ -108,6 +108,12 @@ int hmx_xITransformSkip(hmx_ctx *ctx, const int32_t *coef, hmx_pel *resi, unsign
 /* xQuant, flat path + signBitHidingHDQ (TComTrQuant.cpp:1102-1270, 977-1100); ac_sum accumulates */
 int hmx_xQuant(hmx_ctx *ctx, const int32_t *src, hmx_coeff *dst, int w, int h, uint32_t *ac_sum,
                int text_type, const hmx_quant_param *qp);
+/* The pArlDes output of xQuant (ADAPTIVE_QP_SELECTION, m_bUseAdaptQpSelect): arl[n] = (|src[n]| * quantScale + round) >> (iQBits - 7),
+ * what TEncSlice's adaptive QP selection accumulates.  rdoq_form = 0: the flat branch (TComTrQuant.cpp:1229-1249; iQBits from
+ * qp->per_base, the slice's base QP); rdoq_form = 1: as xRateDistOptQuant writes it (:1757-1765, 1886-1891; iQBits from qp->qp.per,
+ * the product limited to MAX_INT - (1 << (iQBits - 1)) first).  It depends on the coefficients alone: call it beside hmx_xQuant /
+ * hmx_xRateDistOptQuant when the encoder runs with AdaptiveQpSelection. */
+int hmx_arlCoeff(hmx_ctx *ctx, const int32_t *src, int32_t *arl, int w, int h, int text_type, const hmx_quant_param *qp, int rdoq_form);
 /* xRateDistOptQuant (TComTrQuant.cpp:1719-2305), the quantiser transformNxN selects when RDOQ is on
  * (:1122-1128; every shipped cfg).  It reads CABAC bit estimates that TEncSbac::estBit leaves in
  * m_pcEstBitsSbac for the block's size and texture type (estBitsSbacStruct, TComTrQuant.h:59-72; same

@@ -311,6 +311,25 @@ void hmo_xQuant(const int32_t *src, int32_t *dst, int N, int B, const hmo_quant_
   if (cfg->sign_hide && sum >= 2) sign_bit_hiding(dst, src, hmo_scan(cfg->scan_idx, lg), deltaU, N);
 }
 
+/* The pArlDes output of the quantiser (ADAPTIVE_QP_SELECTION; what TEncSlice's adaptive QP selection accumulates): the coefficient
+ * scaled like a level but with ARL_C_PRECISION = 7 more fractional bits.  Flat path COM/TComTrQuant.cpp:1229-1249 (iQBits from the
+ * slice's BASE QP, cQpBase); RDOQ path :1757, 1764-1765, 1886-1891 (iQBits from m_cQP, the product limited first). */
+void hmo_arlCoeff(const int32_t *src, int32_t *arl, int N, int B, const hmo_quant_cfg *cfg, int rdoq) {
+  const int lg = ilog2(N), tshift = 15 - B - lg;
+  const int qbits = 14 + (rdoq ? cfg->per : cfg->per_qbits) + tshift, qbits_c = qbits - 7;
+  const int q = hmo_quant_scale(cfg->rem);
+  for (int i = 0; i < N * N; i++) {
+    const int64_t t = (int64_t)abs(src[i]) * q;
+    if (rdoq) {
+      const int64_t lim = (int64_t)2147483647 - ((int64_t)1 << (qbits - 1));
+      const int ld = (int)(t < lim ? t : lim);
+      arl[i] = (ld + (1 << (qbits_c - 1))) >> qbits_c;
+    } else {
+      arl[i] = (int)((t + ((int64_t)1 << (qbits_c - 1))) >> qbits_c);
+    }
+  }
+}
+
 /* ------------------------------------------------------------------------------------------
  * Rate-distortion optimised quantisation (COM/TComTrQuant.cpp:1719-2305)
  *

@@ -54,20 +54,32 @@ ENC_BODIES = {
     xRateDistOptQuant( pcCU, pSrc, pDes, pArlDes, iWidth, iHeight, uiAcSum, eTType, uiAbsPartIdx );
     return;
   }
-  if (m_bUseAdaptQpSelect || getUseScalingList()) { fprintf(stderr, "libhmx shim: adaptive QP selection / scaling lists are outside the built path\\n"); exit(EXIT_FAILURE); }
+  if (getUseScalingList()) { fprintf(stderr, "libhmx shim: scaling lists are outside the built path\\n"); exit(EXIT_FAILURE); }
   """ + _SCAN_DIR % {"w": "iWidth"} + """
+  QpParam cQpBase; /* iQBits of the flat branch comes from the slice's BASE QP (:1162-1193, ADAPTIVE_QP_SELECTION) */
+  {
+    Int qpBDOffset = (eTType == TEXT_LUMA) ? pcCU->getSlice()->getSPS()->getQpBDOffsetY() : pcCU->getSlice()->getSPS()->getQpBDOffsetC();
+    Int qpScaled = pcCU->getSlice()->getSliceQpBase();
+    if (eTType == TEXT_LUMA) qpScaled += qpBDOffset;
+    else {
+      qpScaled = Clip3(-qpBDOffset, 57, qpScaled);
+      qpScaled = qpScaled < 0 ? qpScaled + qpBDOffset : g_aucChromaScale[qpScaled] + qpBDOffset;
+    }
+    cQpBase.setQpParam(qpScaled);
+  }
   hmx_quant_param p;
   p.qp.qp = m_cQP.m_iQP, p.qp.per = m_cQP.m_iPer, p.qp.rem = m_cQP.m_iRem, p.qp.bits = m_cQP.m_iBits;
-  p.per_base = -1; /* cQpBase differs from m_cQP only under adaptive QP selection (:1169-1203) */
+  p.per_base = cQpBase.m_iPer;
   p.slice_type = pcCU->getSlice()->getSliceType();
   p.sign_hide = pcCU->getSlice()->getPPS()->getSignHideFlag();
   p.is_intra = pcCU->isIntra(uiAbsPartIdx);
   p.dir_mode = hmxDir;
   uint32_t ac = uiAcSum;
   HMX_SHIM_CHECK(hmx_xQuant(hmx_shim_ctx(), pSrc, pDes, iWidth, iHeight, &ac, eTType, &p));
-  uiAcSum = ac;""",
+  uiAcSum = ac;
+  if (m_bUseAdaptQpSelect) HMX_SHIM_CHECK(hmx_arlCoeff(hmx_shim_ctx(), pSrc, pArlDes, iWidth, iHeight, eTType, &p, 0)); /* :1246-1249 */""",
         "TComTrQuant::xRateDistOptQuant": """static_assert(sizeof(estBitsSbacStruct) == sizeof(hmx_est_bits), "estBitsSbacStruct and hmx_est_bits share one layout");
-  if (m_bUseAdaptQpSelect || getUseScalingList()) { fprintf(stderr, "libhmx shim: adaptive QP selection / scaling lists are outside the built path\\n"); exit(EXIT_FAILURE); }
+  if (getUseScalingList()) { fprintf(stderr, "libhmx shim: scaling lists are outside the built path\\n"); exit(EXIT_FAILURE); }
   """ + _SCAN_DIR % {"w": "uiWidth"} + """
   hmx_rdoq_param p;
   p.qp.qp = m_cQP.m_iQP, p.qp.per = m_cQP.m_iPer, p.qp.rem = m_cQP.m_iRem, p.qp.bits = m_cQP.m_iBits;
@@ -80,7 +92,12 @@ ENC_BODIES = {
   uint32_t s = 0;
   HMX_SHIM_CHECK(hmx_xRateDistOptQuant(hmx_shim_ctx(), plSrcCoeff, piDstCoeff, uiWidth, uiHeight, &s, eTType, &p,
                                        reinterpret_cast<const hmx_est_bits *>(m_pcEstBitsSbac)));
-  uiAbsSum = s;""",
+  uiAbsSum = s;
+  if (m_bUseAdaptQpSelect) { /* :1886-1891 */
+    hmx_quant_param a;
+    a.qp = p.qp, a.per_base = -1, a.slice_type = pcCU->getSlice()->getSliceType(), a.sign_hide = p.sign_hide, a.is_intra = p.is_intra, a.dir_mode = p.dir_mode;
+    HMX_SHIM_CHECK(hmx_arlCoeff(hmx_shim_ctx(), plSrcCoeff, piArlDstCoeff, uiWidth, uiHeight, eTType, &a, 1));
+  }""",
     },
     "TComPrediction": {
         "TComPrediction::xPredInterLumaBlk": """Pel *ref = refPic->getLumaAddr(cu->getAddr(), cu->getZorderIdxInCU() + partAddr);

@@ -232,6 +232,41 @@ void ref_xRateDistOptQuant(int qpy, int slice_type, int ttype, int is_intra, int
   S->tq.xRateDistOptQuant(cu, coef, level, arl, N, N, sum, (TextType)ttype, 0);
   *abs_sum = sum;
 }
+// xQuant as the encoder runs it under AdaptiveQpSelection: the slice's base QP differs from the block's QP (cQpBase,
+// TComTrQuant.cpp:1162-1193), m_bUseAdaptQpSelect is on and pArlDes receives the ARL coefficients -- from the flat branch or,
+// with rdoq != 0, from xRateDistOptQuant (est_blob / lambda as in ref_xRateDistOptQuant).
+void ref_xQuant_arl(int qpy, int qp_base, int slice_type, int ttype, int is_intra, int dir_mode, int tr_idx, int rdoq, double lambda,
+                    const int *est_blob, int *coef, int *level, int *arl, int N, unsigned *abs_sum) {
+  TComDataCU *cu = S->pic->getCU(0);
+  TComSlice *sl = S->pic->getSlice(0);
+  sl->setSliceType((SliceType)slice_type);
+  sl->setSliceQp(qpy);
+  sl->setSliceQpBase(qp_base);
+  cu->m_pcSlice = sl;
+  cu->m_pePredMode[0] = is_intra ? MODE_INTRA : MODE_INTER;
+  cu->m_puhLumaIntraDir[0] = (UChar)dir_mode;
+  cu->m_puhChromaIntraDir[0] = (UChar)dir_mode;
+  cu->m_puhDepth[0] = 0;
+  cu->m_puhTrIdx[0] = (UChar)tr_idx;
+  cu->m_CUTransquantBypass[0] = false;
+  for (int t = 0; t < 3; t++) cu->m_puhTransformSkip[t][0] = 0;
+  Int bd = (ttype == 0) ? S->sps.getQpBDOffsetY() : S->sps.getQpBDOffsetC();
+  S->tq.setQPforQuant(qpy, (TextType)ttype, bd, 0);
+  const Bool was_rdoq = S->tq.m_bUseRDOQ, was_arl = S->tq.m_bUseAdaptQpSelect;
+  S->tq.m_bUseRDOQ = rdoq != 0;
+  S->tq.m_bUseAdaptQpSelect = true;
+  if (rdoq) {
+    memcpy(S->tq.m_pcEstBitsSbac, est_blob, sizeof(estBitsSbacStruct));
+    S->tq.m_dLambda = lambda;
+  }
+  Int *a = arl;
+  UInt sum = 0;
+  S->tq.xQuant(cu, coef, level, a, N, N, sum, (TextType)ttype, 0);
+  *abs_sum = sum;
+  S->tq.m_bUseRDOQ = was_rdoq;
+  S->tq.m_bUseAdaptQpSelect = was_arl;
+  sl->setSliceQpBase(qpy);
+}
 void ref_invtransformNxN(int qpy, int ttype, int bypass, unsigned mode, short *resi, unsigned stride,
                          int *level, int N, int ts) {
   Int bd = (ttype == 0) ? S->sps.getQpBDOffsetY() : S->sps.getQpBDOffsetC();

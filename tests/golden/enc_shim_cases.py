@@ -17,6 +17,9 @@ CASES = [
     # low delay, P pictures: motion search (half / quarter sample planes through the interpolation members), motion compensation,
     # the inter residual quadtree with RDOQ (root cbf branch), AMP partitions, merge
     {"name": "lowdelay_P_q30", "seed": 53, "w": 192, "h": 128, "frames": 3, "bits": 8, "qp": 30, "inter": True},
+    # AdaptiveQpSelection: the quantiser's pArlDes output (hmx_arlCoeff, flat branch and RDOQ) feeds TEncSlice's statistics, which move
+    # the QP of the following P slices (TEncSlice.cpp:714-722, 1387): one differing ARL coefficient changes the later pictures
+    {"name": "lowdelay_P_aqps_q32", "seed": 54, "w": 128, "h": 128, "frames": 4, "bits": 8, "qp": 32, "inter": True, "extra": ["--AdaptiveQpSelection=1"]},
 ]
 
 
@@ -39,4 +42,4 @@ def options(case, yuv, stream, recon):
         o += ["--IntraPeriod=-1", "--Frame1=P 1 0 0.5 0 1 1 1 -1 0"]  # one P picture per GOP, one reference: the previous picture
     else:
         o += ["--IntraPeriod=1", "--DecodingRefreshType=0", "--Frame1=B 1 0 1 0 1 1 0"]
-    return o
+    return o + case.get("extra", [])

@@ -110,6 +110,42 @@ def rdoq(R, B, rng):
     return out
 
 
+def arl(R, B, rng):
+    """pArlDes of the compiled reference's xQuant under AdaptiveQpSelection: the flat branch (iQBits from the slice's base QP) and
+    xRateDistOptQuant (odd cases); the flat branch's levels with a base QP of its own come along."""
+    out = {}
+    mx = (1 << B) - 1
+    for N in (4, 8, 16, 32):
+        par, coef_l, arl_l, lev_l, sum_l = [], [], [], [], []
+        for it in range(12):
+            rdoq = it % 2
+            ttype = (0, 2, 3)[it % 3] if N < 32 else 0
+            is_intra = int(it % 4 != 3)
+            mode = int(rng.integers(0, 35))
+            qpy = int(rng.choice([4, 10, 22, 27, 32, 37, 45]))
+            qp_base = int(np.clip(qpy + rng.integers(-9, 10), 0, 51))
+            st = 2 if is_intra else (1, 0)[it % 2]
+            amp = int(rng.choice([20, 60, 200, mx, mx]))
+            resi = rng.integers(-amp, amp + 1, N * N).astype(np.int16)
+            coef = np.zeros(N * N, np.int32)
+            R.ref_xT(mode if (ttype == 0 and is_intra) else REG_DCT, resi, N, coef, N)
+            if it % 5 == 0:
+                coef[rng.integers(0, N * N, 2)] = (-32768, 32767)
+            est = ol.make_est_bits(rng)
+            lev, a, s_ = ol.r_quant_arl(coef, N, qpy, qp_base, st, ttype, is_intra, mode, 0, rdoq, 17.5, est)
+            par.append((qpy, qp_base, st, ttype, is_intra, mode, rdoq))
+            coef_l.append(coef)
+            arl_l.append(a.reshape(-1))
+            lev_l.append(lev.reshape(-1))
+            sum_l.append(s_)
+        out[f"a{N}_par"] = np.array(par, np.int32)
+        out[f"a{N}_coef"] = np.stack(coef_l)
+        out[f"a{N}_arl"] = np.stack(arl_l)
+        out[f"a{N}_lev"] = np.stack(lev_l)
+        out[f"a{N}_sum"] = np.array(sum_l, np.uint32)
+    return out
+
+
 def deblock(R, B, rng):
     """The reference's deblocking edge filters on a 128x64 picture, driven with random boundary strengths."""
     w, h = 128, 64
@@ -315,6 +351,11 @@ def main():
     if sys.argv[1:] == ["intra64"]:  # round 3: the 64x64 luma prediction units
         for B in (8, 10):
             np.savez_compressed(os.path.join(HERE, f"intra64_b{B}.npz"), **intra64(R, B, np.random.default_rng(8120 + B)))
+        return
+    if sys.argv[1:] == ["arl"]:  # round 3: the pArlDes output of the quantiser
+        for B in (8, 10):
+            R.ref_init(B, 416, 240, 1)
+            np.savez_compressed(os.path.join(HERE, f"arl_b{B}.npz"), **arl(R, B, np.random.default_rng(9144 + B)))
         return
     if sys.argv[1:] == ["deblock"]:
         for B in (8, 10):

@@ -107,6 +107,8 @@ def oracle():
         L.hmo_xRateDistOptQuant.argtypes = [i32p, i32p, ci, ci, C.POINTER(RdoqCfg), C.POINTER(EstBits), C.POINTER(C.c_uint32)]
         L.hmo_xRateDistOptQuant.restype = None
         L.hmo_xDeQuant.argtypes = [i32p, i32p, ci, ci, ci, ci]
+        L.hmo_arlCoeff.argtypes = [i32p, i32p, ci, ci, C.POINTER(QuantCfg), ci]
+        L.hmo_arlCoeff.restype = None
         L.hmo_transformNxN.argtypes = [i16p, ci, i32p, ci, ci, cu, ci, ci, C.POINTER(QuantCfg),
                                        C.POINTER(C.c_uint32)]
         L.hmo_invtransformNxN.argtypes = [ci, cu, i16p, ci, i32p, ci, ci, ci, ci, ci]
@@ -285,6 +287,25 @@ def o_rdoq(coef, N, B, cfg, est):
     s = C.c_uint32(0)
     oracle().hmo_xRateDistOptQuant(coef, lvl, N, B, C.byref(cfg), C.byref(est), C.byref(s))
     return lvl.reshape(N, N), s.value
+
+
+def o_arl(coef, N, B, cfg, rdoq):
+    coef = np.ascontiguousarray(coef, np.int32).reshape(-1)
+    arl = np.zeros(N * N, np.int32)
+    oracle().hmo_arlCoeff(coef, arl, N, B, C.byref(cfg), int(rdoq))
+    return arl.reshape(N, N)
+
+
+def r_quant_arl(coef, N, qpy, qp_base, slice_type, ttype, is_intra, dir_mode, tr_idx, rdoq, lam, est):
+    """the compiled reference's xQuant with AdaptiveQpSelection on (flat branch or xRateDistOptQuant): levels, pArlDes, uiAcSum"""
+    R = ref()
+    R.ref_xQuant_arl.argtypes = [ci, ci, ci, ci, ci, ci, ci, ci, C.c_double, C.POINTER(EstBits), i32p, i32p, i32p, ci, C.POINTER(C.c_uint32)]
+    R.ref_xQuant_arl.restype = None
+    coef = np.ascontiguousarray(coef, np.int32).reshape(-1).copy()
+    lvl, arl = np.zeros(N * N, np.int32), np.zeros(N * N, np.int32)
+    s = C.c_uint32(0)
+    R.ref_xQuant_arl(qpy, qp_base, slice_type, ttype, is_intra, dir_mode, tr_idx, int(rdoq), lam, C.byref(est), coef, lvl, arl, N, C.byref(s))
+    return lvl.reshape(N, N), arl.reshape(N, N), s.value
 
 
 def r_rdoq(coef, N, qpy, slice_type, ttype, is_intra, dir_mode, tr_idx, lam, est):

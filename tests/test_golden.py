@@ -71,6 +71,25 @@ def test_oracle_rdoq(B):
             assert np.array_equal(lev.reshape(-1), g[f"r{N}_lev"][k]) and s == g[f"r{N}_sum"][k], (N, k)
 
 
+@pytest.mark.parametrize("B", [8, 10])
+def test_oracle_arl(B):
+    """pArlDes (AdaptiveQpSelection) of the reference's xQuant / xRateDistOptQuant, and the flat branch's levels when the slice's
+    base QP is not the block's."""
+    g, O = load(f"arl_b{B}.npz"), ol.oracle()
+    bd = 6 * (B - 8)
+    for N in (4, 8, 16, 32):
+        for k, par in enumerate(g[f"a{N}_par"]):
+            qpy, qp_base, st, ttype, is_intra, mode, rdoq = (int(v) for v in par)
+            q, qb = O.hmo_setQPforQuant(qpy, int(ttype != 0), bd, 0), O.hmo_setQPforQuant(qp_base, int(ttype != 0), bd, 0)
+            scan = O.hmo_coef_scan_idx(N, int(ttype == 0), is_intra, mode)
+            fc = ol.quant_cfg(q.per, q.rem, intra_slice=int(st == 2), sign_hide=1, scan_idx=scan, per_qbits=qb.per)
+            assert np.array_equal(ol.o_arl(g[f"a{N}_coef"][k], N, B, fc, rdoq).reshape(-1), g[f"a{N}_arl"][k]), (N, k)
+            if not rdoq:
+                lev, s = np.zeros(N * N, np.int32), C.c_uint32(0)
+                O.hmo_xQuant(np.ascontiguousarray(g[f"a{N}_coef"][k]), lev, N, B, C.byref(fc), C.byref(s))
+                assert np.array_equal(lev, g[f"a{N}_lev"][k]) and s.value == g[f"a{N}_sum"][k], (N, k)
+
+
 def _deblock_case(g, k):
     par = g[f"d{k}_par"]
     ins = [np.ascontiguousarray(g[f"d{k}_{n}"]) for n in ("y", "cb", "cr", "bsv", "bsh", "qp", "nof")]
@@ -342,6 +361,23 @@ def test_gpu_frame(name, B):
         assert np.array_equal(lev[p], g["lev_" + k].astype(np.int32)), k
     L.hmx_intra_plan_destroy(ctx.h, plan)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_arl(gctx):
+    """hmx_arlCoeff (both forms) and hmx_xQuant with a base QP of its own vs the reference's vectors."""
+    from thevc_amd import capi
+    B = gctx.bit_depth
+    g = load(f"arl_b{B}.npz")
+    for N in (4, 8, 16, 32):
+        for k, par in enumerate(g[f"a{N}_par"]):
+            qpy, qp_base, st, ttype, is_intra, mode, rdoq = (int(v) for v in par)
+            qp, qb = capi.qp_for(qpy, ttype, B), capi.qp_for(qp_base, ttype, B)
+            p = capi.QuantParam(qp, qb.per, st, 1, is_intra, mode)
+            assert np.array_equal(gctx.arlCoeff(g[f"a{N}_coef"][k], N, ttype, p, rdoq), g[f"a{N}_arl"][k]), (N, k, rdoq)
+            if not rdoq:
+                lev, s = gctx.xQuant(g[f"a{N}_coef"][k], N, ttype, p)
+                assert np.array_equal(lev, g[f"a{N}_lev"][k]) and s == g[f"a{N}_sum"][k], (N, k)
 
 
 @pytest.mark.gpu

@@ -216,6 +216,54 @@ def test_xRateDistOptQuant(B, N):
     assert n_nonzero >= 30 and n_differs_from_flat >= 15, (n_nonzero, n_differs_from_flat)  # the RD decisions were exercised
 
 
+@pytest.mark.parametrize("N", [4, 8, 16, 32])
+def test_arl_coefficients_vs_reference(B, N):
+    """pArlDes of xQuant under AdaptiveQpSelection (TComTrQuant.cpp:1229-1249) and of xRateDistOptQuant (:1764-1765, 1886-1891): the
+    slice's base QP differs from the block's QP, so iQBits of the flat branch comes from cQpBase; levels and uiAcSum of the same
+    calls are held too (the flat branch with a base QP of its own is what per_qbits of the oracle's configuration is for)."""
+    R, O = ol.ref(), ol.oracle()
+    rng = np.random.default_rng(4100 + N + B)
+    bd = 6 * (B - 8)
+    mx = (1 << B) - 1
+    differs = 0
+    for it in range(60):
+        rdoq = it % 2
+        ttype = (0, 2, 3)[it % 3] if N < 32 else 0
+        is_intra = it % 4 != 3
+        mode = int(rng.integers(0, 35))
+        tr_idx = int(rng.integers(0, 2))
+        qpy = int(rng.choice([4, 10, 22, 27, 32, 37, 45]))
+        qp_base = int(np.clip(qpy + rng.integers(-9, 10), 0, 51))
+        slice_type = 2 if is_intra else [1, 0][it % 2]
+        lam = float(rng.choice([3.0, 17.5, 58.0, 140.25]))
+        amp = int(rng.choice([4, 20, 60, 200, mx, mx]))
+        resi = rng.integers(-amp, amp + 1, N * N).astype(np.int16)
+        coef = np.zeros(N * N, np.int32)
+        O.hmo_xT(mode if (ttype == 0 and is_intra) else REG_DCT, resi, N, coef, N, B)
+        if it % 7 == 0:
+            coef[rng.integers(0, N * N, 3)] = rng.choice([-32768, 32767, 32768])  # the product's limit in the RDOQ form
+        est = ol.make_est_bits(rng)
+        la, aa, sa = ol.r_quant_arl(coef, N, qpy, qp_base, slice_type, ttype, int(is_intra), mode, tr_idx, rdoq, lam, est)
+        q = O.hmo_setQPforQuant(qpy, int(ttype != 0), bd, 0)
+        qb = O.hmo_setQPforQuant(qp_base, int(ttype != 0), bd, 0)
+        scan = O.hmo_coef_scan_idx(N, int(ttype == 0), int(is_intra), mode)
+        fc = ol.quant_cfg(q.per, q.rem, intra_slice=int(slice_type == 2), sign_hide=1, scan_idx=scan, per_qbits=qb.per)
+        ab = ol.o_arl(coef, N, B, fc, rdoq)
+        assert np.array_equal(aa, ab), (it, N, B, rdoq, qpy, qp_base, np.argwhere(aa != ab)[:4])
+        differs += int(q.per != qb.per)
+        if rdoq:
+            root = int((not is_intra) and ttype == 0 and tr_idx == 0)
+            cfg = ol.RdoqCfg(q.per, q.rem, int(ttype == 0), int(is_intra), scan, root, R.ref_cbf_ctx(ttype, tr_idx), 1, lam)
+            lb, sb = ol.o_rdoq(coef, N, B, cfg, est)
+        else:
+            lb = np.zeros(N * N, np.int32)
+            s = C.c_uint32(0)
+            O.hmo_xQuant(coef, lb, N, B, C.byref(fc), C.byref(s))
+            lb, sb = lb.reshape(N, N), s.value
+        assert np.array_equal(la, lb) and sa == sb, (it, N, B, rdoq)
+    assert differs >= 15  # base and block QP fell into different periods: cQpBase mattered
+
+
 def _rand_flags(rng, n, kind):
     total = 4 * n + 1
     if kind == 0:

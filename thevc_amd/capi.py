@@ -120,6 +120,7 @@ def lib():
         L.hmx_xTransformSkip.argtypes = [vp, vp, cu, vp, ci, ci]
         L.hmx_xITransformSkip.argtypes = [vp, vp, vp, cu, ci, ci]
         L.hmx_xQuant.argtypes = [vp, vp, vp, ci, ci, C.POINTER(C.c_uint32), ci, C.POINTER(QuantParam)]
+        L.hmx_arlCoeff.argtypes = [vp, vp, vp, ci, ci, ci, C.POINTER(QuantParam), ci]
         L.hmx_xDeQuant.argtypes = [vp, vp, vp, ci, ci, C.POINTER(Qp)]
         L.hmx_transformNxN.argtypes = [vp, vp, cu, vp, cu, cu, C.POINTER(C.c_uint32), ci, C.POINTER(QuantParam),
                                        ci, ci]
@@ -345,6 +346,12 @@ class Context:
         s = C.c_uint32(ac_sum)
         self._chk(lib().hmx_xQuant(self.h, _hp(src), _hp(dst), n, n, C.byref(s), text_type, C.byref(qparam)))
         return dst, s.value
+
+    def arlCoeff(self, src, n, text_type, qparam, rdoq_form):
+        src = np.ascontiguousarray(src, np.int32)
+        arl = np.zeros(n * n, np.int32)
+        self._chk(lib().hmx_arlCoeff(self.h, _hp(src), _hp(arl), n, n, text_type, C.byref(qparam), int(rdoq_form)))
+        return arl
 
     def xRateDistOptQuant(self, src, n, text_type, rparam, est, abs_sum=0):
         src = np.ascontiguousarray(src, np.int32)

@@ -105,6 +105,38 @@ extern "C" int hmx_xQuant(hmx_ctx *c, const int32_t *src, hmx_coeff *dst, int w,
   return r;
 }
 
+// ---- the pArlDes output of the quantiser (ADAPTIVE_QP_SELECTION) ----
+// One thread per coefficient: the coefficient scaled like a level with ARL_C_PRECISION = 7 more fractional bits (TComTrQuant.cpp
+// :1229-1249 flat branch, iQBits from the slice's base QP; :1757-1765, 1886-1891 inside xRateDistOptQuant, iQBits from m_cQP and the
+// product limited first).  Independent of every quantiser decision, so it is a pass of its own beside hmx_xQuant / hmx_xRateDistOptQuant.
+__global__ __launch_bounds__(256) void k_arl(const int *src, int *arl, int n, int q, int qbits, int rdoq) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int qbits_c = qbits - 7;
+  const long long t = (long long)abs(src[i]) * q;
+  if (rdoq) {
+    const long long lim = 2147483647ll - (1ll << (qbits - 1));
+    const int ld = (int)(t < lim ? t : lim);
+    arl[i] = (ld + (1 << (qbits_c - 1))) >> qbits_c;
+  } else {
+    arl[i] = (int)((t + (1ll << (qbits_c - 1))) >> qbits_c);
+  }
+}
+extern "C" int hmx_arlCoeff(hmx_ctx *c, const int32_t *src, int32_t *arl, int w, int h, int text_type, const hmx_quant_param *qp, int rdoq_form) {
+  (void)text_type;
+  if (!c || !src || !arl || !qp || !size_ok(w, h)) return fail(c, HMX_ERR_ARG, "hmx_arlCoeff: unsupported size or null");
+  if (qp->qp.rem < 0 || qp->qp.rem > 5 || qp->qp.per < 0) return fail(c, HMX_ERR_ARG, "hmx_arlCoeff: bad QP");
+  Scratch s{c};
+  int *d_in = s.take<int>(w * h), *d_out = s.take<int>(w * h);
+  int r = up2d(c, d_in, src, 4, w, h, w);
+  if (r) return r;
+  const int per = rdoq_form ? qp->qp.per : (qp->per_base >= 0 ? qp->per_base : qp->qp.per);
+  const int qbits = 14 + per + (15 - c->cfg.bit_depth - ilog2i(w));
+  hipLaunchKernelGGL(k_arl, dim3((unsigned)((w * h + 255) / 256)), dim3(256), 0, c->stream, d_in, d_out, w * h, kQuantScales[qp->qp.rem], qbits, rdoq_form != 0);
+  HIPCHK(c, hipGetLastError());
+  return down2d(c, arl, w, d_out, 4, w, h);
+}
+
 // ---- rate-distortion optimised quantisation (hmx_rdoq.h) ----
 static_assert(sizeof(hmx_est_bits) == sizeof(EstBitsDev), "hmx_est_bits mirrors estBitsSbacStruct");
 static const int kRdoqChunk = 16384; // lanes per launch: 41 KB of records each
