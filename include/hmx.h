@@ -108,6 +108,10 @@ int hmx_xITransformSkip(hmx_ctx *ctx, const int32_t *coef, hmx_pel *resi, unsign
 /* xQuant, flat path + signBitHidingHDQ (TComTrQuant.cpp:1102-1270, 977-1100); ac_sum accumulates */
 int hmx_xQuant(hmx_ctx *ctx, const int32_t *src, hmx_coeff *dst, int w, int h, uint32_t *ac_sum,
                int text_type, const hmx_quant_param *qp);
+/* xDeQuant with a scaling list (TComTrQuant.cpp:1311-1342, getUseScalingList()): dequant_coef[w*h] = the table
+ * getDequantCoeff(scalingListType, m_cQP.m_iRem, log2(w) - 2, SCALING_LIST_SQT) that setScalingListDec built from the slice's lists
+ * (:2773-2793, 2852-2873: header handling, stays in HM).  Host pointers like the other scalar drop-ins. */
+int hmx_xDeQuant_scaled(hmx_ctx *ctx, const hmx_coeff *src, int32_t *dst, int w, int h, const hmx_qp *qp, const int32_t *dequant_coef);
 /* The pArlDes output of xQuant (ADAPTIVE_QP_SELECTION, m_bUseAdaptQpSelect): arl[n] = (|src[n]| * quantScale + round) >> (iQBits - 7),
  * what TEncSlice's adaptive QP selection accumulates.  rdoq_form = 0: the flat branch (TComTrQuant.cpp:1229-1249; iQBits from
  * qp->per_base, the slice's base QP); rdoq_form = 1: as xRateDistOptQuant writes it (:1757-1765, 1886-1891; iQBits from qp->qp.per,

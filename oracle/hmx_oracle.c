@@ -732,6 +732,25 @@ void hmo_xDeQuant(const int32_t *src, int32_t *dst, int N, int B, int per, int r
   }
 }
 
+/* xDeQuant with a scaling list (COM/TComTrQuant.cpp:1311-1342): coef = the per-position table HM's setScalingListDec built for
+ * (list type, QP remainder, size) -- scaling-list entry times g_invQuantScales[rem] (:2860-2861, 2979-3003).  The table is an INPUT:
+ * building it from the slice's lists is header handling that stays in HM. */
+void hmo_xDeQuant_scaled(const int32_t *src, int32_t *dst, int N, int B, int per, const int32_t *coef) {
+  const int lg = ilog2(N), shift = 20 - 14 - (15 - B - lg) + 4;
+  const int bit_range = 12 + lg + B - per < 15 ? 12 + lg + B - per : 15, limit = 1 << bit_range;
+  for (int i = 0; i < N * N; i++) {
+    if (shift > per) {
+      const int32_t l = clip3(-32768, 32767, src[i]);
+      const int32_t v = (int32_t)((uint32_t)l * (uint32_t)coef[i] + (uint32_t)(1 << (shift - per - 1))); /* 32-bit Int in the reference */
+      dst[i] = clip3(-32768, 32767, v >> (shift - per));
+    } else {
+      const int32_t l = clip3(-limit, limit - 1, src[i]);
+      const int32_t v = (int32_t)(((uint32_t)l * (uint32_t)coef[i]) << (per - shift));
+      dst[i] = clip3(-32768, 32767, v);
+    }
+  }
+}
+
 void hmo_transformNxN(const int16_t *resi, int stride, int32_t *level, int N, int B, unsigned mode,
                       int transform_skip, int bypass, const hmo_quant_cfg *cfg, uint32_t *abs_sum) {
   int32_t tmp[32 * 32];

@@ -70,6 +70,8 @@ int hmo_coef_scan_idx(int N, int is_luma, int is_intra, int dir_mode);
 void hmo_xQuant(const int32_t *src, int32_t *dst, int N, int B, const hmo_quant_cfg *cfg,
                 uint32_t *ac_sum);
 void hmo_xDeQuant(const int32_t *src, int32_t *dst, int N, int B, int per, int rem);
+/* xDeQuant's scaling-list branch (COM/TComTrQuant.cpp:1311-1342); coef[N*N] = getDequantCoeff(list, rem, size) */
+void hmo_xDeQuant_scaled(const int32_t *src, int32_t *dst, int N, int B, int per, const int32_t *coef);
 /* pArlDes of xQuant (rdoq = 0, COM/TComTrQuant.cpp:1229-1249) / of xRateDistOptQuant (rdoq = 1, :1764-1765, 1886-1891) */
 void hmo_arlCoeff(const int32_t *src, int32_t *arl, int N, int B, const hmo_quant_cfg *cfg, int rdoq);
 

@@ -16,9 +16,13 @@ BODIES = {
         # inverse transform, de-quantiser (flat path; every shipped cfg has ScalingList 0), inverse transform skip
         "TComTrQuant::xIT": "HMX_SHIM_CHECK(hmx_xIT(hmx_shim_ctx(), uiMode, plCoef, pResidual, uiStride, iWidth, iHeight));",
         "TComTrQuant::xITransformSkip": "HMX_SHIM_CHECK(hmx_xITransformSkip(hmx_shim_ctx(), plCoef, pResidual, uiStride, width, height));",
-        "TComTrQuant::xDeQuant": """if (getUseScalingList()) { fprintf(stderr, "libhmx shim: scaling lists are outside the built path\\n"); exit(EXIT_FAILURE); }
-  hmx_qp q = { m_cQP.m_iQP, m_cQP.m_iPer, m_cQP.m_iRem, m_cQP.m_iBits };
-  HMX_SHIM_CHECK(hmx_xDeQuant(hmx_shim_ctx(), pSrc, pDes, iWidth, iHeight, &q));""",
+        "TComTrQuant::xDeQuant": """hmx_qp q = { m_cQP.m_iQP, m_cQP.m_iPer, m_cQP.m_iRem, m_cQP.m_iBits };
+  if (iWidth > (Int)m_uiMaxTrSize) iWidth = iHeight = m_uiMaxTrSize; /* :1290-1294 */
+  if (getUseScalingList()) /* :1311-1342: the table setScalingListDec built for this list type, remainder and size */
+    HMX_SHIM_CHECK(hmx_xDeQuant_scaled(hmx_shim_ctx(), pSrc, pDes, iWidth, iHeight, &q,
+                                       getDequantCoeff(scalingListType, m_cQP.m_iRem, g_aucConvertToBit[iWidth], SCALING_LIST_SQT)));
+  else
+    HMX_SHIM_CHECK(hmx_xDeQuant(hmx_shim_ctx(), pSrc, pDes, iWidth, iHeight, &q));""",
     },
     "TComPrediction": {
         # bAbove / bLeft are always true in this tree (TComPattern.cpp: the padded reference line replaces them)

@@ -232,6 +232,18 @@ void ref_xRateDistOptQuant(int qpy, int slice_type, int ttype, int is_intra, int
   S->tq.xRateDistOptQuant(cu, coef, level, arl, N, N, sum, (TextType)ttype, 0);
   *abs_sum = sum;
 }
+// xDeQuant's scaling-list branch with a caller-supplied table: the table of (list type, QP remainder, size) is overwritten with
+// dq_coef for the call and restored to the flat one afterwards.
+void ref_xDeQuant_scaled(int qpy, int ttype, int bd_off, int list_type, const int *dq_coef, const int *src, int *dst, int N) {
+  S->tq.setQPforQuant(qpy, (TextType)ttype, bd_off, 0);
+  const UInt size_id = g_aucConvertToBit[N];
+  Int *tab = S->tq.getDequantCoeff(list_type, S->tq.m_cQP.m_iRem, size_id, SCALING_LIST_SQT);
+  memcpy(tab, dq_coef, sizeof(Int) * N * N);
+  S->tq.setUseScalingList(true);
+  S->tq.xDeQuant(src, dst, N, N, list_type);
+  S->tq.setUseScalingList(false);
+  S->tq.xsetFlatScalingList(list_type, size_id, S->tq.m_cQP.m_iRem);
+}
 // xQuant as the encoder runs it under AdaptiveQpSelection: the slice's base QP differs from the block's QP (cQpBase,
 // TComTrQuant.cpp:1162-1193), m_bUseAdaptQpSelect is on and pArlDes receives the ARL coefficients -- from the flat branch or,
 // with rdoq != 0, from xRateDistOptQuant (est_blob / lambda as in ref_xRateDistOptQuant).

@@ -24,6 +24,9 @@ STREAMS = [
     ("intra_he10_q30", 32, 128, 128, 1, 10, 30, "encoder_intra_he10.cfg", [], False),
     ("lowdelay_P_main_q32", 33, 192, 128, 3, 8, 32, "encoder_lowdelay_P_main.cfg", [], True),
     ("randomaccess_main_q34", 34, 192, 128, 5, 8, 34, "encoder_randomaccess_main.cfg", [], True),
+    # round 3: the default scaling lists (xDeQuant's scaling-list branch, TComTrQuant.cpp:1311-1342)
+    ("lowdelay_P_scalinglist_q30", 35, 192, 128, 3, 8, 30, "encoder_lowdelay_P_main.cfg", ["--ScalingList=1"], True),
+    ("intra_he10_scalinglist_q24", 36, 128, 128, 1, 10, 24, "encoder_intra_he10.cfg", ["--ScalingList=1"], False),
 ]
 
 

@@ -110,6 +110,32 @@ def rdoq(R, B, rng):
     return out
 
 
+def dequant_scaled(R, B, rng):
+    """xDeQuant's scaling-list branch of the compiled reference, the table as an input (range of setScalingListDec's tables)."""
+    out = {}
+    bd = 6 * (B - 8)
+    for N in (4, 8, 16, 32):
+        par, tab_l, lev_l, out_l = [], [], [], []
+        for it in range(12):
+            qpy = int(rng.choice([0, 4, 10, 22, 27, 32, 37, 45, 51]))
+            inv = (40, 45, 51, 57, 64, 72)[(qpy + bd) % 6]
+            table = (rng.integers(1, 256, N * N) * inv).astype(np.int32)
+            amp = int(rng.choice([3, 40, 700, 32767, 70000]))
+            lev = rng.integers(-amp, amp + 1, N * N).astype(np.int32)
+            lt = int(rng.choice([0, 3]) if N == 32 else rng.integers(0, 6))
+            o = np.zeros(N * N, np.int32)
+            R.ref_xDeQuant_scaled(qpy, 0, bd, lt, table, lev, o, N)
+            par.append((qpy, lt))
+            tab_l.append(table)
+            lev_l.append(lev)
+            out_l.append(o)
+        out[f"s{N}_par"] = np.array(par, np.int32)
+        out[f"s{N}_tab"] = np.stack(tab_l)
+        out[f"s{N}_lev"] = np.stack(lev_l)
+        out[f"s{N}_out"] = np.stack(out_l)
+    return out
+
+
 def arl(R, B, rng):
     """pArlDes of the compiled reference's xQuant under AdaptiveQpSelection: the flat branch (iQBits from the slice's base QP) and
     xRateDistOptQuant (odd cases); the flat branch's levels with a base QP of its own come along."""
@@ -356,6 +382,11 @@ def main():
         for B in (8, 10):
             R.ref_init(B, 416, 240, 1)
             np.savez_compressed(os.path.join(HERE, f"arl_b{B}.npz"), **arl(R, B, np.random.default_rng(9144 + B)))
+        return
+    if sys.argv[1:] == ["dequant_scaled"]:  # round 3: xDeQuant's scaling-list branch
+        for B in (8, 10):
+            R.ref_init(B, 416, 240, 1)
+            np.savez_compressed(os.path.join(HERE, f"dequant_scaled_b{B}.npz"), **dequant_scaled(R, B, np.random.default_rng(10168 + B)))
         return
     if sys.argv[1:] == ["deblock"]:
         for B in (8, 10):

@@ -107,6 +107,8 @@ def oracle():
         L.hmo_xRateDistOptQuant.argtypes = [i32p, i32p, ci, ci, C.POINTER(RdoqCfg), C.POINTER(EstBits), C.POINTER(C.c_uint32)]
         L.hmo_xRateDistOptQuant.restype = None
         L.hmo_xDeQuant.argtypes = [i32p, i32p, ci, ci, ci, ci]
+        L.hmo_xDeQuant_scaled.argtypes = [i32p, i32p, ci, ci, ci, i32p]
+        L.hmo_xDeQuant_scaled.restype = None
         L.hmo_arlCoeff.argtypes = [i32p, i32p, ci, ci, C.POINTER(QuantCfg), ci]
         L.hmo_arlCoeff.restype = None
         L.hmo_transformNxN.argtypes = [i16p, ci, i32p, ci, ci, cu, ci, ci, C.POINTER(QuantCfg),
@@ -164,6 +166,7 @@ def ref():
         L.ref_xITransformSkip.argtypes = [i32p, i16p, cu, ci]
         L.ref_setQPforQuant.argtypes = [ci, ci, ci, ci, i32p]
         L.ref_xDeQuant.argtypes = [ci, ci, ci, ci, i32p, i32p, ci]
+        L.ref_xDeQuant_scaled.argtypes = [ci, ci, ci, ci, i32p, i32p, i32p, ci]
         L.ref_transformNxN.argtypes = [ci, ci, ci, ci, ci, ci, ci, i16p, cu, i32p, ci,
                                        C.POINTER(C.c_uint32)]
         L.ref_invtransformNxN.argtypes = [ci, ci, ci, cu, i16p, cu, i32p, ci, ci]

@@ -72,6 +72,17 @@ def test_oracle_rdoq(B):
 
 
 @pytest.mark.parametrize("B", [8, 10])
+def test_oracle_dequant_scaled(B):
+    g, O = load(f"dequant_scaled_b{B}.npz"), ol.oracle()
+    for N in (4, 8, 16, 32):
+        for k, (qpy, _lt) in enumerate(g[f"s{N}_par"]):
+            q = O.hmo_setQPforQuant(int(qpy), 0, 6 * (B - 8), 0)
+            o = np.zeros(N * N, np.int32)
+            O.hmo_xDeQuant_scaled(np.ascontiguousarray(g[f"s{N}_lev"][k]), o, N, B, q.per, np.ascontiguousarray(g[f"s{N}_tab"][k]))
+            assert np.array_equal(o, g[f"s{N}_out"][k]), (N, k)
+
+
+@pytest.mark.parametrize("B", [8, 10])
 def test_oracle_arl(B):
     """pArlDes (AdaptiveQpSelection) of the reference's xQuant / xRateDistOptQuant, and the flat branch's levels when the slice's
     base QP is not the block's."""
@@ -361,6 +372,18 @@ def test_gpu_frame(name, B):
         assert np.array_equal(lev[p], g["lev_" + k].astype(np.int32)), k
     L.hmx_intra_plan_destroy(ctx.h, plan)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_dequant_scaled(gctx):
+    """hmx_xDeQuant_scaled vs the reference's vectors (both shift directions, extreme levels)."""
+    from thevc_amd import capi
+    B = gctx.bit_depth
+    g = load(f"dequant_scaled_b{B}.npz")
+    for N in (4, 8, 16, 32):
+        for k, (qpy, _lt) in enumerate(g[f"s{N}_par"]):
+            o = gctx.xDeQuant_scaled(g[f"s{N}_lev"][k], N, capi.qp_for(int(qpy), 0, B), g[f"s{N}_tab"][k])
+            assert np.array_equal(o, g[f"s{N}_out"][k]), (N, k)
 
 
 @pytest.mark.gpu

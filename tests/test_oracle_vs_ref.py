@@ -216,6 +216,47 @@ def test_xRateDistOptQuant(B, N):
     assert n_nonzero >= 30 and n_differs_from_flat >= 15, (n_nonzero, n_differs_from_flat)  # the RD decisions were exercised
 
 
+def _scaled_dequant_cases(rng, N, B, n_cases):
+    """(qpy, list type, table, levels): tables in the range setScalingListDec produces (list entry 1..255 times g_invQuantScales),
+    levels up to the extremes (the reference multiplies in 32-bit Int)."""
+    for it in range(n_cases):
+        qpy = int(rng.choice([0, 4, 10, 22, 27, 32, 37, 45, 51]))
+        inv = (40, 45, 51, 57, 64, 72)[(qpy + 6 * (B - 8)) % 6]
+        table = (rng.integers(1, 256, N * N) * inv).astype(np.int32)
+        if it % 3 == 0:
+            table[:] = 16 * inv  # the flat list
+        amp = int(rng.choice([3, 40, 700, 32767, 70000]))
+        lev = rng.integers(-amp, amp + 1, N * N).astype(np.int32)
+        yield qpy, int(rng.choice([0, 3]) if N == 32 else rng.integers(0, 6)), table, lev  # 32x32 has the two luma lists only
+
+
+@pytest.mark.parametrize("N", [4, 8, 16, 32])
+def test_scaled_dequant_vs_reference(B, N):
+    """xDeQuant's scaling-list branch (TComTrQuant.cpp:1311-1342) with the table as an input: both shift directions (low and high
+    QP), the level clip of the left-shift case, 32-bit products."""
+    R, O = ol.ref(), ol.oracle()
+    rng = np.random.default_rng(5200 + N + B)
+    bd = 6 * (B - 8)
+    left = right = 0
+    for qpy, lt, table, lev in _scaled_dequant_cases(rng, N, B, 60):
+        a, b = np.zeros(N * N, np.int32), np.zeros(N * N, np.int32)
+        R.ref_xDeQuant_scaled(qpy, 0, bd, lt, table, lev, a, N)
+        q = O.hmo_setQPforQuant(qpy, 0, bd, 0)
+        O.hmo_xDeQuant_scaled(lev, b, N, B, q.per, table)
+        assert np.array_equal(a, b), (N, B, qpy, np.argwhere(a != b)[:4])
+        shift = 20 - 14 - (15 - B - int(np.log2(N))) + 4
+        left += int(shift <= q.per)
+        right += int(shift > q.per)
+    assert left >= 5 and right >= 5, (left, right)
+    # and the reference's flat branch is untouched afterwards
+    lev = rng.integers(-300, 301, N * N).astype(np.int32)
+    a, b = np.zeros(N * N, np.int32), np.zeros(N * N, np.int32)
+    R.ref_xDeQuant(30, 0, bd, 0, lev, a, N)
+    q = O.hmo_setQPforQuant(30, 0, bd, 0)
+    O.hmo_xDeQuant(lev, b, N, B, q.per, q.rem)
+    assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("N", [4, 8, 16, 32])
 def test_arl_coefficients_vs_reference(B, N):
     """pArlDes of xQuant under AdaptiveQpSelection (TComTrQuant.cpp:1229-1249) and of xRateDistOptQuant (:1764-1765, 1886-1891): the

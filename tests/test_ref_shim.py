@@ -14,7 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF = os.path.join(ROOT, "oracle", "_ref")
 STREAMS = sorted(glob.glob(os.path.join(HERE, "golden", "streams", "*.bin")))
-N_PICTURES = {"intra_main_q32": 2, "intra_he10_q30": 1, "lowdelay_P_main_q32": 3, "randomaccess_main_q34": 5}
+N_PICTURES = {"intra_main_q32": 2, "intra_he10_q30": 1, "lowdelay_P_main_q32": 3, "randomaccess_main_q34": 5,
+              "lowdelay_P_scalinglist_q30": 3, "intra_he10_scalinglist_q24": 1}
 
 
 def _decode(binary, stream, out):

@@ -121,6 +121,7 @@ def lib():
         L.hmx_xITransformSkip.argtypes = [vp, vp, vp, cu, ci, ci]
         L.hmx_xQuant.argtypes = [vp, vp, vp, ci, ci, C.POINTER(C.c_uint32), ci, C.POINTER(QuantParam)]
         L.hmx_arlCoeff.argtypes = [vp, vp, vp, ci, ci, ci, C.POINTER(QuantParam), ci]
+        L.hmx_xDeQuant_scaled.argtypes = [vp, vp, vp, ci, ci, C.POINTER(Qp), vp]
         L.hmx_xDeQuant.argtypes = [vp, vp, vp, ci, ci, C.POINTER(Qp)]
         L.hmx_transformNxN.argtypes = [vp, vp, cu, vp, cu, cu, C.POINTER(C.c_uint32), ci, C.POINTER(QuantParam),
                                        ci, ci]
@@ -346,6 +347,12 @@ class Context:
         s = C.c_uint32(ac_sum)
         self._chk(lib().hmx_xQuant(self.h, _hp(src), _hp(dst), n, n, C.byref(s), text_type, C.byref(qparam)))
         return dst, s.value
+
+    def xDeQuant_scaled(self, src, n, qp, table):
+        src, table = np.ascontiguousarray(src, np.int32), np.ascontiguousarray(table, np.int32)
+        dst = np.zeros(n * n, np.int32)
+        self._chk(lib().hmx_xDeQuant_scaled(self.h, _hp(src), _hp(dst), n, n, C.byref(qp), _hp(table)))
+        return dst
 
     def arlCoeff(self, src, n, text_type, qparam, rdoq_form):
         src = np.ascontiguousarray(src, np.int32)

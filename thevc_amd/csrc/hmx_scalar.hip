@@ -393,6 +393,36 @@ extern "C" int hmx_xDeQuant(hmx_ctx *c, const hmx_coeff *src, int32_t *dst, int 
   return down2d(c, dst, w, d_out, 4, w, h);
 }
 
+// xDeQuant with a scaling list (TComTrQuant.cpp:1311-1342): per position the table entry HM's setScalingListDec left for (list type,
+// QP remainder, size); one thread per coefficient, 32-bit products as the reference forms them.
+__global__ __launch_bounds__(256) void k_dequant_scaled(const int *src, const int *coef, int *dst, int n, int shift, int per, int limit) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int v;
+  if (shift > per) {
+    const int l = clip3(-32768, 32767, src[i]);
+    v = (int)((unsigned)l * (unsigned)coef[i] + (1u << (shift - per - 1))) >> (shift - per);
+  } else {
+    const int l = clip3(-limit, limit - 1, src[i]);
+    v = (int)(((unsigned)l * (unsigned)coef[i]) << (per - shift));
+  }
+  dst[i] = clip3(-32768, 32767, v);
+}
+extern "C" int hmx_xDeQuant_scaled(hmx_ctx *c, const hmx_coeff *src, int32_t *dst, int w, int h, const hmx_qp *qp, const int32_t *dequant_coef) {
+  if (!c || !src || !dst || !qp || !dequant_coef || !size_ok(w, h)) return fail(c, HMX_ERR_ARG, "hmx_xDeQuant_scaled: unsupported size or null");
+  if (qp->per < 0) return fail(c, HMX_ERR_ARG, "hmx_xDeQuant_scaled: bad QP");
+  Scratch s{c};
+  int *d_in = s.take<int>(w * h), *d_tab = s.take<int>(w * h), *d_out = s.take<int>(w * h);
+  int r = up2d(c, d_in, src, 4, w, h, w);
+  if (!r) r = up2d(c, d_tab, dequant_coef, 4, w, h, w);
+  if (r) return r;
+  const int lg = ilog2i(w), shift = 20 - 14 - (15 - c->cfg.bit_depth - lg) + 4;
+  const int bit_range = std::min(15, 12 + lg + c->cfg.bit_depth - qp->per);
+  hipLaunchKernelGGL(k_dequant_scaled, dim3((unsigned)((w * h + 255) / 256)), dim3(256), 0, c->stream, d_in, d_tab, d_out, w * h, shift, qp->per, 1 << bit_range);
+  HIPCHK(c, hipGetLastError());
+  return down2d(c, dst, w, d_out, 4, w, h);
+}
+
 extern "C" int hmx_transformNxN(hmx_ctx *c, const hmx_pel *resi, unsigned stride, hmx_coeff *level, unsigned w, unsigned h,
                                 uint32_t *abs_sum, int text_type, const hmx_quant_param *qp, int use_ts, int bypass) {
   if (!c || !resi || !level || !qp || !abs_sum || !size_ok((int)w, (int)h))
