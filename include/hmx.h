@@ -117,7 +117,15 @@ int hmx_xDeQuant_scaled(hmx_ctx *ctx, const hmx_coeff *src, int32_t *dst, int w,
  * qp->per_base, the slice's base QP); rdoq_form = 1: as xRateDistOptQuant writes it (:1757-1765, 1886-1891; iQBits from qp->qp.per,
  * the product limited to MAX_INT - (1 << (iQBits - 1)) first).  It depends on the coefficients alone: call it beside hmx_xQuant /
  * hmx_xRateDistOptQuant when the encoder runs with AdaptiveQpSelection. */
-int hmx_arlCoeff(hmx_ctx *ctx, const int32_t *src, int32_t *arl, int w, int h, int text_type, const hmx_quant_param *qp, int rdoq_form);
+int hmx_arlCoeff(hmx_ctx *ctx, const int32_t *src, int32_t *arl, int w, int h, int text_type, const hmx_quant_param *qp, int rdoq_form,
+                 const int32_t *quant_coef /* getQuantCoeff table of a scaling list, or NULL */);
+/* The quantisers with a scaling list (getUseScalingList()): the per-position tables HM's setScalingList built for the block's list
+ * type, QP remainder and size are INPUTS (building them from the slice's lists is header handling, TComTrQuant.cpp:2747-2847, 2953-
+ * 2977) -- quant_coef = getQuantCoeff(...), err_scale = getErrScaleCoeff(...), w*h entries each, row-major.
+ * hmx_xQuant_scaled: xQuant's flat branch (:1215, 1244-1255) + signBitHidingHDQ.
+ * hmx_xRateDistOptQuant_scaled: xRateDistOptQuant (:1759-1762, 1882-1883). */
+int hmx_xQuant_scaled(hmx_ctx *ctx, const int32_t *src, hmx_coeff *dst, int w, int h, uint32_t *ac_sum, int text_type,
+                      const hmx_quant_param *qp, const int32_t *quant_coef);
 /* xRateDistOptQuant (TComTrQuant.cpp:1719-2305), the quantiser transformNxN selects when RDOQ is on
  * (:1122-1128; every shipped cfg).  It reads CABAC bit estimates that TEncSbac::estBit leaves in
  * m_pcEstBitsSbac for the block's size and texture type (estBitsSbacStruct, TComTrQuant.h:59-72; same
@@ -145,6 +153,8 @@ typedef struct hmx_rdoq_param {
 } hmx_rdoq_param;
 int hmx_xRateDistOptQuant(hmx_ctx *ctx, const int32_t *src, hmx_coeff *dst, int w, int h, uint32_t *abs_sum,
                           int text_type, const hmx_rdoq_param *rp, const hmx_est_bits *est);
+int hmx_xRateDistOptQuant_scaled(hmx_ctx *ctx, const int32_t *src, hmx_coeff *dst, int w, int h, uint32_t *abs_sum, int text_type,
+                                 const hmx_rdoq_param *rp, const hmx_est_bits *est, const int32_t *quant_coef, const double *err_scale);
 /* xDeQuant, flat path (TComTrQuant.cpp:1272-1355) */
 int hmx_xDeQuant(hmx_ctx *ctx, const hmx_coeff *src, int32_t *dst, int w, int h, const hmx_qp *qp);
 /* transformNxN (TComTrQuant.cpp:1373-1426): uiMode is derived as the reference does

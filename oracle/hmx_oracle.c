@@ -292,8 +292,10 @@ static void sign_bit_hiding(int32_t *q, const int32_t *c, const uint32_t *scan, 
 }
 
 /* Flat quantiser of xQuant (COM/TComTrQuant.cpp:1130-1267). */
-void hmo_xQuant(const int32_t *src, int32_t *dst, int N, int B, const hmo_quant_cfg *cfg,
-                uint32_t *ac_sum) {
+/* qtab != NULL: the per-position table getQuantCoeff(list, rem, size) of a scaling list (COM/TComTrQuant.cpp:1215, 1244) -- an INPUT,
+ * HM's setScalingList builds it (:2747-2771, 2826-2847, 2953-2977); NULL: the flat scale */
+void hmo_xQuant_scaled(const int32_t *src, int32_t *dst, int N, int B, const hmo_quant_cfg *cfg,
+                       uint32_t *ac_sum, const int32_t *qtab) {
   int lg = ilog2(N), tshift = 15 - B - lg;
   int qbits = 14 + cfg->per_qbits + tshift;
   int64_t add = (int64_t)(cfg->intra_slice ? 171 : 85) << (qbits - 9);
@@ -301,7 +303,7 @@ void hmo_xQuant(const int32_t *src, int32_t *dst, int N, int B, const hmo_quant_
   int deltaU[32 * 32];
   uint32_t sum = *ac_sum;
   for (int i = 0; i < N * N; i++) {
-    int64_t t = (int64_t)abs(src[i]) * q;
+    int64_t t = (int64_t)abs(src[i]) * (qtab ? qtab[i] : q);
     int lvl = (int)((t + add) >> qbits);
     deltaU[i] = (int)((t - ((int64_t)lvl << qbits)) >> (qbits - 8));
     sum += (uint32_t)lvl;
@@ -310,16 +312,19 @@ void hmo_xQuant(const int32_t *src, int32_t *dst, int N, int B, const hmo_quant_
   *ac_sum = sum;
   if (cfg->sign_hide && sum >= 2) sign_bit_hiding(dst, src, hmo_scan(cfg->scan_idx, lg), deltaU, N);
 }
+void hmo_xQuant(const int32_t *src, int32_t *dst, int N, int B, const hmo_quant_cfg *cfg, uint32_t *ac_sum) {
+  hmo_xQuant_scaled(src, dst, N, B, cfg, ac_sum, NULL);
+}
 
 /* The pArlDes output of the quantiser (ADAPTIVE_QP_SELECTION; what TEncSlice's adaptive QP selection accumulates): the coefficient
  * scaled like a level but with ARL_C_PRECISION = 7 more fractional bits.  Flat path COM/TComTrQuant.cpp:1229-1249 (iQBits from the
  * slice's BASE QP, cQpBase); RDOQ path :1757, 1764-1765, 1886-1891 (iQBits from m_cQP, the product limited first). */
-void hmo_arlCoeff(const int32_t *src, int32_t *arl, int N, int B, const hmo_quant_cfg *cfg, int rdoq) {
+void hmo_arlCoeff(const int32_t *src, int32_t *arl, int N, int B, const hmo_quant_cfg *cfg, int rdoq, const int32_t *qtab) {
   const int lg = ilog2(N), tshift = 15 - B - lg;
   const int qbits = 14 + (rdoq ? cfg->per : cfg->per_qbits) + tshift, qbits_c = qbits - 7;
   const int q = hmo_quant_scale(cfg->rem);
   for (int i = 0; i < N * N; i++) {
-    const int64_t t = (int64_t)abs(src[i]) * q;
+    const int64_t t = (int64_t)abs(src[i]) * (qtab ? qtab[i] : q);
     if (rdoq) {
       const int64_t lim = (int64_t)2147483647 - ((int64_t)1 << (qbits - 1));
       const int ld = (int)(t < lim ? t : lim);
@@ -437,18 +442,29 @@ static double rdoq_last_cost(const rdoq_rates *r, unsigned px, unsigned py) { /*
   return r->lambda * cost;
 }
 
+/* qtab / estab != NULL: getQuantCoeff / getErrScaleCoeff of a scaling list per position (COM/TComTrQuant.cpp:1759-1762, 1882-1883) */
+static void rdoq_tables(const int32_t *src, int32_t *dst, int N, int B, const hmo_rdoq_cfg *cfg, const hmo_est_bits *est,
+                        uint32_t *abs_sum, const int32_t *qtab, const double *estab);
 void hmo_xRateDistOptQuant(const int32_t *src, int32_t *dst, int N, int B, const hmo_rdoq_cfg *cfg,
                            const hmo_est_bits *est, uint32_t *abs_sum) {
+  rdoq_tables(src, dst, N, B, cfg, est, abs_sum, NULL, NULL);
+}
+void hmo_xRateDistOptQuant_scaled(const int32_t *src, int32_t *dst, int N, int B, const hmo_rdoq_cfg *cfg, const hmo_est_bits *est,
+                                  uint32_t *abs_sum, const int32_t *qtab, const double *estab) {
+  rdoq_tables(src, dst, N, B, cfg, est, abs_sum, qtab, estab);
+}
+static void rdoq_tables(const int32_t *src, int32_t *dst, int N, int B, const hmo_rdoq_cfg *cfg, const hmo_est_bits *est,
+                        uint32_t *abs_sum, const int32_t *qtab, const double *estab) {
   const int lg = ilog2(N), nn = N * N, G = N / 4, n_cg = nn >> 4;
   const int tshift = 15 - B - lg, qbits = 14 + cfg->per + tshift, inc = B - 8;
-  const int q = hmo_quant_scale(cfg->rem);
+  const int q_flat = hmo_quant_scale(cfg->rem);
   const int scan_idx = cfg->scan_idx == HMO_SCAN_ZIGZAG ? HMO_SCAN_DIAG : cfg->scan_idx; /* :1770-1774 */
   const uint32_t *scan = hmo_scan(scan_idx, lg);
   const rdoq_rates R = {est, cfg->lambda};
   /* flat error scale (setErrScaleCoeff :2794-2818) */
-  double err_scale = (double)(1 << 15);
-  err_scale = err_scale * ldexp(1.0, -2 * tshift); /* pow(2.0, -2.0 * iTransformShift): an exact power of two */
-  err_scale = err_scale / (double)q / (double)q / (double)(1 << (2 * inc));
+  double err_flat = (double)(1 << 15);
+  err_flat = err_flat * ldexp(1.0, -2 * tshift); /* pow(2.0, -2.0 * iTransformShift): an exact power of two */
+  err_flat = err_flat / (double)q_flat / (double)q_flat / (double)(1 << (2 * inc));
 
   static double cost_coded[1024], cost_sig[1024], cost_zero[1024], cost_cg_sig[64];
   static int rate_up[1024], rate_down[1024], sig_delta[1024], delta_u[1024];
@@ -483,6 +499,8 @@ void hmo_xRateDistOptQuant(const int32_t *src, int32_t *dst, int N, int B, const
     for (int k = 15; k >= 0; k--) {
       const int sp = cg * 16 + k;
       const unsigned bp = scan[sp];
+      const int q = qtab ? qtab[bp] : q_flat;
+      const double err_scale = estab ? estab[bp] : err_flat;
       int64_t wide = (int64_t)abs(src[bp]) * q;
       const int64_t cap = (int64_t)2147483647 - ((int64_t)1 << (qbits - 1));
       const int ld = (int)(wide < cap ? wide : cap); /* "level double": |c| * q */

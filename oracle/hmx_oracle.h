@@ -73,7 +73,9 @@ void hmo_xDeQuant(const int32_t *src, int32_t *dst, int N, int B, int per, int r
 /* xDeQuant's scaling-list branch (COM/TComTrQuant.cpp:1311-1342); coef[N*N] = getDequantCoeff(list, rem, size) */
 void hmo_xDeQuant_scaled(const int32_t *src, int32_t *dst, int N, int B, int per, const int32_t *coef);
 /* pArlDes of xQuant (rdoq = 0, COM/TComTrQuant.cpp:1229-1249) / of xRateDistOptQuant (rdoq = 1, :1764-1765, 1886-1891) */
-void hmo_arlCoeff(const int32_t *src, int32_t *arl, int N, int B, const hmo_quant_cfg *cfg, int rdoq);
+void hmo_arlCoeff(const int32_t *src, int32_t *arl, int N, int B, const hmo_quant_cfg *cfg, int rdoq, const int32_t *qtab);
+/* xQuant's flat branch with a scaling list: qtab[N*N] = getQuantCoeff(list, rem, size) (COM/TComTrQuant.cpp:1215, 1244); NULL = flat */
+void hmo_xQuant_scaled(const int32_t *src, int32_t *dst, int N, int B, const hmo_quant_cfg *cfg, uint32_t *ac_sum, const int32_t *qtab);
 
 /* Rate-distortion optimised quantisation, xRateDistOptQuant (COM/TComTrQuant.cpp:1719-2305) with its
  * helpers (:2315-2735), flat scaling (setErrScaleCoeff :2794-2818), as compiled in the reference
@@ -102,6 +104,9 @@ typedef struct {
 } hmo_rdoq_cfg;
 void hmo_xRateDistOptQuant(const int32_t *src, int32_t *dst, int N, int B, const hmo_rdoq_cfg *cfg,
                            const hmo_est_bits *est, uint32_t *abs_sum);
+/* the same with a scaling list: qtab = getQuantCoeff, estab = getErrScaleCoeff of (list, rem, size), per position (NULL = flat) */
+void hmo_xRateDistOptQuant_scaled(const int32_t *src, int32_t *dst, int N, int B, const hmo_rdoq_cfg *cfg, const hmo_est_bits *est,
+                                  uint32_t *abs_sum, const int32_t *qtab, const double *estab);
 /* transformNxN / invtransformNxN without the TComDataCU plumbing (COM/TComTrQuant.cpp:1373-1450) */
 void hmo_transformNxN(const int16_t *resi, int stride, int32_t *level, int N, int B, unsigned mode,
                       int transform_skip, int bypass, const hmo_quant_cfg *cfg, uint32_t *abs_sum);

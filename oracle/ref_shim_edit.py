@@ -58,8 +58,9 @@ ENC_BODIES = {
     xRateDistOptQuant( pcCU, pSrc, pDes, pArlDes, iWidth, iHeight, uiAcSum, eTType, uiAbsPartIdx );
     return;
   }
-  if (getUseScalingList()) { fprintf(stderr, "libhmx shim: scaling lists are outside the built path\\n"); exit(EXIT_FAILURE); }
   """ + _SCAN_DIR % {"w": "iWidth"} + """
+  const Int *hmxQ = getUseScalingList() /* :1212-1215: the table setScalingList built for this list type, remainder and size */
+      ? getQuantCoeff((pcCU->isIntra(uiAbsPartIdx) ? 0 : 3) + g_eTTable[(Int)eTType], m_cQP.m_iRem, g_aucConvertToBit[iWidth], SCALING_LIST_SQT) : NULL;
   QpParam cQpBase; /* iQBits of the flat branch comes from the slice's BASE QP (:1162-1193, ADAPTIVE_QP_SELECTION) */
   {
     Int qpBDOffset = (eTType == TEXT_LUMA) ? pcCU->getSlice()->getSPS()->getQpBDOffsetY() : pcCU->getSlice()->getSPS()->getQpBDOffsetC();
@@ -79,12 +80,15 @@ ENC_BODIES = {
   p.is_intra = pcCU->isIntra(uiAbsPartIdx);
   p.dir_mode = hmxDir;
   uint32_t ac = uiAcSum;
-  HMX_SHIM_CHECK(hmx_xQuant(hmx_shim_ctx(), pSrc, pDes, iWidth, iHeight, &ac, eTType, &p));
+  if (hmxQ) HMX_SHIM_CHECK(hmx_xQuant_scaled(hmx_shim_ctx(), pSrc, pDes, iWidth, iHeight, &ac, eTType, &p, hmxQ));
+  else HMX_SHIM_CHECK(hmx_xQuant(hmx_shim_ctx(), pSrc, pDes, iWidth, iHeight, &ac, eTType, &p));
   uiAcSum = ac;
-  if (m_bUseAdaptQpSelect) HMX_SHIM_CHECK(hmx_arlCoeff(hmx_shim_ctx(), pSrc, pArlDes, iWidth, iHeight, eTType, &p, 0)); /* :1246-1249 */""",
+  if (m_bUseAdaptQpSelect) HMX_SHIM_CHECK(hmx_arlCoeff(hmx_shim_ctx(), pSrc, pArlDes, iWidth, iHeight, eTType, &p, 0, hmxQ)); /* :1246-1249 */""",
         "TComTrQuant::xRateDistOptQuant": """static_assert(sizeof(estBitsSbacStruct) == sizeof(hmx_est_bits), "estBitsSbacStruct and hmx_est_bits share one layout");
-  if (getUseScalingList()) { fprintf(stderr, "libhmx shim: scaling lists are outside the built path\\n"); exit(EXIT_FAILURE); }
   """ + _SCAN_DIR % {"w": "uiWidth"} + """
+  const Int hmxList = (pcCU->isIntra(uiAbsPartIdx) ? 0 : 3) + g_eTTable[(Int)eTType];
+  const Int *hmxQ = getUseScalingList() ? getQuantCoeff(hmxList, m_cQP.m_iRem, g_aucConvertToBit[uiWidth], SCALING_LIST_SQT) : NULL;       /* :1760 */
+  const double *hmxE = getUseScalingList() ? getErrScaleCoeff(hmxList, g_aucConvertToBit[uiWidth], m_cQP.m_iRem, SCALING_LIST_SQT) : NULL; /* :1759 */
   hmx_rdoq_param p;
   p.qp.qp = m_cQP.m_iQP, p.qp.per = m_cQP.m_iPer, p.qp.rem = m_cQP.m_iRem, p.qp.bits = m_cQP.m_iBits;
   p.sign_hide = pcCU->getSlice()->getPPS()->getSignHideFlag();
@@ -94,13 +98,15 @@ ENC_BODIES = {
   p.cbf_ctx = (eTType ? TEXT_CHROMA : eTType) * NUM_QT_CBF_CTX + pcCU->getCtxQtCbf(uiAbsPartIdx, eTType, pcCU->getTransformIdx(uiAbsPartIdx));
   p.lambda = m_dLambda; /* what setLambda / selectLambda left for this component */
   uint32_t s = 0;
-  HMX_SHIM_CHECK(hmx_xRateDistOptQuant(hmx_shim_ctx(), plSrcCoeff, piDstCoeff, uiWidth, uiHeight, &s, eTType, &p,
-                                       reinterpret_cast<const hmx_est_bits *>(m_pcEstBitsSbac)));
+  if (hmxQ) HMX_SHIM_CHECK(hmx_xRateDistOptQuant_scaled(hmx_shim_ctx(), plSrcCoeff, piDstCoeff, uiWidth, uiHeight, &s, eTType, &p,
+                                                        reinterpret_cast<const hmx_est_bits *>(m_pcEstBitsSbac), hmxQ, hmxE));
+  else HMX_SHIM_CHECK(hmx_xRateDistOptQuant(hmx_shim_ctx(), plSrcCoeff, piDstCoeff, uiWidth, uiHeight, &s, eTType, &p,
+                                            reinterpret_cast<const hmx_est_bits *>(m_pcEstBitsSbac)));
   uiAbsSum = s;
   if (m_bUseAdaptQpSelect) { /* :1886-1891 */
     hmx_quant_param a;
     a.qp = p.qp, a.per_base = -1, a.slice_type = pcCU->getSlice()->getSliceType(), a.sign_hide = p.sign_hide, a.is_intra = p.is_intra, a.dir_mode = p.dir_mode;
-    HMX_SHIM_CHECK(hmx_arlCoeff(hmx_shim_ctx(), plSrcCoeff, piArlDstCoeff, uiWidth, uiHeight, eTType, &a, 1));
+    HMX_SHIM_CHECK(hmx_arlCoeff(hmx_shim_ctx(), plSrcCoeff, piArlDstCoeff, uiWidth, uiHeight, eTType, &a, 1, hmxQ));
   }""",
     },
     "TComPrediction": {

@@ -247,8 +247,10 @@ void ref_xDeQuant_scaled(int qpy, int ttype, int bd_off, int list_type, const in
 // xQuant as the encoder runs it under AdaptiveQpSelection: the slice's base QP differs from the block's QP (cQpBase,
 // TComTrQuant.cpp:1162-1193), m_bUseAdaptQpSelect is on and pArlDes receives the ARL coefficients -- from the flat branch or,
 // with rdoq != 0, from xRateDistOptQuant (est_blob / lambda as in ref_xRateDistOptQuant).
+// q_coef / err_scale != NULL: the quantiser's per-position tables of a scaling list (getQuantCoeff / getErrScaleCoeff of the block's
+// list type, QP remainder and size) are overwritten for the call and restored to the flat ones afterwards.
 void ref_xQuant_arl(int qpy, int qp_base, int slice_type, int ttype, int is_intra, int dir_mode, int tr_idx, int rdoq, double lambda,
-                    const int *est_blob, int *coef, int *level, int *arl, int N, unsigned *abs_sum) {
+                    const int *est_blob, int *coef, int *level, int *arl, int N, unsigned *abs_sum, const int *q_coef, const double *err_scale) {
   TComDataCU *cu = S->pic->getCU(0);
   TComSlice *sl = S->pic->getSlice(0);
   sl->setSliceType((SliceType)slice_type);
@@ -271,10 +273,17 @@ void ref_xQuant_arl(int qpy, int qp_base, int slice_type, int ttype, int is_intr
     memcpy(S->tq.m_pcEstBitsSbac, est_blob, sizeof(estBitsSbacStruct));
     S->tq.m_dLambda = lambda;
   }
+  const UInt size_id = g_aucConvertToBit[N], list_type = (is_intra ? 0 : 3) + g_eTTable[ttype];
+  if (q_coef) memcpy(S->tq.getQuantCoeff(list_type, S->tq.m_cQP.m_iRem, size_id, SCALING_LIST_SQT), q_coef, sizeof(Int) * N * N);
+  if (err_scale) memcpy(S->tq.getErrScaleCoeff(list_type, size_id, S->tq.m_cQP.m_iRem, SCALING_LIST_SQT), err_scale, sizeof(double) * N * N);
   Int *a = arl;
   UInt sum = 0;
   S->tq.xQuant(cu, coef, level, a, N, N, sum, (TextType)ttype, 0);
   *abs_sum = sum;
+  if (q_coef || err_scale) {
+    S->tq.xsetFlatScalingList(list_type, size_id, S->tq.m_cQP.m_iRem);
+    S->tq.setErrScaleCoeff(list_type, size_id, S->tq.m_cQP.m_iRem, SCALING_LIST_SQT);
+  }
   S->tq.m_bUseRDOQ = was_rdoq;
   S->tq.m_bUseAdaptQpSelect = was_arl;
   sl->setSliceQpBase(qpy);

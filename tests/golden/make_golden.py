@@ -136,6 +136,52 @@ def dequant_scaled(R, B, rng):
     return out
 
 
+def quant_scaled(R, B, rng):
+    """The compiled reference's quantisers under a scaling list, the per-position tables as inputs (oracle_lib.scaling_tables): xQuant's
+    flat branch with sign-bit hiding and pArlDes (even cases), xRateDistOptQuant (odd cases)."""
+    out = {}
+    mx = (1 << B) - 1
+    bd = 6 * (B - 8)
+    for N in (4, 8, 16, 32):
+        par, lam_l, est_l, coef_l, q_l, e_l, lev_l, arl_l, sum_l = [], [], [], [], [], [], [], [], []
+        for it in range(12):
+            rdoq = it % 2
+            ttype = (0, 2, 3)[it % 3] if N < 32 else 0
+            is_intra = int(it % 4 != 3)
+            mode = int(rng.integers(0, 35))
+            tr_idx = int(rng.integers(0, 2))
+            qpy = int(rng.choice([10, 22, 27, 32, 37, 45]))
+            st = 2 if is_intra else (1, 0)[it % 2]
+            lam = float(rng.choice([3.0, 17.5, 58.0, 140.25]))
+            amp = int(rng.choice([20, 60, 200, mx, mx]))
+            resi = rng.integers(-amp, amp + 1, N * N).astype(np.int16)
+            coef = np.zeros(N * N, np.int32)
+            R.ref_xT(mode if (ttype == 0 and is_intra) else REG_DCT, resi, N, coef, N)
+            est = ol.make_est_bits(rng)
+            rem = (qpy + bd if ttype == 0 else ol.oracle().hmo_setQPforQuant(qpy, 1, bd, 0).qp) % 6
+            qtab, estab, _ = ol.scaling_tables(rng, N, B, rem)
+            lev, a, s_ = ol.r_quant_arl(coef, N, qpy, qpy, st, ttype, is_intra, mode, tr_idx, rdoq, lam, est, qtab, estab)
+            par.append((qpy, st, ttype, is_intra, mode, tr_idx, R.ref_cbf_ctx(ttype, tr_idx), rdoq))
+            lam_l.append(lam)
+            est_l.append(np.frombuffer(bytes(est), np.int32).copy())
+            coef_l.append(coef)
+            q_l.append(qtab)
+            e_l.append(estab)
+            lev_l.append(lev.reshape(-1))
+            arl_l.append(a.reshape(-1))
+            sum_l.append(s_)
+        out[f"q{N}_par"] = np.array(par, np.int32)
+        out[f"q{N}_lambda"] = np.array(lam_l, np.float64)
+        out[f"q{N}_est"] = np.stack(est_l)
+        out[f"q{N}_coef"] = np.stack(coef_l)
+        out[f"q{N}_qtab"] = np.stack(q_l)
+        out[f"q{N}_estab"] = np.stack(e_l)
+        out[f"q{N}_lev"] = np.stack(lev_l)
+        out[f"q{N}_arl"] = np.stack(arl_l)
+        out[f"q{N}_sum"] = np.array(sum_l, np.uint32)
+    return out
+
+
 def arl(R, B, rng):
     """pArlDes of the compiled reference's xQuant under AdaptiveQpSelection: the flat branch (iQBits from the slice's base QP) and
     xRateDistOptQuant (odd cases); the flat branch's levels with a base QP of its own come along."""
@@ -382,6 +428,11 @@ def main():
         for B in (8, 10):
             R.ref_init(B, 416, 240, 1)
             np.savez_compressed(os.path.join(HERE, f"arl_b{B}.npz"), **arl(R, B, np.random.default_rng(9144 + B)))
+        return
+    if sys.argv[1:] == ["quant_scaled"]:  # round 3: the quantisers under a scaling list
+        for B in (8, 10):
+            R.ref_init(B, 416, 240, 1)
+            np.savez_compressed(os.path.join(HERE, f"quant_scaled_b{B}.npz"), **quant_scaled(R, B, np.random.default_rng(11192 + B)))
         return
     if sys.argv[1:] == ["dequant_scaled"]:  # round 3: xDeQuant's scaling-list branch
         for B in (8, 10):

@@ -109,7 +109,11 @@ def oracle():
         L.hmo_xDeQuant.argtypes = [i32p, i32p, ci, ci, ci, ci]
         L.hmo_xDeQuant_scaled.argtypes = [i32p, i32p, ci, ci, ci, i32p]
         L.hmo_xDeQuant_scaled.restype = None
-        L.hmo_arlCoeff.argtypes = [i32p, i32p, ci, ci, C.POINTER(QuantCfg), ci]
+        L.hmo_arlCoeff.argtypes = [i32p, i32p, ci, ci, C.POINTER(QuantCfg), ci, C.c_void_p]
+        L.hmo_xQuant_scaled.argtypes = [i32p, i32p, ci, ci, C.POINTER(QuantCfg), C.POINTER(C.c_uint32), C.c_void_p]
+        L.hmo_xQuant_scaled.restype = None
+        L.hmo_xRateDistOptQuant_scaled.argtypes = [i32p, i32p, ci, ci, C.POINTER(RdoqCfg), C.POINTER(EstBits), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
+        L.hmo_xRateDistOptQuant_scaled.restype = None
         L.hmo_arlCoeff.restype = None
         L.hmo_transformNxN.argtypes = [i16p, ci, i32p, ci, ci, cu, ci, ci, C.POINTER(QuantCfg),
                                        C.POINTER(C.c_uint32)]
@@ -292,22 +296,60 @@ def o_rdoq(coef, N, B, cfg, est):
     return lvl.reshape(N, N), s.value
 
 
-def o_arl(coef, N, B, cfg, rdoq):
+def scaling_tables(rng, N, B, rem, flat=False):
+    """Per-position tables as HM's setScalingList leaves them for one (list, remainder, size): quant coefficient = (quantScale << 4) /
+    list entry (processScalingListEnc, TComTrQuant.cpp:2953-2977), error scale from it (setErrScaleCoeff :2794-2818), de-quantiser
+    coefficient = invQuantScale * list entry (:2979-3003).  Entries 1..255 at random (or the flat 16)."""
+    q6, iq6 = (26214, 23302, 20560, 18396, 16384, 14564), (40, 45, 51, 57, 64, 72)
+    entry = np.full(N * N, 16, np.int64) if flat else rng.integers(1, 256, N * N).astype(np.int64)
+    qtab = ((q6[rem] << 4) // entry).astype(np.int32)
+    lg = int(np.log2(N))
+    e = np.float64(1 << 15) * np.float64(2.0) ** np.float64(-2 * (15 - B - lg))
+    estab = e / qtab.astype(np.float64) / qtab.astype(np.float64) / np.float64(1 << (2 * (B - 8)))
+    return qtab, estab, (iq6[rem] * entry).astype(np.int32)
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def o_arl(coef, N, B, cfg, rdoq, qtab=None):
     coef = np.ascontiguousarray(coef, np.int32).reshape(-1)
+    qtab = None if qtab is None else np.ascontiguousarray(qtab, np.int32)
     arl = np.zeros(N * N, np.int32)
-    oracle().hmo_arlCoeff(coef, arl, N, B, C.byref(cfg), int(rdoq))
+    oracle().hmo_arlCoeff(coef, arl, N, B, C.byref(cfg), int(rdoq), _vp(qtab))
     return arl.reshape(N, N)
 
 
-def r_quant_arl(coef, N, qpy, qp_base, slice_type, ttype, is_intra, dir_mode, tr_idx, rdoq, lam, est):
-    """the compiled reference's xQuant with AdaptiveQpSelection on (flat branch or xRateDistOptQuant): levels, pArlDes, uiAcSum"""
+def o_quant_scaled(coef, N, B, cfg, qtab):
+    coef, qtab = np.ascontiguousarray(coef, np.int32).reshape(-1), np.ascontiguousarray(qtab, np.int32)
+    lvl, s = np.zeros(N * N, np.int32), C.c_uint32(0)
+    oracle().hmo_xQuant_scaled(coef, lvl, N, B, C.byref(cfg), C.byref(s), _vp(qtab))
+    return lvl.reshape(N, N), s.value
+
+
+def o_rdoq_scaled(coef, N, B, cfg, est, qtab, estab):
+    coef = np.ascontiguousarray(coef, np.int32).reshape(-1)
+    qtab, estab = np.ascontiguousarray(qtab, np.int32), np.ascontiguousarray(estab, np.float64)
+    lvl, s = np.zeros(N * N, np.int32), C.c_uint32(0)
+    oracle().hmo_xRateDistOptQuant_scaled(coef, lvl, N, B, C.byref(cfg), C.byref(est), C.byref(s), _vp(qtab), _vp(estab))
+    return lvl.reshape(N, N), s.value
+
+
+def r_quant_arl(coef, N, qpy, qp_base, slice_type, ttype, is_intra, dir_mode, tr_idx, rdoq, lam, est, qtab=None, estab=None):
+    """the compiled reference's xQuant with AdaptiveQpSelection on (flat branch or xRateDistOptQuant): levels, pArlDes, uiAcSum;
+    qtab / estab: the per-position tables of a scaling list for the call"""
     R = ref()
-    R.ref_xQuant_arl.argtypes = [ci, ci, ci, ci, ci, ci, ci, ci, C.c_double, C.POINTER(EstBits), i32p, i32p, i32p, ci, C.POINTER(C.c_uint32)]
+    R.ref_xQuant_arl.argtypes = [ci, ci, ci, ci, ci, ci, ci, ci, C.c_double, C.POINTER(EstBits), i32p, i32p, i32p, ci, C.POINTER(C.c_uint32),
+                                 C.c_void_p, C.c_void_p]
     R.ref_xQuant_arl.restype = None
     coef = np.ascontiguousarray(coef, np.int32).reshape(-1).copy()
+    qtab = None if qtab is None else np.ascontiguousarray(qtab, np.int32)
+    estab = None if estab is None else np.ascontiguousarray(estab, np.float64)
     lvl, arl = np.zeros(N * N, np.int32), np.zeros(N * N, np.int32)
     s = C.c_uint32(0)
-    R.ref_xQuant_arl(qpy, qp_base, slice_type, ttype, is_intra, dir_mode, tr_idx, int(rdoq), lam, C.byref(est), coef, lvl, arl, N, C.byref(s))
+    R.ref_xQuant_arl(qpy, qp_base, slice_type, ttype, is_intra, dir_mode, tr_idx, int(rdoq), lam, C.byref(est), coef, lvl, arl, N, C.byref(s),
+                     _vp(qtab), _vp(estab))
     return lvl.reshape(N, N), arl.reshape(N, N), s.value
 
 

@@ -71,6 +71,33 @@ def test_oracle_rdoq(B):
             assert np.array_equal(lev.reshape(-1), g[f"r{N}_lev"][k]) and s == g[f"r{N}_sum"][k], (N, k)
 
 
+def _quant_scaled_case(O, B, N, par):
+    qpy, st, ttype, is_intra, mode, tr_idx, cbf_ctx, rdoq = (int(v) for v in par)
+    q = O.hmo_setQPforQuant(qpy, int(ttype != 0), 6 * (B - 8), 0)
+    scan = O.hmo_coef_scan_idx(N, int(ttype == 0), is_intra, mode)
+    fc = ol.quant_cfg(q.per, q.rem, intra_slice=int(st == 2), sign_hide=1, scan_idx=scan)
+    root = int((not is_intra) and ttype == 0 and tr_idx == 0)
+    return fc, (q, scan, root, cbf_ctx), rdoq
+
+
+@pytest.mark.parametrize("B", [8, 10])
+def test_oracle_quant_scaled(B):
+    """The quantisers under a scaling list (tables in): the oracle against the reference's levels, uiAcSum and pArlDes."""
+    g, O = load(f"quant_scaled_b{B}.npz"), ol.oracle()
+    for N in (4, 8, 16, 32):
+        for k, par in enumerate(g[f"q{N}_par"]):
+            fc, (q, scan, root, cbf_ctx), rdoq = _quant_scaled_case(O, B, N, par)
+            coef, qtab, estab = g[f"q{N}_coef"][k], g[f"q{N}_qtab"][k], g[f"q{N}_estab"][k]
+            assert np.array_equal(ol.o_arl(coef, N, B, fc, rdoq, qtab).reshape(-1), g[f"q{N}_arl"][k]), (N, k, "arl")
+            if rdoq:
+                cfg = ol.RdoqCfg(q.per, q.rem, int(par[2] == 0), int(par[3]), scan, root, cbf_ctx, 1, float(g[f"q{N}_lambda"][k]))
+                est = ol.EstBits.from_buffer_copy(np.ascontiguousarray(g[f"q{N}_est"][k], np.int32).tobytes())
+                lev, s = ol.o_rdoq_scaled(coef, N, B, cfg, est, qtab, estab)
+            else:
+                lev, s = ol.o_quant_scaled(coef, N, B, fc, qtab)
+            assert np.array_equal(lev.reshape(-1), g[f"q{N}_lev"][k]) and s == g[f"q{N}_sum"][k], (N, k, rdoq)
+
+
 @pytest.mark.parametrize("B", [8, 10])
 def test_oracle_dequant_scaled(B):
     g, O = load(f"dequant_scaled_b{B}.npz"), ol.oracle()
@@ -372,6 +399,29 @@ def test_gpu_frame(name, B):
         assert np.array_equal(lev[p], g["lev_" + k].astype(np.int32)), k
     L.hmx_intra_plan_destroy(ctx.h, plan)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_quant_scaled(gctx):
+    """hmx_xQuant_scaled, hmx_xRateDistOptQuant_scaled and hmx_arlCoeff with a table vs the reference's vectors."""
+    from thevc_amd import capi
+    B = gctx.bit_depth
+    g = load(f"quant_scaled_b{B}.npz")
+    for N in (4, 8, 16, 32):
+        for k, par in enumerate(g[f"q{N}_par"]):
+            qpy, st, ttype, is_intra, mode, tr_idx, cbf_ctx, rdoq = (int(v) for v in par)
+            qp = capi.qp_for(qpy, ttype, B)
+            coef, qtab, estab = g[f"q{N}_coef"][k], g[f"q{N}_qtab"][k], g[f"q{N}_estab"][k]
+            p = capi.QuantParam(qp, -1, st, 1, is_intra, mode)
+            assert np.array_equal(gctx.arlCoeff(coef, N, ttype, p, rdoq, qtab), g[f"q{N}_arl"][k]), (N, k, "arl")
+            if rdoq:
+                root = int((not is_intra) and ttype == 0 and tr_idx == 0)
+                rp = capi.RdoqParam(qp, 1, is_intra, mode, root, cbf_ctx, float(g[f"q{N}_lambda"][k]))
+                est = capi.EstBits.from_buffer_copy(np.ascontiguousarray(g[f"q{N}_est"][k], np.int32).tobytes())
+                lev, s = gctx.xRateDistOptQuant_scaled(coef, N, ttype, rp, est, qtab, estab)
+            else:
+                lev, s = gctx.xQuant_scaled(coef, N, ttype, p, qtab)
+            assert np.array_equal(lev, g[f"q{N}_lev"][k]) and s == g[f"q{N}_sum"][k], (N, k, rdoq)
 
 
 @pytest.mark.gpu

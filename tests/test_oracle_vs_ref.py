@@ -258,6 +258,61 @@ def test_scaled_dequant_vs_reference(B, N):
 
 
 @pytest.mark.parametrize("N", [4, 8, 16, 32])
+def test_scaled_quantisers_vs_reference(B, N):
+    """The quantiser with a scaling list (tables as inputs): xQuant's flat branch with getQuantCoeff per position (TComTrQuant.cpp
+    :1215, 1244-1255) incl. sign-bit hiding and pArlDes, and xRateDistOptQuant with getQuantCoeff / getErrScaleCoeff per position
+    (:1759-1762, 1882-1883)."""
+    R, O = ol.ref(), ol.oracle()
+    rng = np.random.default_rng(6300 + N + B)
+    bd = 6 * (B - 8)
+    mx = (1 << B) - 1
+    differs = 0
+    for it in range(60):
+        rdoq = it % 2
+        ttype = (0, 2, 3)[it % 3] if N < 32 else 0
+        is_intra = it % 4 != 3
+        mode = int(rng.integers(0, 35))
+        tr_idx = int(rng.integers(0, 2))
+        qpy = int(rng.choice([4, 10, 22, 27, 32, 37, 45]))
+        slice_type = 2 if is_intra else [1, 0][it % 2]
+        lam = float(rng.choice([3.0, 17.5, 58.0, 140.25]))
+        amp = int(rng.choice([20, 60, 200, mx, mx]))
+        resi = rng.integers(-amp, amp + 1, N * N).astype(np.int16)
+        coef = np.zeros(N * N, np.int32)
+        O.hmo_xT(mode if (ttype == 0 and is_intra) else REG_DCT, resi, N, coef, N, B)
+        est = ol.make_est_bits(rng)
+        q = O.hmo_setQPforQuant(qpy, int(ttype != 0), bd, 0)
+        qtab, estab, _ = ol.scaling_tables(rng, N, B, q.rem, flat=it % 10 == 9)
+        la, aa, sa = ol.r_quant_arl(coef, N, qpy, qpy, slice_type, ttype, int(is_intra), mode, tr_idx, rdoq, lam, est, qtab, estab)
+        scan = O.hmo_coef_scan_idx(N, int(ttype == 0), int(is_intra), mode)
+        fc = ol.quant_cfg(q.per, q.rem, intra_slice=int(slice_type == 2), sign_hide=1, scan_idx=scan)
+        assert np.array_equal(aa, ol.o_arl(coef, N, B, fc, rdoq, qtab)), (it, N, B, rdoq, "arl")
+        if rdoq:
+            root = int((not is_intra) and ttype == 0 and tr_idx == 0)
+            cfg = ol.RdoqCfg(q.per, q.rem, int(ttype == 0), int(is_intra), scan, root, R.ref_cbf_ctx(ttype, tr_idx), 1, lam)
+            lb, sb = ol.o_rdoq_scaled(coef, N, B, cfg, est, qtab, estab)
+            lf, _ = ol.o_rdoq(coef, N, B, cfg, est)
+        else:
+            lb, sb = ol.o_quant_scaled(coef, N, B, fc, qtab)
+            lf = np.zeros(N * N, np.int32)
+            O.hmo_xQuant(coef, lf, N, B, C.byref(fc), C.byref(C.c_uint32(0)))
+            lf = lf.reshape(N, N)
+        assert np.array_equal(la, lb) and sa == sb, (it, N, B, rdoq, qpy, np.argwhere(la != lb)[:4])
+        differs += int(not np.array_equal(lb, lf))
+    assert differs >= 25  # the lists changed the levels
+    # the reference's flat tables are back
+    coef = rng.integers(-500, 501, N * N).astype(np.int32)
+    est = ol.make_est_bits(rng)
+    la, _, sa = ol.r_quant_arl(coef, N, 30, 30, 2, 0, 1, 0, 0, 0, 10.0, est)
+    q = O.hmo_setQPforQuant(30, 0, bd, 0)
+    fc = ol.quant_cfg(q.per, q.rem, intra_slice=1, sign_hide=1, scan_idx=O.hmo_coef_scan_idx(N, 1, 1, 0))
+    lb = np.zeros(N * N, np.int32)
+    s = C.c_uint32(0)
+    O.hmo_xQuant(coef, lb, N, B, C.byref(fc), C.byref(s))
+    assert np.array_equal(la.reshape(-1), lb) and sa == s.value
+
+
+@pytest.mark.parametrize("N", [4, 8, 16, 32])
 def test_arl_coefficients_vs_reference(B, N):
     """pArlDes of xQuant under AdaptiveQpSelection (TComTrQuant.cpp:1229-1249) and of xRateDistOptQuant (:1764-1765, 1886-1891): the
     slice's base QP differs from the block's QP, so iQBits of the flat branch comes from cQpBase; levels and uiAcSum of the same

@@ -120,7 +120,9 @@ def lib():
         L.hmx_xTransformSkip.argtypes = [vp, vp, cu, vp, ci, ci]
         L.hmx_xITransformSkip.argtypes = [vp, vp, vp, cu, ci, ci]
         L.hmx_xQuant.argtypes = [vp, vp, vp, ci, ci, C.POINTER(C.c_uint32), ci, C.POINTER(QuantParam)]
-        L.hmx_arlCoeff.argtypes = [vp, vp, vp, ci, ci, ci, C.POINTER(QuantParam), ci]
+        L.hmx_arlCoeff.argtypes = [vp, vp, vp, ci, ci, ci, C.POINTER(QuantParam), ci, vp]
+        L.hmx_xQuant_scaled.argtypes = [vp, vp, vp, ci, ci, C.POINTER(C.c_uint32), ci, C.POINTER(QuantParam), vp]
+        L.hmx_xRateDistOptQuant_scaled.argtypes = [vp, vp, vp, ci, ci, C.POINTER(C.c_uint32), ci, C.POINTER(RdoqParam), C.POINTER(EstBits), vp, vp]
         L.hmx_xDeQuant_scaled.argtypes = [vp, vp, vp, ci, ci, C.POINTER(Qp), vp]
         L.hmx_xDeQuant.argtypes = [vp, vp, vp, ci, ci, C.POINTER(Qp)]
         L.hmx_transformNxN.argtypes = [vp, vp, cu, vp, cu, cu, C.POINTER(C.c_uint32), ci, C.POINTER(QuantParam),
@@ -354,11 +356,26 @@ class Context:
         self._chk(lib().hmx_xDeQuant_scaled(self.h, _hp(src), _hp(dst), n, n, C.byref(qp), _hp(table)))
         return dst
 
-    def arlCoeff(self, src, n, text_type, qparam, rdoq_form):
+    def arlCoeff(self, src, n, text_type, qparam, rdoq_form, qtab=None):
         src = np.ascontiguousarray(src, np.int32)
+        qtab = None if qtab is None else np.ascontiguousarray(qtab, np.int32)
         arl = np.zeros(n * n, np.int32)
-        self._chk(lib().hmx_arlCoeff(self.h, _hp(src), _hp(arl), n, n, text_type, C.byref(qparam), int(rdoq_form)))
+        self._chk(lib().hmx_arlCoeff(self.h, _hp(src), _hp(arl), n, n, text_type, C.byref(qparam), int(rdoq_form), None if qtab is None else _hp(qtab)))
         return arl
+
+    def xQuant_scaled(self, src, n, text_type, qparam, qtab, ac_sum=0):
+        src, qtab = np.ascontiguousarray(src, np.int32), np.ascontiguousarray(qtab, np.int32)
+        dst = np.zeros(n * n, np.int32)
+        s = C.c_uint32(ac_sum)
+        self._chk(lib().hmx_xQuant_scaled(self.h, _hp(src), _hp(dst), n, n, C.byref(s), text_type, C.byref(qparam), _hp(qtab)))
+        return dst, s.value
+
+    def xRateDistOptQuant_scaled(self, src, n, text_type, rparam, est, qtab, estab, abs_sum=0):
+        src, qtab, estab = np.ascontiguousarray(src, np.int32), np.ascontiguousarray(qtab, np.int32), np.ascontiguousarray(estab, np.float64)
+        dst = np.zeros(n * n, np.int32)
+        s = C.c_uint32(abs_sum)
+        self._chk(lib().hmx_xRateDistOptQuant_scaled(self.h, _hp(src), _hp(dst), n, n, C.byref(s), text_type, C.byref(rparam), C.byref(est), _hp(qtab), _hp(estab)))
+        return dst, s.value
 
     def xRateDistOptQuant(self, src, n, text_type, rparam, est, abs_sum=0):
         src = np.ascontiguousarray(src, np.int32)

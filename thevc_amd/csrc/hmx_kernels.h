@@ -203,7 +203,7 @@ __device__ __forceinline__ unsigned sse_samples(const int *org, const int *rec, 
 // ---------------------------------------------------------------------------------------------
 template <int N, int NL, int NCOEF, bool WIDE, typename LT, typename RowFn, typename ColFn>
 __device__ __forceinline__ int quant_sbh_block(LT &L, int gl, bool active, const int *coef, RowFn row_of, ColFn col_of,
-                                               bool luma, int scan_idx, const PicDev &P) {
+                                               bool luma, int scan_idx, const PicDev &P, const int *qtab = nullptr) {
   constexpr int LG = Log2<N>::v;
   const int tshift = 15 - P.bit_depth - LG;
   const QuantDev qd = pick_qd(P, luma);
@@ -214,7 +214,8 @@ __device__ __forceinline__ int quant_sbh_block(LT &L, int gl, bool active, const
 #pragma unroll
     for (int k = 0; k < NCOEF; k++) {
       int al;
-      const int word = quant_one<WIDE>(coef[k], qd.q, qbits, qd.rnd_factor, al);
+      // qtab: getQuantCoeff of a scaling list, per position (TComTrQuant.cpp:1215, 1244); the chains pass none
+      const int word = quant_one<WIDE>(coef[k], qtab ? qtab[row_of(k) * N + col_of(k)] : qd.q, qbits, qd.rnd_factor, al);
       sum += al;
       L.tile[row_of(k)][col_of(k)] = word;
     }

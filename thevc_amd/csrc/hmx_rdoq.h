@@ -49,6 +49,10 @@ struct RdoqArgs {
   double lambda[2];
   double err_scale[2][4]; // [plane type][log2n - 2]: 2^15 * 2^(-2 tshift) / q / q / 2^(2 inc)
   long long rd_factor[2]; // (Int64)(invq * invq * 2^(2 per) / lambda / 16 / 2^(2 inc) + 0.5)
+  // scaling list (hmx_xRateDistOptQuant_scaled; k_rdoq only): getQuantCoeff / getErrScaleCoeff of the launch's ONE block per position
+  // (row-major N x N), NULL = the flat values above
+  const int *qtab;
+  const double *estab;
 };
 
 __device__ __forceinline__ unsigned rdoq_scan_pos(int log2n, int scan_idx, int sp) {
@@ -69,9 +73,9 @@ __global__ __launch_bounds__(64) void k_rdoq(RdoqArgs A) {
   const int lg = K.log2n, N = 1 << lg, nn = N * N, G = N >> 2, n_cg = nn >> 4;
   const int pt = K.plane_type, B = A.bit_depth;
   const int tshift = 15 - B - lg, qbits = 14 + A.per[pt] + tshift;
-  const int q = A.q[pt], scan_idx = K.scan_idx;
+  const int q_flat = A.q[pt], scan_idx = K.scan_idx;
   const bool is_luma = K.is_luma;
-  const double lambda = A.lambda[pt], err_scale = A.err_scale[pt][lg - 2];
+  const double lambda = A.lambda[pt], err_flat = A.err_scale[pt][lg - 2];
   const int *src = K.src;
   int *dst = K.dst;
   const int ss = K.src_stride, ds = K.dst_stride;
@@ -105,6 +109,8 @@ __global__ __launch_bounds__(64) void k_rdoq(RdoqArgs A) {
     for (int k = 15; k >= 0; k--) {
       const int sp = cg * 16 + k;
       const unsigned bp = rdoq_scan_pos(lg, scan_idx, sp);
+      const int q = A.qtab ? A.qtab[bp] : q_flat;                 // TComTrQuant.cpp:1882-1883: per position under a scaling list
+      const double err_scale = A.estab ? A.estab[bp] : err_flat;
       const long long wide = (long long)abs(SRC(bp)) * q, cap = 2147483647ll - (1ll << (qbits - 1));
       const int ld = (int)(wide < cap ? wide : cap);
       const unsigned max_lvl = (unsigned)((ld + (1 << (qbits - 1))) >> qbits);

@@ -105,15 +105,60 @@ extern "C" int hmx_xQuant(hmx_ctx *c, const int32_t *src, hmx_coeff *dst, int w,
   return r;
 }
 
+static int rdoq_scan_index(int n, bool luma, bool intra, int mode);
+// ---- xQuant's flat branch with a scaling list: getQuantCoeff per position (TComTrQuant.cpp:1215, 1244-1255), then signBitHidingHDQ ----
+// One block, one wave: lane gl holds row gl (quant_sbh_block, the quantiser of the list kernels, with the table).
+template <int N>
+__global__ __launch_bounds__(64) void k_quant_scaled(const int *src, const int *qtab, int *dst, uint32_t *sum_out, PicDev P, int luma, int scan_idx) {
+  __shared__ TuLds<N> L;
+  const int gl = threadIdx.x;
+  const bool active = gl < N;
+  int row[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) row[k] = active ? src[gl * N + k] : 0;
+  const int sum = quant_sbh_block<N, N, N, true>(
+      L, gl, active, row, [&](int) { return gl; }, [&](int k) { return k; }, luma != 0, scan_idx, P, qtab);
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < N; k++) dst[gl * N + k] = level_of(L.tile[gl][k]);
+    if (gl == 0) *sum_out = (uint32_t)sum;
+  }
+}
+extern "C" int hmx_xQuant_scaled(hmx_ctx *c, const int32_t *src, hmx_coeff *dst, int w, int h, uint32_t *ac_sum, int text_type,
+                                 const hmx_quant_param *qp, const int32_t *quant_coef) {
+  if (!c || !src || !dst || !qp || !ac_sum || !quant_coef || !size_ok(w, h)) return fail(c, HMX_ERR_ARG, "hmx_xQuant_scaled: unsupported size or null");
+  Scratch s{c};
+  int *d_in = s.take<int>(w * h), *d_tab = s.take<int>(w * h), *d_out = s.take<int>(w * h);
+  uint32_t *d_sum = s.take<uint32_t>(1);
+  int r = up2d(c, d_in, src, 4, w, h, w);
+  if (!r) r = up2d(c, d_tab, quant_coef, 4, w, h, w);
+  if (r) return r;
+  const PicDev P = scalar_picdev(c, &qp->qp, qp->per_base, qp->slice_type, qp->sign_hide);
+  const bool luma = text_type == HMX_TEXT_LUMA;
+  const int scan = rdoq_scan_index(w, luma, qp->is_intra != 0, qp->dir_mode); // getCoefScanIdx: 0 diagonal, 1 horizontal, 2 vertical
+  switch (w) {
+  case 4: hipLaunchKernelGGL(k_quant_scaled<4>, dim3(1), dim3(64), 0, c->stream, d_in, d_tab, d_out, d_sum, P, (int)luma, scan); break;
+  case 8: hipLaunchKernelGGL(k_quant_scaled<8>, dim3(1), dim3(64), 0, c->stream, d_in, d_tab, d_out, d_sum, P, (int)luma, scan); break;
+  case 16: hipLaunchKernelGGL(k_quant_scaled<16>, dim3(1), dim3(64), 0, c->stream, d_in, d_tab, d_out, d_sum, P, (int)luma, scan); break;
+  default: hipLaunchKernelGGL(k_quant_scaled<32>, dim3(1), dim3(64), 0, c->stream, d_in, d_tab, d_out, d_sum, P, (int)luma, scan); break;
+  }
+  HIPCHK(c, hipGetLastError());
+  uint32_t hs = 0;
+  HIPCHK(c, hipMemcpyAsync(&hs, d_sum, 4, hipMemcpyDeviceToHost, c->stream));
+  r = down2d(c, dst, w, d_out, 4, w, h);
+  *ac_sum += hs;
+  return r;
+}
+
 // ---- the pArlDes output of the quantiser (ADAPTIVE_QP_SELECTION) ----
 // One thread per coefficient: the coefficient scaled like a level with ARL_C_PRECISION = 7 more fractional bits (TComTrQuant.cpp
 // :1229-1249 flat branch, iQBits from the slice's base QP; :1757-1765, 1886-1891 inside xRateDistOptQuant, iQBits from m_cQP and the
 // product limited first).  Independent of every quantiser decision, so it is a pass of its own beside hmx_xQuant / hmx_xRateDistOptQuant.
-__global__ __launch_bounds__(256) void k_arl(const int *src, int *arl, int n, int q, int qbits, int rdoq) {
+__global__ __launch_bounds__(256) void k_arl(const int *src, const int *qtab, int *arl, int n, int q, int qbits, int rdoq) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int qbits_c = qbits - 7;
-  const long long t = (long long)abs(src[i]) * q;
+  const long long t = (long long)abs(src[i]) * (qtab ? qtab[i] : q);
   if (rdoq) {
     const long long lim = 2147483647ll - (1ll << (qbits - 1));
     const int ld = (int)(t < lim ? t : lim);
@@ -122,17 +167,19 @@ __global__ __launch_bounds__(256) void k_arl(const int *src, int *arl, int n, in
     arl[i] = (int)((t + (1ll << (qbits_c - 1))) >> qbits_c);
   }
 }
-extern "C" int hmx_arlCoeff(hmx_ctx *c, const int32_t *src, int32_t *arl, int w, int h, int text_type, const hmx_quant_param *qp, int rdoq_form) {
+extern "C" int hmx_arlCoeff(hmx_ctx *c, const int32_t *src, int32_t *arl, int w, int h, int text_type, const hmx_quant_param *qp, int rdoq_form,
+                            const int32_t *quant_coef) {
   (void)text_type;
   if (!c || !src || !arl || !qp || !size_ok(w, h)) return fail(c, HMX_ERR_ARG, "hmx_arlCoeff: unsupported size or null");
   if (qp->qp.rem < 0 || qp->qp.rem > 5 || qp->qp.per < 0) return fail(c, HMX_ERR_ARG, "hmx_arlCoeff: bad QP");
   Scratch s{c};
-  int *d_in = s.take<int>(w * h), *d_out = s.take<int>(w * h);
+  int *d_in = s.take<int>(w * h), *d_out = s.take<int>(w * h), *d_tab = quant_coef ? s.take<int>(w * h) : nullptr;
   int r = up2d(c, d_in, src, 4, w, h, w);
+  if (!r && quant_coef) r = up2d(c, d_tab, quant_coef, 4, w, h, w);
   if (r) return r;
   const int per = rdoq_form ? qp->qp.per : (qp->per_base >= 0 ? qp->per_base : qp->qp.per);
   const int qbits = 14 + per + (15 - c->cfg.bit_depth - ilog2i(w));
-  hipLaunchKernelGGL(k_arl, dim3((unsigned)((w * h + 255) / 256)), dim3(256), 0, c->stream, d_in, d_out, w * h, kQuantScales[qp->qp.rem], qbits, rdoq_form != 0);
+  hipLaunchKernelGGL(k_arl, dim3((unsigned)((w * h + 255) / 256)), dim3(256), 0, c->stream, d_in, d_tab, d_out, w * h, kQuantScales[qp->qp.rem], qbits, rdoq_form != 0);
   HIPCHK(c, hipGetLastError());
   return down2d(c, arl, w, d_out, 4, w, h);
 }
@@ -232,7 +279,7 @@ static int rdoq_issue(hmx_ctx *c, RdoqArgs A) {
   // blocks arrive sorted by size, largest first: 8x8 and larger go through the wave-cooperative routine (the decomposition
   // of hmx_rdoq_core.h), 4x4 blocks -- a single coefficient group, nothing to decompose -- one LANE per block (k_rdoq)
   const size_t n_wave = c->rdoq_class_n[0] + c->rdoq_class_n[1] + c->rdoq_class_n[2], n_all = n_wave + c->rdoq_class_n[3];
-  const bool lane_only = c->knob.rdoq_lane_only;
+  const bool lane_only = c->knob.rdoq_lane_only || A.qtab; // per-position tables: the sequential kernel reads them
   if (n_wave && !lane_only) {
     // 8x8 and larger: the wave-cooperative routine of the whole-picture chain (rdoq_wave_tiles), a wave per 8 / 4 / 1 blocks
     if (!c->rdoq_consts && hipMalloc((void **)&c->rdoq_consts, 4 * sizeof(double)) != hipSuccess) return fail(c, HMX_ERR_NOMEM, "hipMalloc RDOQ constants");
@@ -330,6 +377,39 @@ extern "C" int hmx_xRateDistOptQuant(hmx_ctx *c, const int32_t *src, hmx_coeff *
   HIPCHK(c, hipMemcpyAsync(&hs, d_sum, 4, hipMemcpyDeviceToHost, c->stream));
   r = down2d(c, dst, w, d_out, 4, w, h);
   *abs_sum += hs; // uiAbsSum accumulates (:2187)
+  return r;
+}
+
+// xRateDistOptQuant under a scaling list: getQuantCoeff and getErrScaleCoeff per position (TComTrQuant.cpp:1759-1762, 1882-1883).  The
+// block goes through the sequential lane kernel (k_rdoq), which reads the two tables where it reads the flat values otherwise.
+extern "C" int hmx_xRateDistOptQuant_scaled(hmx_ctx *c, const int32_t *src, hmx_coeff *dst, int w, int h, uint32_t *abs_sum, int text_type,
+                                            const hmx_rdoq_param *rp, const hmx_est_bits *est, const int32_t *quant_coef, const double *err_scale) {
+  if (!c || !src || !dst || !rp || !est || !abs_sum || !quant_coef || !err_scale || !size_ok(w, h) || !(rp->lambda > 0))
+    return fail(c, HMX_ERR_ARG, "hmx_xRateDistOptQuant_scaled: unsupported size, null or non-positive lambda");
+  Scratch s{c};
+  int *d_in = s.take<int>(w * h), *d_out = s.take<int>(w * h), *d_q = s.take<int>(w * h);
+  double *d_e = s.take<double>(w * h);
+  uint32_t *d_sum = s.take<uint32_t>(1);
+  int r = up2d(c, d_in, src, 4, w, h, w);
+  if (!r) r = up2d(c, d_q, quant_coef, 4, w, h, w);
+  if (!r) r = up2d(c, d_e, err_scale, 8, w, h, w);
+  if (r) return r;
+  RdoqArgs A{};
+  const hmx_qp qps[2] = {rp->qp, rp->qp};
+  const double lam[2] = {rp->lambda, rp->lambda};
+  rdoq_constants(A, c->cfg.bit_depth, qps, lam);
+  A.sign_hide = rp->sign_hide;
+  A.qtab = d_q, A.estab = d_e;
+  const bool luma = text_type == HMX_TEXT_LUMA;
+  std::vector<RdoqBlock> b(1);
+  b[0] = RdoqBlock{d_in, d_out, w, w, d_sum, (unsigned char)ilog2i(w), (unsigned char)luma,
+                   (unsigned char)rdoq_scan_index(w, luma, rp->is_intra != 0, rp->dir_mode), (unsigned char)(rp->root_cbf != 0),
+                   (unsigned char)rp->cbf_ctx, 0, 0};
+  if ((r = rdoq_launch(c, A, b, est, 1))) return r;
+  uint32_t hs = 0;
+  HIPCHK(c, hipMemcpyAsync(&hs, d_sum, 4, hipMemcpyDeviceToHost, c->stream));
+  r = down2d(c, dst, w, d_out, 4, w, h);
+  *abs_sum += hs;
   return r;
 }
 
