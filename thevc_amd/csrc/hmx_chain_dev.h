@@ -185,6 +185,7 @@ __device__ __forceinline__ void wave_chain_valu(char *smem, const SRC &src, cons
 template <bool ENC, typename SRC>
 __device__ __forceinline__ void wave_chain_8x2(char *smem, const SRC &src, const PicDev &P, int count) {
   constexpr int N = 8, NL = 4, LG = 3;
+  HMX_MARK(82, 0);
   const int lane = lane_id(), slot = lane >> 2, gl = lane & 3, r0 = 2 * gl;
   TuLds8x2 &L = reinterpret_cast<TuLds8x2 *>(smem)[slot];
   const bool active = slot < count;
@@ -204,8 +205,11 @@ __device__ __forceinline__ void wave_chain_8x2(char *smem, const SRC &src, const
     tload_row<N>(V.org + pb0, R.qstride, r0, v);
     tload_row<N>(V.org + pb0, R.qstride, r0 + 1, v + 8);
   }
+  HMX_MARK(82, 1);
   src.wait();
+  HMX_MARK(82, 2);
   intra_refs_tiled<N, NL, SRC::kCoherent>(L, gl, active, R, x, y, pb0, luma, avail, P);
+  HMX_MARK(82, 3);
   {
     const int *RL = (luma && use_filtered_refs(t.mode, LG)) ? L.fline : L.line;
     const int dcs = dc_sum_block<N, NL>(L, gl);
@@ -214,6 +218,7 @@ __device__ __forceinline__ void wave_chain_8x2(char *smem, const SRC &src, const
     intra_pred_samples<N, 16>(RL, L.me, t.mode, luma, B, dcs, [&](int s) { return r0 + (s >> 3); }, [](int s) { return s & 7; }, pred);
     wave_sync(); // the main reference shares the tile's memory
   }
+  HMX_MARK(82, 4);
   int *const lev_blk = V.lev + lev_row_off<N>(V, x, y, 0); // stride 0: the block's 64 levels are contiguous, row-major
   if (ENC) {
     int coef[16];
@@ -242,8 +247,10 @@ __device__ __forceinline__ void wave_chain_8x2(char *smem, const SRC &src, const
       }
       wave_sync();
     }
+    HMX_MARK(82, 5);
     quant_sbh_block<N, NL, 16, false>(
         L, gl, active, coef, [&](int k) { return ts ? r0 + (k >> 3) : (k & 7); }, [&](int k) { return ts ? (k & 7) : r0 + (k >> 3); }, luma, scan_idx, P);
+    HMX_MARK(82, 6);
     if (active) {
       if (V.lev_stride == 0) { // four lanes, 16 bytes each, in the order of the addresses: an instruction writes one whole 64-byte line
 #pragma unroll
@@ -285,6 +292,7 @@ __device__ __forceinline__ void wave_chain_8x2(char *smem, const SRC &src, const
     }
     wave_sync();
   }
+  HMX_MARK(82, 7);
   // inverse (inv_tq_block's steps for the two columns, then the two rows, of this lane)
   const QuantDev qd = pick_qd(P, luma);
   const int dshift = 6 - tshift;
@@ -319,12 +327,14 @@ __device__ __forceinline__ void wave_chain_8x2(char *smem, const SRC &src, const
     }
     wave_sync();
   }
+  HMX_MARK(82, 8);
   if (active) {
 #pragma unroll
     for (int k = 0; k < 16; k++) out[k] = clip3(0, mx, pred[k] + out[k]);
     tstore_row<N, SRC::kWriteThrough>(R.p + pb0, R.qstride, r0, out);
     tstore_row<N, SRC::kWriteThrough>(R.p + pb0, R.qstride, r0 + 1, out + 8);
   }
+  HMX_MARK(82, 9);
   if constexpr (ENC && SRC::kSse) {
     if (src.want_sse()) {
       int o[16];

@@ -22,9 +22,9 @@ for ln in open(path):
     if s.startswith(".end_amdhsa_kernel") or s.startswith(".Lfunc_end"):
         cur = None
         continue
-    m = re.search(r"; HMXMARK (\d+) (\d+)", s)
+    m = re.search(r"; HMXMARK (0x[0-9a-f]+|\d+) (\d+)", s)
     if m:
-        sec = f"N={m.group(1)} s{m.group(2)}"
+        sec = f"N={int(m.group(1), 0)} s{m.group(2)}"
         if sec not in order:
             order.append(sec)
         continue
