@@ -355,7 +355,8 @@ void hmx_intra_plan_destroy(hmx_ctx *ctx, hmx_intra_plan *plan);
 void hmx_intra_plan_destroy_many(hmx_ctx *ctx, hmx_intra_plan *const *plans, int n);
 /* The two tables of a plan that the packed and the level schedule run on, copied to the HOST (for tests and tools that hold a
  * device-built plan against a host-built one): blocks[n_blocks] = the blocks sorted by (dependency level, size, code path,
- * coding index), 16 bytes each: the hmx_tu followed by the 64-bit neighbour-availability mask of initAdiPattern;
+ * coding index), 16 bytes each: the hmx_tu followed by a 64-bit mask over the 4n+1 neighbour units in initAdiPattern's order: the
+ * units the block's mode READS among the available ones, closed under the padding rule (hmx_intra_dependency_mask of the availability);
  * levels[n_levels] = per dependency level {uint32 start[4], count[4]} by transform size (4, 8, 16, 32), starts into blocks.
  * Either pointer may be NULL. */
 int hmx_intra_plan_download(hmx_ctx *ctx, const hmx_intra_plan *plan, void *blocks, void *levels);
