@@ -22,7 +22,7 @@ CASES = [
     # the default scaling lists: per-position tables through xQuant / xRateDistOptQuant / xDeQuant (hmx_x*_scaled), intra and inter lists
     {"name": "intra_scalinglist_q30", "seed": 55, "w": 128, "h": 64, "frames": 1, "bits": 8, "qp": 30, "inter": False, "extra": ["--ScalingList=1"]},
     {"name": "lowdelay_P_scalinglist_q32", "seed": 56, "w": 128, "h": 128, "frames": 2, "bits": 8, "qp": 32, "inter": True, "extra": ["--ScalingList=1"]},
-    {"name": "lowdelay_P_aqps_q32", "seed": 54, "w": 128, "h": 128, "frames": 4, "bits": 8, "qp": 32, "inter": True, "extra": ["--AdaptiveQpSelection=1"]},
+    {"name": "lowdelay_P_aqps_q32", "seed": 54, "w": 128, "h": 128, "frames": 3, "bits": 8, "qp": 32, "inter": True, "extra": ["--AdaptiveQpSelection=1"]},
 ]
 
 
