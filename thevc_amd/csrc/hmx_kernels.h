@@ -223,7 +223,11 @@ __device__ __forceinline__ int quant_sbh_block(LT &L, int gl, bool active, const
   sum = group_sum(active ? sum : 0, NL);
   wave_sync();
   constexpr int NG = (N / 4) * (N / 4), PER = (NG + NL - 1) / NL;
+#ifdef HMX_X_NO_SBH /* timing experiment (results wrong): the quantiser without sign-bit hiding */
+  const bool hide = false;
+#else
   const bool hide = P.sign_hide && sum >= 2; // uniform over the block's lanes
+#endif
   int w[PER][16];
   ScanPos<N> pos[PER];
   if (hide) {
