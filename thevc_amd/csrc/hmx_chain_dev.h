@@ -248,8 +248,74 @@ __device__ __forceinline__ void wave_chain_8x2(char *smem, const SRC &src, const
       wave_sync();
     }
     HMX_MARK(82, 5);
-    quant_sbh_block<N, NL, 16, false>(
-        L, gl, active, coef, [&](int k) { return ts ? r0 + (k >> 3) : (k & 7); }, [&](int k) { return ts ? (k & 7) : r0 + (k >> 3); }, luma, scan_idx, P);
+    if (__any(ts)) { // (no transform-skip block is 8x8 in the reference's streams: the general routine keeps the case)
+      quant_sbh_block<N, NL, 16, false>(
+          L, gl, active, coef, [&](int k) { return ts ? r0 + (k >> 3) : (k & 7); }, [&](int k) { return ts ? (k & 7) : r0 + (k >> 3); }, luma, scan_idx, P);
+    } else {
+      // Quantiser and sign-bit hiding on a coefficient group held by ONE lane, in registers (what the lane-per-block 4x4 chain does):
+      // the two lanes that hold a group's columns swap halves (a lane keeps rows 0-3 or 4-7 of four columns: group gx = gl >> 1,
+      // gy = gl & 1), quantise their sixteen coefficients and decide for them.  quant_sbh_block gathers a group's words from LDS in
+      // scan order, with a table load, an LDS atomic and two more passes over the tile: 813 -> ~580 instructions for the step.
+      const bool odd = gl & 1;
+      int rcv[8], cgc[16];
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          const int snd = odd ? coef[8 * h + kk] : coef[8 * h + 4 + kk]; // the rows of the partner's group
+          rcv[4 * h + kk] = __builtin_amdgcn_update_dpp(0, snd, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+        }
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+        for (int xx = 0; xx < 4; xx++) { // column xx of the group: own columns are 0,1 in the even lane, 2,3 in the odd one
+          const int h = xx & 1, mine = odd ? coef[8 * h + 4 + kk] : coef[8 * h + kk];
+          cgc[4 * kk + xx] = ((xx >= 2) == odd) ? mine : rcv[4 * h + kk];
+        }
+      const QuantDev qd = pick_qd(P, luma);
+      const int qbits = 14 + qd.per_qbits + tshift;
+      int w[16], sum = 0;
+      unsigned nzb = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        int al;
+        w[k] = quant_one<false>(cgc[k], qd.q, qbits, qd.rnd_factor, al);
+        sum += al;
+        nzb |= (unsigned)w[k];
+      }
+      const bool nz = (nzb & 0xffffu) != 0;
+      sum = group_sum(active ? sum : 0, NL);
+      const bool hide = P.sign_hide && sum >= 2; // uniform over the block's lanes
+      // which groups of the block hold a level, in the order of the block's group scan (diagonal and vertical: gx * 2 + gy = gl;
+      // horizontal: gy * 2 + gx)
+      const unsigned nzq = (unsigned)(__ballot(nz) >> (lane & ~3)) & 15u;
+      const bool hor = scan_idx == 1, ver = scan_idx == 2;
+      const unsigned nzs = hor ? ((nzq & 9u) | ((nzq & 2u) << 1) | ((nzq & 4u) >> 1)) : nzq;
+      const int sidx = hor ? (((gl & 1) << 1) | (gl >> 1)) : gl;
+      if (hide && nz) {
+        constexpr int dg[16] = {0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15};
+        int ws[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const int d = w[dg[k]], hv = w[k], vv = w[((k & 3) << 2) | (k >> 2)];
+          ws[k] = hor ? hv : (ver ? vv : d);
+        }
+        int nw;
+        const int bi = sbh_decide(ws, (nzs >> (sidx + 1)) == 0, nw);
+        if (bi >= 0) {
+          const int bd = (int)((0xfbe7ad369c258140ull >> (4 * bi)) & 15); // dg[bi], one nibble per entry
+          const int bp = hor ? bi : (ver ? (((bi & 3) << 2) | (bi >> 2)) : bd);
+#pragma unroll
+          for (int q = 0; q < 16; q++) w[q] = (q == bp) ? nw : w[q];
+        }
+      }
+      if (active) {
+        int *tb = &L.tile[4 * (gl & 1)][4 * (gl >> 1)];
+#pragma unroll
+        for (int k = 0; k < 16; k++) tb[(k >> 2) * 9 + (k & 3)] = w[k];
+      }
+      wave_sync();
+    }
     HMX_MARK(82, 6);
     if (active) {
       if (V.lev_stride == 0) { // four lanes, 16 bytes each, in the order of the addresses: an instruction writes one whole 64-byte line
